@@ -1,0 +1,40 @@
+import glob
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+GOLDEN = os.path.join(REPO, 'tests', 'golden')
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+def pytest_collection_modifyitems(config, items):
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason='no GPU visible')
+    for it in items:
+        if 'gpu' in it.keywords:
+            it.add_marker(skip)
+
+
+def load_weights(name):
+    """Shipped checkpoint (converted to .npz by tools/gen_golden.py) as a state_dict."""
+    with np.load(os.path.join(GOLDEN, 'weights', name + '.npz')) as f:
+        return {k: torch.from_numpy(f[k]) for k in f.files}
+
+
+def golden_files(prefix):
+    pat = prefix if prefix.endswith('.npz') else prefix + '*.npz'
+    return sorted(glob.glob(os.path.join(GOLDEN, pat)))
+
+
+def env_of(path):
+    return os.path.basename(path).split('_')[1]

@@ -1,0 +1,170 @@
+#!/usr/bin/env python
+"""Generate the golden fixtures under tests/golden/ by importing the UNMODIFIED reference.
+
+Runs only in the authoring container (needs /root/reference, which never travels to the GPU
+box).  The reference's third-party dependencies (torch_geometric, torch_scatter,
+torch_sparse, pybullet ...) are absent here, so our own stand-ins for the handful of
+primitives the hot path calls are put first on sys.path (tools/standins/, SURVEY.md
+Appendix C).  What is written is DATA: inputs, the reference's outputs (fp32 and the same
+module run in fp64) and intermediate activations captured with forward hooks, plus the
+shipped checkpoints converted to .npz (MIT-licensed data).  No reference source is copied.
+
+    python tools/gen_golden.py            # writes tests/golden/*.npz
+"""
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = '/root/reference'
+os.environ.setdefault('CUDA_VISIBLE_DEVICES', '')
+sys.dont_write_bytecode = True
+sys.path.insert(0, REF)
+sys.path.insert(0, os.path.join(REPO, 'tools', 'standins'))
+sys.path.insert(0, REPO)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+os.chdir(REF)   # the reference uses relative paths (str2name.py:15-17, maze_env.py:21)
+import model as ref_model  # noqa: E402
+import model_smoother as ref_smoother  # noqa: E402
+
+import gnnmp  # noqa: E402,F401
+from gnnmp.synth import ENVS, synth_graph  # noqa: E402
+
+OUT = os.path.join(REPO, 'tests', 'golden')
+SMOOTHERS = {  # name: (config_size, scale)   str2name.py:16,32,40,48,56,64
+    'smooth_2d_attv3': (2, 1.0), 'smooth_7d_attv3': (7, 1.0), 'smooth_ur5_attv3': (6, 2 * np.pi),
+    'smooth_snake_attv3': (7, 1.0), 'smooth_13d_attv3': (13, 1.0), 'smooth_14d_attv3': (14, 1.0),
+}
+
+
+def save_weights(name):
+    sd = torch.load(os.path.join(REF, 'data', 'weights', name + '.pt'), map_location='cpu')
+    os.makedirs(os.path.join(OUT, 'weights'), exist_ok=True)
+    np.savez(os.path.join(OUT, 'weights', name + '.npz'),
+             **{k: v.numpy() for k, v in sd.items()})
+    return sd
+
+
+def run_explorer(env, sd, g, loop, use_obstacles, dtype, want_taps):
+    e = ENVS[env]
+    m = ref_model.EncoderProcessDecoder(e['workspace'], e['C'], e['d'], e['S'])
+    m.load_state_dict(sd, strict=True)
+    m.eval().to(dtype)
+    m.use_obstacles = use_obstacles
+    taps = {}
+    hooks = []
+    if want_taps:
+        def grab(key, first=False, many=False):
+            def fn(_mod, _inp, out):
+                o = out[0] if first else out
+                o = o.detach().clone()
+                if many:
+                    taps.setdefault(key, []).append(o)
+                else:
+                    taps[key] = o
+            return fn
+        hooks += [m.node_code.register_forward_hook(grab('node_code')),
+                  m.edge_code.register_forward_hook(grab('edge_code')),
+                  m.encoder.register_forward_hook(grab('encode', many=True)),
+                  m.process.register_forward_hook(grab('h', many=True)),
+                  m.decoder.register_forward_hook(grab('decode', many=True))]
+        if use_obstacles:
+            hooks += [m.node_attentions[2].register_forward_hook(grab('node_free_code', first=True)),
+                      m.edge_attentions[2].register_forward_hook(grab('edge_free_code', first=True))]
+        else:
+            hooks += [m.node_free_code.register_forward_hook(grab('node_free_code')),
+                      m.edge_free_code.register_forward_hook(grab('edge_free_code'))]
+    with torch.no_grad():
+        n = g['v'].shape[0]
+        P = m(goal=g['goal'].to(dtype), loop=loop, v=g['v'].to(dtype),
+              obstacles=g['obstacles'].to(dtype), free=g['v'][:g['n_free']].to(dtype),
+              collided=g['v'][g['n_free']:].to(dtype), edge_index=g['edge_index'],
+              labels=torch.zeros(n, 3), k=10)
+    for h in hooks:
+        h.remove()
+    ei = g['edge_index']
+    scores = P[ei[1], ei[0]]
+    assert int((P != 0).sum()) <= ei.shape[1]
+    return scores, taps
+
+
+def explorer_case(env, sd, n, k1, loop=5, use_obstacles=True, taps=True, seed=1234, tag=''):
+    g = synth_graph(env, n, k1, seed=seed)
+    s32, t32 = run_explorer(env, sd, g, loop, use_obstacles, torch.float32, taps)
+    s64, _ = run_explorer(env, sd, g, loop, use_obstacles, torch.float64, False)
+    rec = dict(v=g['v'].numpy(), goal=g['goal'].numpy(), obstacles=g['obstacles'].numpy(),
+               edge_index=g['edge_index'].numpy(), n_free=g['n_free'], loop=loop,
+               use_obstacles=int(use_obstacles), scores_fp32=s32.numpy(), scores_fp64=s64.numpy())
+    if taps:
+        rec.update(tap_node_code=t32['node_code'].numpy(), tap_edge_code=t32['edge_code'].numpy(),
+                   tap_node_free_code=t32['node_free_code'].numpy(),
+                   tap_edge_free_code=t32['edge_free_code'].numpy(),
+                   tap_encode=torch.stack(t32['encode']).numpy(),
+                   tap_h=torch.stack(t32['h']).numpy(),
+                   tap_decode=t32['decode'][-1].numpy())
+    fn = 'explorer_%s_N%d_k%d_L%d%s%s.npz' % (env, n, k1, loop, '' if use_obstacles else '_noobs', tag)
+    np.savez_compressed(os.path.join(OUT, fn), **rec)
+    err = (s32.double() - s64).abs().max().item()
+    print('%-44s E=%6d  score range [%.2f, %.2f]  fp32-vs-fp64 max|d|=%.2e' %
+          (fn, g['edge_index'].shape[1], s64.min(), s64.max(), err))
+
+
+def smoother_case(name, C, scale, P=12, F=60, Co=60, loop=1, seed=4321):
+    sd = save_weights(name)
+    gen = torch.Generator().manual_seed(seed)
+    lim = float(scale) if scale != 1.0 else 1.0
+    path = ((torch.rand(P, C, generator=gen, dtype=torch.float64) * 2 - 1) * lim).float()
+    free = ((torch.rand(F, C, generator=gen, dtype=torch.float64) * 2 - 1) * lim).float()
+    coll = ((torch.rand(Co, C, generator=gen, dtype=torch.float64) * 2 - 1) * lim).float()
+    # chain i<->i+1 + self loops, as the caller builds it (smoother.py:238-241)
+    a = torch.arange(1, P)
+    b = torch.arange(0, P - 1)
+    ei = torch.cat((torch.stack((a, b)), torch.stack((b, a)), torch.stack((torch.arange(P),) * 2)), dim=1)
+    outs = {}
+    for dt, key in ((torch.float32, 'fp32'), (torch.float64, 'fp64')):
+        m = ref_smoother.ModelSmoother(workspace_size=3, config_size=C, embed_size=128, obs_size=6,
+                                       scale=scale)
+        m.load_state_dict(sd, strict=True)
+        m.eval().to(dt)
+        with torch.no_grad():
+            p_in = path.to(dt).clone()
+            outs[key] = m(path=p_in, free=free.to(dt), collided=coll.to(dt),
+                          obstacles=torch.zeros(1, 6, dtype=dt), edge_index=ei, loop=loop)
+            assert torch.equal(p_in, path.to(dt)), 'caller path must not be mutated'
+    fn = 'smoother_%s_P%d_L%d.npz' % (name, P, loop)
+    np.savez_compressed(os.path.join(OUT, fn), path=path.numpy(), free=free.numpy(),
+                        collided=coll.numpy(), edge_index=ei.numpy(), loop=loop, scale=scale,
+                        out_fp32=outs['fp32'].numpy(), out_fp64=outs['fp64'].numpy())
+    print('%-44s max|fp32-fp64|=%.2e  max|out-in|=%.3f' %
+          (fn, (outs['fp32'].double() - outs['fp64']).abs().max().item(),
+           (outs['fp32'] - path).abs().max().item()))
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    sds = {env: save_weights(ENVS[env]['ckpt']) for env in ENVS}
+    # every shipped explorer checkpoint on a tiny graph, with taps
+    for env in ENVS:
+        explorer_case(env, sds[env], 64, 4)
+    # the BASELINE configs' own shapes at CPU-friendly sizes
+    explorer_case('maze2', sds['maze2'], 200, 6)                       # cfg 1
+    explorer_case('kuka7', sds['kuka7'], 200, 6)
+    explorer_case('kuka14', sds['kuka14'], 200, 8, taps=False)
+    # behaviour switches: use_obstacles toggle (eval_gnn.py:88), loop count (train_explorer.py:148)
+    explorer_case('maze2', sds['maze2'], 64, 4, use_obstacles=False)
+    explorer_case('maze2', sds['maze2'], 64, 4, loop=1)
+    explorer_case('maze2', sds['maze2'], 64, 4, loop=3)
+    explorer_case('kuka7', sds['kuka7'], 64, 4, loop=2, use_obstacles=False, taps=False)
+    # full-size cfg 2 graph: scores only (no taps) to keep the fixture small
+    explorer_case('maze2', sds['maze2'], 1000, 8, taps=False)
+    for name, (C, scale) in SMOOTHERS.items():
+        smoother_case(name, C, scale)
+    smoother_case('smooth_2d_attv3', 2, 1.0, P=30, F=500, Co=500, loop=1)
+    smoother_case('smooth_14d_attv3', 14, 1.0, P=7, F=40, Co=3, loop=3)
+
+
+if __name__ == '__main__':
+    main()
