@@ -7,5 +7,7 @@ There is no CPU fallback: constructing a model without the library, or calling i
 tensors, raises.
 """
 from . import graph_build, synth  # noqa: F401  (host-side helpers, no native code needed)
+from .batch import GraphBatch  # noqa: F401
+from .explorer import EncoderProcessDecoder  # noqa: F401
 
-__all__ = ['graph_build', 'synth']
+__all__ = ['graph_build', 'synth', 'GraphBatch', 'EncoderProcessDecoder']

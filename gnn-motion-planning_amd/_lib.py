@@ -1,0 +1,104 @@
+"""ctypes binding of libgnnmp.so (C ABI: include/gnnmp.h).  There is no fallback: if the
+library is missing every model constructor raises."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libgnnmp.so')
+
+c_float_p = ctypes.POINTER(ctypes.c_float)
+c_int32_p = ctypes.POINTER(ctypes.c_int32)
+c_int64_p = ctypes.POINTER(ctypes.c_int64)
+
+
+class ExplorerDims(ctypes.Structure):
+    _fields_ = [('config_size', ctypes.c_int32), ('embed_size', ctypes.c_int32), ('obs_size', ctypes.c_int32)]
+
+
+class Batch(ctypes.Structure):
+    _fields_ = [('n_graphs', ctypes.c_int32), ('total_nodes', ctypes.c_int32), ('total_edges', ctypes.c_int32),
+                ('total_obstacles', ctypes.c_int32), ('max_obstacles', ctypes.c_int32),
+                ('v', ctypes.c_void_p), ('goal', ctypes.c_void_p), ('obstacles', ctypes.c_void_p),
+                ('edge_index', ctypes.c_void_p), ('node_ptr', ctypes.c_void_p), ('edge_ptr', ctypes.c_void_p),
+                ('obs_ptr', ctypes.c_void_p)]
+
+
+class SmootherDims(ctypes.Structure):
+    _fields_ = [('config_size', ctypes.c_int32), ('embed_size', ctypes.c_int32), ('scale', ctypes.c_float)]
+
+
+class SmoothBatch(ctypes.Structure):
+    _fields_ = [('n_problems', ctypes.c_int32), ('total_path', ctypes.c_int32), ('total_free', ctypes.c_int32),
+                ('total_collided', ctypes.c_int32), ('total_edges', ctypes.c_int32), ('max_path', ctypes.c_int32),
+                ('max_samples', ctypes.c_int32), ('max_edges', ctypes.c_int32),
+                ('path', ctypes.c_void_p), ('free_pts', ctypes.c_void_p), ('collided', ctypes.c_void_p),
+                ('edge_index', ctypes.c_void_p), ('path_ptr', ctypes.c_void_p), ('free_ptr', ctypes.c_void_p),
+                ('coll_ptr', ctypes.c_void_p), ('edge_ptr', ctypes.c_void_p)]
+
+
+_lib = None
+
+
+def lib():
+    """The loaded library (raises RuntimeError with a build hint if it is not there)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            'libgnnmp.so not found at %s -- build it with `python -c "import __graft_entry__ as g; g.build()"` '
+            '(hipcc --offload-arch=gfx950).  There is no CPU / PyTorch fallback for the forward passes.' % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    vp, sz = ctypes.c_void_p, ctypes.c_size_t
+    L.gnnmp_status_string.restype = ctypes.c_char_p
+    L.gnnmp_status_string.argtypes = [ctypes.c_int]
+    L.gnnmp_last_hip_error.restype = ctypes.c_char_p
+    L.gnnmp_abi_version.restype = ctypes.c_int
+    L.gnnmp_explorer_manifest.argtypes = [ctypes.POINTER(ExplorerDims), ctypes.c_int, ctypes.c_char_p, sz, c_int64_p]
+    L.gnnmp_explorer_create.argtypes = [ctypes.POINTER(vp), ctypes.POINTER(ExplorerDims), vp, sz, ctypes.c_int]
+    L.gnnmp_explorer_destroy.argtypes = [vp]
+    L.gnnmp_explorer_workspace_bytes.argtypes = [vp, ctypes.POINTER(Batch), ctypes.POINTER(sz)]
+    L.gnnmp_explorer_forward.argtypes = [vp, ctypes.POINTER(Batch), ctypes.c_int, ctypes.c_int, vp, vp, vp, sz, vp]
+    L.gnnmp_explorer_debug_tap.argtypes = [vp, ctypes.POINTER(Batch), ctypes.c_int, vp, vp, sz, vp]
+    L.gnnmp_pack_a_tiles.restype = ctypes.c_int64
+    L.gnnmp_pack_a_tiles.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp]
+    L.gnnmp_pack_a_small.restype = ctypes.c_int64
+    L.gnnmp_pack_a_small.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp]
+    L.gnnmp_pack_vec.restype = ctypes.c_int64
+    L.gnnmp_pack_vec.argtypes = [vp, ctypes.c_int, vp]
+    for name in ('gnnmp_smoother_manifest', 'gnnmp_smoother_create', 'gnnmp_smoother_destroy',
+                 'gnnmp_smoother_workspace_bytes', 'gnnmp_smoother_forward'):
+        if not hasattr(L, name):
+            continue
+    if hasattr(L, 'gnnmp_smoother_create'):
+        L.gnnmp_smoother_manifest.argtypes = [ctypes.POINTER(SmootherDims), ctypes.c_int, ctypes.c_char_p, sz, c_int64_p]
+        L.gnnmp_smoother_create.argtypes = [ctypes.POINTER(vp), ctypes.POINTER(SmootherDims), vp, sz, ctypes.c_int]
+        L.gnnmp_smoother_destroy.argtypes = [vp]
+        L.gnnmp_smoother_workspace_bytes.argtypes = [vp, ctypes.POINTER(SmoothBatch), ctypes.POINTER(sz)]
+        L.gnnmp_smoother_forward.argtypes = [vp, ctypes.POINTER(SmoothBatch), ctypes.c_int, vp, vp, sz, vp]
+    _lib = L
+    return L
+
+
+def check(status, what):
+    if status != 0:
+        L = lib()
+        msg = L.gnnmp_status_string(status).decode()
+        hip = L.gnnmp_last_hip_error().decode()
+        raise RuntimeError('%s failed: %s%s' % (what, msg, (' [' + hip + ']') if hip else ''))
+
+
+def manifest(kind, dims):
+    """[(reference parameter name, numel)] in blob order."""
+    L = lib()
+    fn = L.gnnmp_explorer_manifest if kind == 'explorer' else L.gnnmp_smoother_manifest
+    n = fn(ctypes.byref(dims), -1, None, 0, None)
+    if n < 0:
+        check(n, 'gnnmp_%s_manifest' % kind)
+    out = []
+    buf = ctypes.create_string_buffer(256)
+    numel = ctypes.c_int64()
+    for i in range(n):
+        check(fn(ctypes.byref(dims), i, buf, 256, ctypes.byref(numel)), 'gnnmp_%s_manifest' % kind)
+        out.append((buf.value.decode(), int(numel.value)))
+    return out

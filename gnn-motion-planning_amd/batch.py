@@ -1,0 +1,55 @@
+"""Block-diagonal batches of independent planning graphs (one RGG per environment instance).
+
+The reference scores one graph per call (eval_gnn.py:113-116,194); the batch is what lets one
+launch sequence keep the whole GPU busy.  Graphs stay independent: node ids in ``edge_index``
+remain local to their graph, membership comes from the ``*_ptr`` prefix arrays."""
+import torch
+
+
+class GraphBatch:
+    """Device-resident concatenation of G graphs: v [sumN, C], goal [G, C], obstacles [sumO, S],
+    edge_index [2, sumE] (graph-local ids), node_ptr / edge_ptr / obs_ptr int32 [G+1]."""
+
+    def __init__(self, v, goal, obstacles, edge_index, node_ptr, edge_ptr, obs_ptr, max_obstacles):
+        self.v, self.goal, self.obstacles, self.edge_index = v, goal, obstacles, edge_index
+        self.node_ptr, self.edge_ptr, self.obs_ptr = node_ptr, edge_ptr, obs_ptr
+        self.max_obstacles = int(max_obstacles)
+        self.n_graphs = int(node_ptr.numel() - 1)
+
+    @property
+    def total_nodes(self):
+        return int(self.v.shape[0])
+
+    @property
+    def total_edges(self):
+        return int(self.edge_index.shape[1])
+
+    @property
+    def total_obstacles(self):
+        return int(self.obstacles.shape[0])
+
+    @staticmethod
+    def from_graphs(graphs, obs_size, device):
+        """``graphs``: iterable of dicts with v [N,C], goal [C], obstacles [O,S] or [O,2,3],
+        edge_index [2,E] (any device)."""
+        graphs = list(graphs)
+        vs = [g['v'].float() for g in graphs]
+        goals = [g['goal'].float().reshape(1, -1) for g in graphs]
+        obs = [g['obstacles'].float().reshape(-1, obs_size) for g in graphs]
+        eis = [g['edge_index'].long() for g in graphs]
+
+        def prefix(counts):
+            p = torch.zeros(len(counts) + 1, dtype=torch.int64)
+            p[1:] = torch.tensor(counts, dtype=torch.int64).cumsum(0)
+            return p.to(torch.int32)
+
+        return GraphBatch(
+            torch.cat(vs).contiguous().to(device), torch.cat(goals).contiguous().to(device),
+            torch.cat(obs).contiguous().to(device), torch.cat(eis, dim=1).contiguous().to(device),
+            prefix([x.shape[0] for x in vs]).to(device), prefix([x.shape[1] for x in eis]).to(device),
+            prefix([x.shape[0] for x in obs]).to(device), max([x.shape[0] for x in obs] + [0]))
+
+    def split_edges(self, scores):
+        """Per-graph views of a [sumE] score vector."""
+        ptr = self.edge_ptr.tolist()
+        return [scores[ptr[i]:ptr[i + 1]] for i in range(self.n_graphs)]

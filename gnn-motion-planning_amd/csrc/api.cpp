@@ -1,0 +1,619 @@
+// api.cpp -- host side of the C ABI (include/gnnmp.h): weight manifest and packing, workspace
+// carving and the kernel sequence of the explorer forward pass.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/gnnmp.h"
+#include "kernels.hpp"
+#include "layout.hpp"
+
+using namespace gnnmp;
+
+namespace {
+
+thread_local std::string g_hip_error;
+
+int hip_fail(hipError_t e) {
+    g_hip_error = hipGetErrorString(e);
+    return GNNMP_ERR_HIP;
+}
+
+#define HIP_TRY(expr)                              \
+    do {                                           \
+        hipError_t _e = (expr);                    \
+        if (_e != hipSuccess) return hip_fail(_e); \
+    } while (0)
+
+struct Entry {
+    std::string name;
+    int rows, cols;     // cols == 0 -> vector of `rows`
+    int64_t numel() const { return (int64_t)rows * (cols ? cols : 1); }
+};
+
+// ---------------------------------------------------------------------------------------------
+// explorer manifest: the 142 state_dict tensors forward() reads
+// ---------------------------------------------------------------------------------------------
+std::vector<Entry> explorer_manifest(const gnnmp_explorer_dims& d) {
+    const int C = d.config_size, D = d.embed_size, S = d.obs_size;
+    std::vector<Entry> m;
+    auto lin = [&](const std::string& n, int out, int in, bool bias = true) {
+        m.push_back({n + ".weight", out, in});
+        if (bias) m.push_back({n + ".bias", out, 0});
+    };
+    auto mlp2 = [&](const std::string& n, int in) { lin(n + ".0", D, in); lin(n + ".2", D, D); };
+    m.push_back({"goal_encoder", D, 0});
+    mlp2("node_code", 4 * C);
+    mlp2("edge_code", 2 * C);
+    mlp2("obs_node_code", S);
+    mlp2("obs_edge_code", S);
+    mlp2("node_free_code", C);
+    mlp2("edge_free_code", 2 * C);
+    for (const char* side : {"node_attentions", "edge_attentions"})
+        for (int b = 0; b < 3; ++b) {
+            const std::string p = std::string(side) + "." + std::to_string(b);
+            lin(p + ".attention.key", D, D, false);
+            lin(p + ".attention.query", D, D, false);
+            lin(p + ".attention.value", D, D, false);
+            m.push_back({p + ".attention.layer_norm.weight", D, 0});
+            m.push_back({p + ".attention.layer_norm.bias", D, 0});
+            for (const char* ff : {"map_feed", "obs_feed"}) {
+                lin(p + "." + ff + ".w_1", D, D);
+                lin(p + "." + ff + ".w_2", D, D);
+                m.push_back({p + "." + ff + ".layer_norm.weight", D, 0});
+                m.push_back({p + "." + ff + ".layer_norm.bias", D, 0});
+            }
+        }
+    lin("encoder", D, 4 * D);
+    lin("process.lin_0.0", D, 5 * D);
+    lin("process.lin_0.2", D, D);
+    lin("process.lin_1", D, 2 * D);
+    lin("decoder", D, 2 * D);
+    lin("policy.0", D, 3 * D);
+    lin("policy.2", D, D);
+    lin("policy.4", 1, D, false);
+    return m;
+}
+
+struct Blob {          // host view of the caller's concatenated weights
+    std::vector<Entry> man;
+    std::vector<int64_t> off;
+    const float* base;
+    const float* get(const std::string& n) const {
+        for (size_t i = 0; i < man.size(); ++i)
+            if (man[i].name == n) return base + off[i];
+        return nullptr;
+    }
+};
+
+bool dims_ok(const gnnmp_explorer_dims& d) {
+    return d.config_size >= 1 && d.config_size <= 64 && (d.embed_size == 32 || d.embed_size == 64) &&
+           d.obs_size >= 1 && d.obs_size <= 64;
+}
+
+// dst <- a (+/-) b over a [D x n] column block of row-major matrices with leading dimension ld
+std::vector<float> colblock(const float* w, int D, int ld, int col0, int n) {
+    std::vector<float> r((size_t)D * n);
+    for (int i = 0; i < D; ++i)
+        for (int k = 0; k < n; ++k) r[(size_t)i * n + k] = w[(size_t)i * ld + col0 + k];
+    return r;
+}
+
+std::vector<float> matvec(const float* w, int D, int ld, int col0, int n, const float* x) {
+    std::vector<float> r(D);
+    for (int i = 0; i < D; ++i) {
+        float s = 0.f;
+        for (int k = 0; k < n; ++k) s = std::fmaf(w[(size_t)i * ld + col0 + k], x[k], s);
+        r[i] = s;
+    }
+    return r;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// exported host-only packing helpers
+// ---------------------------------------------------------------------------------------------
+extern "C" int64_t gnnmp_pack_a_tiles(const float* w, int out_f, int ld, int col0, int n_in, float* dst) {
+    const int nto = out_f / 32, nti = n_in / 32;
+    for (int ot = 0; ot < nto; ++ot)
+        for (int it = 0; it < nti; ++it)
+            for (int r = 0; r < 16; ++r)
+                for (int lane = 0; lane < 64; ++lane)
+                    dst[(size_t)(ot * nti + it) * 1024 + ((r >> 2) * 64 + lane) * 4 + (r & 3)] =
+                        w[(size_t)(32 * ot + (lane & 31)) * ld + col0 + 32 * it + phi(r, lane >> 5)];
+    return (int64_t)nto * nti * 1024;
+}
+
+extern "C" int64_t gnnmp_pack_a_small(const float* w, int out_f, int ld, int col0, int n_in, float* dst) {
+    const int nto = out_f / 32, ks = (n_in + 1) / 2;
+    for (int ot = 0; ot < nto; ++ot)
+        for (int st = 0; st < ks; ++st)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int k = 2 * st + (lane >> 5);
+                dst[(size_t)(ot * ks + st) * 64 + lane] = (k < n_in) ? w[(size_t)(32 * ot + (lane & 31)) * ld + col0 + k] : 0.f;
+            }
+    return (int64_t)nto * ks * 64;
+}
+
+extern "C" int64_t gnnmp_pack_vec(const float* b, int n, float* dst) {
+    const int nt = n / 32;
+    for (int t = 0; t < nt; ++t)
+        for (int h = 0; h < 2; ++h)
+            for (int r = 0; r < 16; ++r) dst[(t * 2 + h) * 16 + r] = b[32 * t + phi(r, h)];
+    return (int64_t)nt * 32;
+}
+
+// ---------------------------------------------------------------------------------------------
+// status
+// ---------------------------------------------------------------------------------------------
+extern "C" const char* gnnmp_status_string(int s) {
+    switch (s) {
+        case GNNMP_OK: return "ok";
+        case GNNMP_ERR_NULL: return "null pointer argument";
+        case GNNMP_ERR_DIMS: return "unsupported or inconsistent dimensions";
+        case GNNMP_ERR_WEIGHTS: return "weight blob size does not match the manifest";
+        case GNNMP_ERR_WORKSPACE: return "workspace too small or misaligned";
+        case GNNMP_ERR_HIP: return "HIP runtime error";
+        case GNNMP_ERR_ARG: return "bad scalar argument";
+    }
+    return "unknown status";
+}
+extern "C" const char* gnnmp_last_hip_error(void) { return g_hip_error.c_str(); }
+extern "C" int gnnmp_abi_version(void) { return 1; }
+
+// ---------------------------------------------------------------------------------------------
+// explorer handle
+// ---------------------------------------------------------------------------------------------
+struct gnnmp_explorer {
+    gnnmp_explorer_dims dims;
+    int device;
+    float* w_dev;
+    ExplorerOffsets off;
+    EncBlob enc_e, enc_n;
+    ObsBlob obs;
+};
+
+extern "C" int gnnmp_explorer_manifest(const gnnmp_explorer_dims* dims, int index, char* name, size_t name_cap,
+                                       int64_t* numel) {
+    if (!dims) return GNNMP_ERR_NULL;
+    if (!dims_ok(*dims)) return GNNMP_ERR_DIMS;
+    const auto m = explorer_manifest(*dims);
+    if (index < 0) return (int)m.size();
+    if (index >= (int)m.size()) return GNNMP_ERR_ARG;
+    if (name && name_cap) {
+        std::strncpy(name, m[index].name.c_str(), name_cap - 1);
+        name[name_cap - 1] = 0;
+    }
+    if (numel) *numel = m[index].numel();
+    return GNNMP_OK;
+}
+
+namespace {
+
+template <int D>
+void pack_explorer(const Blob& B, const gnnmp_explorer_dims& dm, gnnmp_explorer* h, std::vector<float>& out) {
+    const int C = dm.config_size, S = dm.obs_size;
+    h->enc_e = EncBlob::make(D, C, C);                         // K = 2C for both edge encoders
+    h->enc_n = EncBlob::make(D, 2 * C, (C + 1) / 2);           // node_code K = 4C, node_free_code K = C
+    h->obs = ObsBlob::make(D, (S + 1) / 2);
+    ExplorerOffsets& o = h->off;
+    int cur = 0;
+    auto take = [&](int n) { const int r = cur; cur += (n + 3) & ~3; return r; };
+    o.enc_e = take(h->enc_e.size);
+    o.enc_n = take(h->enc_n.size);
+    o.att_e = take(3 * AttBlob<D>::size);
+    o.att_n = take(3 * AttBlob<D>::size);
+    o.out_e = take(OutEBlob<D>::size);
+    o.out_n = take(OutNBlob<D>::size);
+    o.mpn = take(MpNBlob<D>::size);
+    o.mpn_last = take(MpNBlob<D>::size);
+    o.mpe = take(MpEBlob<D>::size);
+    o.pol = take(PolBlob<D>::size);
+    o.obs_e = take(h->obs.size);
+    o.obs_n = take(h->obs.size);
+    o.total = cur;
+    out.assign(cur, 0.f);
+    float* P = out.data();
+    auto W = [&](const std::string& n) { return B.get(n); };
+    auto tiles = [&](const float* w, int ld, int col0, float* dst) { gnnmp_pack_a_tiles(w, D, ld, col0, D, dst); };
+    auto vec = [&](const float* b, float* dst) { gnnmp_pack_vec(b, D, dst); };
+
+    // --- encoders on raw inputs
+    auto enc = [&](const EncBlob& e, float* dst, const std::string& n0, int k0, const std::string& n1, int k1) {
+        gnnmp_pack_a_small(W(n0 + ".0.weight"), D, k0, 0, k0, dst + e.as0);
+        vec(W(n0 + ".0.bias"), dst + e.b0);
+        tiles(W(n0 + ".2.weight"), D, 0, dst + e.a0);
+        vec(W(n0 + ".2.bias"), dst + e.c0);
+        gnnmp_pack_a_small(W(n1 + ".0.weight"), D, k1, 0, k1, dst + e.as1);
+        vec(W(n1 + ".0.bias"), dst + e.b1);
+        tiles(W(n1 + ".2.weight"), D, 0, dst + e.a1);
+        vec(W(n1 + ".2.bias"), dst + e.c1);
+    };
+    enc(h->enc_e, P + o.enc_e, "edge_code", 2 * C, "edge_free_code", 2 * C);
+    enc(h->enc_n, P + o.enc_n, "node_code", 4 * C, "node_free_code", C);
+
+    // --- attention blocks (map side) and obstacle side
+    using A = AttBlob<D>;
+    for (int side = 0; side < 2; ++side) {
+        const std::string sname = side == 0 ? "edge_attentions" : "node_attentions";
+        float* att = P + (side == 0 ? o.att_e : o.att_n);
+        float* ob = P + (side == 0 ? o.obs_e : o.obs_n);
+        const std::string oc = side == 0 ? "obs_edge_code" : "obs_node_code";
+        const ObsBlob& L = h->obs;
+        gnnmp_pack_a_small(W(oc + ".0.weight"), D, S, 0, S, ob + L.as0);
+        vec(W(oc + ".0.bias"), ob + L.b0);
+        tiles(W(oc + ".2.weight"), D, 0, ob + L.a0);
+        vec(W(oc + ".2.bias"), ob + L.c0);
+        for (int b = 0; b < 3; ++b) {
+            const std::string p = sname + "." + std::to_string(b);
+            float* a = att + (size_t)b * A::size;
+            tiles(W(p + ".attention.query.weight"), D, 0, a + A::wq);
+            tiles(W(p + ".attention.key.weight"), D, 0, a + A::wk);
+            tiles(W(p + ".attention.value.weight"), D, 0, a + A::wv);
+            vec(W(p + ".attention.layer_norm.weight"), a + A::ln1g);
+            vec(W(p + ".attention.layer_norm.bias"), a + A::ln1b);
+            tiles(W(p + ".map_feed.w_1.weight"), D, 0, a + A::w1);
+            vec(W(p + ".map_feed.w_1.bias"), a + A::b1);
+            tiles(W(p + ".map_feed.w_2.weight"), D, 0, a + A::w2);
+            vec(W(p + ".map_feed.w_2.bias"), a + A::b2);
+            vec(W(p + ".map_feed.layer_norm.weight"), a + A::ln2g);
+            vec(W(p + ".map_feed.layer_norm.bias"), a + A::ln2b);
+            float* q = ob + L.blk0 + (size_t)b * L.blk_stride;
+            tiles(W(p + ".attention.key.weight"), D, 0, q + L.wk);
+            tiles(W(p + ".attention.value.weight"), D, 0, q + L.wv);
+            tiles(W(p + ".obs_feed.w_1.weight"), D, 0, q + L.fw1);
+            vec(W(p + ".obs_feed.w_1.bias"), q + L.fb1);
+            tiles(W(p + ".obs_feed.w_2.weight"), D, 0, q + L.fw2);
+            vec(W(p + ".obs_feed.w_2.bias"), q + L.fb2);
+            vec(W(p + ".obs_feed.layer_norm.weight"), q + L.lng);
+            vec(W(p + ".obs_feed.layer_norm.bias"), q + L.lnb);
+        }
+    }
+
+    // --- message first layer W1 = [xj-xi | xj | xi | EF | EC]  (model.py:38-39)
+    const float* w1 = W("process.lin_0.0.weight");
+    std::vector<float> wsrc((size_t)D * D), wdst((size_t)D * D);
+    for (int i = 0; i < D; ++i)
+        for (int k = 0; k < D; ++k) {
+            const float a = w1[(size_t)i * 5 * D + k], b = w1[(size_t)i * 5 * D + D + k], c = w1[(size_t)i * 5 * D + 2 * D + k];
+            wsrc[(size_t)i * D + k] = a + b;      // multiplies x_j (source)
+            wdst[(size_t)i * D + k] = c - a;      // multiplies x_i (target)
+        }
+    // --- policy first layer P0 = [D_s | D_s - D_t | EF]  (model.py:145)
+    const float* p0 = W("policy.0.weight");
+    std::vector<float> wps((size_t)D * D), wpt((size_t)D * D);
+    for (int i = 0; i < D; ++i)
+        for (int k = 0; k < D; ++k) {
+            wps[(size_t)i * D + k] = p0[(size_t)i * 3 * D + k] + p0[(size_t)i * 3 * D + D + k];
+            wpt[(size_t)i * D + k] = p0[(size_t)i * 3 * D + D + k];
+        }
+    {
+        using L = OutEBlob<D>;
+        float* q = P + o.out_e;
+        tiles(w1, 5 * D, 3 * D, q + L::w1d);
+        tiles(w1, 5 * D, 4 * D, q + L::w1e);
+        vec(W("process.lin_0.0.bias"), q + L::b1);
+        tiles(p0, 3 * D, 2 * D, q + L::wpc);
+        vec(W("policy.0.bias"), q + L::bp0);
+    }
+    const float* we = W("encoder.weight");      // [NC | NF | H0 | H]  (model.py:141)
+    const float* wd = W("decoder.weight");      // [NC | H]            (model.py:143)
+    const float* wl1 = W("process.lin_1.weight");   // [X | agg]       (model.py:36)
+    {
+        using L = OutNBlob<D>;
+        float* q = P + o.out_n;
+        tiles(we, 4 * D, 0, q + L::we_nc);
+        tiles(we, 4 * D, D, q + L::we_nf);
+        vec(W("encoder.bias"), q + L::be);
+        const float* ge = W("goal_encoder");
+        vec(matvec(we, D, 4 * D, 2 * D, D, ge).data(), q + L::weg);
+        vec(matvec(we, D, 4 * D, 3 * D, D, ge).data(), q + L::wehg);
+        tiles(wsrc.data(), D, 0, q + L::wsrc);
+        tiles(wdst.data(), D, 0, q + L::wdst);
+        tiles(wd, 2 * D, 0, q + L::wd_nc);
+        vec(W("decoder.bias"), q + L::bd);
+    }
+    for (int last = 0; last < 2; ++last) {
+        using L = MpNBlob<D>;
+        float* q = P + (last ? o.mpn_last : o.mpn);
+        tiles(wl1, 2 * D, 0, q + L::wlx);
+        tiles(wl1, 2 * D, D, q + L::wla);
+        vec(W("process.lin_1.bias"), q + L::bl);
+        if (!last) {
+            tiles(we, 4 * D, 3 * D, q + L::m1);
+            tiles(wsrc.data(), D, 0, q + L::m2);
+            tiles(wdst.data(), D, 0, q + L::m3);
+        } else {
+            tiles(wd, 2 * D, D, q + L::m1);
+            tiles(wps.data(), D, 0, q + L::m2);
+            tiles(wpt.data(), D, 0, q + L::m3);
+        }
+    }
+    {
+        using L = MpEBlob<D>;
+        float* q = P + o.mpe;
+        tiles(W("process.lin_0.2.weight"), D, 0, q + L::w2);
+        vec(W("process.lin_0.2.bias"), q + L::b2);
+    }
+    {
+        using L = PolBlob<D>;
+        float* q = P + o.pol;
+        tiles(W("policy.2.weight"), D, 0, q + L::w2);
+        vec(W("policy.2.bias"), q + L::b2);
+        vec(W("policy.4.weight"), q + L::w3);
+    }
+}
+
+}  // namespace
+
+extern "C" int gnnmp_explorer_create(gnnmp_explorer** out, const gnnmp_explorer_dims* dims, const float* weights_host,
+                                     size_t n_floats, int device) {
+    if (!out || !dims || !weights_host) return GNNMP_ERR_NULL;
+    if (!dims_ok(*dims)) return GNNMP_ERR_DIMS;
+    Blob B;
+    B.man = explorer_manifest(*dims);
+    B.base = weights_host;
+    int64_t tot = 0;
+    for (auto& e : B.man) { B.off.push_back(tot); tot += e.numel(); }
+    if ((int64_t)n_floats != tot) return GNNMP_ERR_WEIGHTS;
+    gnnmp_explorer* h = new gnnmp_explorer();
+    h->dims = *dims;
+    h->device = device;
+    h->w_dev = nullptr;
+    std::vector<float> packed;
+    if (dims->embed_size == 32) pack_explorer<32>(B, *dims, h, packed);
+    else pack_explorer<64>(B, *dims, h, packed);
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipMalloc((void**)&h->w_dev, packed.size() * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(h->w_dev, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        if (h->w_dev) (void)hipFree(h->w_dev);
+        delete h;
+        return hip_fail(e);
+    }
+    *out = h;
+    return GNNMP_OK;
+}
+
+extern "C" int gnnmp_explorer_destroy(gnnmp_explorer* h) {
+    if (!h) return GNNMP_ERR_NULL;
+    if (h->w_dev) (void)hipFree(h->w_dev);
+    delete h;
+    return GNNMP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// workspace
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+struct Carve {
+    // sizes
+    int G, Npad, Epad, ot_max, kv_stride, D;
+    // offsets in bytes
+    size_t node_ptr_pad, edge_ptr_pad, goal_node, dense_ptr;
+    size_t zero_beg, deg, cursor, zero_end;
+    size_t ff_beg, ntile_graph, etile_graph, csr_src, csr_dst, csr_eid, ff_end;
+    size_t row_beg;
+    size_t XI, X, A, B, DN, H, agg, Ke, PE, part_first, part_last, kv_e, kv_n;
+    size_t total;
+};
+
+int round_up_i(int x, int m) { return (x + m - 1) / m * m; }
+
+bool carve(const gnnmp_explorer* h, const gnnmp_batch* b, Carve& c) {
+    if (b->n_graphs < 1 || b->total_nodes < 0 || b->total_edges < 0 || b->total_obstacles < 0 || b->max_obstacles < 0)
+        return false;
+    const int D = h->dims.embed_size, NT = D / 32;
+    c.D = D;
+    c.G = b->n_graphs;
+    const long long np = (long long)b->total_nodes + (long long)c.G * (kPad - 1);
+    const long long ep = (long long)b->total_edges + (long long)c.G * (kPad - 1);
+    if (np > 0x3fffffff || ep > 0x3fffffff) return false;
+    c.Npad = round_up_i((int)np, kPad);
+    c.Epad = round_up_i((int)ep, kPad);
+    c.ot_max = (b->max_obstacles + 31) / 32;
+    if (c.ot_max < 1) c.ot_max = 1;
+    c.kv_stride = 2 * c.ot_max * NT * 1024;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { const size_t r = o; o += (bytes + 255) & ~(size_t)255; return r; };
+    c.node_ptr_pad = take(sizeof(int) * (c.G + 1));
+    c.edge_ptr_pad = take(sizeof(int) * (c.G + 1));
+    c.goal_node = take(sizeof(int) * c.G);
+    c.dense_ptr = take(sizeof(long long) * (c.G + 1));
+    c.zero_beg = o;
+    c.deg = take(sizeof(int) * c.Npad);
+    c.cursor = take(sizeof(int) * c.Npad);
+    c.zero_end = o;
+    c.ff_beg = o;
+    c.ntile_graph = take(sizeof(int) * (c.Npad / 32));
+    c.etile_graph = take(sizeof(int) * (c.Epad / 32));
+    c.csr_src = take(sizeof(int) * c.Epad);
+    c.csr_dst = take(sizeof(int) * c.Epad);
+    c.csr_eid = take(sizeof(int) * c.Epad);
+    c.ff_end = o;
+    c.row_beg = take(sizeof(int) * c.Npad);
+    const size_t nrow = sizeof(float) * (size_t)c.Npad * D, erow = sizeof(float) * (size_t)c.Epad * D;
+    c.XI = take(nrow); c.X = take(nrow); c.A = take(nrow); c.B = take(nrow); c.DN = take(nrow); c.H = take(nrow);
+    c.agg = take(nrow);
+    c.Ke = take(erow); c.PE = take(erow);
+    c.part_first = take(sizeof(float) * (size_t)(c.Epad / 32) * D);
+    c.part_last = take(sizeof(float) * (size_t)(c.Epad / 32) * D);
+    c.kv_e = take(sizeof(float) * (size_t)c.G * 3 * c.kv_stride);
+    c.kv_n = take(sizeof(float) * (size_t)c.G * 3 * c.kv_stride);
+    c.total = o;
+    return true;
+}
+
+template <class T>
+T* at(void* ws, size_t off) { return reinterpret_cast<T*>(static_cast<char*>(ws) + off); }
+
+// LDS plan of pre_kernel: weight region + K/V chunk region
+struct PrePlan { int waves, ot_chunk, wregion; size_t lds_bytes; };
+
+PrePlan plan_pre(int D, int ot_max, int enc_size, int out_size, bool use_obs) {
+    const int NT = D / 32;
+    const int att = (D == 32) ? AttBlob<32>::size : AttBlob<64>::size;
+    int wr = enc_size > out_size ? enc_size : out_size;
+    if (use_obs && att > wr) wr = att;
+    wr = (wr + 3) & ~3;
+    PrePlan p;
+    p.wregion = wr;
+    p.waves = (D == 32) ? 4 : 8;
+    const size_t per_tile = (size_t)2 * NT * 1024 * sizeof(float);
+    p.ot_chunk = 1;
+    if (use_obs) {
+        // prefer the highest workgroups-per-CU residency that still keeps a graph's whole K/V resident
+        const size_t limit = 163840, wbytes = (size_t)wr * sizeof(float);
+        for (int target = (D == 32 ? 3 : 1); target >= 1; --target) {
+            const size_t budget = (limit / target) & ~(size_t)1023;
+            if (budget < wbytes + per_tile) continue;
+            int ch = (int)((budget - wbytes) / per_tile);
+            if (ch > ot_max) ch = ot_max;
+            p.ot_chunk = ch;
+            if (ch >= ot_max) break;
+        }
+    }
+    p.lds_bytes = (size_t)wr * sizeof(float) + (use_obs ? (size_t)p.ot_chunk * per_tile : 0);
+    return p;
+}
+
+}  // namespace
+
+extern "C" int gnnmp_explorer_workspace_bytes(const gnnmp_explorer* h, const gnnmp_batch* shape, size_t* bytes) {
+    if (!h || !shape || !bytes) return GNNMP_ERR_NULL;
+    Carve c;
+    if (!carve(h, shape, c)) return GNNMP_ERR_ARG;
+    *bytes = c.total;
+    return GNNMP_OK;
+}
+
+extern "C" int gnnmp_explorer_forward(const gnnmp_explorer* h, const gnnmp_batch* b, int loop, int use_obstacles,
+                                      float* edge_scores, float* dense, void* ws, size_t ws_bytes, void* hip_stream) {
+    if (!h || !b || !ws) return GNNMP_ERR_NULL;
+    if (!b->v || !b->goal || !b->node_ptr || !b->edge_ptr || !b->obs_ptr) return GNNMP_ERR_NULL;
+    if (b->total_edges > 0 && (!b->edge_index || !edge_scores)) return GNNMP_ERR_NULL;
+    if (use_obstacles && b->total_obstacles > 0 && !b->obstacles) return GNNMP_ERR_NULL;
+    if (loop < 1) return GNNMP_ERR_ARG;                    // model.py:139-145: decode unbound for loop = 0
+    Carve c;
+    if (!carve(h, b, c)) return GNNMP_ERR_ARG;
+    if (ws_bytes < c.total || (reinterpret_cast<uintptr_t>(ws) & 255)) return GNNMP_ERR_WORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    const int D = h->dims.embed_size, C = h->dims.config_size;
+    const float* W = h->w_dev;
+
+    HIP_TRY(hipMemsetAsync(at<char>(ws, c.zero_beg), 0, c.zero_end - c.zero_beg, st));
+    HIP_TRY(hipMemsetAsync(at<char>(ws, c.ff_beg), 0xFF, c.ff_end - c.ff_beg, st));
+
+    PrepParams q;
+    q.G = c.G; q.E = b->total_edges; q.C = C;
+    q.edge_index = reinterpret_cast<const long long*>(b->edge_index);
+    q.node_ptr = b->node_ptr; q.edge_ptr = b->edge_ptr; q.v = b->v; q.goal = b->goal;
+    q.node_ptr_pad = at<int>(ws, c.node_ptr_pad); q.edge_ptr_pad = at<int>(ws, c.edge_ptr_pad);
+    q.dense_ptr = at<long long>(ws, c.dense_ptr);
+    q.deg = at<int>(ws, c.deg); q.cursor = at<int>(ws, c.cursor); q.row_beg = at<int>(ws, c.row_beg);
+    q.ntile_graph = at<int>(ws, c.ntile_graph); q.etile_graph = at<int>(ws, c.etile_graph);
+    q.csr_src = at<int>(ws, c.csr_src); q.csr_dst = at<int>(ws, c.csr_dst); q.csr_eid = at<int>(ws, c.csr_eid);
+    q.goal_node = at<int>(ws, c.goal_node);
+    HIP_TRY(launch_prep(q, st));
+    // zero-fill of policy_output (model.py:148); sum_g N_g^2 is read from dense_ptr[G] on the device
+    if (dense) HIP_TRY(launch_zero_dense(dense, q.dense_ptr + c.G, st));
+
+    const bool use_obs = use_obstacles != 0;
+    if (use_obs) {
+        ObsParams op;
+        op.obstacles = b->obstacles; op.obs_ptr = b->obs_ptr; op.S = h->dims.obs_size;
+        op.w[0] = W + h->off.obs_n; op.w[1] = W + h->off.obs_e;
+        op.blob = h->obs;
+        op.kv[0] = at<float>(ws, c.kv_n); op.kv[1] = at<float>(ws, c.kv_e);
+        op.kv_stride = c.kv_stride; op.ot_max = c.ot_max;
+        HIP_TRY(launch_obs(D, op, c.G, st));
+    }
+
+    for (int edge = 0; edge < 2; ++edge) {
+        PreParams p;
+        p.v = b->v; p.goal = b->goal; p.C = C;
+        p.node_ptr = b->node_ptr; p.node_ptr_pad = q.node_ptr_pad;
+        p.tile_graph = edge ? q.etile_graph : q.ntile_graph;
+        p.csr_src = q.csr_src; p.csr_dst = q.csr_dst;
+        p.obs_ptr = b->obs_ptr; p.goal_node = q.goal_node;
+        p.enc = W + (edge ? h->off.enc_e : h->off.enc_n);
+        p.encb = edge ? h->enc_e : h->enc_n;
+        p.att = W + (edge ? h->off.att_e : h->off.att_n);
+        p.out = W + (edge ? h->off.out_e : h->off.out_n);
+        p.out_size = edge ? (D == 32 ? OutEBlob<32>::size : OutEBlob<64>::size)
+                          : (D == 32 ? OutNBlob<32>::size : OutNBlob<64>::size);
+        p.kv = at<float>(ws, edge ? c.kv_e : c.kv_n);
+        p.kv_stride = c.kv_stride; p.ot_max = c.ot_max;
+        const PrePlan pl = plan_pre(D, c.ot_max, p.encb.size, p.out_size, use_obs);
+        p.ot_chunk = pl.ot_chunk; p.wregion = pl.wregion; p.use_obstacles = use_obs ? 1 : 0;
+        if (edge) { p.o0 = at<float>(ws, c.Ke); p.o1 = at<float>(ws, c.PE); p.o2 = p.o3 = p.o4 = nullptr; }
+        else {
+            p.o0 = at<float>(ws, c.XI); p.o1 = at<float>(ws, c.X); p.o2 = at<float>(ws, c.A);
+            p.o3 = at<float>(ws, c.B); p.o4 = at<float>(ws, c.DN);
+        }
+        if (edge && b->total_edges == 0) continue;
+        HIP_TRY(launch_pre(D, edge != 0, pl.waves, p, (edge ? c.Epad : c.Npad) / 32, pl.lds_bytes, st));
+    }
+
+    for (int it = 0; it < loop; ++it) {
+        const bool last = (it == loop - 1);
+        if (b->total_edges > 0) {
+            MpEdgeParams e;
+            e.csr_src = q.csr_src; e.csr_dst = q.csr_dst; e.row_beg = q.row_beg; e.deg = q.deg;
+            e.etile_graph = q.etile_graph;
+            e.A = at<float>(ws, c.A); e.B = at<float>(ws, c.B); e.Ke = at<float>(ws, c.Ke);
+            e.w = W + h->off.mpe;
+            e.agg = at<float>(ws, c.agg); e.part_first = at<float>(ws, c.part_first);
+            e.part_last = at<float>(ws, c.part_last);
+            e.n_tiles = c.Epad / 32;
+            HIP_TRY(launch_mp_edge(D, e, st));
+        }
+        MpNodeParams n;
+        n.row_beg = q.row_beg; n.deg = q.deg; n.ntile_graph = q.ntile_graph;
+        n.X = at<float>(ws, c.X); n.R = at<float>(ws, last ? c.DN : c.XI);
+        n.agg = at<float>(ws, c.agg); n.part_first = at<float>(ws, c.part_first); n.part_last = at<float>(ws, c.part_last);
+        n.w = W + (last ? h->off.mpn_last : h->off.mpn);
+        n.Hout = at<float>(ws, c.H); n.Xout = at<float>(ws, c.X); n.Aout = at<float>(ws, c.A); n.Bout = at<float>(ws, c.B);
+        n.n_tiles = c.Npad / 32;
+        HIP_TRY(launch_mp_node(D, n, st));
+    }
+
+    if (b->total_edges > 0) {
+        PolicyParams p;
+        p.csr_src = q.csr_src; p.csr_dst = q.csr_dst; p.csr_eid = q.csr_eid; p.etile_graph = q.etile_graph;
+        p.node_ptr = b->node_ptr; p.node_ptr_pad = q.node_ptr_pad; p.dense_ptr = q.dense_ptr;
+        p.PS = at<float>(ws, c.A); p.PT = at<float>(ws, c.B); p.PE = at<float>(ws, c.PE);
+        p.w = W + h->off.pol;
+        p.scores = edge_scores; p.dense = dense;
+        p.n_tiles = c.Epad / 32;
+        HIP_TRY(launch_policy(D, p, st));
+    }
+    return GNNMP_OK;
+}
+
+extern "C" int gnnmp_explorer_debug_tap(const gnnmp_explorer* h, const gnnmp_batch* b, int which, float* dst, void* ws,
+                                        size_t ws_bytes, void* hip_stream) {
+    if (!h || !b || !dst || !ws) return GNNMP_ERR_NULL;
+    Carve c;
+    if (!carve(h, b, c)) return GNNMP_ERR_ARG;
+    if (ws_bytes < c.total) return GNNMP_ERR_WORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    const int D = h->dims.embed_size;
+    size_t src;
+    switch (which) {
+        case 0: src = c.XI; break;
+        case 1: src = c.H; break;
+        case 2: src = c.X; break;
+        case 3:
+            HIP_TRY(launch_goal_tap(c.G, at<int>(ws, c.goal_node), at<int>(ws, c.node_ptr_pad), dst, st));
+            return GNNMP_OK;
+        default: return GNNMP_ERR_ARG;
+    }
+    HIP_TRY(launch_unpad_rows(c.G, b->total_nodes, D, b->node_ptr, at<int>(ws, c.node_ptr_pad), at<float>(ws, src), dst, st));
+    return GNNMP_OK;
+}

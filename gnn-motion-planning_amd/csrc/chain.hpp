@@ -1,0 +1,190 @@
+// chain.hpp -- register-resident MLP chains on the fp32 MFMA of gfx950 (CDNA4).
+//
+// One wavefront (64 lanes) owns a group of 32 rows (edges, nodes or obstacles).  Every linear
+// layer is computed TRANSPOSED, Y^T = W . X^T, with v_mfma_f32_32x32x2_f32:
+//     A operand = weights   A[i = out feature][k]        (one f32 per lane: i = lane&31, k = lane>>5)
+//     B operand = X^T       B[k][j = row]                (one f32 per lane: j = lane&31, k = lane>>5)
+//     D         = Y^T       D[i][j]: lane holds column j = lane&31 and the 16 out features
+//                           i = phi(r, h) = (r&3) + 8*(r>>2) + 4*h,   r = register, h = lane>>5.
+// So after a layer, lane (j, h) holds 16 features of row j -- which is exactly what the NEXT
+// layer's B operand needs if its K loop visits, at step r, feature phi(r,0) in the lower half
+// wave and phi(r,1) in the upper one.  Sums over k are order-free, so we simply permute the
+// weight columns to that order when packing ("A-tile format", gnnmp_pack_a_tiles in gnnmp.h).
+// Result: arbitrarily long chains of Linear / bias / ReLU / residual / LayerNorm / softmax run
+// entirely in registers, with no LDS transpose between layers; only the (pre-permuted) weights
+// stream in from LDS, 256 B per MFMA per wave.  A row's features live in two lanes (l, l^32),
+// so row reductions (LayerNorm, softmax, dot products) are 16 in-lane ops + one cross-half swap.
+//
+// fp32 MFMA is a k-ordered fmaf chain (exact fp32, 64 FLOP/clk/SIMD = the fp32 peak of the chip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "layout.hpp"
+
+namespace gnnmp {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kTile = 32;             // rows per wave, features per tile
+constexpr int kATile = 1024;          // floats in one 32x32 A tile
+
+
+__device__ __forceinline__ float xhalf(float x) {       // value held by the partner lane (l ^ 32)
+    return __shfl_xor(x, 32, 64);
+}
+
+__device__ __forceinline__ f32x16 splat16(float x) {
+    f32x16 v;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = x;
+    return v;
+}
+
+// acc += A_tile . x   for one (out tile, in tile) pair; a points at the 1024-float A tile.
+__device__ __forceinline__ void mfma_tile(const float* a, const f32x16& x, f32x16& acc, int lane) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(a + (q * 64 + lane) * 4);
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[c], x[q * 4 + c], acc, 0, 0, 0);
+    }
+}
+
+// y[ot] += sum_it A[ot][it] . x[it]      (A: [NTO][NTI][1024] floats, LDS or global)
+template <int NTO, int NTI>
+__device__ __forceinline__ void linear_acc(const float* A, const f32x16 (&x)[NTI], f32x16 (&y)[NTO], int lane) {
+#pragma unroll
+    for (int it = 0; it < NTI; ++it)
+#pragma unroll
+        for (int ot = 0; ot < NTO; ++ot)
+            mfma_tile(A + (ot * NTI + it) * kATile, x[it], y[ot], lane);
+}
+
+// per-feature vector in register order: vec[(t*2 + h)*16 + r]
+template <int NT>
+__device__ __forceinline__ void load_vec(const float* vec, f32x16 (&y)[NT], int lane) {
+    const int h = lane >> 5;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(vec + (t * 2 + h) * 16 + q * 4);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) y[t][q * 4 + c] = b[c];
+        }
+}
+
+// First layer on raw inputs: y[ot] += sum_k W[.., k] in[k]; lane supplies in[2*st + h] at step st.
+// Asmall: [NTO][ksteps][64] floats.
+template <int NTO, class GetIn>
+__device__ __forceinline__ void linear_in(const float* Asmall, int ksteps, GetIn getin, f32x16 (&y)[NTO], int lane) {
+    const int h = lane >> 5;
+    for (int st = 0; st < ksteps; ++st) {
+        const float b = getin(2 * st + h);
+#pragma unroll
+        for (int ot = 0; ot < NTO; ++ot)
+            y[ot] = __builtin_amdgcn_mfma_f32_32x32x2f32(Asmall[(ot * ksteps + st) * 64 + lane], b, y[ot], 0, 0, 0);
+    }
+}
+
+template <int NT>
+__device__ __forceinline__ void relu_(f32x16 (&x)[NT]) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x[t][r] = fmaxf(x[t][r], 0.0f);
+}
+
+// LayerNorm over the D = 32*NT features of each row (biased variance, eps inside the sqrt).
+template <int NT>
+__device__ __forceinline__ void layer_norm_(f32x16 (&x)[NT], const float* gamma, const float* beta, float eps, int lane) {
+    constexpr float inv_d = 1.0f / (32 * NT);
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += x[t][r];
+    s += xhalf(s);
+    const float mean = s * inv_d;
+    float v = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float c = x[t][r] - mean;
+            x[t][r] = c;
+            v = fmaf(c, c, v);
+        }
+    v += xhalf(v);
+    const float rstd = 1.0f / sqrtf(v * inv_d + eps);
+    f32x16 g[NT], b[NT];
+    load_vec<NT>(gamma, g, lane);
+    load_vec<NT>(beta, b, lane);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x[t][r] = fmaf(x[t][r] * rstd, g[t][r], b[t][r]);
+}
+
+// ---- row-major [rows, D] <-> register order.  Lane (j,h) touches 16-byte pieces
+//      [8q + 4h, 8q + 4h + 4) of its row's 32-float tile t.
+template <int NT>
+__device__ __forceinline__ void load_row(const float* base /* row start */, f32x16 (&x)[NT], int h) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(base + t * 32 + q * 8 + h * 4);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) x[t][q * 4 + c] = a[c];
+        }
+}
+
+template <int NT>
+__device__ __forceinline__ void store_row(float* base, const f32x16 (&x)[NT], int h) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 a;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) a[c] = x[t][q * 4 + c];
+            *reinterpret_cast<f32x4*>(base + t * 32 + q * 8 + h * 4) = a;
+        }
+}
+
+// ---- "tile-native" storage of a [32 rows, D] register block: [NT][4][64 lanes][4] floats, every
+//      store instruction writes 1 KiB contiguous.  Used for private per-edge intermediates.
+template <int NT>
+__device__ __forceinline__ void store_tile(float* tile_base, const f32x16 (&x)[NT], int lane) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 a;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) a[c] = x[t][q * 4 + c];
+            *reinterpret_cast<f32x4*>(tile_base + ((t * 4 + q) * 64 + lane) * 4) = a;
+        }
+}
+
+template <int NT>
+__device__ __forceinline__ void load_tile(const float* tile_base, f32x16 (&x)[NT], int lane) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(tile_base + ((t * 4 + q) * 64 + lane) * 4);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) x[t][q * 4 + c] = a[c];
+        }
+}
+
+// cooperative global -> LDS copy by the whole workgroup (n multiple of 4 floats, 16-B aligned)
+__device__ __forceinline__ void stage(float* lds, const float* g, int n) {
+    for (int i = threadIdx.x * 4; i < n; i += blockDim.x * 4)
+        *reinterpret_cast<f32x4*>(lds + i) = *reinterpret_cast<const f32x4*>(g + i);
+}
+
+}  // namespace gnnmp

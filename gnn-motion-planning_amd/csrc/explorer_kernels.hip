@@ -1,0 +1,794 @@
+// explorer_kernels.hip -- HIP kernels (gfx950) of the GNN path-explorer forward pass,
+// EncoderProcessDecoder.forward of the reference (model.py:115-150), restructured for MI355X:
+//
+//   prep_*        caller edge list -> CSR-by-destination in a per-graph padded index space
+//   goal_kernel   goal node = argmin_i |v_i - goal|                         (model.py:132)
+//   obs_kernel    obstacle codes, their 3+3 FFN stages and the K/V projections of all six
+//                 attention blocks, written as ready-made MFMA A operands   (model.py:126-130, obstacle rows)
+//   pre_kernel    per node / per edge: encoders + 3 obstacle cross-attention blocks, all in
+//                 registers, + the loop-invariant halves of the first message / encoder /
+//                 decoder / policy layers                                   (model.py:119-130)
+//   mp_edge       message second layer + segmented max over incoming edges  (model.py:33,38-41)
+//   mp_node       lin_1, encoder, and the next iteration's node-level first-layer terms
+//                                                                            (model.py:36,141,143)
+//   policy        per-edge 3-layer head, scattered to caller order / dense  (model.py:145-149)
+//
+// The algebra follows SURVEY.md Appendix E: first layers acting on concatenations are split into
+// per-operand matrices so nothing of shape [E, 5d] / [E, 3d] / [E, O+1, d] is ever materialised.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include "chain.hpp"
+#include "layout.hpp"
+#include "kernels.hpp"
+
+namespace gnnmp {
+
+// =====================================================================================================
+// prep: padded index spaces + CSR by destination
+// =====================================================================================================
+__device__ __forceinline__ int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// one workgroup: node_ptr_pad / edge_ptr_pad / dense_ptr prefix arrays
+__global__ void prep_ptrs_kernel(int G, const int* __restrict__ node_ptr, const int* __restrict__ edge_ptr,
+                                 int* __restrict__ node_ptr_pad, int* __restrict__ edge_ptr_pad,
+                                 long long* __restrict__ dense_ptr) {
+    __shared__ int s_n[256], s_e[256];
+    __shared__ long long s_d[256];
+    __shared__ int carry_n, carry_e;
+    __shared__ long long carry_d;
+    const int tid = threadIdx.x;
+    if (tid == 0) { carry_n = 0; carry_e = 0; carry_d = 0; node_ptr_pad[0] = 0; edge_ptr_pad[0] = 0; dense_ptr[0] = 0; }
+    __syncthreads();
+    for (int base = 0; base < G; base += 256) {
+        const int g = base + tid;
+        int n = 0, e = 0;
+        long long dd = 0;
+        if (g < G) {
+            const int ng = node_ptr[g + 1] - node_ptr[g];
+            n = round_up(ng, kPad);
+            e = round_up(edge_ptr[g + 1] - edge_ptr[g], kPad);
+            dd = (long long)ng * ng;
+        }
+        s_n[tid] = n; s_e[tid] = e; s_d[tid] = dd;
+        __syncthreads();
+        for (int off = 1; off < 256; off <<= 1) {     // Hillis-Steele inclusive scan
+            int an = 0, ae = 0;
+            long long ad = 0;
+            if (tid >= off) { an = s_n[tid - off]; ae = s_e[tid - off]; ad = s_d[tid - off]; }
+            __syncthreads();
+            s_n[tid] += an; s_e[tid] += ae; s_d[tid] += ad;
+            __syncthreads();
+        }
+        if (g < G) {
+            node_ptr_pad[g + 1] = carry_n + s_n[tid];
+            edge_ptr_pad[g + 1] = carry_e + s_e[tid];
+            dense_ptr[g + 1] = carry_d + s_d[tid];
+        }
+        __syncthreads();
+        if (tid == 255) { carry_n += s_n[255]; carry_e += s_e[255]; carry_d += s_d[255]; }
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ int find_graph(const int* __restrict__ ptr, int G, int x) {
+    int lo = 0, hi = G;            // largest g with ptr[g] <= x
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (ptr[mid] <= x) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ void prep_count_kernel(int G, int E, const long long* __restrict__ edge_index, const int* __restrict__ edge_ptr,
+                                  const int* __restrict__ node_ptr_pad, int* __restrict__ deg) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    const int g = find_graph(edge_ptr, G, e);
+    const int dst = node_ptr_pad[g] + (int)edge_index[(size_t)E + e];
+    atomicAdd(&deg[dst], 1);
+}
+
+// one workgroup per graph: exclusive scan of deg over the graph's padded node range
+__global__ void prep_scan_kernel(const int* __restrict__ node_ptr_pad, const int* __restrict__ edge_ptr_pad,
+                                 const int* __restrict__ deg, int* __restrict__ row_beg,
+                                 int* __restrict__ ntile_graph, int* __restrict__ etile_graph) {
+    __shared__ int s[256];
+    __shared__ int carry;
+    const int g = blockIdx.x, tid = threadIdx.x;
+    const int n0 = node_ptr_pad[g], n1 = node_ptr_pad[g + 1];
+    const int e0 = edge_ptr_pad[g], e1 = edge_ptr_pad[g + 1];
+    if (tid == 0) carry = e0;
+    __syncthreads();
+    for (int base = n0; base < n1; base += 256) {
+        const int i = base + tid;
+        const int d = (i < n1) ? deg[i] : 0;
+        s[tid] = d;
+        __syncthreads();
+        for (int off = 1; off < 256; off <<= 1) {
+            int a = 0;
+            if (tid >= off) a = s[tid - off];
+            __syncthreads();
+            s[tid] += a;
+            __syncthreads();
+        }
+        if (i < n1) row_beg[i] = carry + s[tid] - d;
+        __syncthreads();
+        if (tid == 255) carry += s[255];
+        __syncthreads();
+    }
+    for (int t = n0 / 32 + tid; t < n1 / 32; t += 256) ntile_graph[t] = g;
+    for (int t = e0 / 32 + tid; t < e1 / 32; t += 256) etile_graph[t] = g;
+}
+
+__global__ void prep_fill_kernel(int G, int E, const long long* __restrict__ edge_index, const int* __restrict__ edge_ptr,
+                                 const int* __restrict__ node_ptr_pad, const int* __restrict__ row_beg,
+                                 int* __restrict__ cursor, int* __restrict__ csr_src, int* __restrict__ csr_dst,
+                                 int* __restrict__ csr_eid) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    const int g = find_graph(edge_ptr, G, e);
+    const int base = node_ptr_pad[g];
+    const int src = base + (int)edge_index[e];
+    const int dst = base + (int)edge_index[(size_t)E + e];
+    const int pos = row_beg[dst] + atomicAdd(&cursor[dst], 1);
+    csr_src[pos] = src;
+    csr_dst[pos] = dst;
+    csr_eid[pos] = e;
+}
+
+// =====================================================================================================
+// goal node: argmin_i |v_i - goal|^2, lowest index on ties; one workgroup per graph
+// =====================================================================================================
+__global__ void goal_kernel(int C, const float* __restrict__ v, const float* __restrict__ goal,
+                            const int* __restrict__ node_ptr, const int* __restrict__ node_ptr_pad,
+                            int* __restrict__ goal_node) {
+    __shared__ float s_d[256];
+    __shared__ int s_i[256];
+    const int g = blockIdx.x, tid = threadIdx.x;
+    const int n0 = node_ptr[g], n = node_ptr[g + 1] - n0;
+    float best = INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = tid; i < n; i += 256) {
+        float d = 0.f;
+        for (int c = 0; c < C; ++c) {
+            const float x = v[(size_t)(n0 + i) * C + c] - goal[(size_t)g * C + c];
+            d = fmaf(x, x, d);
+        }
+        if (d < best) { best = d; bi = i; }
+    }
+    s_d[tid] = best; s_i[tid] = bi;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (tid < off) {
+            const float od = s_d[tid + off];
+            const int oi = s_i[tid + off];
+            if (od < s_d[tid] || (od == s_d[tid] && oi < s_i[tid])) { s_d[tid] = od; s_i[tid] = oi; }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) goal_node[g] = (n > 0) ? node_ptr_pad[g] + s_i[0] : -1;
+}
+
+// =====================================================================================================
+// shared pieces of the register-resident chains
+// =====================================================================================================
+// y = W2 . relu(W1s . in + b0) + c0          (Seq(Lin, ReLU, Lin) on raw inputs)
+template <int NT, class GetIn>
+__device__ __forceinline__ void mlp2_in(const float* as0, int ks, const float* b0, const float* a0, const float* c0,
+                                        GetIn getin, f32x16 (&y)[NT], int lane) {
+    f32x16 hdn[NT];
+    load_vec<NT>(b0, hdn, lane);
+    linear_in<NT>(as0, ks, getin, hdn, lane);
+    relu_<NT>(hdn);
+    load_vec<NT>(c0, y, lane);
+    linear_acc<NT, NT>(a0, hdn, y, lane);
+}
+
+// FeedForward (model.py:192-201): x <- LN(w_2 relu(w_1 x + b1) + b2 + x)
+template <int NT>
+__device__ __forceinline__ void ffn_(const float* w1, const float* b1, const float* w2, const float* b2,
+                                     const float* lng, const float* lnb, f32x16 (&x)[NT], int lane) {
+    f32x16 hdn[NT], z[NT];
+    load_vec<NT>(b1, hdn, lane);
+    linear_acc<NT, NT>(w1, x, hdn, lane);
+    relu_<NT>(hdn);
+    load_vec<NT>(b2, z, lane);
+    linear_acc<NT, NT>(w2, hdn, z, lane);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) x[t] += z[t];
+    layer_norm_<NT>(x, lng, lnb, 1e-6f, lane);
+}
+
+// =====================================================================================================
+// obs_kernel: one workgroup (4 waves) per graph; wave w owns obstacle tiles w, w+4, ...
+// Weights are read straight from global memory (this stage is ~0.1 % of the work).
+// For side in {node, edge}: code = MLP2(ob); for b in 0..2: K = Wk code, V = Wv code -> KV slab;
+// code = FFN_obs_b(code).
+// KV slab of (graph, block): Ko A-tiles [ot][ft][1024] then Vo A-tiles [ot][ft][1024] (stride ot_max).
+// =====================================================================================================
+template <int D>
+__global__ __launch_bounds__(256) void obs_kernel(ObsParams p) {
+    constexpr int NT = D / 32;
+    const int g = blockIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
+    const int o0 = p.obs_ptr[g], O = p.obs_ptr[g + 1] - o0;
+    const int OT = (O + 31) / 32;
+    for (int side = 0; side < 2; ++side) {
+        const float* W = p.w[side];
+        const ObsBlob L = p.blob;
+        float* kv_side = p.kv[side];
+        for (int ot = wave; ot < OT; ot += 4) {
+            const int o = ot * 32 + j;
+            const bool valid = o < O;
+            const float* orow = p.obstacles + (size_t)(o0 + (valid ? o : 0)) * p.S;
+            const int S = p.S;
+            f32x16 code[NT];
+            mlp2_in<NT>(W + L.as0, L.ks, W + L.b0, W + L.a0, W + L.c0,
+                        [&](int k) { return (k < S) ? orow[k] : 0.f; }, code, lane);
+            for (int b = 0; b < 3; ++b) {
+                const float* Wb = W + L.blk0 + b * L.blk_stride;
+                f32x16 K[NT], V[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) { K[t] = splat16(0.f); V[t] = splat16(0.f); }
+                linear_acc<NT, NT>(Wb + L.wk, code, K, lane);
+                linear_acc<NT, NT>(Wb + L.wv, code, V, lane);
+                float* slab = kv_side + (size_t)(g * 3 + b) * p.kv_stride;
+                // Ko: A[i = obstacle][k = feature] -> tile (ot, ft) is exactly the register block
+                if (!valid) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) { K[t] = splat16(0.f); V[t] = splat16(0.f); }
+                }
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    float* kt = slab + (size_t)(ot * NT + t) * kATile;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        f32x4 a;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) a[c] = K[t][q * 4 + c];
+                        *reinterpret_cast<f32x4*>(kt + (q * 64 + lane) * 4) = a;
+                    }
+                }
+                // Vo: A[i = feature][k = obstacle]: element V[o = 32 ot + j][f = 32 t + phi(r,h)] goes to
+                // lane' = phi(r,h) + 32 h', register r' with phi(r', h') = j
+                float* vbase = slab + (size_t)p.ot_max * NT * kATile;
+                const int hp = (j >> 2) & 1, rp = (j & 3) + 4 * (j >> 3);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    float* vt = vbase + (size_t)(ot * NT + t) * kATile;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int lp = phi(r, h) + 32 * hp;
+                        vt[((rp >> 2) * 64 + lp) * 4 + (rp & 3)] = V[t][r];
+                    }
+                }
+                if (b < 2)
+                    ffn_<NT>(Wb + L.fw1, Wb + L.fb1, Wb + L.fw2, Wb + L.fb2, Wb + L.lng, Wb + L.lnb, code, lane);
+            }
+        }
+    }
+}
+
+// =====================================================================================================
+// attention Block on the map rows held in registers (model.py:164-181 + map_feed :212-216).
+// wl: LDS copy of AttBlob<D>; kvl: LDS K/V chunk region; kvg: this (graph, block)'s slab in global.
+// =====================================================================================================
+template <int D>
+__device__ __forceinline__ void attention_block(const float* wl, float* kvl, const float* kvg, int O, int ot_max,
+                                                int ot_chunk, f32x16 (&m)[D / 32], int lane) {
+    constexpr int NT = D / 32;
+    using L = AttBlob<D>;
+    const int h = lane >> 5;
+    const int OT = (O + 31) / 32;
+    f32x16 Q[NT], acc[NT];
+    float mx, psum;
+    {
+        f32x16 Km[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { Q[t] = splat16(0.f); Km[t] = splat16(0.f); acc[t] = splat16(0.f); }
+        linear_acc<NT, NT>(wl + L::wq, m, Q, lane);
+        linear_acc<NT, NT>(wl + L::wk, m, Km, lane);
+        linear_acc<NT, NT>(wl + L::wv, m, acc, lane);      // acc starts as 1 * V_self
+        float l0 = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) l0 = fmaf(Q[t][r], Km[t][r], l0);
+        l0 += xhalf(l0);
+        // softmax(x / sqrt(d)) evaluated as exp2((x - max) * log2(e) / sqrt(d))
+        mx = l0;
+        psum = (h == 0) ? 1.0f : 0.0f;     // the self term exp(0) is counted once per row
+    }
+    const float cs = 1.4426950408889634f / sqrtf((float)D);
+    const int chunk_floats = ot_chunk * NT * kATile;
+    for (int c0 = 0; c0 < OT; c0 += ot_chunk) {
+        const int c1 = min(OT, c0 + ot_chunk);
+        if (c0 > 0) {       // first chunk was staged together with the weights
+            __syncthreads();
+            stage(kvl, kvg + (size_t)c0 * NT * kATile, (c1 - c0) * NT * kATile);
+            stage(kvl + chunk_floats, kvg + (size_t)(ot_max + c0) * NT * kATile, (c1 - c0) * NT * kATile);
+            __syncthreads();
+        }
+        for (int ot = c0; ot < c1; ++ot) {
+            const float* ko = kvl + (size_t)(ot - c0) * NT * kATile;
+            const float* vo = kvl + chunk_floats + (size_t)(ot - c0) * NT * kATile;
+            f32x16 s = splat16(0.f);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) mfma_tile(ko + t * kATile, Q[t], s, lane);
+            float tmax = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const bool ok = (ot * 32 + phi(r, h)) < O;
+                s[r] = ok ? s[r] : -INFINITY;
+                tmax = fmaxf(tmax, s[r]);
+            }
+            tmax = fmaxf(tmax, xhalf(tmax));
+            const float nmx = fmaxf(mx, tmax);
+            const float alpha = exp2f((mx - nmx) * cs);
+            float ps = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                s[r] = exp2f((s[r] - nmx) * cs);
+                ps += s[r];
+            }
+            psum = fmaf(psum, alpha, ps);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                acc[t] *= alpha;
+                mfma_tile(vo + t * kATile, s, acc[t], lane);
+            }
+            mx = nmx;
+        }
+    }
+    const float inv = 1.0f / (psum + xhalf(psum));
+#pragma unroll
+    for (int t = 0; t < NT; ++t) m[t] = acc[t] * inv + m[t];         // value mix + residual
+    layer_norm_<NT>(m, wl + L::ln1g, wl + L::ln1b, 1e-6f, lane);
+    ffn_<NT>(wl + L::w1, wl + L::b1, wl + L::w2, wl + L::b2, wl + L::ln2g, wl + L::ln2b, m, lane);
+}
+
+// =====================================================================================================
+// pre_kernel: encoders + 3 attention blocks + loop-invariant epilogue, one 32-row tile per wave.
+// =====================================================================================================
+template <int D, bool EDGE, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void pre_kernel(PreParams p) {
+    constexpr int NT = D / 32;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* wl = lds;
+    float* kvl = lds + p.wregion;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
+    const int tile = blockIdx.x * WAVES + wave;
+    const int g = p.tile_graph[blockIdx.x * WAVES];       // kPad is a multiple of 32*WAVES: uniform per WG
+    if (g < 0) return;
+    const int row = tile * 32 + j;                        // padded index
+    const int nbase_pad = p.node_ptr_pad[g], nbase = p.node_ptr[g];
+    const int C = p.C;
+
+    stage(wl, p.enc, p.encb.size);
+    __syncthreads();
+    const EncBlob E = p.encb;
+    f32x16 m[NT], aux[NT];      // m: the "free" code that goes through attention; aux: node_code / edge_code
+    if constexpr (EDGE) {
+        const int s = p.csr_src[row], t = p.csr_dst[row];
+        const float* vs = p.v + (size_t)(nbase + (s >= 0 ? s - nbase_pad : 0)) * C;
+        const float* vt = p.v + (size_t)(nbase + (t >= 0 ? t - nbase_pad : 0)) * C;
+        auto getin = [&](int k) { return (k < C) ? vs[k] : ((k < 2 * C) ? vt[k - C] : 0.f); };
+        mlp2_in<NT>(wl + E.as0, E.ks0, wl + E.b0, wl + E.a0, wl + E.c0, getin, aux, lane);   // edge_code
+        mlp2_in<NT>(wl + E.as1, E.ks1, wl + E.b1, wl + E.a1, wl + E.c1, getin, m, lane);     // edge_free_code
+    } else {
+        const int local = row - nbase_pad;
+        const int ng = p.node_ptr[g + 1] - nbase;
+        const float* vr = p.v + (size_t)(nbase + (local < ng ? local : 0)) * C;
+        const float* gl = p.goal + (size_t)g * C;
+        auto getin_nc = [&](int k) {                      // [v, goal, (v-goal)^2, v-goal]  model.py:119
+            if (k >= 4 * C) return 0.f;
+            const int part = k / C, c = k - part * C;
+            const float x = vr[c], gg = gl[c];
+            const float dlt = x - gg;
+            return part == 0 ? x : (part == 1 ? gg : (part == 2 ? dlt * dlt : dlt));
+        };
+        auto getin_nf = [&](int k) { return (k < C) ? vr[k] : 0.f; };
+        mlp2_in<NT>(wl + E.as0, E.ks0, wl + E.b0, wl + E.a0, wl + E.c0, getin_nc, aux, lane);  // node_code
+        mlp2_in<NT>(wl + E.as1, E.ks1, wl + E.b1, wl + E.a1, wl + E.c1, getin_nf, m, lane);    // node_free_code
+    }
+
+    if (p.use_obstacles) {
+        const int O = p.obs_ptr[g + 1] - p.obs_ptr[g];
+        const int OT = (O + 31) / 32;
+        const int chunk_floats = p.ot_chunk * NT * kATile;
+        for (int b = 0; b < 3; ++b) {
+            const float* kvg = p.kv + (size_t)(g * 3 + b) * p.kv_stride;
+            __syncthreads();
+            stage(wl, p.att + (size_t)b * AttBlob<D>::size, AttBlob<D>::size);
+            const int c1 = min(OT, p.ot_chunk);
+            stage(kvl, kvg, c1 * NT * kATile);
+            stage(kvl + chunk_floats, kvg + (size_t)p.ot_max * NT * kATile, c1 * NT * kATile);
+            __syncthreads();
+            attention_block<D>(wl, kvl, kvg, O, p.ot_max, p.ot_chunk, m, lane);
+        }
+    }
+
+    __syncthreads();
+    stage(wl, p.out, p.out_size);
+    __syncthreads();
+    if constexpr (EDGE) {
+        using L = OutEBlob<D>;
+        f32x16 y[NT];
+        load_vec<NT>(wl + L::b1, y, lane);
+        linear_acc<NT, NT>(wl + L::w1d, m, y, lane);
+        linear_acc<NT, NT>(wl + L::w1e, aux, y, lane);
+        store_tile<NT>(p.o0 + (size_t)tile * NT * kATile, y, lane);          // K_e
+        load_vec<NT>(wl + L::bp0, y, lane);
+        linear_acc<NT, NT>(wl + L::wpc, m, y, lane);
+        store_tile<NT>(p.o1 + (size_t)tile * NT * kATile, y, lane);          // PE_e
+    } else {
+        using L = OutNBlob<D>;
+        const bool isgoal = (row == p.goal_node[g]);
+        f32x16 xi[NT], tmp[NT], y[NT];
+        load_vec<NT>(wl + L::be, xi, lane);
+        linear_acc<NT, NT>(wl + L::we_nc, aux, xi, lane);
+        linear_acc<NT, NT>(wl + L::we_nf, m, xi, lane);
+        load_vec<NT>(wl + L::weg, tmp, lane);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) xi[t] += isgoal ? tmp[t] : splat16(0.f);
+        store_row<NT>(p.o0 + (size_t)row * D, xi, h);                         // XI
+        load_vec<NT>(wl + L::wehg, tmp, lane);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) xi[t] += isgoal ? tmp[t] : splat16(0.f);
+        store_row<NT>(p.o1 + (size_t)row * D, xi, h);                         // X_0
+#pragma unroll
+        for (int t = 0; t < NT; ++t) y[t] = splat16(0.f);
+        linear_acc<NT, NT>(wl + L::wsrc, xi, y, lane);
+        store_row<NT>(p.o2 + (size_t)row * D, y, h);                          // A_0
+#pragma unroll
+        for (int t = 0; t < NT; ++t) y[t] = splat16(0.f);
+        linear_acc<NT, NT>(wl + L::wdst, xi, y, lane);
+        store_row<NT>(p.o3 + (size_t)row * D, y, h);                          // B_0
+        load_vec<NT>(wl + L::bd, y, lane);
+        linear_acc<NT, NT>(wl + L::wd_nc, aux, y, lane);
+        store_row<NT>(p.o4 + (size_t)row * D, y, h);                          // DN
+    }
+}
+
+// =====================================================================================================
+// mp_edge: per 32-edge CSR tile: hidden = relu(A[src] + B[dst] + K_e); M = W2 hidden + b2;
+// segmented max over runs of equal destination.  Complete segments go to agg[dst]; segments cut by
+// the tile boundary go to part_first / part_last and are merged by mp_node.
+// =====================================================================================================
+template <int D>
+__global__ __launch_bounds__(256) void mp_edge_kernel(MpEdgeParams p) {
+    constexpr int NT = D / 32;
+    constexpr int LD = D + 1;
+    using L = MpEBlob<D>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* wl = lds;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
+    float* scr = lds + ((L::size + 3) & ~3) + wave * (32 * LD);
+    stage(wl, p.w, L::size);
+    __syncthreads();
+    for (int grp = blockIdx.x; grp * 4 < p.n_tiles; grp += gridDim.x) {
+        const int tile = grp * 4 + wave;
+        if (tile >= p.n_tiles || p.etile_graph[tile] < 0) continue;
+        const int e = tile * 32 + j;
+        const int s = p.csr_src[e], t = p.csr_dst[e];
+        const float* ar = p.A + (size_t)(s >= 0 ? s : 0) * D;
+        const float* br = p.B + (size_t)(t >= 0 ? t : 0) * D;
+        f32x16 hid[NT], a[NT], b[NT];
+        load_tile<NT>(p.Ke + (size_t)tile * NT * kATile, hid, lane);
+        load_row<NT>(ar, a, h);
+        load_row<NT>(br, b, h);
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) hid[tt] += a[tt] + b[tt];
+        relu_<NT>(hid);
+        f32x16 M[NT];
+        load_vec<NT>(wl + L::b2, M, lane);
+        linear_acc<NT, NT>(wl + L::w2, hid, M, lane);
+        // transpose through this wave's LDS scratch: scr[edge j][feature]
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) scr[j * LD + tt * 32 + phi(r, h)] = M[tt][r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int tile_start = tile * 32;
+        const int td = t;                                  // lanes j and j+32 hold the same value
+#pragma unroll
+        for (int fc = 0; fc < (D + 63) / 64; ++fc) {
+            const int f = fc * 64 + lane;
+            const bool fok = f < D;
+            float run = -INFINITY;
+            int cur = __builtin_amdgcn_readlane(td, 0);
+            bool first = true;
+            auto flush = [&](bool last) {
+                if (cur < 0) return;
+                const int a0 = p.row_beg[cur];
+                const int b0 = a0 + p.deg[cur];
+                const bool closed = (a0 >= tile_start) && (b0 <= tile_start + 32);
+                if (fok) {
+                    if (closed) p.agg[(size_t)cur * D + f] = run;
+                    else {
+                        if (first) p.part_first[(size_t)tile * D + f] = run;
+                        if (last) p.part_last[(size_t)tile * D + f] = run;
+                    }
+                }
+            };
+#pragma unroll
+            for (int jj = 0; jj < 32; ++jj) {
+                const int dj = __builtin_amdgcn_readlane(td, jj);
+                if (dj != cur) {
+                    flush(dj < 0);
+                    first = false;
+                    cur = dj;
+                    run = -INFINITY;
+                }
+                if (fok) run = fmaxf(run, scr[jj * LD + f]);
+            }
+            flush(true);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// =====================================================================================================
+// mp_node: per 32-node tile: agg (merge partial maxima; 0 for empty), H = Wlx X + Wla agg + bl,
+// Y = R + M1 H, A' = M2 Y, B' = M3 Y.
+// =====================================================================================================
+template <int D>
+__global__ __launch_bounds__(256) void mp_node_kernel(MpNodeParams p) {
+    constexpr int NT = D / 32;
+    using L = MpNBlob<D>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* wl = lds;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
+    stage(wl, p.w, L::size);
+    __syncthreads();
+    for (int grp = blockIdx.x; grp * 4 < p.n_tiles; grp += gridDim.x) {
+        const int tile = grp * 4 + wave;
+        if (tile >= p.n_tiles || p.ntile_graph[tile] < 0) continue;
+        const int t = tile * 32 + j;
+        f32x16 x[NT], ag[NT];
+        load_row<NT>(p.X + (size_t)t * D, x, h);
+        const int a0 = p.row_beg[t], dg = p.deg[t];
+        if (dg == 0) {
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt) ag[tt] = splat16(0.f);      // torch_scatter: empty -> 0
+        } else {
+            const int k0 = a0 >> 5, k1 = (a0 + dg - 1) >> 5;
+            if (k0 == k1) {
+                load_row<NT>(p.agg + (size_t)t * D, ag, h);
+            } else {
+                load_row<NT>(p.part_last + (size_t)k0 * D, ag, h);
+                for (int k = k0 + 1; k <= k1; ++k) {
+                    f32x16 o[NT];
+                    load_row<NT>(p.part_first + (size_t)k * D, o, h);
+#pragma unroll
+                    for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) ag[tt][r] = fmaxf(ag[tt][r], o[tt][r]);
+                }
+            }
+        }
+        f32x16 H[NT], y[NT], z[NT];
+        load_vec<NT>(wl + L::bl, H, lane);
+        linear_acc<NT, NT>(wl + L::wlx, x, H, lane);
+        linear_acc<NT, NT>(wl + L::wla, ag, H, lane);
+        store_row<NT>(p.Hout + (size_t)t * D, H, h);
+        load_row<NT>(p.R + (size_t)t * D, y, h);
+        linear_acc<NT, NT>(wl + L::m1, H, y, lane);
+        store_row<NT>(p.Xout + (size_t)t * D, y, h);
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) z[tt] = splat16(0.f);
+        linear_acc<NT, NT>(wl + L::m2, y, z, lane);
+        store_row<NT>(p.Aout + (size_t)t * D, z, h);
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) z[tt] = splat16(0.f);
+        linear_acc<NT, NT>(wl + L::m3, y, z, lane);
+        store_row<NT>(p.Bout + (size_t)t * D, z, h);
+    }
+}
+
+// =====================================================================================================
+// policy: score_e = w3 . relu(W2 relu(PS[src] - PT[dst] + PE_e) + b2)
+// =====================================================================================================
+template <int D>
+__global__ __launch_bounds__(256) void policy_kernel(PolicyParams p) {
+    constexpr int NT = D / 32;
+    using L = PolBlob<D>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* wl = lds;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
+    stage(wl, p.w, L::size);
+    __syncthreads();
+    for (int grp = blockIdx.x; grp * 4 < p.n_tiles; grp += gridDim.x) {
+        const int tile = grp * 4 + wave;
+        if (tile >= p.n_tiles) continue;
+        const int g = p.etile_graph[tile];
+        if (g < 0) continue;
+        const int e = tile * 32 + j;
+        const int s = p.csr_src[e], t = p.csr_dst[e];
+        f32x16 hid[NT], a[NT], b[NT];
+        load_tile<NT>(p.PE + (size_t)tile * NT * kATile, hid, lane);
+        load_row<NT>(p.PS + (size_t)(s >= 0 ? s : 0) * D, a, h);
+        load_row<NT>(p.PT + (size_t)(t >= 0 ? t : 0) * D, b, h);
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) hid[tt] += a[tt] - b[tt];
+        relu_<NT>(hid);
+        f32x16 y[NT], w3[NT];
+        load_vec<NT>(wl + L::b2, y, lane);
+        linear_acc<NT, NT>(wl + L::w2, hid, y, lane);
+        relu_<NT>(y);
+        load_vec<NT>(wl + L::w3, w3, lane);
+        float sc = 0.f;
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sc = fmaf(w3[tt][r], y[tt][r], sc);
+        sc += xhalf(sc);
+        if (h == 0 && s >= 0) {
+            const int eid = p.csr_eid[e];
+            p.scores[eid] = sc;
+            if (p.dense) {
+                const int nb = p.node_ptr_pad[g];
+                const long long ng = p.node_ptr[g + 1] - p.node_ptr[g];
+                p.dense[p.dense_ptr[g] + (long long)(t - nb) * ng + (s - nb)] = sc;   // P[target, source]
+            }
+        }
+    }
+}
+
+__global__ void zero_dense_kernel(float* __restrict__ dense, const long long* __restrict__ n_ptr) {
+    const long long n = *n_ptr;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        dense[i] = 0.f;
+}
+
+// tap helper: gather padded-node-space rows back to caller node order
+__global__ void unpad_rows_kernel(int G, int total_nodes, int D, const int* __restrict__ node_ptr,
+                                  const int* __restrict__ node_ptr_pad, const float* __restrict__ src,
+                                  float* __restrict__ dst) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)total_nodes * D) return;
+    const int n = (int)(i / D), f = (int)(i % D);
+    const int g = find_graph(node_ptr, G, n);
+    dst[i] = src[(size_t)(node_ptr_pad[g] + n - node_ptr[g]) * D + f];
+}
+
+__global__ void goal_tap_kernel(int G, const int* __restrict__ goal_node, const int* __restrict__ node_ptr_pad,
+                                float* __restrict__ dst) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < G) dst[g] = (float)(goal_node[g] - node_ptr_pad[g]);
+}
+
+// =====================================================================================================
+// host-side launchers (called from api.cpp)
+// =====================================================================================================
+#define LAUNCH_CHECK()                        \
+    do {                                      \
+        hipError_t _e = hipGetLastError();    \
+        if (_e != hipSuccess) return _e;      \
+    } while (0)
+
+hipError_t launch_prep(const PrepParams& q, hipStream_t st) {
+    hipLaunchKernelGGL(prep_ptrs_kernel, dim3(1), dim3(256), 0, st, q.G, q.node_ptr, q.edge_ptr, q.node_ptr_pad,
+                       q.edge_ptr_pad, q.dense_ptr);
+    LAUNCH_CHECK();
+    if (q.E > 0) {
+        hipLaunchKernelGGL(prep_count_kernel, dim3((q.E + 255) / 256), dim3(256), 0, st, q.G, q.E, q.edge_index,
+                           q.edge_ptr, q.node_ptr_pad, q.deg);
+        LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(prep_scan_kernel, dim3(q.G), dim3(256), 0, st, q.node_ptr_pad, q.edge_ptr_pad, q.deg, q.row_beg,
+                       q.ntile_graph, q.etile_graph);
+    LAUNCH_CHECK();
+    if (q.E > 0) {
+        hipLaunchKernelGGL(prep_fill_kernel, dim3((q.E + 255) / 256), dim3(256), 0, st, q.G, q.E, q.edge_index,
+                           q.edge_ptr, q.node_ptr_pad, q.row_beg, q.cursor, q.csr_src, q.csr_dst, q.csr_eid);
+        LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(goal_kernel, dim3(q.G), dim3(256), 0, st, q.C, q.v, q.goal, q.node_ptr, q.node_ptr_pad,
+                       q.goal_node);
+    LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+template <class K>
+static hipError_t set_lds(K kernel, size_t bytes) {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)bytes);
+}
+
+template <int D>
+static hipError_t launch_obs_t(const ObsParams& p, int G, hipStream_t st) {
+    hipLaunchKernelGGL(obs_kernel<D>, dim3(G), dim3(256), 0, st, p);
+    LAUNCH_CHECK();
+    return hipSuccess;
+}
+hipError_t launch_obs(int D, const ObsParams& p, int G, hipStream_t st) {
+    return D == 32 ? launch_obs_t<32>(p, G, st) : launch_obs_t<64>(p, G, st);
+}
+
+template <int D, bool EDGE, int WAVES>
+static hipError_t launch_pre_t(const PreParams& p, int n_wg, size_t lds_bytes, hipStream_t st) {
+    hipError_t e = set_lds(pre_kernel<D, EDGE, WAVES>, lds_bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((pre_kernel<D, EDGE, WAVES>), dim3(n_wg), dim3(WAVES * 64), lds_bytes, st, p);
+    LAUNCH_CHECK();
+    return hipSuccess;
+}
+hipError_t launch_pre(int D, bool edge, int waves, const PreParams& p, int n_tiles32, size_t lds_bytes, hipStream_t st) {
+    const int n_wg = n_tiles32 / waves;
+    if (D == 32 && waves == 4) return edge ? launch_pre_t<32, true, 4>(p, n_wg, lds_bytes, st) : launch_pre_t<32, false, 4>(p, n_wg, lds_bytes, st);
+    if (D == 32 && waves == 8) return edge ? launch_pre_t<32, true, 8>(p, n_wg, lds_bytes, st) : launch_pre_t<32, false, 8>(p, n_wg, lds_bytes, st);
+    if (D == 64 && waves == 8) return edge ? launch_pre_t<64, true, 8>(p, n_wg, lds_bytes, st) : launch_pre_t<64, false, 8>(p, n_wg, lds_bytes, st);
+    if (D == 64 && waves == 4) return edge ? launch_pre_t<64, true, 4>(p, n_wg, lds_bytes, st) : launch_pre_t<64, false, 4>(p, n_wg, lds_bytes, st);
+    return hipErrorInvalidValue;
+}
+
+static int grid_for(int n_tiles) {
+    const int groups = (n_tiles + 3) / 4;
+    return groups < 256 * 8 ? (groups > 0 ? groups : 1) : 256 * 8;
+}
+
+template <int D>
+static hipError_t launch_mp_edge_t(const MpEdgeParams& p, hipStream_t st) {
+    const size_t lds = (size_t)(((MpEBlob<D>::size + 3) & ~3) + 4 * 32 * (D + 1)) * sizeof(float);
+    hipError_t e = set_lds(mp_edge_kernel<D>, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(mp_edge_kernel<D>, dim3(grid_for(p.n_tiles)), dim3(256), lds, st, p);
+    LAUNCH_CHECK();
+    return hipSuccess;
+}
+hipError_t launch_mp_edge(int D, const MpEdgeParams& p, hipStream_t st) {
+    return D == 32 ? launch_mp_edge_t<32>(p, st) : launch_mp_edge_t<64>(p, st);
+}
+
+template <int D>
+static hipError_t launch_mp_node_t(const MpNodeParams& p, hipStream_t st) {
+    const size_t lds = (size_t)MpNBlob<D>::size * sizeof(float);
+    hipError_t e = set_lds(mp_node_kernel<D>, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(mp_node_kernel<D>, dim3(grid_for(p.n_tiles)), dim3(256), lds, st, p);
+    LAUNCH_CHECK();
+    return hipSuccess;
+}
+hipError_t launch_mp_node(int D, const MpNodeParams& p, hipStream_t st) {
+    return D == 32 ? launch_mp_node_t<32>(p, st) : launch_mp_node_t<64>(p, st);
+}
+
+template <int D>
+static hipError_t launch_policy_t(const PolicyParams& p, hipStream_t st) {
+    const size_t lds = (size_t)PolBlob<D>::size * sizeof(float);
+    hipError_t e = set_lds(policy_kernel<D>, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(policy_kernel<D>, dim3(grid_for(p.n_tiles)), dim3(256), lds, st, p);
+    LAUNCH_CHECK();
+    return hipSuccess;
+}
+hipError_t launch_policy(int D, const PolicyParams& p, hipStream_t st) {
+    return D == 32 ? launch_policy_t<32>(p, st) : launch_policy_t<64>(p, st);
+}
+
+hipError_t launch_unpad_rows(int G, int total_nodes, int D, const int* node_ptr, const int* node_ptr_pad,
+                             const float* src, float* dst, hipStream_t st) {
+    const size_t n = (size_t)total_nodes * D;
+    hipLaunchKernelGGL(unpad_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, G, total_nodes, D,
+                       node_ptr, node_ptr_pad, src, dst);
+    LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_zero_dense(float* dense, const long long* n_ptr, hipStream_t st) {
+    hipLaunchKernelGGL(zero_dense_kernel, dim3(2048), dim3(256), 0, st, dense, n_ptr);
+    LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_goal_tap(int G, const int* goal_node, const int* node_ptr_pad, float* dst, hipStream_t st) {
+    hipLaunchKernelGGL(goal_tap_kernel, dim3((G + 255) / 256), dim3(256), 0, st, G, goal_node, node_ptr_pad, dst);
+    LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+}  // namespace gnnmp

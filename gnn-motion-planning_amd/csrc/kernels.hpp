@@ -1,0 +1,85 @@
+// kernels.hpp -- parameter blocks and launcher prototypes shared by api.cpp and the .hip files.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "layout.hpp"
+
+namespace gnnmp {
+
+struct PrepParams {
+    int G, E, C;
+    const long long* edge_index;                 // [2, E] graph-local ids
+    const int *node_ptr, *edge_ptr;              // caller prefix arrays [G+1]
+    const float *v, *goal;
+    int *node_ptr_pad, *edge_ptr_pad;            // [G+1]
+    long long* dense_ptr;                        // [G+1]
+    int *deg, *cursor, *row_beg;                 // [Npad]
+    int *ntile_graph, *etile_graph;              // per 32-row tile
+    int *csr_src, *csr_dst, *csr_eid;            // [Epad]
+    int* goal_node;                              // [G] padded node id
+};
+
+struct ObsParams {
+    const float* obstacles;
+    const int* obs_ptr;
+    int S;
+    const float* w[2];       // packed ObsBlob for node side / edge side
+    ObsBlob blob;
+    float* kv[2];            // K/V slabs, node side / edge side
+    int kv_stride;           // floats per (graph, block) slab = 2 * ot_max * NT * 1024
+    int ot_max;
+};
+
+struct PreParams {
+    const float *v, *goal;
+    int C;
+    const int *node_ptr, *node_ptr_pad;
+    const int* tile_graph;
+    const int *csr_src, *csr_dst;
+    const int* obs_ptr;
+    const int* goal_node;
+    const float* enc;
+    EncBlob encb;
+    const float* att;        // 3 consecutive AttBlob
+    const float* out;
+    int out_size;
+    const float* kv;
+    int kv_stride, ot_max, ot_chunk;
+    int wregion;             // floats reserved for the weight region of LDS
+    int use_obstacles;
+    float *o0, *o1, *o2, *o3, *o4;
+};
+
+struct MpEdgeParams {
+    const int *csr_src, *csr_dst, *row_beg, *deg, *etile_graph;
+    const float *A, *B, *Ke, *w;
+    float *agg, *part_first, *part_last;
+    int n_tiles;
+};
+
+struct MpNodeParams {
+    const int *row_beg, *deg, *ntile_graph;
+    const float *X, *R, *agg, *part_first, *part_last, *w;
+    float *Hout, *Xout, *Aout, *Bout;
+    int n_tiles;
+};
+
+struct PolicyParams {
+    const int *csr_src, *csr_dst, *csr_eid, *etile_graph, *node_ptr, *node_ptr_pad;
+    const long long* dense_ptr;
+    const float *PS, *PT, *PE, *w;
+    float *scores, *dense;
+    int n_tiles;
+};
+
+hipError_t launch_prep(const PrepParams& q, hipStream_t st);
+hipError_t launch_obs(int D, const ObsParams& p, int G, hipStream_t st);
+hipError_t launch_pre(int D, bool edge, int waves, const PreParams& p, int n_tiles32, size_t lds_bytes, hipStream_t st);
+hipError_t launch_mp_edge(int D, const MpEdgeParams& p, hipStream_t st);
+hipError_t launch_mp_node(int D, const MpNodeParams& p, hipStream_t st);
+hipError_t launch_policy(int D, const PolicyParams& p, hipStream_t st);
+hipError_t launch_unpad_rows(int G, int total_nodes, int D, const int* node_ptr, const int* node_ptr_pad,
+                             const float* src, float* dst, hipStream_t st);
+hipError_t launch_zero_dense(float* dense, const long long* n_ptr, hipStream_t st);
+hipError_t launch_goal_tap(int G, const int* goal_node, const int* node_ptr_pad, float* dst, hipStream_t st);
+
+}  // namespace gnnmp

@@ -1,0 +1,117 @@
+// layout.hpp -- packed-weight and workspace layouts shared by host packing code and kernels.
+// All offsets / sizes are in floats and multiples of 4 (16-byte aligned sections).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstddef>
+#include <cstdint>
+
+namespace gnnmp {
+
+constexpr int kPad = 256;          // per-graph padding granularity of the node and edge index spaces
+constexpr int kRowsPerWave = 32;
+
+// feature (within a 32-feature tile) held by accumulator register r of a lane in half-wave h
+__host__ __device__ constexpr int phi(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+__host__ __device__ constexpr int tile_floats(int D) { return (D / 32) * (D / 32) * 1024; }   // one DxD matrix
+__host__ __device__ constexpr int vec_floats(int D) { return (D / 32) * 32; }                 // one D-vector
+__host__ __device__ constexpr int small_floats(int D, int ksteps) { return (D / 32) * ksteps * 64; }
+
+// One attention Block (model.py:204-218) in LDS staging order.
+template <int D>
+struct AttBlob {
+    static constexpr int T = tile_floats(D), V = vec_floats(D);
+    static constexpr int wq = 0, wk = T, wv = 2 * T, ln1g = 3 * T, ln1b = 3 * T + V, w1 = 3 * T + 2 * V,
+                         b1 = 4 * T + 2 * V, w2 = 4 * T + 3 * V, b2 = 5 * T + 3 * V, ln2g = 5 * T + 4 * V,
+                         ln2b = 5 * T + 5 * V, size = 5 * T + 6 * V;
+};
+
+// Two Seq(Lin, ReLU, Lin) encoders on raw inputs (node_code + node_free_code, or edge_code +
+// edge_free_code): [As0][b0][A0][c0][As1][b1][A1][c1]
+struct EncBlob {
+    int as0, b0, a0, c0, as1, b1, a1, c1, size, ks0, ks1;
+    __host__ __device__ static EncBlob make(int D, int ks0, int ks1) {
+        EncBlob e;
+        const int T = tile_floats(D), V = vec_floats(D);
+        int o = 0;
+        e.ks0 = ks0; e.ks1 = ks1;
+        e.as0 = o; o += small_floats(D, ks0);
+        e.b0 = o; o += V;
+        e.a0 = o; o += T;
+        e.c0 = o; o += V;
+        e.as1 = o; o += small_floats(D, ks1);
+        e.b1 = o; o += V;
+        e.a1 = o; o += T;
+        e.c1 = o; o += V;
+        e.size = o;
+        return e;
+    }
+};
+
+// Edge epilogue: K_e = W1d.EF + W1e.EC + b1 (message first-layer edge constant),
+//                PE  = Wpc.EF + bp0        (policy first-layer edge constant)
+template <int D>
+struct OutEBlob {
+    static constexpr int T = tile_floats(D), V = vec_floats(D);
+    static constexpr int w1d = 0, w1e = T, b1 = 2 * T, wpc = 2 * T + V, bp0 = 3 * T + V, size = 3 * T + 2 * V;
+};
+
+// Node epilogue: XI = We_nc.NC + We_nf.NF + be (+ weg on the goal row); X0 = XI (+ wehg on the goal
+// row); A0 = Wsrc.X0; B0 = Wdst.X0; DN = Wd_nc.NC + bd
+template <int D>
+struct OutNBlob {
+    static constexpr int T = tile_floats(D), V = vec_floats(D);
+    static constexpr int we_nc = 0, we_nf = T, be = 2 * T, weg = 2 * T + V, wehg = 2 * T + 2 * V, wsrc = 2 * T + 3 * V,
+                         wdst = 3 * T + 3 * V, wd_nc = 4 * T + 3 * V, bd = 5 * T + 3 * V, size = 5 * T + 4 * V;
+};
+
+// Node update of one message-passing iteration: H = Wlx.X + Wla.agg + bl; Y = R + M1.H;
+// A' = M2.Y; B' = M3.Y.   (loop body: R = XI, M1 = Weh, M2 = Wsrc, M3 = Wdst;
+//                          after the last iteration: R = DN, M1 = Wdh, M2 = Wpa+Wpb, M3 = Wpb)
+template <int D>
+struct MpNBlob {
+    static constexpr int T = tile_floats(D), V = vec_floats(D);
+    static constexpr int wlx = 0, wla = T, bl = 2 * T, m1 = 2 * T + V, m2 = 3 * T + V, m3 = 4 * T + V, size = 5 * T + V;
+};
+
+template <int D>
+struct MpEBlob {   // message second layer
+    static constexpr int T = tile_floats(D), V = vec_floats(D);
+    static constexpr int w2 = 0, b2 = T, size = T + V;
+};
+
+template <int D>
+struct PolBlob {   // policy.2 and policy.4
+    static constexpr int T = tile_floats(D), V = vec_floats(D);
+    static constexpr int w2 = 0, b2 = T, w3 = T + V, size = T + 2 * V;
+};
+
+// Obstacle side (node or edge): encoder + per block {Wk, Wv, obs_feed}
+struct ObsBlob {
+    int as0, b0, a0, c0, blk0, blk_stride, size, ks;
+    // inside a block:
+    int wk, wv, fw1, fb1, fw2, fb2, lng, lnb;
+    __host__ __device__ static ObsBlob make(int D, int ks) {
+        ObsBlob e;
+        const int T = tile_floats(D), V = vec_floats(D);
+        int o = 0;
+        e.ks = ks;
+        e.as0 = o; o += small_floats(D, ks);
+        e.b0 = o; o += V;
+        e.a0 = o; o += T;
+        e.c0 = o; o += V;
+        e.blk0 = o;
+        e.wk = 0; e.wv = T; e.fw1 = 2 * T; e.fb1 = 3 * T; e.fw2 = 3 * T + V; e.fb2 = 4 * T + V;
+        e.lng = 4 * T + 2 * V; e.lnb = 4 * T + 3 * V;
+        e.blk_stride = 4 * T + 4 * V;
+        e.size = o + 3 * e.blk_stride;
+        return e;
+    }
+};
+
+// Offsets of every blob inside the device weight buffer of an explorer handle.
+struct ExplorerOffsets {
+    int enc_e, enc_n, att_e, att_n, out_e, out_n, mpn, mpn_last, mpe, pol, obs_e, obs_n, total;
+};
+
+}  // namespace gnnmp

@@ -1,0 +1,220 @@
+"""Drop-in counterpart of the reference's ``EncoderProcessDecoder`` (model.py:48-150).
+
+Same constructor signature, same parameter / buffer names (so ``load_state_dict`` of the shipped
+``.pt`` files succeeds with ``strict=True``), same ``forward`` keyword signature and the same dense
+``[N, N]`` return value -- but the arithmetic runs in libgnnmp.so's HIP kernels (gfx950).  The
+``torch.nn`` layers below are parameter containers only; this class never calls them.
+"""
+import ctypes
+
+import torch
+from torch import nn
+from torch.nn import Linear as Lin, ReLU, Sequential as Seq
+
+from . import _lib
+from .batch import GraphBatch
+
+
+class _Attention(nn.Module):                      # parameter names of model.py:153-162
+    def __init__(self, d):
+        super().__init__()
+        self.key = Lin(d, d, bias=False)
+        self.query = Lin(d, d, bias=False)
+        self.value = Lin(d, d, bias=False)
+        self.layer_norm = nn.LayerNorm(d, eps=1e-6)
+
+
+class _FeedForward(nn.Module):                    # model.py:184-190
+    def __init__(self, d):
+        super().__init__()
+        self.w_1 = Lin(d, d)
+        self.w_2 = Lin(d, d)
+        self.layer_norm = nn.LayerNorm(d, eps=1e-6)
+
+
+class _Block(nn.Module):                          # model.py:204-210
+    def __init__(self, d):
+        super().__init__()
+        self.attention = _Attention(d)
+        self.map_feed = _FeedForward(d)
+        self.obs_feed = _FeedForward(d)
+
+
+class _MPNN(nn.Module):                           # model.py:22-28
+    def __init__(self, d):
+        super().__init__()
+        self.lin_0 = Seq(Lin(d * 5, d), ReLU(), Lin(d, d))
+        self.lin_1 = Lin(d * 2, d)
+        self.bn = nn.BatchNorm1d(d)
+
+
+class EncoderProcessDecoder(nn.Module):
+    """``EncoderProcessDecoder(workspace_size, config_size, embed_size, obs_size, use_obstacles=True)``
+    (model.py:49).  ``use_obstacles`` is read at call time (model.py:125; toggled by eval_gnn.py:88)."""
+
+    def __init__(self, workspace_size, config_size, embed_size, obs_size, use_obstacles=True):
+        super().__init__()
+        _lib.lib()                                  # fail loudly if the native library is absent
+        self.workspace = workspace_size
+        self.config_size = config_size
+        self.obs_size = obs_size
+        self.use_obstacles = use_obstacles
+        self.embed_size = embed_size
+        C, d, S = config_size, embed_size, obs_size
+        mlp = lambda i: Seq(Lin(i, d), ReLU(), Lin(d, d))       # noqa: E731
+        # --- tensors forward() reads
+        self.node_code = mlp(C * 4)
+        self.edge_code = mlp(C * 2)
+        self.obs_node_code = mlp(S)
+        self.obs_edge_code = mlp(S)
+        self.node_free_code = mlp(C)
+        self.edge_free_code = mlp(C * 2)
+        self.node_attentions = nn.ModuleList([_Block(d) for _ in range(3)])
+        self.edge_attentions = nn.ModuleList([_Block(d) for _ in range(3)])
+        self.goal_encoder = nn.Parameter(torch.rand(d))
+        self.encoder = Lin(d * 4, d)
+        self.process = _MPNN(d)
+        self.decoder = Lin(d * 2, d)
+        self.policy = Seq(Lin(d * 3, d), ReLU(), Lin(d, d), ReLU(), Lin(d, 1, bias=False))
+        # --- present in the reference's state_dict, never read by forward(); kept so that
+        #     load_state_dict(strict=True) accepts the shipped checkpoints (model.py:64-67,79,83-105)
+        self.free_code = mlp(C)
+        self.collided_code = mlp(C)
+        self.env_code = mlp(d * 3)
+        self.node_pos = Lin(C, d)
+        self.lstm = nn.LSTMCell(d, d)
+        self.ln = nn.LayerNorm(d)
+        self.bn_node = nn.BatchNorm1d(d)
+        self.bn_edge = nn.BatchNorm1d(d)
+        self.bn_hi = nn.BatchNorm1d(d)
+        self.ln_node = nn.LayerNorm(d)
+        self.ln_edge = nn.LayerNorm(d)
+        self.ln_hi = nn.LayerNorm(d)
+        self.process_cat = Lin(d * 2, d)
+        self.value = Seq(Lin(d, d), ReLU(), Lin(d, d), ReLU(), Lin(d, 1))
+        self.node_free = Lin(d, 1)
+        self.edge_free = Lin(d, 1)
+        self._handle = None
+        self._handle_key = None
+        self._ws = None
+        self.register_load_state_dict_post_hook(lambda m, _k: m._drop_handle())
+
+    # ------------------------------------------------------------------ native handle
+    def _drop_handle(self):
+        if getattr(self, '_handle', None):
+            _lib.lib().gnnmp_explorer_destroy(self._handle)
+        self._handle = None
+        self._handle_key = None
+
+    def __del__(self):
+        try:
+            self._drop_handle()
+        except Exception:
+            pass
+
+    def _dims(self):
+        return _lib.ExplorerDims(self.config_size, self.embed_size, self.obs_size)
+
+    def _native(self, device):
+        """Opaque library handle holding the packed weights on ``device`` (rebuilt when the
+        parameters were replaced or modified in place)."""
+        sd = self.state_dict()
+        dims = self._dims()
+        names = _lib.manifest('explorer', dims)
+        key = (str(device),) + tuple((sd[n].data_ptr(), sd[n]._version) for n, _ in names)
+        if self._handle is not None and key == self._handle_key:
+            return self._handle
+        self._drop_handle()
+        parts = []
+        for n, numel in names:
+            t = sd[n].detach().to('cpu', torch.float32).contiguous().reshape(-1)
+            if t.numel() != numel:
+                raise RuntimeError('parameter %s has %d elements, library expects %d' % (n, t.numel(), numel))
+            parts.append(t)
+        blob = torch.cat(parts).contiguous()
+        h = ctypes.c_void_p()
+        _lib.check(_lib.lib().gnnmp_explorer_create(ctypes.byref(h), ctypes.byref(dims), blob.data_ptr(),
+                                                    blob.numel(), torch.device(device).index or 0),
+                   'gnnmp_explorer_create')
+        self._handle, self._handle_key = h, key
+        return h
+
+    @staticmethod
+    def _cbatch(b):
+        return _lib.Batch(b.n_graphs, b.total_nodes, b.total_edges, b.total_obstacles, b.max_obstacles,
+                          b.v.data_ptr(), b.goal.data_ptr(), b.obstacles.data_ptr() if b.total_obstacles else None,
+                          b.edge_index.data_ptr() if b.total_edges else None, b.node_ptr.data_ptr(),
+                          b.edge_ptr.data_ptr(), b.obs_ptr.data_ptr())
+
+    def _workspace(self, h, cb, device):
+        need = ctypes.c_size_t()
+        _lib.check(_lib.lib().gnnmp_explorer_workspace_bytes(h, ctypes.byref(cb), ctypes.byref(need)),
+                   'gnnmp_explorer_workspace_bytes')
+        if self._ws is None or self._ws.numel() < need.value or self._ws.device != torch.device(device):
+            self._ws = torch.empty(need.value, dtype=torch.uint8, device=device)
+        return self._ws
+
+    # ------------------------------------------------------------------ batched entry points
+    @torch.no_grad()
+    def forward_batch(self, batch, loop, dense=False):
+        """Score every edge of a :class:`GraphBatch`.  Returns ``scores [sumE]`` in the batch's
+        column order, or ``(scores, dense_blocks)`` with the concatenated zero-filled
+        ``P_g[target, source]`` matrices (model.py:148-149) when ``dense``."""
+        dev = batch.v.device
+        if dev.type != 'cuda':
+            raise RuntimeError('gnnmp runs on the GPU only (got %s tensors); there is no CPU fallback' % dev)
+        if int(loop) < 1:
+            raise ValueError('loop must be >= 1: the reference binds `decode` only inside the loop '
+                             '(model.py:139-145)')
+        h = self._native(dev)
+        cb = self._cbatch(batch)
+        ws = self._workspace(h, cb, dev)
+        scores = torch.empty(batch.total_edges, dtype=torch.float32, device=dev)
+        dn = None
+        if dense:
+            n = (batch.node_ptr[1:] - batch.node_ptr[:-1]).to(torch.int64)
+            dn = torch.empty(int((n * n).sum()), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            st = torch.cuda.current_stream().cuda_stream
+            _lib.check(_lib.lib().gnnmp_explorer_forward(
+                h, ctypes.byref(cb), int(loop), 1 if self.use_obstacles else 0, scores.data_ptr(),
+                dn.data_ptr() if dense else None, ws.data_ptr(), ws.numel(), st), 'gnnmp_explorer_forward')
+        return (scores, dn) if dense else scores
+
+    def debug_tap(self, batch, which):
+        """Intermediate of the LAST forward_batch on this module (tests only; see gnnmp.h)."""
+        dev = batch.v.device
+        h = self._native(dev)
+        cb = self._cbatch(batch)
+        n = batch.n_graphs if which == 3 else batch.total_nodes * self.embed_size
+        out = torch.empty(n, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            st = torch.cuda.current_stream().cuda_stream
+            _lib.check(_lib.lib().gnnmp_explorer_debug_tap(h, ctypes.byref(cb), which, out.data_ptr(),
+                                                           self._ws.data_ptr(), self._ws.numel(), st), 'debug_tap')
+        return out if which == 3 else out.view(batch.total_nodes, self.embed_size)
+
+    def _single(self, goal, v, obstacles, edge_index):
+        dev = v.device
+        S = self.obs_size
+        obs = obstacles.reshape(-1, S).float() if (obstacles is not None and self.use_obstacles) else \
+            torch.zeros(0, S, device=dev)
+        i32 = lambda *a: torch.tensor(a, dtype=torch.int32, device=dev)      # noqa: E731
+        return GraphBatch(v.float().contiguous(), goal.reshape(1, -1).float().contiguous(), obs.contiguous(),
+                          edge_index.long().contiguous(), i32(0, v.shape[0]), i32(0, edge_index.shape[1]),
+                          i32(0, obs.shape[0]), obs.shape[0])
+
+    @torch.no_grad()
+    def edge_scores(self, goal, loop, v, obstacles, edge_index, **_ignored):
+        """Sparse form of :meth:`forward`: scores [E] in ``edge_index`` column order."""
+        return self.forward_batch(self._single(goal, v, obstacles, edge_index), loop)
+
+    # ------------------------------------------------------------------ reference signature
+    @torch.no_grad()
+    def forward(self, goal, loop, v, obstacles, free=None, collided=None, edge_index=None, k=10, **kwargs):
+        """Reference call (eval_gnn.py:194): returns the dense ``policy_output[N, N]`` with
+        ``P[target, source] = score`` (model.py:148-149).  ``free``, ``collided``, ``k``, ``labels``
+        and any other extra keyword are accepted and ignored exactly like the reference does
+        (model.py:115)."""
+        _, dn = self.forward_batch(self._single(goal, v, obstacles, edge_index), loop, dense=True)
+        return dn.view(v.shape[0], v.shape[0])

@@ -1,0 +1,181 @@
+/*
+ * gnnmp.h -- C ABI of libgnnmp.so: MI355X (gfx950) implementation of the GNN path-explorer and
+ * path-smoother forward passes of rainorangelemon/gnn-motion-planning.
+ *
+ * The reference has no FFI layer; its boundary for this path is the torch.nn.Module protocol
+ * of two classes.  Each entry point below names the reference interface it replaces:
+ *
+ *   gnnmp_explorer_manifest / _create / _destroy
+ *       EncoderProcessDecoder.__init__ + load_state_dict      model.py:49-105, eval_gnn.py:99-101
+ *   gnnmp_explorer_workspace_bytes / gnnmp_explorer_forward
+ *       EncoderProcessDecoder.forward                         model.py:115-150 (call eval_gnn.py:194)
+ *   gnnmp_smoother_manifest / _create / _destroy
+ *       ModelSmoother.__init__ + load_state_dict              model_smoother.py:51-94, eval_gnn.py:102-104
+ *   gnnmp_smoother_workspace_bytes / gnnmp_smoother_forward
+ *       ModelSmoother.forward                                 model_smoother.py:104-142 (call smoother.py:243)
+ *
+ * Conventions
+ *   - plain C types only; every pointer in a batch / forward call is a DEVICE pointer unless the
+ *     name ends in _host; tensors are contiguous row-major fp32 / int64 / int32.
+ *   - the library owns only the opaque handle (device copy of the packed weights).  Inputs,
+ *     outputs and workspace are caller-allocated; nothing is retained past the call.
+ *   - every kernel is enqueued on the hipStream_t passed in (as void*); no hidden device
+ *     synchronisation, no allocation inside forward -> forward is hipGraph-capturable.
+ *   - functions return 0 (GNNMP_OK) or a negative gnnmp_status; no C++ exception crosses the ABI.
+ *   - a handle is immutable after create: concurrent forwards from several host threads are legal
+ *     with distinct workspaces / streams.
+ */
+#ifndef GNNMP_H
+#define GNNMP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    GNNMP_OK = 0,
+    GNNMP_ERR_NULL = -1,          /* required pointer is NULL                               */
+    GNNMP_ERR_DIMS = -2,          /* unsupported / inconsistent dimensions                   */
+    GNNMP_ERR_WEIGHTS = -3,       /* weight blob size does not match the manifest            */
+    GNNMP_ERR_WORKSPACE = -4,     /* workspace too small or misaligned                       */
+    GNNMP_ERR_HIP = -5,           /* a HIP runtime call failed (see gnnmp_last_hip_error)    */
+    GNNMP_ERR_ARG = -6            /* bad scalar argument (loop < 1, negative counts, ...)    */
+} gnnmp_status;
+
+const char* gnnmp_status_string(int status);
+/* hipGetErrorString of the last failing HIP call on this host thread ("" if none). */
+const char* gnnmp_last_hip_error(void);
+/* ABI version of this build (bumped on any incompatible change). */
+int gnnmp_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Explorer   (EncoderProcessDecoder, model.py:48-150)
+ * ---------------------------------------------------------------------------------------- */
+typedef struct gnnmp_explorer gnnmp_explorer;   /* opaque */
+
+typedef struct {
+    int32_t config_size;   /* C  (model.py:49 config_size)                                    */
+    int32_t embed_size;    /* d  (embed_size): 32, 64 or 128                                  */
+    int32_t obs_size;      /* S  (obs_size): obstacles are viewed as [-1, S] (model.py:126)   */
+} gnnmp_explorer_dims;
+
+/* Manifest of the state_dict tensors forward() actually uses (142 of the 200 keys), in the
+ * order the weight blob of gnnmp_explorer_create must concatenate them (row-major fp32, exactly
+ * as stored in the reference's .pt files).  Returns the number of entries when index < 0;
+ * otherwise writes the reference parameter name (NUL-terminated, <= name_cap) and its element
+ * count and returns 0. */
+int gnnmp_explorer_manifest(const gnnmp_explorer_dims* dims, int index,
+                            char* name, size_t name_cap, int64_t* numel);
+
+/* weights_host: HOST pointer to the concatenated manifest tensors; n_floats must equal the
+ * manifest total.  device: HIP device ordinal the handle lives on. */
+int gnnmp_explorer_create(gnnmp_explorer** out, const gnnmp_explorer_dims* dims,
+                          const float* weights_host, size_t n_floats, int device);
+int gnnmp_explorer_destroy(gnnmp_explorer* h);
+
+/* A block-diagonal batch of independent planning graphs (the reference processes one graph per
+ * call; G = 1 reproduces that).  Graph g owns node rows [node_ptr[g], node_ptr[g+1]) of v,
+ * columns [edge_ptr[g], edge_ptr[g+1]) of edge_index and rows [obs_ptr[g], obs_ptr[g+1]) of
+ * obstacles.  edge_index holds GRAPH-LOCAL node ids (what each problem's create_data produced),
+ * row 0 = message source j, row 1 = message target i (PyG flow source_to_target); any order,
+ * duplicates allowed (each column is scored independently). */
+typedef struct {
+    int32_t n_graphs;            /* G >= 1                                                    */
+    int32_t total_nodes;         /* sum_g N_g                                                 */
+    int32_t total_edges;         /* sum_g E_g                                                 */
+    int32_t total_obstacles;     /* sum_g O_g (may be 0)                                      */
+    int32_t max_obstacles;       /* >= max_g O_g (upper bound is fine; sizes the K/V slabs)   */
+    const float* v;              /* [total_nodes, C]                                          */
+    const float* goal;           /* [G, C]                                                    */
+    const float* obstacles;      /* [total_obstacles, S]                                      */
+    const int64_t* edge_index;   /* [2, total_edges]                                          */
+    const int32_t* node_ptr;     /* [G+1]                                                     */
+    const int32_t* edge_ptr;     /* [G+1]                                                     */
+    const int32_t* obs_ptr;      /* [G+1]                                                     */
+} gnnmp_batch;
+
+int gnnmp_explorer_workspace_bytes(const gnnmp_explorer* h, const gnnmp_batch* shape /* counts only */,
+                                   size_t* bytes);
+
+/* edge_scores [total_edges]: score of every edge_index column, in the caller's column order
+ *   (= policy_output[target, source] of model.py:149).
+ * dense_or_null: if non-NULL, sum_g N_g^2 floats; graph g's block starts at sum_{g'<g} N_g'^2 and
+ *   is the reference's zero-filled policy_output[N_g, N_g] with P[target, source] = score.
+ * loop >= 1 (model.py:139); use_obstacles mirrors the attribute read at model.py:125.
+ * workspace must be 256-byte aligned. */
+int gnnmp_explorer_forward(const gnnmp_explorer* h, const gnnmp_batch* batch, int loop, int use_obstacles,
+                           float* edge_scores, float* dense_or_null,
+                           void* workspace, size_t workspace_bytes, void* hip_stream);
+
+/* Test hook: after a forward, copy an intermediate out of `workspace` into `dst` (device, fp32,
+ * row-major, caller node/edge order).  which: 0 = loop-0 encoder output X_0 [total_nodes, d]
+ * (model.py:141), 1 = final h_i [total_nodes, d] (model.py:142), 2 = decode [total_nodes, d]
+ * (model.py:143), 3 = goal node per graph as float [G].  Returns GNNMP_ERR_ARG if unknown. */
+int gnnmp_explorer_debug_tap(const gnnmp_explorer* h, const gnnmp_batch* batch, int which, float* dst,
+                             void* workspace, size_t workspace_bytes, void* hip_stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Smoother   (ModelSmoother, model_smoother.py:46-142)
+ * ---------------------------------------------------------------------------------------- */
+typedef struct gnnmp_smoother gnnmp_smoother;   /* opaque */
+
+typedef struct {
+    int32_t config_size;   /* C                                                               */
+    int32_t embed_size;    /* d (128 in every shipped checkpoint; 32/64/128 supported)         */
+    float scale;           /* ModelSmoother(scale=...) (model_smoother.py:51, str2name.py:40)   */
+} gnnmp_smoother_dims;
+
+int gnnmp_smoother_manifest(const gnnmp_smoother_dims* dims, int index,
+                            char* name, size_t name_cap, int64_t* numel);
+int gnnmp_smoother_create(gnnmp_smoother** out, const gnnmp_smoother_dims* dims,
+                          const float* weights_host, size_t n_floats, int device);
+int gnnmp_smoother_destroy(gnnmp_smoother* h);
+
+/* A batch of independent smoothing problems.  Problem b: path rows [path_ptr[b], path_ptr[b+1]),
+ * free rows [free_ptr[b], ...), collided rows [coll_ptr[b], ...), edge columns
+ * [edge_ptr[b], ...) with node ids local to that problem's [path; free; collided] stacking
+ * (model_smoother.py:121).  The caller's path is never written. */
+typedef struct {
+    int32_t n_problems;
+    int32_t total_path, total_free, total_collided, total_edges;
+    int32_t max_path;            /* >= max_b P_b                                              */
+    int32_t max_samples;         /* >= max_b (F_b + Co_b)                                     */
+    int32_t max_edges;           /* >= max_b E_b                                              */
+    const float* path;           /* [total_path, C]                                           */
+    const float* free_pts;       /* [total_free, C]                                           */
+    const float* collided;       /* [total_collided, C]                                       */
+    const int64_t* edge_index;   /* [2, total_edges]                                          */
+    const int32_t* path_ptr;     /* [B+1]                                                     */
+    const int32_t* free_ptr;     /* [B+1]                                                     */
+    const int32_t* coll_ptr;     /* [B+1]                                                     */
+    const int32_t* edge_ptr;     /* [B+1]                                                     */
+} gnnmp_smooth_batch;
+
+int gnnmp_smoother_workspace_bytes(const gnnmp_smoother* h, const gnnmp_smooth_batch* shape, size_t* bytes);
+
+/* out_path [total_path, C]: the new waypoints (end points copied through, model_smoother.py:139). */
+int gnnmp_smoother_forward(const gnnmp_smoother* h, const gnnmp_smooth_batch* batch, int loop,
+                           float* out_path, void* workspace, size_t workspace_bytes, void* hip_stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Host-only helpers exported for the CPU test-suite (no device needed)
+ * ---------------------------------------------------------------------------------------- */
+/* Pack a row-major weight matrix W[out_f, in_f] (leading dimension ld, column offset col0, n_in
+ * columns used) into the MFMA A-operand tile format consumed by the kernels:
+ * dst[((ot*NTI + it)*1024) + ((r>>2)*64 + lane)*4 + (r&3)] =
+ *     W[32*ot + (lane&31)][col0 + 32*it + phi(r, lane>>5)],  phi(r,h) = (r&3) + 8*(r>>2) + 4*h.
+ * out_f and n_in must be multiples of 32.  Returns the number of floats written. */
+int64_t gnnmp_pack_a_tiles(const float* w, int out_f, int ld, int col0, int n_in, float* dst);
+/* Pack the first-layer ("raw input") form: dst[(ot*ksteps + st)*64 + lane] =
+ *     W[32*ot + (lane&31)][col0 + 2*st + (lane>>5)]  (0 beyond n_in); ksteps = ceil(n_in/2). */
+int64_t gnnmp_pack_a_small(const float* w, int out_f, int ld, int col0, int n_in, float* dst);
+/* Per-feature vector in register order: dst[(t*2 + h)*16 + r] = b[32*t + phi(r,h)]. */
+int64_t gnnmp_pack_vec(const float* b, int n, float* dst);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GNNMP_H */

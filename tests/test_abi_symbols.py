@@ -1,0 +1,36 @@
+"""The C-ABI library loads without a GPU and exports every symbol include/gnnmp.h declares."""
+import ctypes
+import os
+import re
+
+import gnnmp  # noqa: F401
+from gnnmp import _lib
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    src = open(os.path.join(REPO, 'include', 'gnnmp.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(gnnmp_[a-z0-9_]+)\s*\(', src)))
+
+
+def test_every_declared_symbol_is_exported():
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    names = declared_functions()
+    assert len(names) >= 10
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, missing
+
+
+def test_status_strings_and_manifest():
+    L = _lib.lib()
+    assert L.gnnmp_abi_version() >= 1
+    assert L.gnnmp_status_string(0) == b'ok'
+    assert b'dimension' in L.gnnmp_status_string(-2)
+    man = _lib.manifest('explorer', _lib.ExplorerDims(2, 32, 2))
+    assert len(man) == 142 and sum(n for _, n in man) == 70880
+    man = _lib.manifest('explorer', _lib.ExplorerDims(7, 64, 6))
+    assert sum(n for _, n in man) == 280320
+    # unsupported embed size is refused, not silently accepted
+    assert L.gnnmp_explorer_manifest(ctypes.byref(_lib.ExplorerDims(2, 48, 2)), -1, None, 0, None) == -2

@@ -1,0 +1,118 @@
+"""CPU check of the MFMA operand packing (gnnmp_pack_* in include/gnnmp.h) against a numpy
+emulation of v_mfma_f32_32x32x2_f32's lane/register layout: a chain of packed layers evaluated
+exactly the way the kernels' linear_acc / linear_in do must equal plain X @ W^T."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import gnnmp  # noqa: F401
+from gnnmp import _lib
+
+
+def phi(r, h):
+    return (r & 3) + 8 * (r >> 2) + 4 * h
+
+
+LANE = np.arange(64)
+
+
+def mfma(a, b, acc):
+    """acc[r][lane] += sum_k A[i][k] B[k][j]; A[i=l&31][k=l>>5]=a[l]; B[k=l>>5][j=l&31]=b[l];
+    D lane l, reg r <-> (i = phi(r, l>>5), j = l&31)."""
+    A = np.zeros((32, 2)); B = np.zeros((2, 32))
+    A[LANE & 31, LANE >> 5] = a
+    B[LANE >> 5, LANE & 31] = b
+    Dm = A @ B
+    for r in range(16):
+        acc[r] += Dm[phi(r, LANE >> 5), LANE & 31]
+    return acc
+
+
+def to_regs(X, nt):
+    """X [32 rows, 32*nt] -> x[t][r][lane]."""
+    return np.stack([np.stack([X[LANE & 31, 32 * t + phi(r, LANE >> 5)] for r in range(16)]) for t in range(nt)])
+
+
+def from_regs(x):
+    nt = x.shape[0]
+    X = np.zeros((32, 32 * nt))
+    for t in range(nt):
+        for r in range(16):
+            X[LANE & 31, 32 * t + phi(r, LANE >> 5)] = x[t][r]
+    return X
+
+
+def pack_tiles(W, col0, n_in):
+    out_f, ld = W.shape
+    dst = np.zeros((out_f // 32) * (n_in // 32) * 1024, dtype=np.float32)
+    Wc = np.ascontiguousarray(W, dtype=np.float32)
+    n = _lib.lib().gnnmp_pack_a_tiles(Wc.ctypes.data, out_f, ld, col0, n_in, dst.ctypes.data)
+    assert n == dst.size
+    return dst
+
+
+def linear_acc(A, x, y, nto, nti):
+    for it in range(nti):
+        for ot in range(nto):
+            tile = A[(ot * nti + it) * 1024:(ot * nti + it + 1) * 1024]
+            for q in range(4):
+                w = tile[(q * 64 + LANE[:, None]) * 4 + np.arange(4)[None, :]]      # [lane, 4]
+                for c in range(4):
+                    y[ot] = mfma(w[:, c], x[it][q * 4 + c], y[ot])
+    return y
+
+
+@pytest.mark.parametrize('d', [32, 64])
+def test_tile_chain_matches_matmul(d):
+    rng = np.random.default_rng(d)
+    nt = d // 32
+    X = rng.standard_normal((32, d))
+    W1 = rng.standard_normal((d, 3 * d)).astype(np.float32)     # use the middle column block
+    W2 = rng.standard_normal((d, d)).astype(np.float32)
+    A1 = pack_tiles(W1, d, d)
+    A2 = pack_tiles(W2, 0, d)
+    x = to_regs(X, nt)
+    y = linear_acc(A1, x, np.zeros((nt, 16, 64)), nt, nt)
+    y = np.maximum(y, 0)
+    z = linear_acc(A2, y, np.zeros((nt, 16, 64)), nt, nt)
+    ref = np.maximum(X @ W1[:, d:2 * d].T.astype(np.float64), 0) @ W2.T.astype(np.float64)
+    assert np.allclose(from_regs(z), ref, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize('n_in', [2, 5, 8, 28])
+def test_small_first_layer(n_in):
+    d = 64
+    nt = d // 32
+    rng = np.random.default_rng(n_in)
+    W = rng.standard_normal((d, n_in)).astype(np.float32)
+    X = rng.standard_normal((32, n_in))
+    ks = (n_in + 1) // 2
+    dst = np.zeros(nt * ks * 64, dtype=np.float32)
+    assert _lib.lib().gnnmp_pack_a_small(W.ctypes.data, d, n_in, 0, n_in, dst.ctypes.data) == dst.size
+    y = np.zeros((nt, 16, 64))
+    for st in range(ks):
+        k = 2 * st + (LANE >> 5)
+        b = np.where(k < n_in, X[LANE & 31, np.minimum(k, n_in - 1)], 0.0)
+        for ot in range(nt):
+            y[ot] = mfma(dst[(ot * ks + st) * 64 + LANE], b, y[ot])
+    assert np.allclose(from_regs(y), X @ W.T.astype(np.float64), rtol=1e-6, atol=1e-6)
+
+
+def test_vec_order():
+    d = 64
+    b = np.arange(d, dtype=np.float32)
+    dst = np.zeros(d, dtype=np.float32)
+    assert _lib.lib().gnnmp_pack_vec(b.ctypes.data, d, dst.ctypes.data) == d
+    for t in range(2):
+        for h in range(2):
+            for r in range(16):
+                assert dst[(t * 2 + h) * 16 + r] == 32 * t + phi(r, h)
+
+
+def test_obstacle_value_transpose_rule():
+    """obs_kernel writes V[o][f] (held as row j = o, register r, half h) into the A tile of the
+    P.V product, whose (lane', r') element must be V[o = phi(r', lane'>>5)][f = lane'&31]."""
+    for j in range(32):
+        hp, rp = (j >> 2) & 1, (j & 3) + 4 * (j >> 3)
+        assert phi(rp, hp) == j
