@@ -1,0 +1,200 @@
+#!/usr/bin/env python
+"""Headline benchmark: RGG graphs/s of the GNN explorer forward on MI355X (BASELINE.json).
+
+A step = one explorer forward (loop=5, use_obstacles=True, all E edge scores produced) over one
+batch of 256 independent synthetic 1000-node k=8 maze2 RGGs (BASELINE.json configs[1]) with the
+inputs already resident in HBM; everything the reference's forward() does per call is inside the
+timed region (CSR build from the raw edge_index included).  N > 1: one process per GPU, every rank
+owns its own 256 problems (weak scaling, no data-path collective); the only RCCL traffic is the
+result gather after the timed region.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
+        --master-port P bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, 'tests'))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_FP32_TFLOPS = 157.3      # MI355X fp32 matrix = vector peak (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0
+
+
+def algorithmic_flops(N, E, O, C, d, S, L):
+    """FLOPs of the reference formulation per graph (2 per MAC)."""
+    f_enc = 2 * N * (4 * C * d + d * d) + 2 * 2 * E * (2 * C * d + d * d) + 2 * N * (C * d + d * d) \
+        + 2 * 2 * O * (S * d + d * d)
+    f_att = 3 * ((N + E) * (10 * d * d + 4 * d * (O + 1)) + 16 * O * d * d)
+    f_loop = L * (8 * N * d * d + 12 * E * d * d + E * d + 4 * N * d * d) + 4 * N * d * d
+    f_pol = E * (8 * d * d + 2 * d)
+    return f_enc + f_att + f_loop + f_pol
+
+
+def edge_pre_flops(E, O, C, d):
+    """Reference-formulation FLOPs of what the dominant kernel (edge_pre) replaces: the two edge
+    encoders (model.py:120,123) and the three edge attention blocks (model.py:128-130, map rows)."""
+    return 2 * 2 * E * (2 * C * d + d * d) + 3 * E * (10 * d * d + 4 * d * (O + 1))
+
+
+def algorithmic_bytes(N, E, O, C, S):
+    """SURVEY.md section 8(d) B_sparse: v, goal, obstacles, int32 edge pairs, scores out."""
+    return 4 * N * C + 4 * C + 4 * O * S + 8 * E + 4 * E
+
+
+def cpu_baseline(env, n_nodes, k1, budget_s, seed0):
+    """The oracle (a port of the reference's CPU path, materialising attention form) timed on this
+    host: single-graph calls in a loop exactly like eval_gnn.py:113-116,194."""
+    from conftest import load_weights
+    from gnnmp.synth import ENVS, synth_graph
+    from oracle import ref_cpu
+    w = load_weights(ENVS[env]['ckpt'])
+    threads = torch.get_num_threads()
+    graphs = [synth_graph(env, n_nodes, k1, seed=seed0 + i) for i in range(4)]
+    run = lambda g: ref_cpu.explorer_forward(w, g['v'], g['goal'], g['obstacles'], g['edge_index'], 5,  # noqa: E731
+                                             materialize=True)
+    run(graphs[0])                      # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        run(graphs[n % len(graphs)])
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 64:
+            break
+    return {'value': n / el, 'unit': 'graphs/s', 'cores': threads, 'kind': 'port',
+            'sample': '%d single-graph oracle forwards (%s N=%d k1=%d loop=5, materialising attention as '
+                      'model.py:178-179) in %.1f s on %d torch CPU threads' % (n, env, n_nodes, k1, el, threads)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--graphs', type=int, default=256, help='graphs per GPU per step')
+    ap.add_argument('--env', default='maze2')
+    ap.add_argument('--nodes', type=int, default=1000)
+    ap.add_argument('--k1', type=int, default=8)
+    ap.add_argument('--loop', type=int, default=5)
+    ap.add_argument('--cpu-seconds', type=float, default=15.0)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--unique', type=int, default=0, help='distinct synthetic graphs per GPU (0 = all)')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('launch with torch.distributed.run --nproc-per-node %d for --gpus %d' % (args.gpus, args.gpus))
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        dist.init_process_group('nccl', device_id=dev)
+
+    import gnnmp
+    from conftest import load_weights
+    from gnnmp.synth import ENVS, synth_graph
+    e = ENVS[args.env]
+    G = args.graphs
+    uniq = G if args.unique <= 0 else min(G, args.unique)
+    base = [synth_graph(args.env, args.nodes, args.k1, seed=1234 + rank * G + i) for i in range(uniq)]
+    graphs = [base[i % uniq] for i in range(G)]
+    batch = gnnmp.GraphBatch.from_graphs(graphs, e['S'], dev)
+    model = gnnmp.EncoderProcessDecoder(e['workspace'], e['C'], e['d'], e['S'])
+    model.load_state_dict(load_weights(e['ckpt']), strict=True)
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    scores = None
+    for _ in range(args.warmup):
+        scores = model.forward_batch(batch, args.loop)
+    model.profile(dev, True)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        scores = model.forward_batch(batch, args.loop)
+    sync()
+    elapsed = time.perf_counter() - t0
+    prof = model.profile_read(dev)
+    model.profile(dev, False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # final result gather (the only collective of the job): per-rank edge scores -> every rank
+    checksum = float(scores.double().sum().item())
+    if world > 1:
+        n = torch.tensor([scores.numel()], dtype=torch.int64, device=dev)
+        sizes = [torch.zeros_like(n) for _ in range(world)]
+        dist.all_gather(sizes, n)
+        cap = int(max(int(s.item()) for s in sizes))
+        pad = torch.zeros(cap, dtype=torch.float32, device=dev)
+        pad[:scores.numel()] = scores
+        out = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(out, pad)
+        checksum = float(sum(o[:int(s.item())].double().sum().item() for o, s in zip(out, sizes)))
+
+    if rank == 0:
+        Ns = [g['v'].shape[0] for g in graphs]
+        Es = [g['edge_index'].shape[1] for g in graphs]
+        Os = [g['obstacles'].reshape(-1, e['S']).shape[0] for g in graphs]
+        flops_batch = sum(algorithmic_flops(n, m, o, e['C'], e['d'], e['S'], args.loop) for n, m, o in zip(Ns, Es, Os))
+        bytes_batch = sum(algorithmic_bytes(n, m, o, e['C'], e['S']) for n, m, o in zip(Ns, Es, Os))
+        ep_flops = sum(edge_pre_flops(m, o, e['C'], e['d']) for m, o in zip(Es, Os))
+        ep_ms, ep_n = prof['edge_pre']
+        ep_avg_ms = ep_ms / max(ep_n, 1)
+        achieved = ep_flops / (ep_avg_ms * 1e-3) / 1e12 if ep_avg_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(REPO, 'profiles', 'edge_pre_traffic.json')
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get('hbm_bytes_per_launch')
+            except Exception:
+                traffic = None
+        ms_step = elapsed / args.steps * 1e3
+        value = world * G * args.steps / elapsed
+        stages = {k: round(v[0] / max(args.steps, 1), 4) for k, v in prof.items()}
+        res = {
+            'metric': 'RGG graphs/sec (GNN explorer forward), 1000-node k=8',
+            'value': round(value, 2), 'unit': 'graphs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(ms_step, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'BASELINE configs[1]: %s, batch of %d problems per GPU, %d-node k1=%d RGGs '
+                                   '(mean E=%.0f, O=%d), loop=%d, use_obstacles, real %s checkpoint, fp32, sparse '
+                                   'per-edge scores' % (args.env, G, args.nodes, args.k1, sum(Es) / len(Es), Os[0],
+                                                        args.loop, e['ckpt']),
+                       'graphs_per_gpu': G, 'parallelism': 'problem-sharded x%d' % world,
+                       'whole_forward': {'algorithmic_TFLOPs': round(flops_batch * args.steps / elapsed / 1e12, 2),
+                                         'algorithmic_GBs': round(bytes_batch * args.steps / elapsed / 1e9, 3),
+                                         'frac_fp32_peak': round(flops_batch * args.steps / elapsed / 1e12 / PEAK_FP32_TFLOPS, 4),
+                                         'frac_hbm_peak': round(bytes_batch * args.steps / elapsed / 1e9 / PEAK_HBM_GBS, 6)},
+                       'stage_ms_per_step': stages, 'result_checksum': checksum},
+            'roofline': {'kernel': 'pre_kernel<%d,EDGE> (edge encoders + 3 obstacle-attention blocks)' % e['d'],
+                         'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_FP32_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': round(achieved / PEAK_FP32_TFLOPS, 4), 'traffic': traffic,
+                         'launch_ms': round(ep_avg_ms, 4), 'algorithmic_flops_per_launch': ep_flops},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res['cpu_baseline'] = cpu_baseline(args.env, args.nodes, args.k1, args.cpu_seconds, 1234)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

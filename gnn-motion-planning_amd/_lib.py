@@ -36,6 +36,8 @@ class SmoothBatch(ctypes.Structure):
                 ('coll_ptr', ctypes.c_void_p), ('edge_ptr', ctypes.c_void_p)]
 
 
+STAGES = ('prep', 'obs', 'node_pre', 'edge_pre', 'mp_edge', 'mp_node', 'policy')
+
 _lib = None
 
 
@@ -60,6 +62,8 @@ def lib():
     L.gnnmp_explorer_workspace_bytes.argtypes = [vp, ctypes.POINTER(Batch), ctypes.POINTER(sz)]
     L.gnnmp_explorer_forward.argtypes = [vp, ctypes.POINTER(Batch), ctypes.c_int, ctypes.c_int, vp, vp, vp, sz, vp]
     L.gnnmp_explorer_debug_tap.argtypes = [vp, ctypes.POINTER(Batch), ctypes.c_int, vp, vp, sz, vp]
+    L.gnnmp_explorer_profile.argtypes = [vp, ctypes.c_int]
+    L.gnnmp_explorer_profile_read.argtypes = [vp, ctypes.POINTER(ctypes.c_double), c_int64_p]
     L.gnnmp_pack_a_tiles.restype = ctypes.c_int64
     L.gnnmp_pack_a_tiles.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp]
     L.gnnmp_pack_a_small.restype = ctypes.c_int64

@@ -168,6 +168,20 @@ extern "C" int gnnmp_abi_version(void) { return 1; }
 // ---------------------------------------------------------------------------------------------
 // explorer handle
 // ---------------------------------------------------------------------------------------------
+// optional per-stage timing with HIP events recorded on the forward's own stream
+struct StageProf {
+    bool on = false;
+    struct Rec { int stage; hipEvent_t a, b; };
+    std::vector<Rec> recs;
+    std::vector<hipEvent_t> pool;
+    hipEvent_t get() {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        (void)hipEventCreate(&e);
+        return e;
+    }
+};
+
 struct gnnmp_explorer {
     gnnmp_explorer_dims dims;
     int device;
@@ -175,7 +189,22 @@ struct gnnmp_explorer {
     ExplorerOffsets off;
     EncBlob enc_e, enc_n;
     ObsBlob obs;
+    StageProf* prof;      // mutable side state (profiling is single-threaded by contract)
 };
+
+namespace {
+struct StageScope {
+    StageProf* p; hipStream_t st; hipEvent_t b = nullptr;
+    StageScope(StageProf* p_, int stage, hipStream_t s) : p(p_ && p_->on ? p_ : nullptr), st(s) {
+        if (!p) return;
+        hipEvent_t a = p->get();
+        b = p->get();
+        (void)hipEventRecord(a, st);
+        p->recs.push_back({stage, a, b});
+    }
+    ~StageScope() { if (p) (void)hipEventRecord(b, st); }
+};
+}  // namespace
 
 extern "C" int gnnmp_explorer_manifest(const gnnmp_explorer_dims* dims, int index, char* name, size_t name_cap,
                                        int64_t* numel) {
@@ -364,6 +393,7 @@ extern "C" int gnnmp_explorer_create(gnnmp_explorer** out, const gnnmp_explorer_
     h->dims = *dims;
     h->device = device;
     h->w_dev = nullptr;
+    h->prof = new StageProf();
     std::vector<float> packed;
     if (dims->embed_size == 32) pack_explorer<32>(B, *dims, h, packed);
     else pack_explorer<64>(B, *dims, h, packed);
@@ -372,6 +402,7 @@ extern "C" int gnnmp_explorer_create(gnnmp_explorer** out, const gnnmp_explorer_
     if (e == hipSuccess) e = hipMemcpy(h->w_dev, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         if (h->w_dev) (void)hipFree(h->w_dev);
+        delete h->prof;
         delete h;
         return hip_fail(e);
     }
@@ -382,7 +413,34 @@ extern "C" int gnnmp_explorer_create(gnnmp_explorer** out, const gnnmp_explorer_
 extern "C" int gnnmp_explorer_destroy(gnnmp_explorer* h) {
     if (!h) return GNNMP_ERR_NULL;
     if (h->w_dev) (void)hipFree(h->w_dev);
+    if (h->prof) {
+        for (auto& r : h->prof->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+        for (auto e : h->prof->pool) (void)hipEventDestroy(e);
+        delete h->prof;
+    }
     delete h;
+    return GNNMP_OK;
+}
+
+extern "C" int gnnmp_explorer_profile(gnnmp_explorer* h, int enable) {
+    if (!h) return GNNMP_ERR_NULL;
+    h->prof->on = enable != 0;
+    return GNNMP_OK;
+}
+
+extern "C" int gnnmp_explorer_profile_read(gnnmp_explorer* h, double* ms_sum, int64_t* launches) {
+    if (!h || !ms_sum || !launches) return GNNMP_ERR_NULL;
+    for (int i = 0; i < GNNMP_N_STAGES; ++i) { ms_sum[i] = 0.0; launches[i] = 0; }
+    for (auto& r : h->prof->recs) {
+        HIP_TRY(hipEventSynchronize(r.b));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, r.a, r.b));
+        ms_sum[r.stage] += ms;
+        launches[r.stage] += 1;
+        h->prof->pool.push_back(r.a);
+        h->prof->pool.push_back(r.b);
+    }
+    h->prof->recs.clear();
     return GNNMP_OK;
 }
 
@@ -506,10 +564,13 @@ extern "C" int gnnmp_explorer_forward(const gnnmp_explorer* h, const gnnmp_batch
     const int D = h->dims.embed_size, C = h->dims.config_size;
     const float* W = h->w_dev;
 
+    StageProf* prof = h->prof;
+    PrepParams q;
+    {
+    StageScope sc(prof, GNNMP_STAGE_PREP, st);
     HIP_TRY(hipMemsetAsync(at<char>(ws, c.zero_beg), 0, c.zero_end - c.zero_beg, st));
     HIP_TRY(hipMemsetAsync(at<char>(ws, c.ff_beg), 0xFF, c.ff_end - c.ff_beg, st));
 
-    PrepParams q;
     q.G = c.G; q.E = b->total_edges; q.C = C;
     q.edge_index = reinterpret_cast<const long long*>(b->edge_index);
     q.node_ptr = b->node_ptr; q.edge_ptr = b->edge_ptr; q.v = b->v; q.goal = b->goal;
@@ -522,6 +583,7 @@ extern "C" int gnnmp_explorer_forward(const gnnmp_explorer* h, const gnnmp_batch
     HIP_TRY(launch_prep(q, st));
     // zero-fill of policy_output (model.py:148); sum_g N_g^2 is read from dense_ptr[G] on the device
     if (dense) HIP_TRY(launch_zero_dense(dense, q.dense_ptr + c.G, st));
+    }
 
     const bool use_obs = use_obstacles != 0;
     if (use_obs) {
@@ -531,6 +593,7 @@ extern "C" int gnnmp_explorer_forward(const gnnmp_explorer* h, const gnnmp_batch
         op.blob = h->obs;
         op.kv[0] = at<float>(ws, c.kv_n); op.kv[1] = at<float>(ws, c.kv_e);
         op.kv_stride = c.kv_stride; op.ot_max = c.ot_max;
+        StageScope sc(prof, GNNMP_STAGE_OBS, st);
         HIP_TRY(launch_obs(D, op, c.G, st));
     }
 
@@ -557,6 +620,7 @@ extern "C" int gnnmp_explorer_forward(const gnnmp_explorer* h, const gnnmp_batch
             p.o3 = at<float>(ws, c.B); p.o4 = at<float>(ws, c.DN);
         }
         if (edge && b->total_edges == 0) continue;
+        StageScope sc(prof, edge ? GNNMP_STAGE_EDGE_PRE : GNNMP_STAGE_NODE_PRE, st);
         HIP_TRY(launch_pre(D, edge != 0, pl.waves, p, (edge ? c.Epad : c.Npad) / 32, pl.lds_bytes, st));
     }
 
@@ -571,6 +635,7 @@ extern "C" int gnnmp_explorer_forward(const gnnmp_explorer* h, const gnnmp_batch
             e.agg = at<float>(ws, c.agg); e.part_first = at<float>(ws, c.part_first);
             e.part_last = at<float>(ws, c.part_last);
             e.n_tiles = c.Epad / 32;
+            StageScope sc(prof, GNNMP_STAGE_MP_EDGE, st);
             HIP_TRY(launch_mp_edge(D, e, st));
         }
         MpNodeParams n;
@@ -580,6 +645,7 @@ extern "C" int gnnmp_explorer_forward(const gnnmp_explorer* h, const gnnmp_batch
         n.w = W + (last ? h->off.mpn_last : h->off.mpn);
         n.Hout = at<float>(ws, c.H); n.Xout = at<float>(ws, c.X); n.Aout = at<float>(ws, c.A); n.Bout = at<float>(ws, c.B);
         n.n_tiles = c.Npad / 32;
+        StageScope sc(prof, GNNMP_STAGE_MP_NODE, st);
         HIP_TRY(launch_mp_node(D, n, st));
     }
 
@@ -591,6 +657,7 @@ extern "C" int gnnmp_explorer_forward(const gnnmp_explorer* h, const gnnmp_batch
         p.w = W + h->off.pol;
         p.scores = edge_scores; p.dense = dense;
         p.n_tiles = c.Epad / 32;
+        StageScope sc(prof, GNNMP_STAGE_POLICY, st);
         HIP_TRY(launch_policy(D, p, st));
     }
     return GNNMP_OK;

@@ -181,6 +181,19 @@ class EncoderProcessDecoder(nn.Module):
                 dn.data_ptr() if dense else None, ws.data_ptr(), ws.numel(), st), 'gnnmp_explorer_forward')
         return (scores, dn) if dense else scores
 
+    def profile(self, device, enable=True):
+        """Switch per-stage HIP-event timing on/off for this module's handle on ``device``."""
+        _lib.check(_lib.lib().gnnmp_explorer_profile(self._native(torch.device(device)), 1 if enable else 0),
+                   'gnnmp_explorer_profile')
+
+    def profile_read(self, device):
+        """{stage: (milliseconds summed, launches)} since the last read (waits for the events)."""
+        ms = (ctypes.c_double * len(_lib.STAGES))()
+        cnt = (ctypes.c_int64 * len(_lib.STAGES))()
+        _lib.check(_lib.lib().gnnmp_explorer_profile_read(self._native(torch.device(device)), ms, cnt),
+                   'gnnmp_explorer_profile_read')
+        return {n: (ms[i], int(cnt[i])) for i, n in enumerate(_lib.STAGES)}
+
     def debug_tap(self, batch, which):
         """Intermediate of the LAST forward_batch on this module (tests only; see gnnmp.h)."""
         dev = batch.v.device

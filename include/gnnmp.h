@@ -58,7 +58,7 @@ typedef struct gnnmp_explorer gnnmp_explorer;   /* opaque */
 
 typedef struct {
     int32_t config_size;   /* C  (model.py:49 config_size)                                    */
-    int32_t embed_size;    /* d  (embed_size): 32, 64 or 128                                  */
+    int32_t embed_size;    /* d  (embed_size): 32 or 64 (every shipped checkpoint)             */
     int32_t obs_size;      /* S  (obs_size): obstacles are viewed as [-1, S] (model.py:126)   */
 } gnnmp_explorer_dims;
 
@@ -110,9 +110,28 @@ int gnnmp_explorer_forward(const gnnmp_explorer* h, const gnnmp_batch* batch, in
                            float* edge_scores, float* dense_or_null,
                            void* workspace, size_t workspace_bytes, void* hip_stream);
 
+/* Optional per-stage timing.  While enabled, every forward on this handle records a HIP event pair
+ * around each stage ON THE STREAM THE STAGE IS LAUNCHED ON; gnnmp_explorer_profile_read waits for
+ * the recorded events, returns the summed milliseconds and the number of launches per stage since
+ * the last read, and recycles the events.  Profiling mutates the handle: use it from one host
+ * thread.  (There is no reference counterpart; eval_gnn.py:193-196 only wall-clocks the call.) */
+enum {
+    GNNMP_STAGE_PREP = 0,      /* memsets + CSR-by-destination build + goal node                */
+    GNNMP_STAGE_OBS = 1,       /* obstacle codes and K/V operands                               */
+    GNNMP_STAGE_NODE_PRE = 2,  /* node encoders + 3 attention blocks + loop invariants          */
+    GNNMP_STAGE_EDGE_PRE = 3,  /* edge encoders + 3 attention blocks + loop invariants (dominant) */
+    GNNMP_STAGE_MP_EDGE = 4,   /* message MLP + segmented max, one launch per loop iteration    */
+    GNNMP_STAGE_MP_NODE = 5,   /* node update, one launch per loop iteration                    */
+    GNNMP_STAGE_POLICY = 6,    /* per-edge policy head                                          */
+    GNNMP_N_STAGES = 7
+};
+int gnnmp_explorer_profile(gnnmp_explorer* h, int enable);
+int gnnmp_explorer_profile_read(gnnmp_explorer* h, double* ms_sum /* [GNNMP_N_STAGES] */,
+                                int64_t* launches /* [GNNMP_N_STAGES] */);
+
 /* Test hook: after a forward, copy an intermediate out of `workspace` into `dst` (device, fp32,
- * row-major, caller node/edge order).  which: 0 = loop-0 encoder output X_0 [total_nodes, d]
- * (model.py:141), 1 = final h_i [total_nodes, d] (model.py:142), 2 = decode [total_nodes, d]
+ * row-major, caller node/edge order).  which: 0 = loop-invariant part of the encoder output [total_nodes, d]
+ * (model.py:141 without the h_i term), 1 = final h_i [total_nodes, d] (model.py:142), 2 = decode [total_nodes, d]
  * (model.py:143), 3 = goal node per graph as float [G].  Returns GNNMP_ERR_ARG if unknown. */
 int gnnmp_explorer_debug_tap(const gnnmp_explorer* h, const gnnmp_batch* batch, int which, float* dst,
                              void* workspace, size_t workspace_bytes, void* hip_stream);
