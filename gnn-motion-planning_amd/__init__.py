@@ -9,5 +9,6 @@ tensors, raises.
 from . import graph_build, synth  # noqa: F401  (host-side helpers, no native code needed)
 from .batch import GraphBatch  # noqa: F401
 from .explorer import EncoderProcessDecoder  # noqa: F401
+from .smoother import ModelSmoother, SmoothBatch  # noqa: F401
 
-__all__ = ['graph_build', 'synth', 'GraphBatch', 'EncoderProcessDecoder']
+__all__ = ['graph_build', 'synth', 'GraphBatch', 'EncoderProcessDecoder', 'ModelSmoother', 'SmoothBatch']

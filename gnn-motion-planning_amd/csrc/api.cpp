@@ -515,7 +515,7 @@ struct PrePlan { int waves, ot_chunk, wregion; size_t lds_bytes; };
 
 PrePlan plan_pre(int D, int ot_max, int enc_size, int out_size, bool use_obs) {
     const int NT = D / 32;
-    const int att = (D == 32) ? AttBlob<32>::size : AttBlob<64>::size;
+    const int att = (D == 32) ? AttBlob<32>::staged : AttBlob<64>::staged;
     int wr = enc_size > out_size ? enc_size : out_size;
     if (use_obs && att > wr) wr = att;
     wr = (wr + 3) & ~3;
@@ -682,5 +682,225 @@ extern "C" int gnnmp_explorer_debug_tap(const gnnmp_explorer* h, const gnnmp_bat
         default: return GNNMP_ERR_ARG;
     }
     HIP_TRY(launch_unpad_rows(c.G, b->total_nodes, D, b->node_ptr, at<int>(ws, c.node_ptr_pad), at<float>(ws, src), dst, st));
+    return GNNMP_OK;
+}
+
+// =============================================================================================
+// smoother
+// =============================================================================================
+namespace {
+
+std::vector<Entry> smoother_manifest(const gnnmp_smoother_dims& d) {
+    const int C = d.config_size, D = d.embed_size;
+    std::vector<Entry> m;
+    auto lin = [&](const std::string& n, int out, int in) {
+        m.push_back({n + ".weight", out, in});
+        m.push_back({n + ".bias", out, 0});
+    };
+    lin("node_code.0", D, C + 3);
+    m.push_back({"node_code.1.weight", D, 0});
+    m.push_back({"node_code.1.bias", D, 0});
+    m.push_back({"node_code.1.running_mean", D, 0});
+    m.push_back({"node_code.1.running_var", D, 0});
+    lin("node_code.3", D, D);
+    lin("process.lin_0.0", D, 3 * D);
+    lin("process.lin_0.2", D, D);
+    lin("process.lin_1.0", D, D);
+    lin("process.lin_1.2", D, D);
+    lin("smooth_node", C, D);
+    return m;
+}
+
+bool sm_dims_ok(const gnnmp_smoother_dims& d) {
+    return d.config_size >= 1 && d.config_size <= 29 && (d.embed_size == 32 || d.embed_size == 64 || d.embed_size == 128) &&
+           d.scale > 0.f;
+}
+
+}  // namespace
+
+struct gnnmp_smoother {
+    gnnmp_smoother_dims dims;
+    int device;
+    float* w_dev;
+    SmLayout L;
+};
+
+extern "C" int gnnmp_smoother_manifest(const gnnmp_smoother_dims* dims, int index, char* name, size_t name_cap,
+                                       int64_t* numel) {
+    if (!dims) return GNNMP_ERR_NULL;
+    if (!sm_dims_ok(*dims)) return GNNMP_ERR_DIMS;
+    const auto m = smoother_manifest(*dims);
+    if (index < 0) return (int)m.size();
+    if (index >= (int)m.size()) return GNNMP_ERR_ARG;
+    if (name && name_cap) {
+        std::strncpy(name, m[index].name.c_str(), name_cap - 1);
+        name[name_cap - 1] = 0;
+    }
+    if (numel) *numel = m[index].numel();
+    return GNNMP_OK;
+}
+
+extern "C" int gnnmp_smoother_create(gnnmp_smoother** out, const gnnmp_smoother_dims* dims, const float* weights_host,
+                                     size_t n_floats, int device) {
+    if (!out || !dims || !weights_host) return GNNMP_ERR_NULL;
+    if (!sm_dims_ok(*dims)) return GNNMP_ERR_DIMS;
+    Blob B;
+    B.man = smoother_manifest(*dims);
+    B.base = weights_host;
+    int64_t tot = 0;
+    for (auto& e : B.man) { B.off.push_back(tot); tot += e.numel(); }
+    if ((int64_t)n_floats != tot) return GNNMP_ERR_WEIGHTS;
+    const int C = dims->config_size, D = dims->embed_size;
+    gnnmp_smoother* h = new gnnmp_smoother();
+    h->dims = *dims;
+    h->device = device;
+    h->w_dev = nullptr;
+    h->L = SmLayout::make(D, C);
+    const SmLayout& L = h->L;
+    std::vector<float> P(L.total, 0.f);
+    auto W = [&](const std::string& n) { return B.get(n); };
+    // fold eval-mode BatchNorm (eps 1e-5) into node_code.0:  y = (W x + b - mean) * g + beta,  g = gamma / sqrt(var + eps)
+    {
+        const float *w0 = W("node_code.0.weight"), *b0 = W("node_code.0.bias"), *ga = W("node_code.1.weight"),
+                    *be = W("node_code.1.bias"), *mu = W("node_code.1.running_mean"), *va = W("node_code.1.running_var");
+        const int K = C + 3;
+        std::vector<float> wf((size_t)D * K), bf(D);
+        for (int i = 0; i < D; ++i) {
+            const float g = ga[i] / std::sqrt(va[i] + 1e-5f);
+            for (int k = 0; k < K; ++k) wf[(size_t)i * K + k] = w0[(size_t)i * K + k] * g;
+            bf[i] = (b0[i] - mu[i]) * g + be[i];
+        }
+        gnnmp_pack_a_small(wf.data(), D, K, 0, K, P.data() + L.as0);
+        gnnmp_pack_vec(bf.data(), D, P.data() + L.b0);
+    }
+    gnnmp_pack_a_tiles(W("node_code.3.weight"), D, D, 0, D, P.data() + L.w3);
+    gnnmp_pack_vec(W("node_code.3.bias"), D, P.data() + L.b3);
+    {
+        const float* w1 = W("process.lin_0.0.weight");      // [x_j - x_i | x_j | x_i]  model_smoother.py:37
+        std::vector<float> ws((size_t)D * D), wd((size_t)D * D);
+        for (int i = 0; i < D; ++i)
+            for (int k = 0; k < D; ++k) {
+                const float a = w1[(size_t)i * 3 * D + k], b = w1[(size_t)i * 3 * D + D + k], c = w1[(size_t)i * 3 * D + 2 * D + k];
+                ws[(size_t)i * D + k] = a + b;
+                wd[(size_t)i * D + k] = c - a;
+            }
+        gnnmp_pack_a_tiles(ws.data(), D, D, 0, D, P.data() + L.wsrc);
+        gnnmp_pack_a_tiles(wd.data(), D, D, 0, D, P.data() + L.wdst);
+        gnnmp_pack_vec(W("process.lin_0.0.bias"), D, P.data() + L.b00);
+    }
+    gnnmp_pack_a_tiles(W("process.lin_0.2.weight"), D, D, 0, D, P.data() + L.w02);
+    gnnmp_pack_vec(W("process.lin_0.2.bias"), D, P.data() + L.b02);
+    gnnmp_pack_a_tiles(W("process.lin_1.0.weight"), D, D, 0, D, P.data() + L.w10);
+    gnnmp_pack_vec(W("process.lin_1.0.bias"), D, P.data() + L.b10);
+    gnnmp_pack_a_tiles(W("process.lin_1.2.weight"), D, D, 0, D, P.data() + L.w12);
+    gnnmp_pack_vec(W("process.lin_1.2.bias"), D, P.data() + L.b12);
+    {
+        std::vector<float> ws((size_t)32 * D, 0.f), bs(32, 0.f);
+        const float *w = W("smooth_node.weight"), *b = W("smooth_node.bias");
+        for (int i = 0; i < C; ++i) {
+            for (int k = 0; k < D; ++k) ws[(size_t)i * D + k] = w[(size_t)i * D + k];
+            bs[i] = b[i];
+        }
+        gnnmp_pack_a_tiles(ws.data(), 32, D, 0, D, P.data() + L.ws);
+        gnnmp_pack_vec(bs.data(), 32, P.data() + L.bs);
+    }
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipMalloc((void**)&h->w_dev, P.size() * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(h->w_dev, P.data(), P.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        if (h->w_dev) (void)hipFree(h->w_dev);
+        delete h;
+        return hip_fail(e);
+    }
+    *out = h;
+    return GNNMP_OK;
+}
+
+extern "C" int gnnmp_smoother_destroy(gnnmp_smoother* h) {
+    if (!h) return GNNMP_ERR_NULL;
+    if (h->w_dev) (void)hipFree(h->w_dev);
+    delete h;
+    return GNNMP_OK;
+}
+
+namespace {
+struct SmCarve {
+    int ecap, pcap;
+    size_t cur, knn, e_src, e_dst, e_count, seg_beg, seg_cnt, ff_beg, etile, ptile, ff_end, msg, total;
+};
+
+bool sm_carve(const gnnmp_smoother* h, const gnnmp_smooth_batch* b, SmCarve& c) {
+    if (b->n_problems < 1 || b->total_path < 0 || b->total_edges < 0 || b->total_free < 0 || b->total_collided < 0)
+        return false;
+    const int D = h->dims.embed_size, C = h->dims.config_size;
+    const long long ecap = (long long)b->total_edges + (long long)kSmK * b->total_path + 64LL * b->n_problems + 32;
+    const long long pcap = (long long)b->total_path + 64LL * b->n_problems + 32;
+    if (ecap > 0x3fffffff || pcap > 0x3fffffff) return false;
+    c.ecap = (int)((ecap + 31) / 32 * 32);
+    c.pcap = (int)((pcap + 31) / 32 * 32);
+    size_t o = 0;
+    auto take = [&](size_t bytes) { const size_t r = o; o += (bytes + 255) & ~(size_t)255; return r; };
+    c.cur = take(sizeof(float) * (size_t)b->total_path * C);
+    c.knn = take(sizeof(int) * (size_t)b->total_path * kSmK);
+    c.e_src = take(sizeof(int) * c.ecap);
+    c.e_dst = take(sizeof(int) * c.ecap);
+    c.e_count = take(sizeof(int) * b->n_problems);
+    c.seg_beg = take(sizeof(int) * c.pcap);
+    c.seg_cnt = take(sizeof(int) * c.pcap);
+    c.ff_beg = o;
+    c.etile = take(sizeof(int) * (c.ecap / 32));
+    c.ptile = take(sizeof(int) * (c.pcap / 32));
+    c.ff_end = o;
+    c.msg = take(sizeof(float) * (size_t)c.ecap * D);
+    c.total = o;
+    return true;
+}
+}  // namespace
+
+extern "C" int gnnmp_smoother_workspace_bytes(const gnnmp_smoother* h, const gnnmp_smooth_batch* shape, size_t* bytes) {
+    if (!h || !shape || !bytes) return GNNMP_ERR_NULL;
+    SmCarve c;
+    if (!sm_carve(h, shape, c)) return GNNMP_ERR_ARG;
+    *bytes = c.total;
+    return GNNMP_OK;
+}
+
+extern "C" int gnnmp_smoother_forward(const gnnmp_smoother* h, const gnnmp_smooth_batch* b, int loop, float* out_path,
+                                      void* ws, size_t ws_bytes, void* hip_stream) {
+    if (!h || !b || !ws || !out_path) return GNNMP_ERR_NULL;
+    if (!b->path || !b->path_ptr || !b->free_ptr || !b->coll_ptr || !b->edge_ptr) return GNNMP_ERR_NULL;
+    if ((b->total_free > 0 && !b->free_pts) || (b->total_collided > 0 && !b->collided) ||
+        (b->total_edges > 0 && !b->edge_index))
+        return GNNMP_ERR_NULL;
+    if (loop < 0) return GNNMP_ERR_ARG;
+    if (b->max_samples > 2048) return GNNMP_ERR_DIMS;          // kNN keeps <= 32 samples per lane
+    SmCarve c;
+    if (!sm_carve(h, b, c)) return GNNMP_ERR_ARG;
+    if (ws_bytes < c.total || (reinterpret_cast<uintptr_t>(ws) & 255)) return GNNMP_ERR_WORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    const int C = h->dims.config_size, D = h->dims.embed_size;
+    SmParams p;
+    p.B = b->n_problems; p.C = C; p.total_path = b->total_path; p.total_edges = b->total_edges;
+    p.scale = h->dims.scale;
+    p.path = b->path; p.free_pts = b->free_pts; p.collided = b->collided;
+    p.edge_index = reinterpret_cast<const long long*>(b->edge_index);
+    p.path_ptr = b->path_ptr; p.free_ptr = b->free_ptr; p.coll_ptr = b->coll_ptr; p.edge_ptr = b->edge_ptr;
+    p.w = h->w_dev; p.L = h->L;
+    p.cur = at<float>(ws, c.cur); p.cur_next = p.cur;
+    p.knn = at<int>(ws, c.knn);
+    p.e_src = at<int>(ws, c.e_src); p.e_dst = at<int>(ws, c.e_dst); p.e_count = at<int>(ws, c.e_count);
+    p.seg_beg = at<int>(ws, c.seg_beg); p.seg_cnt = at<int>(ws, c.seg_cnt);
+    p.etile_prob = at<int>(ws, c.etile); p.ptile_prob = at<int>(ws, c.ptile);
+    p.msg = at<float>(ws, c.msg);
+    p.cand_cap = b->max_edges + kSmK * b->max_path;
+    if (p.cand_cap < 1) p.cand_cap = 1;
+    if ((size_t)2 * p.cand_cap * sizeof(int) > 60000) return GNNMP_ERR_DIMS;
+    p.n_etiles = c.ecap / 32; p.n_ptiles = c.pcap / 32;
+    HIP_TRY(launch_sm_init(b->total_path * C, p.scale, b->path, p.cur, st));
+    for (int it = 0; it < loop; ++it) {
+        HIP_TRY(hipMemsetAsync(at<char>(ws, c.ff_beg), 0xFF, c.ff_end - c.ff_beg, st));
+        HIP_TRY(launch_sm_iter(D, p, st));
+    }
+    HIP_TRY(launch_sm_final(b->total_path * C, p.scale, p.cur, out_path, st));
     return GNNMP_OK;
 }

@@ -181,10 +181,20 @@ __device__ __forceinline__ void load_tile(const float* tile_base, f32x16 (&x)[NT
         }
 }
 
-// cooperative global -> LDS copy by the whole workgroup (n multiple of 4 floats, 16-B aligned)
+// cooperative global -> LDS copy by the whole workgroup (n multiple of 4 floats, 16-B aligned).
+// Uses the gfx950 LDS-DMA path (global_load_lds_dwordx4): every wave issues all of its 1-KiB pieces
+// back to back with no VGPR round trip, so the L2 latency is paid once per phase instead of once
+// per piece.  The LDS destination of one instruction is wave-uniform base + lane*16, which is exactly
+// a linear copy.  Completion: the DMA counts on vmcnt; the following __syncthreads() drains it.
 __device__ __forceinline__ void stage(float* lds, const float* g, int n) {
-    for (int i = threadIdx.x * 4; i < n; i += blockDim.x * 4)
-        *reinterpret_cast<f32x4*>(lds + i) = *reinterpret_cast<const f32x4*>(g + i);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int base = wave * 256; base < n; base += nw * 256) {
+        const int idx = base + lane * 4;
+        if (idx < n)
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(g + idx),
+                (__attribute__((address_space(3))) void*)(lds + base), 16, 0, 0);
+    }
 }
 
 }  // namespace gnnmp

@@ -274,8 +274,8 @@ __global__ __launch_bounds__(256) void obs_kernel(ObsParams p) {
 // wl: LDS copy of AttBlob<D>; kvl: LDS K/V chunk region; kvg: this (graph, block)'s slab in global.
 // =====================================================================================================
 template <int D>
-__device__ __forceinline__ void attention_block(const float* wl, float* kvl, const float* kvg, int O, int ot_max,
-                                                int ot_chunk, f32x16 (&m)[D / 32], int lane) {
+__device__ __forceinline__ void attention_block(const float* wl, const float* wg, float* kvl, const float* kvg, int O,
+                                                int ot_max, int ot_chunk, f32x16 (&m)[D / 32], int lane) {
     constexpr int NT = D / 32;
     using L = AttBlob<D>;
     const int h = lane >> 5;
@@ -324,11 +324,11 @@ __device__ __forceinline__ void attention_block(const float* wl, float* kvl, con
             }
             tmax = fmaxf(tmax, xhalf(tmax));
             const float nmx = fmaxf(mx, tmax);
-            const float alpha = exp2f((mx - nmx) * cs);
+            const float alpha = __builtin_amdgcn_exp2f((mx - nmx) * cs);
             float ps = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                s[r] = exp2f((s[r] - nmx) * cs);
+                s[r] = __builtin_amdgcn_exp2f((s[r] - nmx) * cs);
                 ps += s[r];
             }
             psum = fmaf(psum, alpha, ps);
@@ -343,8 +343,8 @@ __device__ __forceinline__ void attention_block(const float* wl, float* kvl, con
     const float inv = 1.0f / (psum + xhalf(psum));
 #pragma unroll
     for (int t = 0; t < NT; ++t) m[t] = acc[t] * inv + m[t];         // value mix + residual
-    layer_norm_<NT>(m, wl + L::ln1g, wl + L::ln1b, 1e-6f, lane);
-    ffn_<NT>(wl + L::w1, wl + L::b1, wl + L::w2, wl + L::b2, wl + L::ln2g, wl + L::ln2b, m, lane);
+    layer_norm_<NT>(m, wg + L::ln1g, wg + L::ln1b, 1e-6f, lane);        // vectors: global (L1/L2 hits)
+    ffn_<NT>(wl + L::w1, wg + L::b1, wl + L::w2, wg + L::b2, wg + L::ln2g, wg + L::ln2b, m, lane);
 }
 
 // =====================================================================================================
@@ -399,12 +399,13 @@ __global__ __launch_bounds__(WAVES * 64) void pre_kernel(PreParams p) {
         for (int b = 0; b < 3; ++b) {
             const float* kvg = p.kv + (size_t)(g * 3 + b) * p.kv_stride;
             __syncthreads();
-            stage(wl, p.att + (size_t)b * AttBlob<D>::size, AttBlob<D>::size);
+            const float* attg = p.att + (size_t)b * AttBlob<D>::size;
+            stage(wl, attg, AttBlob<D>::staged);
             const int c1 = min(OT, p.ot_chunk);
             stage(kvl, kvg, c1 * NT * kATile);
             stage(kvl + chunk_floats, kvg + (size_t)p.ot_max * NT * kATile, c1 * NT * kATile);
             __syncthreads();
-            attention_block<D>(wl, kvl, kvg, O, p.ot_max, p.ot_chunk, m, lane);
+            attention_block<D>(wl, attg, kvl, kvg, O, p.ot_max, p.ot_chunk, m, lane);
         }
     }
 

@@ -71,6 +71,27 @@ struct PolicyParams {
     int n_tiles;
 };
 
+struct SmParams {
+    int B, C, total_path, total_edges;
+    float scale;
+    const float *path, *free_pts, *collided;
+    const long long* edge_index;
+    const int *path_ptr, *free_ptr, *coll_ptr, *edge_ptr;
+    const float* w;
+    SmLayout L;
+    float *cur, *cur_next;            // scaled working path [total_path, C]
+    int* knn;                         // [total_path, kSmK] sample index or -1
+    int *e_src, *e_dst, *e_count;     // sorted unique edges per problem (padded space), count per problem
+    int *seg_beg, *seg_cnt;           // per padded path node: its run of incoming edges
+    int *etile_prob, *ptile_prob;     // tile -> problem (-1 unused)
+    float* msg;                       // [edge capacity, d]
+    int cand_cap, n_etiles, n_ptiles;
+};
+
+hipError_t launch_sm_init(int n, float scale, const float* path, float* cur, hipStream_t st);
+hipError_t launch_sm_final(int n, float scale, const float* cur, float* out, hipStream_t st);
+hipError_t launch_sm_iter(int D, const SmParams& p, hipStream_t st);
+
 hipError_t launch_prep(const PrepParams& q, hipStream_t st);
 hipError_t launch_obs(int D, const ObsParams& p, int G, hipStream_t st);
 hipError_t launch_pre(int D, bool edge, int waves, const PreParams& p, int n_tiles32, size_t lds_bytes, hipStream_t st);

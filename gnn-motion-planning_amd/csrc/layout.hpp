@@ -17,12 +17,14 @@ __host__ __device__ constexpr int tile_floats(int D) { return (D / 32) * (D / 32
 __host__ __device__ constexpr int vec_floats(int D) { return (D / 32) * 32; }                 // one D-vector
 __host__ __device__ constexpr int small_floats(int D, int ksteps) { return (D / 32) * ksteps * 64; }
 
-// One attention Block (model.py:204-218) in LDS staging order.
+// One attention Block (model.py:204-218).  The five DxD matrices come first and are what gets staged
+// into LDS (`staged` floats); the six D-vectors behind them are read straight from global memory
+// (768 B at d = 32: keeping them out of LDS is what lets three workgroups share a CU at O <= 128).
 template <int D>
 struct AttBlob {
     static constexpr int T = tile_floats(D), V = vec_floats(D);
-    static constexpr int wq = 0, wk = T, wv = 2 * T, ln1g = 3 * T, ln1b = 3 * T + V, w1 = 3 * T + 2 * V,
-                         b1 = 4 * T + 2 * V, w2 = 4 * T + 3 * V, b2 = 5 * T + 3 * V, ln2g = 5 * T + 4 * V,
+    static constexpr int wq = 0, wk = T, wv = 2 * T, w1 = 3 * T, w2 = 4 * T, staged = 5 * T;
+    static constexpr int ln1g = 5 * T, ln1b = 5 * T + V, b1 = 5 * T + 2 * V, b2 = 5 * T + 3 * V, ln2g = 5 * T + 4 * V,
                          ln2b = 5 * T + 5 * V, size = 5 * T + 6 * V;
 };
 
@@ -106,6 +108,41 @@ struct ObsBlob {
         e.blk_stride = 4 * T + 4 * V;
         e.size = o + 3 * e.blk_stride;
         return e;
+    }
+};
+
+// ---- smoother (ModelSmoother, model_smoother.py:46-142)
+constexpr int kSmK = 10;            // knn(..., k=10) at model_smoother.py:125
+
+struct SmLayout {
+    int ks;                          // K steps of node_code.0 (inputs: C coords + 3 one-hot)
+    int as0, b0, w3, b3;             // node_code.0 (BatchNorm folded) and node_code.3
+    int wsrc, wdst, b00, w02, b02;   // process.lin_0: (W_a + W_b), (W_c - W_a), bias; second layer
+    int w10, b10, w12, b12;          // process.lin_1
+    int ws, bs;                      // smooth_node, out features padded to 32
+    int total;
+    __host__ __device__ static SmLayout make(int D, int C) {
+        SmLayout L;
+        const int T = tile_floats(D), V = vec_floats(D);
+        int o = 0;
+        L.ks = (C + 3 + 1) / 2;
+        L.as0 = o; o += small_floats(D, L.ks);
+        L.b0 = o; o += V;
+        L.w3 = o; o += T;
+        L.b3 = o; o += V;
+        L.wsrc = o; o += T;
+        L.wdst = o; o += T;
+        L.b00 = o; o += V;
+        L.w02 = o; o += T;
+        L.b02 = o; o += V;
+        L.w10 = o; o += T;
+        L.b10 = o; o += V;
+        L.w12 = o; o += T;
+        L.b12 = o; o += V;
+        L.ws = o; o += (D / 32) * 1024;
+        L.bs = o; o += 32;
+        L.total = o;
+        return L;
     }
 };
 

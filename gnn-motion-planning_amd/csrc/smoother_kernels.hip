@@ -1,0 +1,351 @@
+// smoother_kernels.hip -- HIP kernels (gfx950) of the GNN path-smoother forward pass,
+// ModelSmoother.forward of the reference (model_smoother.py:104-142), batched over independent
+// smoothing problems.  Per `loop` iteration:
+//
+//   sm_knn     10 nearest samples (free + collided) of every path node     (model_smoother.py:125)
+//   sm_edges   caller edges + kNN edges -> sorted by (target, source), duplicates dropped
+//                                                                            (model_smoother.py:126-128)
+//   sm_msg     per edge: x_j, x_i = node_code(...), message = lin_0([x_j - x_i, x_j, x_i])
+//                                                                            (model_smoother.py:135-136, 36-39)
+//   sm_node    per path node: S = ordered sum of incoming messages, h = x + lin_1(S),
+//              new waypoint = smooth_node(h); end points kept              (model_smoother.py:32-34,139-140)
+//
+// Only rows < P of h are ever consumed (model_smoother.py:139), so only edges whose target is a path
+// node are evaluated, and x is recomputed per edge endpoint instead of per node (13 P endpoints vs
+// P + F + Co nodes).  The sum over incoming messages runs in coalesced edge order (increasing source
+// id per target), i.e. the order a sequential scatter-add over the coalesced edge list uses.
+// Weights (d = 128: 0.46 MB) are read as MFMA A operands straight from global memory / L2.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include "chain.hpp"
+#include "layout.hpp"
+#include "kernels.hpp"
+
+namespace gnnmp {
+
+__device__ __forceinline__ int sm_round32(int x) { return (x + 31) & ~31; }
+// start of problem b in the padded path-node / edge index spaces (no scan needed)
+__device__ __forceinline__ int sm_poff(const int* path_ptr, int b) { return sm_round32(path_ptr[b]) + 32 * b; }
+__device__ __forceinline__ int sm_eoff(const int* edge_ptr, const int* path_ptr, int b) {
+    return sm_round32(edge_ptr[b] + kSmK * path_ptr[b]) + 32 * b;
+}
+
+// path_cur = path / scale     (model_smoother.py:118)
+__global__ void sm_init_kernel(int n, float scale, const float* __restrict__ path, float* __restrict__ cur) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) cur[i] = path[i] / scale;
+}
+
+// out = path_cur * scale      (model_smoother.py:142)
+__global__ void sm_final_kernel(int n, float scale, const float* __restrict__ cur, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = cur[i] * scale;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// kNN: one wave per path node; lanes stride over the problem's samples keeping a per-lane running
+// best; k rounds of (lane-local argmin, wave argmin, retire the winner).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sm_knn_kernel(SmParams p) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int node = blockIdx.x * 4 + wave;               // global path row
+    if (node >= p.total_path) return;
+    int lo = 0, hi = p.B;                                  // problem of this path row
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (p.path_ptr[mid] <= node) lo = mid; else hi = mid; }
+    const int b = lo;
+    const int C = p.C;
+    const int f0 = p.free_ptr[b], F = p.free_ptr[b + 1] - f0;
+    const int c0 = p.coll_ptr[b], Co = p.coll_ptr[b + 1] - c0;
+    const int ns = F + Co;
+    const float* q = p.cur + (size_t)node * C;
+    constexpr int kMaxPerLane = 32;                        // up to 2048 samples per problem
+    float dist[kMaxPerLane];
+#pragma unroll
+    for (int t = 0; t < kMaxPerLane; ++t) {
+        const int s = t * 64 + lane;
+        float d = INFINITY;
+        if (s < ns) {
+            const float* x = (s < F) ? p.free_pts + (size_t)(f0 + s) * C : p.collided + (size_t)(c0 + s - F) * C;
+            d = 0.f;
+            for (int c = 0; c < C; ++c) {
+                const float df = x[c] / p.scale - q[c];
+                d = fmaf(df, df, d);
+            }
+        }
+        dist[t] = d;
+    }
+    const int k = ns < kSmK ? ns : kSmK;
+    for (int r = 0; r < kSmK; ++r) {
+        int res = -1;
+        if (r < k) {
+            float bd = INFINITY;
+            int bi = 0x7fffffff;
+#pragma unroll
+            for (int t = 0; t < kMaxPerLane; ++t) {
+                const int s = t * 64 + lane;
+                if (dist[t] < bd) { bd = dist[t]; bi = s; }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const float od = __shfl_xor(bd, off, 64);
+                const int oi = __shfl_xor(bi, off, 64);
+                if (od < bd || (od == bd && oi < bi)) { bd = od; bi = oi; }
+            }
+            res = bi;
+#pragma unroll
+            for (int t = 0; t < kMaxPerLane; ++t)
+                if (t * 64 + lane == bi) dist[t] = INFINITY;
+        }
+        if (lane == 0) p.knn[(size_t)node * kSmK + r] = res;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// edge list: one workgroup per problem.  Candidates = caller edges with a path-node target + kNN
+// edges (sample -> path node).  Sorted by key = target * M + source, duplicates dropped.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sm_edges_kernel(SmParams p) {
+    extern __shared__ int sm_lds[];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int p0 = p.path_ptr[b], P = p.path_ptr[b + 1] - p0;
+    const int F = p.free_ptr[b + 1] - p.free_ptr[b], Co = p.coll_ptr[b + 1] - p.coll_ptr[b];
+    const int M = P + F + Co;
+    const int e0 = p.edge_ptr[b], ne = p.edge_ptr[b + 1] - e0;
+    const int ncand = ne + kSmK * P;
+    int* key = sm_lds;                    // [cap]
+    int* sorted = sm_lds + p.cand_cap;    // [cap]
+    __shared__ int s_scan[256];
+    __shared__ int s_carry;
+    for (int c = tid; c < ncand; c += 256) {
+        int src, dst;
+        if (c < ne) {
+            src = (int)p.edge_index[e0 + c];
+            dst = (int)p.edge_index[(size_t)p.total_edges + e0 + c];
+        } else {
+            const int pn = (c - ne) / kSmK, r = (c - ne) % kSmK;
+            const int s = p.knn[(size_t)(p0 + pn) * kSmK + r];
+            src = (s >= 0) ? P + s : -1;
+            dst = pn;
+        }
+        const bool ok = src >= 0 && src < M && dst >= 0 && dst < P;   // only rows < P of h are consumed
+        key[c] = ok ? dst * M + src : 0x7fffffff;
+    }
+    __syncthreads();
+    for (int c = tid; c < ncand; c += 256) {          // stable rank sort
+        const int kc = key[c];
+        int rank = 0;
+        for (int x = 0; x < ncand; ++x) {
+            const int kx = key[x];
+            rank += (kx < kc) || (kx == kc && x < c);
+        }
+        sorted[rank] = kc;
+    }
+    __syncthreads();
+    const int eoff = sm_eoff(p.edge_ptr, p.path_ptr, b);
+    const int poff = sm_poff(p.path_ptr, b);
+    if (tid == 0) s_carry = 0;
+    for (int i = tid; i < sm_round32(P); i += 256) { p.seg_beg[poff + i] = 0; p.seg_cnt[poff + i] = 0; }
+    __syncthreads();
+    for (int base = 0; base < ncand; base += 256) {   // unique + compaction
+        const int c = base + tid;
+        const int kc = (c < ncand) ? sorted[c] : 0x7fffffff;
+        const int keep = (c < ncand) && kc != 0x7fffffff && (c == 0 || sorted[c - 1] != kc);
+        s_scan[tid] = keep;
+        __syncthreads();
+        for (int off = 1; off < 256; off <<= 1) {
+            int a = 0;
+            if (tid >= off) a = s_scan[tid - off];
+            __syncthreads();
+            s_scan[tid] += a;
+            __syncthreads();
+        }
+        if (keep) {
+            const int pos = s_carry + s_scan[tid] - 1;
+            const int dst = kc / M, src = kc - dst * M;
+            p.e_src[eoff + pos] = src;
+            p.e_dst[eoff + pos] = dst;
+            atomicAdd(&p.seg_cnt[poff + dst], 1);
+            // first edge of a target's run
+            if (c == 0 || sorted[c - 1] / M != dst || sorted[c - 1] == 0x7fffffff) p.seg_beg[poff + dst] = eoff + pos;
+        }
+        __syncthreads();
+        if (tid == 255) s_carry += s_scan[255];
+        __syncthreads();
+    }
+    const int n = s_carry;
+    if (tid == 0) p.e_count[b] = n;
+    for (int t = eoff / 32 + tid; t < (eoff + sm_round32(n)) / 32; t += 256) p.etile_prob[t] = b;
+    for (int t = poff / 32 + tid; t < (poff + sm_round32(P)) / 32; t += 256) p.ptile_prob[t] = b;
+}
+
+// node features [coords / scale (path rows are already scaled), one-hot(kind)]   model_smoother.py:130-135
+struct SmNodeIn {
+    const float* row;
+    float inv_is_path;     // 1 -> row already divided by scale
+    float scale;
+    int C, kind;
+    __device__ __forceinline__ float operator()(int k) const {
+        if (k < C) return inv_is_path != 0.f ? row[k] : row[k] / scale;
+        return (k - C == kind) ? 1.0f : 0.f;
+    }
+};
+
+__device__ __forceinline__ SmNodeIn sm_node_in(const SmParams& p, int b, int n) {
+    const int p0 = p.path_ptr[b], P = p.path_ptr[b + 1] - p0;
+    const int f0 = p.free_ptr[b], F = p.free_ptr[b + 1] - f0;
+    const int c0 = p.coll_ptr[b];
+    SmNodeIn in;
+    in.C = p.C; in.scale = p.scale;
+    if (n < P) { in.row = p.cur + (size_t)(p0 + n) * p.C; in.kind = 0; in.inv_is_path = 1.f; }
+    else if (n < P + F) { in.row = p.free_pts + (size_t)(f0 + n - P) * p.C; in.kind = 1; in.inv_is_path = 0.f; }
+    else { in.row = p.collided + (size_t)(c0 + n - P - F) * p.C; in.kind = 2; in.inv_is_path = 0.f; }
+    return in;
+}
+
+// x = node_code.3( relu( BN_eval( node_code.0(in) ) ) ) with BN folded into node_code.0 at pack time
+template <int NT>
+__device__ __forceinline__ void sm_node_code(const SmParams& p, const SmNodeIn& in, f32x16 (&x)[NT], int lane) {
+    const float* W = p.w;
+    f32x16 hdn[NT];
+    load_vec<NT>(W + p.L.b0, hdn, lane);
+    linear_in<NT>(W + p.L.as0, p.L.ks, in, hdn, lane);
+    relu_<NT>(hdn);
+    load_vec<NT>(W + p.L.b3, x, lane);
+    linear_acc<NT, NT>(W + p.L.w3, hdn, x, lane);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// messages: one wave per 32-edge tile
+// ---------------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256) void sm_msg_kernel(SmParams p) {
+    constexpr int NT = D / 32;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
+    const int tile = blockIdx.x * 4 + wave;
+    if (tile >= p.n_etiles) return;
+    const int b = p.etile_prob[tile];
+    if (b < 0) return;
+    const int eoff = sm_eoff(p.edge_ptr, p.path_ptr, b);
+    const int e = tile * 32 + j;
+    const bool valid = (e - eoff) < p.e_count[b];
+    const int src = valid ? p.e_src[e] : 0, dst = valid ? p.e_dst[e] : 0;
+    const float* W = p.w;
+    f32x16 z[NT];
+    load_vec<NT>(W + p.L.b00, z, lane);
+    {
+        f32x16 x[NT];
+        sm_node_code<NT>(p, sm_node_in(p, b, dst), x, lane);          // x_i (target)
+        linear_acc<NT, NT>(W + p.L.wdst, x, z, lane);                  // (W_c - W_a) x_i
+    }
+    {
+        f32x16 x[NT];
+        sm_node_code<NT>(p, sm_node_in(p, b, src), x, lane);          // x_j (source)
+        linear_acc<NT, NT>(W + p.L.wsrc, x, z, lane);                  // (W_a + W_b) x_j
+    }
+    relu_<NT>(z);
+    f32x16 m[NT];
+    load_vec<NT>(W + p.L.b02, m, lane);
+    linear_acc<NT, NT>(W + p.L.w02, z, m, lane);
+    store_row<NT>(p.msg + (size_t)e * D, m, h);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// path-node update: one wave per 32 path nodes
+// ---------------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256) void sm_node_kernel(SmParams p) {
+    constexpr int NT = D / 32;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
+    const int tile = blockIdx.x * 4 + wave;
+    if (tile >= p.n_ptiles) return;
+    const int b = p.ptile_prob[tile];
+    if (b < 0) return;
+    const int poff = sm_poff(p.path_ptr, b);
+    const int p0 = p.path_ptr[b], P = p.path_ptr[b + 1] - p0;
+    const int n = tile * 32 + j - poff;                  // local path index
+    const bool valid = n < P;
+    const float* W = p.w;
+    f32x16 S[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) S[t] = splat16(0.f);
+    if (valid) {
+        const int beg = p.seg_beg[poff + n], cnt = p.seg_cnt[poff + n];
+        for (int i = 0; i < cnt; ++i) {                  // coalesced edge order: increasing source id
+            f32x16 m[NT];
+            load_row<NT>(p.msg + (size_t)(beg + i) * D, m, h);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) S[t] += m[t];
+        }
+    }
+    f32x16 y[NT];
+    {
+        f32x16 hdn[NT];
+        load_vec<NT>(W + p.L.b10, hdn, lane);
+        linear_acc<NT, NT>(W + p.L.w10, S, hdn, lane);
+        relu_<NT>(hdn);
+        load_vec<NT>(W + p.L.b12, y, lane);
+        linear_acc<NT, NT>(W + p.L.w12, hdn, y, lane);
+    }
+    {
+        f32x16 x[NT];
+        sm_node_code<NT>(p, sm_node_in(p, b, valid ? n : 0), x, lane);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) y[t] += x[t];        // h = x + lin_1(S)      model_smoother.py:34
+    }
+    f32x16 o[1];
+    load_vec<1>(W + p.L.bs, o, lane);
+    linear_acc<1, NT>(W + p.L.ws, y, o, lane);            // smooth_node (out features padded to 32)
+    if (valid && n >= 1 && n <= P - 2) {                  // path[1:-1] = ...       model_smoother.py:139
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int f = phi(r, h);
+            if (f < p.C) p.cur_next[(size_t)(p0 + n) * p.C + f] = o[0][r];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+#define LAUNCH_CHECK()                        \
+    do {                                      \
+        hipError_t _e = hipGetLastError();    \
+        if (_e != hipSuccess) return _e;      \
+    } while (0)
+
+hipError_t launch_sm_init(int n, float scale, const float* path, float* cur, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(sm_init_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, scale, path, cur);
+    LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_sm_final(int n, float scale, const float* cur, float* out, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(sm_final_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, scale, cur, out);
+    LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+template <int D>
+static hipError_t launch_sm_iter_t(const SmParams& p, hipStream_t st) {
+    hipLaunchKernelGGL(sm_knn_kernel, dim3((p.total_path + 3) / 4), dim3(256), 0, st, p);
+    LAUNCH_CHECK();
+    const size_t lds = (size_t)2 * p.cand_cap * sizeof(int);
+    hipLaunchKernelGGL(sm_edges_kernel, dim3(p.B), dim3(256), lds, st, p);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(sm_msg_kernel<D>, dim3((p.n_etiles + 3) / 4), dim3(256), 0, st, p);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(sm_node_kernel<D>, dim3((p.n_ptiles + 3) / 4), dim3(256), 0, st, p);
+    LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_sm_iter(int D, const SmParams& p, hipStream_t st) {
+    switch (D) {
+        case 32: return launch_sm_iter_t<32>(p, st);
+        case 64: return launch_sm_iter_t<64>(p, st);
+        case 128: return launch_sm_iter_t<128>(p, st);
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace gnnmp

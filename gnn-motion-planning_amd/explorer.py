@@ -97,6 +97,8 @@ class EncoderProcessDecoder(nn.Module):
         self._handle = None
         self._handle_key = None
         self._ws = None
+        self._manifest = None
+        self._wt = None
         self.register_load_state_dict_post_hook(lambda m, _k: m._drop_handle())
 
     # ------------------------------------------------------------------ native handle
@@ -115,24 +117,33 @@ class EncoderProcessDecoder(nn.Module):
     def _dims(self):
         return _lib.ExplorerDims(self.config_size, self.embed_size, self.obs_size)
 
+    def _apply(self, fn, *a, **k):          # .to() / .float() / .cuda(): parameters are replaced
+        self._drop_handle()
+        return super()._apply(fn, *a, **k)
+
     def _native(self, device):
         """Opaque library handle holding the packed weights on ``device`` (rebuilt when the
-        parameters were replaced or modified in place)."""
-        sd = self.state_dict()
-        dims = self._dims()
-        names = _lib.manifest('explorer', dims)
-        key = (str(device),) + tuple((sd[n].data_ptr(), sd[n]._version) for n, _ in names)
+        parameters were reloaded, moved or modified in place)."""
+        if self._manifest is None:
+            self._manifest = _lib.manifest('explorer', self._dims())
+            sd = self.state_dict(keep_vars=True)
+            self._wt = [sd[n] for n, _ in self._manifest]
+        key = (str(device), tuple(t._version for t in self._wt))
         if self._handle is not None and key == self._handle_key:
             return self._handle
         self._drop_handle()
+        sd = self.state_dict(keep_vars=True)
+        self._wt = [sd[n] for n, _ in self._manifest]
+        key = (str(device), tuple(t._version for t in self._wt))
         parts = []
-        for n, numel in names:
-            t = sd[n].detach().to('cpu', torch.float32).contiguous().reshape(-1)
+        for (n, numel), t in zip(self._manifest, self._wt):
+            t = t.detach().to('cpu', torch.float32).contiguous().reshape(-1)
             if t.numel() != numel:
                 raise RuntimeError('parameter %s has %d elements, library expects %d' % (n, t.numel(), numel))
             parts.append(t)
         blob = torch.cat(parts).contiguous()
         h = ctypes.c_void_p()
+        dims = self._dims()
         _lib.check(_lib.lib().gnnmp_explorer_create(ctypes.byref(h), ctypes.byref(dims), blob.data_ptr(),
                                                     blob.numel(), torch.device(device).index or 0),
                    'gnnmp_explorer_create')

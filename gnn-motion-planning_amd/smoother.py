@@ -1,0 +1,150 @@
+"""Drop-in counterpart of the reference's ``ModelSmoother`` (model_smoother.py:46-142).
+
+Same constructor signature, parameter / buffer names (``load_state_dict(strict=True)`` of the
+shipped ``smooth_*_attv3.pt`` files works) and ``forward`` keyword signature; the arithmetic runs
+in libgnnmp.so's HIP kernels.  The ``torch.nn`` layers are parameter containers only.
+"""
+import ctypes
+
+import torch
+from torch import nn
+from torch.nn import Linear as Lin, ReLU, Sequential as Seq
+
+from . import _lib
+
+
+class _MPNN(nn.Module):                            # model_smoother.py:22-28
+    def __init__(self, d):
+        super().__init__()
+        self.lin_0 = Seq(Lin(d * 3, d), ReLU(), Lin(d, d))
+        self.lin_1 = Seq(Lin(d, d), ReLU(), Lin(d, d))
+
+
+class SmoothBatch:
+    """Device-resident concatenation of B smoothing problems (see gnnmp_smooth_batch in gnnmp.h)."""
+
+    def __init__(self, paths, frees, collideds, edge_indexes, device):
+        def prefix(counts):
+            p = torch.zeros(len(counts) + 1, dtype=torch.int64)
+            p[1:] = torch.tensor(counts, dtype=torch.int64).cumsum(0)
+            return p.to(torch.int32).to(device)
+        f32 = lambda ts: torch.cat([t.float().reshape(t.shape[0], -1) for t in ts]).contiguous().to(device)  # noqa: E731
+        self.n = len(paths)
+        self.path, self.free, self.collided = f32(paths), f32(frees), f32(collideds)
+        self.edge_index = torch.cat([e.long() for e in edge_indexes], dim=1).contiguous().to(device)
+        self.path_ptr = prefix([t.shape[0] for t in paths])
+        self.free_ptr = prefix([t.shape[0] for t in frees])
+        self.coll_ptr = prefix([t.shape[0] for t in collideds])
+        self.edge_ptr = prefix([e.shape[1] for e in edge_indexes])
+        self.max_path = max(t.shape[0] for t in paths)
+        self.max_samples = max(f.shape[0] + c.shape[0] for f, c in zip(frees, collideds))
+        self.max_edges = max(e.shape[1] for e in edge_indexes)
+        self.path_counts = [t.shape[0] for t in paths]
+
+
+class ModelSmoother(nn.Module):
+    """``ModelSmoother(workspace_size, config_size, obs_size, embed_size, scale=1.)``
+    (model_smoother.py:51; ``scale=np.max(env.bound)`` only for ur5, str2name.py:40)."""
+
+    def __init__(self, workspace_size, config_size, obs_size, embed_size, scale=1.):
+        super().__init__()
+        _lib.lib()
+        self.workspace = workspace_size
+        self.config_size = config_size
+        self.obs_size = obs_size
+        self.latent_dim = workspace_size
+        self.scale = scale
+        self.embed_size = embed_size
+        C, d, S = config_size, embed_size, obs_size
+        self.bn1 = nn.BatchNorm1d(C)
+        self.bn2 = nn.BatchNorm1d(d)
+        # node_code.1 IS bn2 (model_smoother.py:63,65): the state_dict carries both key prefixes
+        self.node_code = Seq(Lin(C + 3, d), self.bn2, ReLU(), Lin(d, d))
+        self.process = _MPNN(d)
+        self.smooth_node = Lin(d, C)
+        # present in the reference's state_dict, never read by forward() (model_smoother.py:66-69,75-76,90,92)
+        self.edge_code = Lin(C * 2, d)
+        self.obs_code = Lin(S, d)
+        self.obs_node_code = Seq(Lin(S, d), ReLU(), Lin(d, d))
+        self.node_free_code = Seq(Lin(C, d), ReLU(), Lin(d, d))
+        self.goal_encoder = nn.Parameter(torch.rand(d))
+        self.node_pos = Lin(C, d)
+        self.encoder = Lin(d * 2, d)
+        self.decoder = Lin(d * 2, d)
+        self._handle = None
+        self._handle_key = None
+        self._manifest = None
+        self._wt = None
+        self._ws = None
+        self.register_load_state_dict_post_hook(lambda m, _k: m._drop_handle())
+
+    def _drop_handle(self):
+        if getattr(self, '_handle', None):
+            _lib.lib().gnnmp_smoother_destroy(self._handle)
+        self._handle = None
+        self._handle_key = None
+
+    def __del__(self):
+        try:
+            self._drop_handle()
+        except Exception:
+            pass
+
+    def _apply(self, fn, *a, **k):
+        self._drop_handle()
+        return super()._apply(fn, *a, **k)
+
+    def _dims(self):
+        return _lib.SmootherDims(self.config_size, self.embed_size, float(self.scale))
+
+    def _native(self, device):
+        if self._manifest is None:
+            self._manifest = _lib.manifest('smoother', self._dims())
+        sd = self.state_dict(keep_vars=True)
+        wt = [sd[n] for n, _ in self._manifest]
+        key = (str(device), float(self.scale), tuple(t._version for t in wt))
+        if self._handle is not None and key == self._handle_key:
+            return self._handle
+        self._drop_handle()
+        blob = torch.cat([t.detach().to('cpu', torch.float32).reshape(-1) for t in wt]).contiguous()
+        h = ctypes.c_void_p()
+        dims = self._dims()
+        _lib.check(_lib.lib().gnnmp_smoother_create(ctypes.byref(h), ctypes.byref(dims), blob.data_ptr(), blob.numel(),
+                                                    torch.device(device).index or 0), 'gnnmp_smoother_create')
+        self._handle, self._handle_key = h, key
+        return h
+
+    @torch.no_grad()
+    def forward_batch(self, sb, loop):
+        """New waypoints [sum P, C] for a :class:`SmoothBatch`."""
+        dev = sb.path.device
+        if dev.type != 'cuda':
+            raise RuntimeError('gnnmp runs on the GPU only (got %s tensors); there is no CPU fallback' % dev)
+        h = self._native(dev)
+        cb = _lib.SmoothBatch(sb.n, sb.path.shape[0], sb.free.shape[0], sb.collided.shape[0], sb.edge_index.shape[1],
+                              sb.max_path, sb.max_samples, sb.max_edges, sb.path.data_ptr(),
+                              sb.free.data_ptr() if sb.free.numel() else None,
+                              sb.collided.data_ptr() if sb.collided.numel() else None,
+                              sb.edge_index.data_ptr() if sb.edge_index.numel() else None,
+                              sb.path_ptr.data_ptr(), sb.free_ptr.data_ptr(), sb.coll_ptr.data_ptr(),
+                              sb.edge_ptr.data_ptr())
+        need = ctypes.c_size_t()
+        _lib.check(_lib.lib().gnnmp_smoother_workspace_bytes(h, ctypes.byref(cb), ctypes.byref(need)),
+                   'gnnmp_smoother_workspace_bytes')
+        if self._ws is None or self._ws.numel() < need.value or self._ws.device != dev:
+            self._ws = torch.empty(need.value, dtype=torch.uint8, device=dev)
+        out = torch.empty_like(sb.path)
+        with torch.cuda.device(dev):
+            st = torch.cuda.current_stream().cuda_stream
+            _lib.check(_lib.lib().gnnmp_smoother_forward(h, ctypes.byref(cb), int(loop), out.data_ptr(),
+                                                         self._ws.data_ptr(), self._ws.numel(), st),
+                       'gnnmp_smoother_forward')
+        return out
+
+    @torch.no_grad()
+    def forward(self, path, free, collided, obstacles=None, edge_index=None, loop=10, **kwargs):
+        """Reference call (smoother.py:243): returns the new path [P, C]; ``obstacles`` and extra
+        keywords are accepted and ignored like the reference does; the caller's ``path`` tensor is
+        never written (model_smoother.py:118)."""
+        sb = SmoothBatch([path], [free], [collided], [edge_index], path.device)
+        return self.forward_batch(sb, loop)

@@ -1,0 +1,95 @@
+"""GPU parity of the HIP smoother forward against the goldens recorded from the reference and the
+CPU oracle.  Tolerance: outputs are O(1) coordinates; reference fp32-vs-fp64 differs by <= 2e-6, the
+bar is allclose(rtol=1e-5, atol=1e-5)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_files, load_weights
+import gnnmp
+from oracle import ref_cpu
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+CONF = {'smooth_2d_attv3': (2, 1.0), 'smooth_7d_attv3': (7, 1.0), 'smooth_ur5_attv3': (6, 2 * np.pi),
+        'smooth_snake_attv3': (7, 1.0), 'smooth_13d_attv3': (13, 1.0), 'smooth_14d_attv3': (14, 1.0)}
+
+
+def make(name):
+    C, scale = CONF[name]
+    m = gnnmp.ModelSmoother(workspace_size=3, config_size=C, embed_size=128, obs_size=6, scale=scale)
+    m.load_state_dict(load_weights(name), strict=True)
+    return m
+
+
+def chain_edges(P):
+    a, b = torch.arange(1, P), torch.arange(0, P - 1)
+    return torch.cat((torch.stack((a, b)), torch.stack((b, a)), torch.stack((torch.arange(P),) * 2)), dim=1)
+
+
+@pytest.mark.parametrize('path', golden_files('smoother_'), ids=os.path.basename)
+def test_golden(path):
+    with np.load(path) as f:
+        r = {k: f[k] for k in f.files}
+    name = os.path.basename(path).split('_P')[0].replace('smoother_', '')
+    m = make(name)
+    p_in = torch.from_numpy(r['path']).to(DEV)
+    keep = p_in.clone()
+    out = m(path=p_in, free=torch.from_numpy(r['free']).to(DEV), collided=torch.from_numpy(r['collided']).to(DEV),
+            obstacles=torch.zeros(1, 6, device=DEV), edge_index=torch.from_numpy(r['edge_index']).to(DEV),
+            loop=int(r['loop'])).cpu()
+    assert torch.equal(keep, p_in)                    # caller's path untouched
+    ref32, ref64 = torch.from_numpy(r['out_fp32']), torch.from_numpy(r['out_fp64'])
+    e32, e64 = (out - ref32).abs().max().item(), (out.double() - ref64).abs().max().item()
+    print('\n%s: max|gpu-ref32|=%.2e max|gpu-ref64|=%.2e' % (os.path.basename(path), e32, e64))
+    assert torch.allclose(out, ref32, rtol=1e-5, atol=1e-5), e32
+    # end points are passed through (x / scale * scale), interior moved
+    assert torch.equal(out[0], ref32[0]) and torch.equal(out[-1], ref32[-1])
+
+
+@pytest.mark.parametrize('case', ['few_samples', 'no_collided_but_one', 'two_nodes', 'dup_edges', 'loop0'])
+def test_edge_cases(case):
+    gen = torch.Generator().manual_seed(11)
+    name = 'smooth_2d_attv3'
+    P, F, Co, loop = 9, 40, 30, 2
+    if case == 'few_samples':
+        F, Co = 4, 3                                 # fewer than k = 10 samples in total
+    elif case == 'no_collided_but_one':
+        F, Co = 25, 1                                # caller substitutes one zero row for an empty list (smoother.py:53-56)
+    elif case == 'two_nodes':
+        P = 2                                        # nothing to move: path[1:-1] is empty
+    elif case == 'loop0':
+        loop = 0
+    path = torch.rand(P, 2, generator=gen) * 2 - 1
+    free = torch.rand(F, 2, generator=gen) * 2 - 1
+    coll = torch.rand(Co, 2, generator=gen) * 2 - 1 if case != 'no_collided_but_one' else torch.zeros(1, 2)
+    ei = chain_edges(P)
+    if case == 'dup_edges':
+        ei = torch.cat((ei, ei[:, :5]), dim=1)       # coalesce must drop duplicates
+    m = make(name)
+    out = m(path=path.to(DEV), free=free.to(DEV), collided=coll.to(DEV), obstacles=None, edge_index=ei.to(DEV),
+            loop=loop).cpu()
+    ref = ref_cpu.smoother_forward(load_weights(name), path, free, coll, ei, loop=loop)
+    assert torch.allclose(out, ref, rtol=1e-5, atol=1e-5), (out - ref).abs().max()
+
+
+def test_batch_equals_single_bitwise():
+    gen = torch.Generator().manual_seed(5)
+    name = 'smooth_7d_attv3'
+    m = make(name)
+    probs = []
+    for P, F, Co in [(5, 30, 20), (33, 100, 80), (12, 11, 1), (20, 500, 500)]:
+        probs.append((torch.rand(P, 7, generator=gen) * 2 - 1, torch.rand(F, 7, generator=gen) * 2 - 1,
+                      torch.rand(Co, 7, generator=gen) * 2 - 1, chain_edges(P)))
+    sb = gnnmp.SmoothBatch([p[0] for p in probs], [p[1] for p in probs], [p[2] for p in probs], [p[3] for p in probs], DEV)
+    out = m.forward_batch(sb, 1)
+    off = 0
+    w = load_weights(name)
+    for path, free, coll, ei in probs:
+        single = m(path=path.to(DEV), free=free.to(DEV), collided=coll.to(DEV), edge_index=ei.to(DEV), loop=1)
+        assert torch.equal(single, out[off:off + path.shape[0]])
+        ref = ref_cpu.smoother_forward(w, path, free, coll, ei, loop=1)
+        assert torch.allclose(single.cpu(), ref, rtol=1e-5, atol=1e-5)
+        off += path.shape[0]
