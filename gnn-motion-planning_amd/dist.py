@@ -1,0 +1,59 @@
+"""Problem-level sharding across the GPUs of one node.
+
+One planning problem = one graph = one forward, with no cross-graph term anywhere
+(eval_gnn.py:113-116), so ranks never exchange data on the compute path.  The only collective is the
+gather of RESULTS (edge scores, or the seven per-problem planner numbers of eval_gnn.py:120-122):
+``torch.distributed`` all_gather, i.e. RCCL over xGMI with the ``nccl`` backend on GPUs and gloo in
+the CPU tests.  Payloads are small (about 45 KB of scores per 1000-node graph), so the gather is
+latency-bound; it is padded to the largest shard because all_gather needs equal sizes.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_items, rank, world, weights=None):
+    """Contiguous block [lo, hi) of ``n_items`` owned by ``rank``.  Without weights the blocks differ by
+    at most one item; with per-item ``weights`` (e.g. edge counts, the cost driver) the split points
+    are the weight quantiles."""
+    if weights is None:
+        base, rem = divmod(n_items, world)
+        lo = rank * base + min(rank, rem)
+        return lo, lo + base + (1 if rank < rem else 0)
+    w = torch.as_tensor(weights, dtype=torch.float64)
+    assert w.numel() == n_items
+    cum = torch.cat((torch.zeros(1, dtype=torch.float64), w.cumsum(0)))
+    total = float(cum[-1])
+    cuts = [0]
+    for r in range(1, world):
+        target = total * r / world
+        cuts.append(int(torch.searchsorted(cum, torch.tensor(target, dtype=torch.float64), right=False)))
+    cuts.append(n_items)
+    for i in range(1, len(cuts)):                       # keep monotone
+        cuts[i] = max(cuts[i], cuts[i - 1])
+    return cuts[rank], cuts[rank + 1]
+
+
+def gather_variable(local, group=None):
+    """all_gather of 1-D tensors of different lengths; returns the list of every rank's tensor
+    (each on the local device).  Works with world_size 1 without an initialised process group."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return [local]
+    world = dist.get_world_size(group)
+    n = torch.tensor([local.numel()], dtype=torch.int64, device=local.device)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n, group=group)
+    sizes = [int(s.item()) for s in sizes]
+    cap = max(sizes + [1])
+    pad = torch.zeros(cap, dtype=local.dtype, device=local.device)
+    pad[:local.numel()] = local
+    out = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(out, pad, group=group)
+    return [o[:s] for o, s in zip(out, sizes)]
+
+
+def gather_problem_results(rows, group=None):
+    """``rows``: float64 tensor [n_local, k] of per-problem numbers (e.g. success, path cost, smoothed
+    cost, c_explore, c_smooth, total, total_explore).  Returns [n_total, k] in rank order."""
+    k = rows.shape[1] if rows.dim() == 2 else 0
+    parts = gather_variable(rows.reshape(-1), group)
+    return torch.cat([p.reshape(-1, k) for p in parts], dim=0) if k else torch.cat(parts)

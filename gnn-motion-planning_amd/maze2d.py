@@ -1,0 +1,117 @@
+"""2-D maze environment (host side): the build's counterpart of the parts of the reference's
+``MazeEnv`` (environment/maze_env.py, dim = 2) that the GNN planner touches.  Pure numpy; collision
+checking stays on the host CPU (north_star).  Needed so the planner counterpart (planner.py) can be
+exercised without the reference tree.
+
+Behaviour restated:
+  * 15 x 15 occupancy grid over [-1, 1]^2; cell of a point = trunc((x + 1) * w / 2), top index clipped
+    (maze_env.py:249-252); obstacles = occupied cells as (i, j) / w - 0.5 (maze_env.py:73-79).
+  * a configuration query counts into ``collision_check_count`` only when the point is inside the
+    bounds (maze_env.py:281-288).
+  * an edge query = both end points, then recursive midpoint bisection while the end cells are more
+    than one grid step apart AND the end points are more than RRT_EPS apart in L1
+    (maze_env.py:304-326); evaluation is short-circuit, left half first.
+  * goal test: within RRT_EPS of the goal and collision-free (maze_env.py:173-178).
+  * rejection sampling: uniform in the bounds, one query per draw, rejected draws are returned as
+    "collided" samples (maze_env.py:85-100); draws come from the global numpy RNG, two per sample.
+"""
+import numpy as np
+
+RRT_EPS = 5e-2                       # environment/env_config.py:3
+LIMITS = np.array([1.0, 1.0])        # environment/env_config.py:5 (first two entries)
+
+
+class Maze2D:
+    RRT_EPS = RRT_EPS
+
+    def __init__(self, maps, init_states, goal_states):
+        self.dim = 2
+        self.config_dim = 2
+        self.maps = np.asarray(maps)
+        self.init_states = np.asarray(init_states)
+        self.goal_states = np.asarray(goal_states)
+        self.size = self.maps.shape[0]
+        self.width = self.maps.shape[1]
+        self.bound = (-1, -1, 1, 1)
+        self.collision_check_count = 0
+        self.episode_i = 0
+
+    @classmethod
+    def from_npz(cls, path):
+        with np.load(path) as f:
+            return cls(f['maps'], f['init_states'], f['goal_states'])
+
+    def __str__(self):
+        return 'maze2'
+
+    def init_new_problem(self, index=None):
+        if index is None:
+            index = self.episode_i
+        self.map = self.maps[index]
+        self.width = self.map.shape[0]
+        self.init_state = self.init_states[index]
+        self.goal_state = self.goal_states[index]
+        self.episode_i = (self.episode_i + 1) % self.size
+        occ = np.argwhere(self.map == 1)                     # row-major (i, j) order
+        self.obstacles = occ / self.map.shape[0] - 0.5
+        self.collision_check_count = 0
+        return {'map': self.map, 'init_state': self.init_state, 'goal_state': self.goal_state}
+
+    # ------------------------------------------------------------------ sampling
+    def uniform_sample(self):
+        return np.random.uniform(-LIMITS, LIMITS, (1, 2)).reshape(-1)
+
+    def sample_n_points(self, n, need_negative=False):
+        free, rejected = [], []
+        for _ in range(n):
+            while True:
+                s = self.uniform_sample()
+                if self._state_fp(s):
+                    free.append(s)
+                    break
+                if need_negative:
+                    rejected.append(s)
+        return (free, rejected) if need_negative else free
+
+    # ------------------------------------------------------------------ geometry
+    def distance(self, a, b):
+        d = np.abs(b - a)
+        return np.sqrt(np.sum(d.reshape(1, -1) ** 2, axis=-1))
+
+    def interpolate(self, a, b, ratio):
+        return a + (b - a) * ratio
+
+    def in_goal_region(self, state):
+        return bool(self.distance(state, self.goal_state) < RRT_EPS and self._state_fp(state))
+
+    # ------------------------------------------------------------------ collision checks
+    def _cell(self, state):
+        w = self.width
+        c = ((np.array(state)[:2].flatten() + 1.0) * w / 2.0).astype(int)
+        c[c > w - 1] = w - 1
+        return c
+
+    def _valid(self, state):
+        return bool((state >= -LIMITS[:state.size]).all() and (state <= LIMITS[:state.size]).all())
+
+    def _state_fp(self, state):
+        if not self._valid(state):
+            return False
+        self.collision_check_count += 1
+        return bool(self.map[tuple(self._cell(state))] == 0)
+
+    def _segment_fp(self, left, right):
+        lc, rc = self._cell(left), self._cell(right)
+        if np.sum(np.abs(lc - rc)) > 1 and np.sum(np.abs(left - right)) > RRT_EPS:
+            mid = (left + right) / 2.0
+            if not self._state_fp(mid):
+                return False
+            return self._segment_fp(left, mid) and self._segment_fp(mid, right)
+        return True
+
+    def _edge_fp(self, a, b):
+        if not self._valid(a) or not self._valid(b):
+            return False
+        if not self._state_fp(a) or not self._state_fp(b):
+            return False
+        return self._segment_fp(a, b)

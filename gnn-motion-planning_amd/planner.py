@@ -1,0 +1,212 @@
+"""Host-side planner around the GPU models: the build's counterparts of the reference callers of the
+hot path (behavioural spec Appendix G):
+
+  * ``obs_data``                 eval_gnn.py:25-36  /  smoother.py:52-64
+  * ``explore``                  eval_gnn.py:168-276  (greedy best-edge expansion on the explorer's output)
+  * ``smooth_step`` / ``model_smooth``   smoother.py:194-216 / :233-246
+  * ``eval_gnn``                 eval_gnn.py:96-145   (aggregates)
+
+The sequential control flow and the collision checks stay on the host CPU (north_star); the GPU
+models are called through the same keyword signatures the reference uses.  ``explore`` reproduces the
+reference's observable behaviour including two quirks (SURVEY.md finding 0.6): the explored-edge mask is
+applied with LEGACY tuple-index semantics, and the pair list is reshaped (2, -1) rather than transposed.
+"""
+import math
+import time
+from copy import deepcopy
+
+import numpy as np
+import torch
+
+from .graph_build import create_data
+
+
+def path_cost(path):
+    """Sum of segment lengths (eval_gnn.py:53-58)."""
+    p = np.array(path)
+    return float(sum(np.linalg.norm(p[i + 1] - p[i]) for i in range(len(p) - 1)))
+
+
+def obs_data(env, free, collided, device, for_smoother=False):
+    """Tensors handed to the models next to the graph (explorer: eval_gnn.py:25-36, collided truncated
+    to len(free); smoother: smoother.py:52-64, empty lists replaced by one zero row -- appended to the
+    CALLER's list like the reference does -- and both truncated to 500)."""
+    if for_smoother:
+        if not len(free):
+            free.append([0. for _ in range(env.config_dim)])
+        if not len(collided):
+            collided.append([0. for _ in range(env.config_dim)])
+        free, collided = free[:500], collided[:500]
+        coll_t = torch.tensor(np.array(collided), dtype=torch.float32)
+    else:
+        coll_t = torch.tensor(np.array(collided), dtype=torch.float32)[:len(free)]
+    return {'free': torch.tensor(np.array(free), dtype=torch.float32).to(device), 'collided': coll_t.to(device),
+            'obstacles': torch.tensor(np.asarray(env.obstacles), dtype=torch.float32).to(device)}
+
+
+def _mask_policy(P, labels, explored, explored_edges):
+    """eval_gnn.py:198-202 on a dense numpy [N, N] matrix P[target, source]."""
+    n = P.shape[0]
+    P[np.arange(n), np.arange(n)] = 0
+    P[:, explored] = 0
+    coll = labels[:, 1] == 1
+    P[:, coll] = 0
+    P[coll, :] = 0
+    idx = np.array(explored_edges).reshape(2, -1)     # reshape, not transpose: part of the observable behaviour
+    P[idx[0], idx[1]] = 0                             # legacy "sequence of sequences == tuple" indexing
+    return P
+
+
+def greedy_expand(P, v, env, state):
+    """The inner while-loop of ``explore`` (eval_gnn.py:204-233) on a masked dense policy.
+    ``state``: dict(explored, explored_edges, costs, prev); mutated in place.  Returns the node-index
+    path if the goal region was reached, else None."""
+    explored, explored_edges = state['explored'], state['explored_edges']
+    while True:
+        sub = P[explored, :]
+        if not (sub.sum(dtype=np.float32) != 0):      # float sum test of the reference (eval_gnn.py:204)
+            return None
+        rows, cols = np.nonzero(sub)                  # row-major: (explored order, column)
+        a = int(np.argmax(sub[rows, cols]))           # first maximum
+        end_a, end_b = int(explored[rows[a]]), int(cols[a])
+        explored_edges.extend([[end_a, end_b], [end_b, end_a]])
+        if env._edge_fp(v[end_a], v[end_b]):
+            explored.append(end_b)
+            state['costs'][end_b] = state['costs'][end_a] + np.linalg.norm(v[end_a] - v[end_b])
+            state['prev'][end_b] = end_a
+            P[:, end_b] = 0
+            if env.in_goal_region(v[end_b]):
+                path, node = [end_b], end_b
+                while node != 0:
+                    node = state['prev'][node]
+                    path.append(node)
+                path.reverse()
+                return path
+        else:
+            P[end_a, end_b] = 0
+            P[end_b, end_a] = 0
+
+
+def smooth_step(old_path, new_path, env):
+    """``proposed_path_smootherv2`` (smoother.py:194-216): steer every interior waypoint at most RRT_EPS
+    per round towards the network's proposal, keep the move only if both adjacent edges stay free
+    (the left neighbour is already updated, the right one is not)."""
+    K = int(np.ceil((np.linalg.norm(np.array(old_path) - np.array(new_path), axis=-1) / env.RRT_EPS).max()))
+    path = deepcopy(old_path)
+    for _ in range(K):
+        diff = 0
+        nxt = deepcopy(path)
+        for i in range(1, len(path) - 1):
+            old_n, new_n = path[i], new_path[i]
+            dist = np.linalg.norm(old_n - new_n)
+            nxt[i] = new_n if dist < env.RRT_EPS else env.interpolate(old_n, new_n, env.RRT_EPS / dist)
+            if not (env._edge_fp(nxt[i - 1], nxt[i]) and env._edge_fp(nxt[i + 1], nxt[i])):
+                nxt[i] = path[i]
+            else:
+                diff += np.linalg.norm(nxt[i] - new_n)
+        path = nxt
+        if diff < 1e-5:
+            return path
+    return path
+
+
+def chain_edge_index(n):
+    """i <-> i+1 in both directions, then self loops appended (smoother.py:238-241)."""
+    a, b = torch.arange(1, n), torch.arange(0, n - 1)
+    e = torch.cat((torch.stack((a, b)), torch.stack((b, a))), dim=1)
+    loops = torch.arange(n)
+    return torch.cat((e, torch.stack((loops, loops))), dim=1)
+
+
+@torch.no_grad()
+def model_smooth(model, free, collided, old_path, env, device, iters=5, trace=None):
+    """smoother.py:233-246: 5 x (smoother forward with loop=1 -> collision-checked steering)."""
+    for _ in range(iters):
+        data = obs_data(env, free, collided, device, for_smoother=True)
+        path_t = torch.tensor(np.array(old_path), dtype=torch.float32).to(device)
+        new_path = model(path=path_t, edge_index=chain_edge_index(len(old_path)).to(device), loop=1, **data)
+        new_path = new_path.detach().cpu().numpy()
+        if trace is not None:
+            trace.append((np.array(old_path, dtype=np.float32), new_path.copy()))
+        old_path = smooth_step(old_path, new_path, env)
+    return old_path
+
+
+@torch.no_grad()
+def explore(env, model, model_s, smooth=True, batch=500, t_max=1000, k=30, smoother='model', loop=5, device='cuda',
+            trace=None):
+    """Counterpart of ``explore`` (eval_gnn.py:168-276).  Returns the same result dict."""
+    c0 = env.collision_check_count
+    t0 = time.time()
+    forward = 0.
+    success, path, smooth_path = False, [], []
+    free, collided = env.sample_n_points(batch, need_negative=True)
+    collided = collided[:len(free)]
+    free = [env.init_state] + [env.goal_state] + list(free)
+    state = {'explored': [0], 'explored_edges': [[0, 0]], 'costs': {0: 0.}, 'prev': {0: 0}}
+    data = create_data(free, collided, env.goal_state, k)
+    while not success and (len(free) - 2) <= t_max:
+        t1 = time.time()
+        od = obs_data(env, free, collided, device)
+        P = model(goal=data['goal'].to(device), v=data['v'].to(device), labels=data['labels'].to(device),
+                  edge_index=data['edge_index'].to(device), loop=loop, **od)
+        P = P.detach().cpu().numpy()                                # the implicit sync of eval_gnn.py:195
+        forward += time.time() - t1
+        if trace is not None:
+            ei = data['edge_index'].numpy()
+            trace.setdefault('forwards', []).append({'v': data['v'].numpy().copy(), 'edge_index': ei.copy(),
+                                                     'scores': P[ei[1], ei[0]].copy()})
+        P = _mask_policy(P, data['labels'].numpy(), state['explored'], state['explored_edges'])
+        v = data['v'].numpy()
+        found = greedy_expand(P, v, env, state)
+        if found is not None:
+            success, path = True, found
+        if not success:
+            if not smooth:
+                return []
+            if (batch + len(free) - 2) > t_max:
+                break
+            new_free, new_coll = env.sample_n_points(batch, need_negative=True)
+            free = free + list(new_free)
+            collided = (collided + list(new_coll))[:len(free)]
+            data = create_data(free, collided, env.goal_state, k)
+    c_explore = env.collision_check_count - c0
+    c1 = env.collision_check_count
+    t1 = time.time()
+    if success and smooth:
+        path = list(data['v'][path].numpy())
+        if smoother == 'model':
+            smooth_path = model_smooth(model_s, free, collided, path, env, device,
+                                       trace=None if trace is None else trace.setdefault('smooth', []))
+        else:
+            smooth_path = path
+    c_smooth = env.collision_check_count - c1
+    if not smooth:
+        return list(data['v'][path].numpy()), free, collided
+    return {'c_explore': c_explore, 'c_smooth': c_smooth, 'data': data, 'explored': state['explored'],
+            'forward': forward, 'total': time.time() - t0, 'total_explore': t1 - t0, 'success': success, 't0': t0,
+            'path': path, 'smooth_path': smooth_path, 'explored_edges': state['explored_edges']}
+
+
+def eval_gnn(env, indexes, model, model_s, seed=1234, smooth=True, batch=500, t_max=500, k=30, device='cuda', **kw):
+    """Counterpart of ``eval_gnn`` (eval_gnn.py:96-145): the seven per-problem numbers and their
+    aggregates, same order as the reference's return tuple."""
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    sol, paths, smooth_paths = [], [], []
+    for index in indexes:
+        env.init_new_problem(index)
+        r = explore(env, model, model_s, smooth, batch=batch, t_max=t_max, k=k, device=device, **kw)
+        paths.append(r['path'])
+        smooth_paths.append(r['smooth_path'])
+        sol.append((r['success'], path_cost(r['path']), path_cost(r['smooth_path']), r['c_explore'], r['c_smooth'],
+                    r['total'], r['total_explore']))
+    n_success = sum(s[0] for s in sol)
+    collision_explore = float(np.mean([s[3] for s in sol]))
+    collision = float(np.mean([s[3] + s[4] for s in sol]))
+    running_time = float(sum(s[5] for s in sol if s[0])) / max(n_success, 1)
+    solution_cost = float(sum(s[2] for s in sol if s[0])) / max(n_success, 1)
+    total_time = sum(s[5] for s in sol)
+    total_time_explore = sum(s[6] for s in sol)
+    return (n_success, collision, running_time, solution_cost, total_time, paths, smooth_paths, collision_explore,
+            total_time_explore)

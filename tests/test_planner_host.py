@@ -1,0 +1,117 @@
+"""Host-side planner counterparts against traces recorded from the
+reference planner on real MazeEnv problems (tools/gen_golden.py planner_cases).  CPU only: the GNNs
+are replaced by replay objects that (a) assert they receive exactly the tensors the reference's
+models received and (b) return the reference's recorded outputs, so the test pins
+  H1 create_data (identical v / coalesced edge_index),
+  H3 obs_data (identical free / collided / obstacles tensors),
+  H2 masking + greedy expansion incl. the legacy-index quirk (identical explored, explored_edges, path,
+     collision-check count),
+  H4 model_smooth + steering (identical smoothed path and collision-check count),
+and the Maze2D environment (identical sample stream from the seeded numpy RNG, identical check counts).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_files
+import gnnmp  # noqa: F401
+from gnnmp import planner
+from gnnmp.maze2d import Maze2D
+
+
+def _load(path):
+    with np.load(path) as f:
+        return {k: f[k] for k in f.files}
+
+
+class ReplayExplorer:
+    def __init__(self, rec):
+        self.rec, self.i = rec, 0
+
+    def __call__(self, goal, v, labels, edge_index, loop, free, collided, obstacles):
+        r, i = self.rec, self.i
+        assert loop == 5
+        assert np.array_equal(v.numpy(), r['e%d_v' % i])
+        assert np.array_equal(edge_index.numpy(), r['e%d_edge_index' % i])
+        assert np.array_equal(free.numpy(), r['e%d_free' % i])
+        assert np.array_equal(collided.numpy(), r['e%d_collided' % i])
+        assert np.array_equal(obstacles.numpy(), r['e%d_obstacles' % i])
+        assert np.array_equal(goal.numpy(), r['e%d_goal' % i])
+        n = v.shape[0]
+        assert labels.shape == (n, 3) and float(labels[1, 2]) == 1.0
+        P = torch.zeros(n, n)
+        P[edge_index[1], edge_index[0]] = torch.from_numpy(r['e%d_scores' % i])
+        self.i += 1
+        return P
+
+
+class ReplaySmoother:
+    def __init__(self, rec):
+        self.rec, self.i = rec, 0
+
+    def __call__(self, path, free, collided, obstacles, edge_index, loop):
+        r, i = self.rec, self.i
+        assert loop == 1
+        assert np.array_equal(path.numpy(), r['s%d_path' % i])
+        assert np.array_equal(free.numpy(), r['s%d_free' % i])
+        assert np.array_equal(collided.numpy(), r['s%d_collided' % i])
+        P = path.shape[0]
+        assert edge_index.shape == (2, 3 * P - 2)
+        self.i += 1
+        return torch.from_numpy(r['s%d_out' % i])
+
+
+def _env(r):
+    env = Maze2D(r['map'][None], r['init_state'][None], r['goal_state'][None])
+    env.init_new_problem(0)
+    return env
+
+
+@pytest.mark.parametrize('path', golden_files('planner_'), ids=os.path.basename)
+def test_planner_replay_matches_reference_trace(path):
+    r = _load(path)
+    env = _env(r)
+    np.random.seed(int(r['seed']))
+    torch.manual_seed(int(r['seed']))
+    ex, sm = ReplayExplorer(r), ReplaySmoother(r)
+    res = planner.explore(env, ex, sm, True, batch=int(r['batch']), t_max=int(r['t_max']), k=int(r['k']), device='cpu')
+    assert ex.i == int(r['n_forward']) and sm.i == int(r['n_smooth'])
+    assert res['success'] == bool(r['success'])
+    assert res['explored'] == r['explored'].tolist()
+    assert res['explored_edges'] == r['explored_edges'].tolist()
+    assert res['c_explore'] == int(r['c_explore'])
+    assert res['c_smooth'] == int(r['c_smooth'])
+    assert np.array_equal(np.array(res['path'], dtype=np.float32), r['path'])
+    assert np.array_equal(np.array(res['smooth_path'], dtype=np.float64), r['smooth_path'])
+
+
+def test_maze_env_counts_and_obstacles():
+    r = _load(golden_files('planner_mazehard_0')[0])
+    env = _env(r)
+    assert env.obstacles.shape == (int(r['map'].sum()), 2)
+    assert np.array_equal(env.obstacles.astype(np.float32), r['e0_obstacles'])
+    # out-of-bounds queries are refused without being counted (maze_env.py:281-288)
+    c = env.collision_check_count
+    assert env._state_fp(np.array([1.5, 0.0])) is False and env.collision_check_count == c
+    assert env._edge_fp(np.array([0.0, 0.0]), np.array([0.0, 2.0])) is False and env.collision_check_count == c
+    # a zero-length edge costs exactly two point queries when free
+    free_pt = env.init_state
+    env._edge_fp(free_pt, free_pt)
+    assert env.collision_check_count == c + 2
+
+
+def test_legacy_index_quirk_is_reproduced():
+    """explored_edges pairs are reshaped (2, -1), not transposed, and used as a (rows, cols) tuple."""
+    P = np.ones((4, 4), dtype=np.float32)
+    labels = np.zeros((4, 3), dtype=np.float32)
+    planner._mask_policy(P, labels, [0], [[0, 0], [0, 2], [2, 0], [0, 3], [3, 0]])
+    # flat list 0,0,0,2,2,0,0,3,3,0 -> rows (0,0,0,2,2), cols (0,0,3,3,0)
+    expect = np.ones((4, 4), dtype=np.float32)
+    expect[np.arange(4), np.arange(4)] = 0
+    expect[:, 0] = 0
+    for a, b in zip((0, 0, 0, 2, 2), (0, 0, 3, 3, 0)):
+        expect[a, b] = 0
+    assert np.array_equal(P, expect)
+    assert P[0, 2] == 1.0          # the (0, 2) edge itself is NOT masked: that is the reference's behaviour

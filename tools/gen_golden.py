@@ -142,6 +142,74 @@ def smoother_case(name, C, scale, P=12, F=60, Co=60, loop=1, seed=4321):
            (outs['fp32'] - path).abs().max().item()))
 
 
+def load_patched_eval_gnn():
+    """The reference's eval_gnn module with the ONE in-memory token patch SURVEY.md finding 0.6
+    describes (torch >= 2 no longer treats a 2 x M ndarray index as a tuple); file on disk untouched."""
+    import types
+    src = open(os.path.join(REF, 'eval_gnn.py')).read()
+    old = 'policy[np.array(explored_edges).reshape(2, -1)] = 0'
+    assert src.count(old) == 1
+    src = src.replace(old, 'policy[tuple(np.array(explored_edges).reshape(2, -1))] = 0')
+    mod = types.ModuleType('eval_gnn_patched')
+    mod.__file__ = os.path.join(REF, 'eval_gnn.py')
+    exec(compile(src, mod.__file__, 'exec'), mod.__dict__)
+    return mod
+
+
+def planner_case(eg, env, idx, sd_e, sd_s, batch, t_max, k, seed):
+    """One real MazeEnv problem through the reference planner; records the problem, every model
+    call's inputs/outputs and the planner trace."""
+    from config import set_random_seed
+    m = ref_model.EncoderProcessDecoder(2, 2, 32, 2)
+    m.load_state_dict(sd_e, strict=True)
+    ms = ref_smoother.ModelSmoother(workspace_size=2, config_size=2, embed_size=128, obs_size=6)
+    ms.load_state_dict(sd_s, strict=True)
+    m.eval(); ms.eval()
+    calls_e, calls_s = [], []
+
+    def hook_e(_m, args, kwargs, out):
+        ei = kwargs['edge_index']
+        calls_e.append(dict(v=kwargs['v'].numpy().copy(), edge_index=ei.numpy().copy(), free=kwargs['free'].numpy().copy(),
+                            collided=kwargs['collided'].numpy().copy(), obstacles=kwargs['obstacles'].numpy().copy(),
+                            goal=kwargs['goal'].numpy().copy(), scores=out[ei[1], ei[0]].numpy().copy()))
+
+    def hook_s(_m, args, kwargs, out):
+        calls_s.append(dict(path=kwargs['path'].numpy().copy(), free=kwargs['free'].numpy().copy(),
+                            collided=kwargs['collided'].numpy().copy(), out=out.detach().numpy().copy()))
+
+    h1 = m.register_forward_hook(hook_e, with_kwargs=True)
+    h2 = ms.register_forward_hook(hook_s, with_kwargs=True)
+    set_random_seed(seed)
+    env.init_new_problem(idx)
+    r = eg.explore(env, m, ms, True, batch=batch, t_max=t_max, k=k)
+    h1.remove(); h2.remove()
+    rec = dict(map=env.map.copy(), init_state=env.init_state.copy(), goal_state=env.goal_state.copy(), seed=seed,
+               batch=batch, t_max=t_max, k=k, success=int(r['success']), c_explore=r['c_explore'], c_smooth=r['c_smooth'],
+               explored=np.array(r['explored']), explored_edges=np.array(r['explored_edges']),
+               path=np.array(r['path'], dtype=np.float32), smooth_path=np.array(r['smooth_path'], dtype=np.float64),
+               n_forward=len(calls_e), n_smooth=len(calls_s))
+    for i, c in enumerate(calls_e):
+        for key, val in c.items():
+            rec['e%d_%s' % (i, key)] = val
+    for i, c in enumerate(calls_s):
+        for key, val in c.items():
+            rec['s%d_%s' % (i, key)] = val
+    fn = 'planner_mazehard_%d_b%d_k%d.npz' % (idx, batch, k)
+    np.savez_compressed(os.path.join(OUT, fn), **rec)
+    print('%-44s success=%d forwards=%d explored=%d c_explore=%d c_smooth=%d |path|=%d' %
+          (fn, r['success'], len(calls_e), len(r['explored']), r['c_explore'], r['c_smooth'], len(r['path'])))
+
+
+def planner_cases(sds):
+    from environment import MazeEnv
+    eg = load_patched_eval_gnn()
+    env = MazeEnv(dim=2, map_file='maze_files/mazes_hard.npz')
+    sd_s = torch.load(os.path.join(REF, 'data', 'weights', 'smooth_2d_attv3.pt'), map_location='cpu')
+    for idx in range(4):
+        planner_case(eg, env, idx, sds['maze2'], sd_s, batch=100, t_max=300, k=10, seed=1234 + idx)
+    planner_case(eg, env, 7, sds['maze2'], sd_s, batch=40, t_max=200, k=8, seed=77)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -164,7 +232,12 @@ def main():
         smoother_case(name, C, scale)
     smoother_case('smooth_2d_attv3', 2, 1.0, P=30, F=500, Co=500, loop=1)
     smoother_case('smooth_14d_attv3', 14, 1.0, P=7, F=40, Co=3, loop=3)
+    planner_cases(sds)
 
 
 if __name__ == '__main__':
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == 'planner':
+        torch.set_num_threads(8)
+        planner_cases({'maze2': save_weights('weights_maze')})
+    else:
+        main()
