@@ -455,7 +455,7 @@ struct Carve {
     // offsets in bytes
     size_t node_ptr_pad, edge_ptr_pad, goal_node, dense_ptr;
     size_t zero_beg, deg, cursor, zero_end;
-    size_t ff_beg, ntile_graph, etile_graph, csr_src, csr_dst, csr_eid, ff_end;
+    size_t ff_beg, ntile_graph, etile_graph, csr, ff_end;
     size_t row_beg;
     size_t XI, X, A, B, DN, H, agg, Ke, PE, part_first, part_last, kv_e, kv_n;
     size_t total;
@@ -490,9 +490,7 @@ bool carve(const gnnmp_explorer* h, const gnnmp_batch* b, Carve& c) {
     c.ff_beg = o;
     c.ntile_graph = take(sizeof(int) * (c.Npad / 32));
     c.etile_graph = take(sizeof(int) * (c.Epad / 32));
-    c.csr_src = take(sizeof(int) * c.Epad);
-    c.csr_dst = take(sizeof(int) * c.Epad);
-    c.csr_eid = take(sizeof(int) * c.Epad);
+    c.csr = take(sizeof(int) * 4 * (size_t)c.Epad);
     c.ff_end = o;
     c.row_beg = take(sizeof(int) * c.Npad);
     const size_t nrow = sizeof(float) * (size_t)c.Npad * D, erow = sizeof(float) * (size_t)c.Epad * D;
@@ -578,7 +576,7 @@ extern "C" int gnnmp_explorer_forward(const gnnmp_explorer* h, const gnnmp_batch
     q.dense_ptr = at<long long>(ws, c.dense_ptr);
     q.deg = at<int>(ws, c.deg); q.cursor = at<int>(ws, c.cursor); q.row_beg = at<int>(ws, c.row_beg);
     q.ntile_graph = at<int>(ws, c.ntile_graph); q.etile_graph = at<int>(ws, c.etile_graph);
-    q.csr_src = at<int>(ws, c.csr_src); q.csr_dst = at<int>(ws, c.csr_dst); q.csr_eid = at<int>(ws, c.csr_eid);
+    q.csr = at<int4>(ws, c.csr);
     q.goal_node = at<int>(ws, c.goal_node);
     HIP_TRY(launch_prep(q, st));
     // zero-fill of policy_output (model.py:148); sum_g N_g^2 is read from dense_ptr[G] on the device
@@ -602,7 +600,7 @@ extern "C" int gnnmp_explorer_forward(const gnnmp_explorer* h, const gnnmp_batch
         p.v = b->v; p.goal = b->goal; p.C = C;
         p.node_ptr = b->node_ptr; p.node_ptr_pad = q.node_ptr_pad;
         p.tile_graph = edge ? q.etile_graph : q.ntile_graph;
-        p.csr_src = q.csr_src; p.csr_dst = q.csr_dst;
+        p.csr = q.csr;
         p.obs_ptr = b->obs_ptr; p.goal_node = q.goal_node;
         p.enc = W + (edge ? h->off.enc_e : h->off.enc_n);
         p.encb = edge ? h->enc_e : h->enc_n;
@@ -628,7 +626,7 @@ extern "C" int gnnmp_explorer_forward(const gnnmp_explorer* h, const gnnmp_batch
         const bool last = (it == loop - 1);
         if (b->total_edges > 0) {
             MpEdgeParams e;
-            e.csr_src = q.csr_src; e.csr_dst = q.csr_dst; e.row_beg = q.row_beg; e.deg = q.deg;
+            e.csr = q.csr; e.row_beg = q.row_beg; e.deg = q.deg;
             e.etile_graph = q.etile_graph;
             e.A = at<float>(ws, c.A); e.B = at<float>(ws, c.B); e.Ke = at<float>(ws, c.Ke);
             e.w = W + h->off.mpe;
@@ -651,7 +649,7 @@ extern "C" int gnnmp_explorer_forward(const gnnmp_explorer* h, const gnnmp_batch
 
     if (b->total_edges > 0) {
         PolicyParams p;
-        p.csr_src = q.csr_src; p.csr_dst = q.csr_dst; p.csr_eid = q.csr_eid; p.etile_graph = q.etile_graph;
+        p.csr = q.csr; p.etile_graph = q.etile_graph;
         p.node_ptr = b->node_ptr; p.node_ptr_pad = q.node_ptr_pad; p.dense_ptr = q.dense_ptr;
         p.PS = at<float>(ws, c.A); p.PT = at<float>(ws, c.B); p.PE = at<float>(ws, c.PE);
         p.w = W + h->off.pol;

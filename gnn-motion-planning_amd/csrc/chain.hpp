@@ -181,6 +181,20 @@ __device__ __forceinline__ void load_tile(const float* tile_base, f32x16 (&x)[NT
         }
 }
 
+// streamed-once variant: non-temporal loads keep the private per-edge streams from evicting the
+// gathered node rows out of L2
+template <int NT>
+__device__ __forceinline__ void load_tile_nt(const float* tile_base, f32x16 (&x)[NT], int lane) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 a = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(tile_base + ((t * 4 + q) * 64 + lane) * 4));
+#pragma unroll
+            for (int c = 0; c < 4; ++c) x[t][q * 4 + c] = a[c];
+        }
+}
+
 // cooperative global -> LDS copy by the whole workgroup (n multiple of 4 floats, 16-B aligned).
 // Uses the gfx950 LDS-DMA path (global_load_lds_dwordx4): every wave issues all of its 1-KiB pieces
 // back to back with no VGPR round trip, so the L2 latency is paid once per phase instead of once

@@ -122,8 +122,7 @@ __global__ void prep_scan_kernel(const int* __restrict__ node_ptr_pad, const int
 
 __global__ void prep_fill_kernel(int G, int E, const long long* __restrict__ edge_index, const int* __restrict__ edge_ptr,
                                  const int* __restrict__ node_ptr_pad, const int* __restrict__ row_beg,
-                                 int* __restrict__ cursor, int* __restrict__ csr_src, int* __restrict__ csr_dst,
-                                 int* __restrict__ csr_eid) {
+                                 int* __restrict__ cursor, int4* __restrict__ csr) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= E) return;
     const int g = find_graph(edge_ptr, G, e);
@@ -131,9 +130,7 @@ __global__ void prep_fill_kernel(int G, int E, const long long* __restrict__ edg
     const int src = base + (int)edge_index[e];
     const int dst = base + (int)edge_index[(size_t)E + e];
     const int pos = row_beg[dst] + atomicAdd(&cursor[dst], 1);
-    csr_src[pos] = src;
-    csr_dst[pos] = dst;
-    csr_eid[pos] = e;
+    csr[pos] = make_int4(src, dst, e, 0);      // one 16-byte record per edge: {source, target, caller column}
 }
 
 // =====================================================================================================
@@ -357,8 +354,13 @@ __global__ __launch_bounds__(WAVES * 64) void pre_kernel(PreParams p) {
     float* wl = lds;
     float* kvl = lds + p.wregion;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
-    const int tile = blockIdx.x * WAVES + wave;
-    const int g = p.tile_graph[blockIdx.x * WAVES];       // kPad is a multiple of 32*WAVES: uniform per WG
+    // XCD-aware order (see XcdWalk): XCD b % 8 works on a contiguous eighth of the workgroup tiles, so a
+    // graph's K/V slabs and weights are staged from ONE XCD's L2
+    const int per = (p.n_wg + 7) >> 3;
+    const int wg = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per || wg >= p.n_wg) return;
+    const int tile = wg * WAVES + wave;
+    const int g = p.tile_graph[wg * WAVES];               // kPad is a multiple of 32*WAVES: uniform per WG
     if (g < 0) return;
     const int row = tile * 32 + j;                        // padded index
     const int nbase_pad = p.node_ptr_pad[g], nbase = p.node_ptr[g];
@@ -369,7 +371,8 @@ __global__ __launch_bounds__(WAVES * 64) void pre_kernel(PreParams p) {
     const EncBlob E = p.encb;
     f32x16 m[NT], aux[NT];      // m: the "free" code that goes through attention; aux: node_code / edge_code
     if constexpr (EDGE) {
-        const int s = p.csr_src[row], t = p.csr_dst[row];
+        const int4 rec = p.csr[row];
+        const int s = rec.x, t = rec.y;
         const float* vs = p.v + (size_t)(nbase + (s >= 0 ? s - nbase_pad : 0)) * C;
         const float* vt = p.v + (size_t)(nbase + (t >= 0 ? t - nbase_pad : 0)) * C;
         auto getin = [&](int k) { return (k < C) ? vs[k] : ((k < 2 * C) ? vt[k - C] : 0.f); };
@@ -451,6 +454,24 @@ __global__ __launch_bounds__(WAVES * 64) void pre_kernel(PreParams p) {
     }
 }
 
+// Grid-stride over tile groups with an XCD-aware order: workgroup b runs on XCD b % 8 (observed
+// dispatch rule; used for speed only), so XCD x walks the contiguous eighth [x*per, (x+1)*per) of the
+// group space.  Consecutive groups belong to the same graphs, hence each XCD's private L2 only ever
+// holds the node rows of "its" graphs instead of every XCD caching every graph.
+struct XcdWalk {
+    int cur, end, step;
+    __device__ __forceinline__ XcdWalk(int n_groups) {
+        const int nb = gridDim.x >> 3;                    // blocks per XCD (gridDim.x is a multiple of 8)
+        const int per = (n_groups + 7) >> 3;
+        const int xcd = blockIdx.x & 7;
+        cur = xcd * per + (blockIdx.x >> 3);
+        end = min(n_groups, (xcd + 1) * per);
+        step = nb;
+    }
+    __device__ __forceinline__ bool valid() const { return cur < end; }
+    __device__ __forceinline__ void next() { cur += step; }
+};
+
 // =====================================================================================================
 // mp_edge: per 32-edge CSR tile: hidden = relu(A[src] + B[dst] + K_e); M = W2 hidden + b2;
 // segmented max over runs of equal destination.  Complete segments go to agg[dst]; segments cut by
@@ -467,15 +488,16 @@ __global__ __launch_bounds__(256) void mp_edge_kernel(MpEdgeParams p) {
     float* scr = lds + ((L::size + 3) & ~3) + wave * (32 * LD);
     stage(wl, p.w, L::size);
     __syncthreads();
-    for (int grp = blockIdx.x; grp * 4 < p.n_tiles; grp += gridDim.x) {
-        const int tile = grp * 4 + wave;
+    for (XcdWalk wk((p.n_tiles + 3) / 4); wk.valid(); wk.next()) {
+        const int tile = wk.cur * 4 + wave;
         if (tile >= p.n_tiles || p.etile_graph[tile] < 0) continue;
         const int e = tile * 32 + j;
-        const int s = p.csr_src[e], t = p.csr_dst[e];
+        const int4 rec = p.csr[e];
+        const int s = rec.x, t = rec.y;
         const float* ar = p.A + (size_t)(s >= 0 ? s : 0) * D;
         const float* br = p.B + (size_t)(t >= 0 ? t : 0) * D;
         f32x16 hid[NT], a[NT], b[NT];
-        load_tile<NT>(p.Ke + (size_t)tile * NT * kATile, hid, lane);
+        load_tile_nt<NT>(p.Ke + (size_t)tile * NT * kATile, hid, lane);
         load_row<NT>(ar, a, h);
         load_row<NT>(br, b, h);
 #pragma unroll
@@ -545,8 +567,8 @@ __global__ __launch_bounds__(256) void mp_node_kernel(MpNodeParams p) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
     stage(wl, p.w, L::size);
     __syncthreads();
-    for (int grp = blockIdx.x; grp * 4 < p.n_tiles; grp += gridDim.x) {
-        const int tile = grp * 4 + wave;
+    for (XcdWalk wk((p.n_tiles + 3) / 4); wk.valid(); wk.next()) {
+        const int tile = wk.cur * 4 + wave;
         if (tile >= p.n_tiles || p.ntile_graph[tile] < 0) continue;
         const int t = tile * 32 + j;
         f32x16 x[NT], ag[NT];
@@ -602,15 +624,16 @@ __global__ __launch_bounds__(256) void policy_kernel(PolicyParams p) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
     stage(wl, p.w, L::size);
     __syncthreads();
-    for (int grp = blockIdx.x; grp * 4 < p.n_tiles; grp += gridDim.x) {
-        const int tile = grp * 4 + wave;
+    for (XcdWalk wk((p.n_tiles + 3) / 4); wk.valid(); wk.next()) {
+        const int tile = wk.cur * 4 + wave;
         if (tile >= p.n_tiles) continue;
         const int g = p.etile_graph[tile];
         if (g < 0) continue;
         const int e = tile * 32 + j;
-        const int s = p.csr_src[e], t = p.csr_dst[e];
+        const int4 rec = p.csr[e];
+        const int s = rec.x, t = rec.y;
         f32x16 hid[NT], a[NT], b[NT];
-        load_tile<NT>(p.PE + (size_t)tile * NT * kATile, hid, lane);
+        load_tile_nt<NT>(p.PE + (size_t)tile * NT * kATile, hid, lane);
         load_row<NT>(p.PS + (size_t)(s >= 0 ? s : 0) * D, a, h);
         load_row<NT>(p.PT + (size_t)(t >= 0 ? t : 0) * D, b, h);
 #pragma unroll
@@ -628,8 +651,7 @@ __global__ __launch_bounds__(256) void policy_kernel(PolicyParams p) {
             for (int r = 0; r < 16; ++r) sc = fmaf(w3[tt][r], y[tt][r], sc);
         sc += xhalf(sc);
         if (h == 0 && s >= 0) {
-            const int eid = p.csr_eid[e];
-            p.scores[eid] = sc;
+            p.scores[rec.z] = sc;
             if (p.dense) {
                 const int nb = p.node_ptr_pad[g];
                 const long long ng = p.node_ptr[g + 1] - p.node_ptr[g];
@@ -685,7 +707,7 @@ hipError_t launch_prep(const PrepParams& q, hipStream_t st) {
     LAUNCH_CHECK();
     if (q.E > 0) {
         hipLaunchKernelGGL(prep_fill_kernel, dim3((q.E + 255) / 256), dim3(256), 0, st, q.G, q.E, q.edge_index,
-                           q.edge_ptr, q.node_ptr_pad, q.row_beg, q.cursor, q.csr_src, q.csr_dst, q.csr_eid);
+                           q.edge_ptr, q.node_ptr_pad, q.row_beg, q.cursor, q.csr);
         LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(goal_kernel, dim3(q.G), dim3(256), 0, st, q.C, q.v, q.goal, q.node_ptr, q.node_ptr_pad,
@@ -718,8 +740,11 @@ static hipError_t launch_pre_t(const PreParams& p, int n_wg, size_t lds_bytes, h
     LAUNCH_CHECK();
     return hipSuccess;
 }
-hipError_t launch_pre(int D, bool edge, int waves, const PreParams& p, int n_tiles32, size_t lds_bytes, hipStream_t st) {
-    const int n_wg = n_tiles32 / waves;
+hipError_t launch_pre(int D, bool edge, int waves, const PreParams& p_in, int n_tiles32, size_t lds_bytes, hipStream_t st) {
+    int n_wg = n_tiles32 / waves;
+    PreParams p = p_in;
+    p.n_wg = n_wg;
+    n_wg = (n_wg + 7) & ~7;
     if (D == 32 && waves == 4) return edge ? launch_pre_t<32, true, 4>(p, n_wg, lds_bytes, st) : launch_pre_t<32, false, 4>(p, n_wg, lds_bytes, st);
     if (D == 32 && waves == 8) return edge ? launch_pre_t<32, true, 8>(p, n_wg, lds_bytes, st) : launch_pre_t<32, false, 8>(p, n_wg, lds_bytes, st);
     if (D == 64 && waves == 8) return edge ? launch_pre_t<64, true, 8>(p, n_wg, lds_bytes, st) : launch_pre_t<64, false, 8>(p, n_wg, lds_bytes, st);
@@ -727,9 +752,10 @@ hipError_t launch_pre(int D, bool edge, int waves, const PreParams& p, int n_til
     return hipErrorInvalidValue;
 }
 
-static int grid_for(int n_tiles) {
-    const int groups = (n_tiles + 3) / 4;
-    return groups < 256 * 8 ? (groups > 0 ? groups : 1) : 256 * 8;
+static int grid_for(int n_tiles) {        // multiple of 8 (XcdWalk), at most 8 workgroups per CU
+    int groups = ((n_tiles + 3) / 4 + 7) & ~7;
+    if (groups < 8) groups = 8;
+    return groups < 256 * 8 ? groups : 256 * 8;
 }
 
 template <int D>

@@ -14,7 +14,7 @@ struct PrepParams {
     long long* dense_ptr;                        // [G+1]
     int *deg, *cursor, *row_beg;                 // [Npad]
     int *ntile_graph, *etile_graph;              // per 32-row tile
-    int *csr_src, *csr_dst, *csr_eid;            // [Epad]
+    int4* csr;                                   // [Epad] {source, target, caller column, 0}; -1 = pad slot
     int* goal_node;                              // [G] padded node id
 };
 
@@ -34,7 +34,7 @@ struct PreParams {
     int C;
     const int *node_ptr, *node_ptr_pad;
     const int* tile_graph;
-    const int *csr_src, *csr_dst;
+    const int4* csr;
     const int* obs_ptr;
     const int* goal_node;
     const float* enc;
@@ -45,12 +45,14 @@ struct PreParams {
     const float* kv;
     int kv_stride, ot_max, ot_chunk;
     int wregion;             // floats reserved for the weight region of LDS
+    int n_wg;                // workgroup tiles in the padded index space (set by launch_pre)
     int use_obstacles;
     float *o0, *o1, *o2, *o3, *o4;
 };
 
 struct MpEdgeParams {
-    const int *csr_src, *csr_dst, *row_beg, *deg, *etile_graph;
+    const int4* csr;
+    const int *row_beg, *deg, *etile_graph;
     const float *A, *B, *Ke, *w;
     float *agg, *part_first, *part_last;
     int n_tiles;
@@ -64,7 +66,8 @@ struct MpNodeParams {
 };
 
 struct PolicyParams {
-    const int *csr_src, *csr_dst, *csr_eid, *etile_graph, *node_ptr, *node_ptr_pad;
+    const int4* csr;
+    const int *etile_graph, *node_ptr, *node_ptr_pad;
     const long long* dense_ptr;
     const float *PS, *PT, *PE, *w;
     float *scores, *dense;
