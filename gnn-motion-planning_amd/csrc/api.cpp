@@ -455,7 +455,7 @@ struct Carve {
     // offsets in bytes
     size_t node_ptr_pad, edge_ptr_pad, goal_node, dense_ptr;
     size_t zero_beg, deg, cursor, zero_end;
-    size_t ff_beg, ntile_graph, etile_graph, csr, ff_end;
+    size_t ff_beg, ntile_graph, etile_graph, csr, ff_end, tile_meta;
     size_t row_beg;
     size_t XI, X, A, B, DN, H, agg, Ke, PE, part_first, part_last, kv_e, kv_n;
     size_t total;
@@ -493,6 +493,7 @@ bool carve(const gnnmp_explorer* h, const gnnmp_batch* b, Carve& c) {
     c.csr = take(sizeof(int) * 4 * (size_t)c.Epad);
     c.ff_end = o;
     c.row_beg = take(sizeof(int) * c.Npad);
+    c.tile_meta = take(sizeof(int) * (c.Epad / 32));
     const size_t nrow = sizeof(float) * (size_t)c.Npad * D, erow = sizeof(float) * (size_t)c.Epad * D;
     c.XI = take(nrow); c.X = take(nrow); c.A = take(nrow); c.B = take(nrow); c.DN = take(nrow); c.H = take(nrow);
     c.agg = take(nrow);
@@ -578,6 +579,7 @@ extern "C" int gnnmp_explorer_forward(const gnnmp_explorer* h, const gnnmp_batch
     q.ntile_graph = at<int>(ws, c.ntile_graph); q.etile_graph = at<int>(ws, c.etile_graph);
     q.csr = at<int4>(ws, c.csr);
     q.goal_node = at<int>(ws, c.goal_node);
+    q.tile_meta = at<int>(ws, c.tile_meta); q.n_etiles = c.Epad / 32;
     HIP_TRY(launch_prep(q, st));
     // zero-fill of policy_output (model.py:148); sum_g N_g^2 is read from dense_ptr[G] on the device
     if (dense) HIP_TRY(launch_zero_dense(dense, q.dense_ptr + c.G, st));
@@ -626,8 +628,7 @@ extern "C" int gnnmp_explorer_forward(const gnnmp_explorer* h, const gnnmp_batch
         const bool last = (it == loop - 1);
         if (b->total_edges > 0) {
             MpEdgeParams e;
-            e.csr = q.csr; e.row_beg = q.row_beg; e.deg = q.deg;
-            e.etile_graph = q.etile_graph;
+            e.csr = q.csr; e.tile_meta = q.tile_meta;
             e.A = at<float>(ws, c.A); e.B = at<float>(ws, c.B); e.Ke = at<float>(ws, c.Ke);
             e.w = W + h->off.mpe;
             e.agg = at<float>(ws, c.agg); e.part_first = at<float>(ws, c.part_first);

@@ -133,6 +133,26 @@ __global__ void prep_fill_kernel(int G, int E, const long long* __restrict__ edg
     csr[pos] = make_int4(src, dst, e, 0);      // one 16-byte record per edge: {source, target, caller column}
 }
 
+// per 32-edge tile: bit0 = its first segment starts in an earlier tile, bit1 = its last segment
+// continues in a later tile, bit2 = tile holds at least one edge; -1 = unused tile.  Lets mp_edge walk
+// its segments without any dependent row_beg/deg loads.
+__global__ void prep_tilemeta_kernel(int n_tiles, const int4* __restrict__ csr, const int* __restrict__ row_beg,
+                                     const int* __restrict__ deg, const int* __restrict__ etile_graph,
+                                     int* __restrict__ tile_meta) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_tiles) return;
+    if (etile_graph[t] < 0) { tile_meta[t] = -1; return; }
+    const int start = t * 32;
+    const int d0 = csr[start].y;
+    if (d0 < 0) { tile_meta[t] = 0; return; }
+    int last = 31;
+    while (last > 0 && csr[start + last].y < 0) --last;
+    const int dl = csr[start + last].y;
+    const int first_open = row_beg[d0] < start;
+    const int last_open = row_beg[dl] + deg[dl] > start + 32;
+    tile_meta[t] = 4 | first_open | (last_open << 1);
+}
+
 // =====================================================================================================
 // goal node: argmin_i |v_i - goal|^2, lowest index on ties; one workgroup per graph
 // =====================================================================================================
@@ -488,11 +508,27 @@ __global__ __launch_bounds__(256) void mp_edge_kernel(MpEdgeParams p) {
     float* scr = lds + ((L::size + 3) & ~3) + wave * (32 * LD);
     stage(wl, p.w, L::size);
     __syncthreads();
-    for (XcdWalk wk((p.n_tiles + 3) / 4); wk.valid(); wk.next()) {
+    // software pipeline: the next tile's edge records and metadata are requested before this tile's
+    // arithmetic starts, so the gathers below never wait behind a dependent index load
+    XcdWalk wk((p.n_tiles + 3) / 4);
+    int4 rec_n = make_int4(-1, -1, -1, 0);
+    int meta_n = -1;
+    auto fetch = [&](int grp) {
+        const int tl = grp * 4 + wave;
+        meta_n = -1;
+        if (tl < p.n_tiles) {
+            meta_n = p.tile_meta[tl];
+            rec_n = p.csr[tl * 32 + j];
+        }
+    };
+    if (wk.valid()) fetch(wk.cur);
+    while (wk.valid()) {
         const int tile = wk.cur * 4 + wave;
-        if (tile >= p.n_tiles || p.etile_graph[tile] < 0) continue;
-        const int e = tile * 32 + j;
-        const int4 rec = p.csr[e];
+        const int4 rec = rec_n;
+        const int meta = __builtin_amdgcn_readfirstlane(meta_n);
+        wk.next();
+        if (wk.valid()) fetch(wk.cur);
+        if (meta < 4) continue;                            // unused or empty tile (wave-uniform)
         const int s = rec.x, t = rec.y;
         const float* ar = p.A + (size_t)(s >= 0 ? s : 0) * D;
         const float* br = p.B + (size_t)(t >= 0 ? t : 0) * D;
@@ -514,7 +550,6 @@ __global__ __launch_bounds__(256) void mp_edge_kernel(MpEdgeParams p) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const int tile_start = tile * 32;
         const int td = t;                                  // lanes j and j+32 hold the same value
 #pragma unroll
         for (int fc = 0; fc < (D + 63) / 64; ++fc) {
@@ -525,9 +560,7 @@ __global__ __launch_bounds__(256) void mp_edge_kernel(MpEdgeParams p) {
             bool first = true;
             auto flush = [&](bool last) {
                 if (cur < 0) return;
-                const int a0 = p.row_beg[cur];
-                const int b0 = a0 + p.deg[cur];
-                const bool closed = (a0 >= tile_start) && (b0 <= tile_start + 32);
+                const bool closed = !((first && (meta & 1)) || (last && (meta & 2)));
                 if (fok) {
                     if (closed) p.agg[(size_t)cur * D + f] = run;
                     else {
@@ -710,6 +743,9 @@ hipError_t launch_prep(const PrepParams& q, hipStream_t st) {
                            q.edge_ptr, q.node_ptr_pad, q.row_beg, q.cursor, q.csr);
         LAUNCH_CHECK();
     }
+    hipLaunchKernelGGL(prep_tilemeta_kernel, dim3((q.n_etiles + 255) / 256), dim3(256), 0, st, q.n_etiles, q.csr,
+                       q.row_beg, q.deg, q.etile_graph, q.tile_meta);
+    LAUNCH_CHECK();
     hipLaunchKernelGGL(goal_kernel, dim3(q.G), dim3(256), 0, st, q.C, q.v, q.goal, q.node_ptr, q.node_ptr_pad,
                        q.goal_node);
     LAUNCH_CHECK();

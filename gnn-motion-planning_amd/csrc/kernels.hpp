@@ -16,6 +16,8 @@ struct PrepParams {
     int *ntile_graph, *etile_graph;              // per 32-row tile
     int4* csr;                                   // [Epad] {source, target, caller column, 0}; -1 = pad slot
     int* goal_node;                              // [G] padded node id
+    int* tile_meta;                              // per 32-edge tile, see prep_tilemeta_kernel
+    int n_etiles;
 };
 
 struct ObsParams {
@@ -52,7 +54,7 @@ struct PreParams {
 
 struct MpEdgeParams {
     const int4* csr;
-    const int *row_beg, *deg, *etile_graph;
+    const int* tile_meta;
     const float *A, *B, *Ke, *w;
     float *agg, *part_first, *part_last;
     int n_tiles;
