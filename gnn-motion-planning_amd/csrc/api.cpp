@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -190,6 +191,8 @@ struct gnnmp_explorer {
     EncBlob enc_e, enc_n;
     ObsBlob obs;
     StageProf* prof;      // mutable side state (profiling is single-threaded by contract)
+    int n_cu;             // compute units of the device (persistent-kernel grid)
+    int resident;         // use pre_resident_kernel when it fits (GNNMP_RESIDENT=0 disables)
 };
 
 namespace {
@@ -398,6 +401,14 @@ extern "C" int gnnmp_explorer_create(gnnmp_explorer** out, const gnnmp_explorer_
     if (dims->embed_size == 32) pack_explorer<32>(B, *dims, h, packed);
     else pack_explorer<64>(B, *dims, h, packed);
     hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) {
+        int ncu = 0;
+        e = hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device);
+        h->n_cu = (ncu > 0 ? ncu : 256) & ~7;
+        if (h->n_cu < 8) h->n_cu = 8;
+        const char* env = std::getenv("GNNMP_RESIDENT");
+        h->resident = !(env && env[0] == '0');
+    }
     if (e == hipSuccess) e = hipMalloc((void**)&h->w_dev, packed.size() * sizeof(float));
     if (e == hipSuccess) e = hipMemcpy(h->w_dev, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
@@ -621,6 +632,15 @@ extern "C" int gnnmp_explorer_forward(const gnnmp_explorer* h, const gnnmp_batch
         }
         if (edge && b->total_edges == 0) continue;
         StageScope sc(prof, edge ? GNNMP_STAGE_EDGE_PRE : GNNMP_STAGE_NODE_PRE, st);
+        // resident variant: all three blocks' weights + the graph's K/V for all three blocks in LDS
+        p.ptr_pad_total = edge ? q.edge_ptr_pad : q.node_ptr_pad;
+        p.tile_meta = q.tile_meta;
+        p.G = c.G;
+        const size_t res_bytes = ((size_t)3 * AttBlob<32>::staged + (size_t)3 * c.kv_stride) * sizeof(float) + 64;
+        if (D == 32 && use_obs && res_bytes <= 163840 && h->resident) {
+            HIP_TRY(launch_pre_resident(edge != 0, p, res_bytes, h->n_cu, st));
+            continue;
+        }
         HIP_TRY(launch_pre(D, edge != 0, pl.waves, p, (edge ? c.Epad : c.Npad) / 32, pl.lds_bytes, st));
     }
 
@@ -644,6 +664,7 @@ extern "C" int gnnmp_explorer_forward(const gnnmp_explorer* h, const gnnmp_batch
         n.w = W + (last ? h->off.mpn_last : h->off.mpn);
         n.Hout = at<float>(ws, c.H); n.Xout = at<float>(ws, c.X); n.Aout = at<float>(ws, c.A); n.Bout = at<float>(ws, c.B);
         n.n_tiles = c.Npad / 32;
+        n.store_h = last ? 1 : 0;
         StageScope sc(prof, GNNMP_STAGE_MP_NODE, st);
         HIP_TRY(launch_mp_node(D, n, st));
     }

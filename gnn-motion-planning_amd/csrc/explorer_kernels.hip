@@ -79,11 +79,21 @@ __device__ __forceinline__ int find_graph(const int* __restrict__ ptr, int G, in
     return lo;
 }
 
+// graph of caller column e: one binary search per workgroup (first column), then a short walk
+__device__ __forceinline__ int find_graph_wg(const int* __restrict__ ptr, int G, int e) {
+    __shared__ int s_g0;
+    if (threadIdx.x == 0) s_g0 = find_graph(ptr, G, blockIdx.x * blockDim.x);
+    __syncthreads();
+    int g = s_g0;
+    while (g + 1 < G && e >= ptr[g + 1]) ++g;
+    return g;
+}
+
 __global__ void prep_count_kernel(int G, int E, const long long* __restrict__ edge_index, const int* __restrict__ edge_ptr,
                                   const int* __restrict__ node_ptr_pad, int* __restrict__ deg) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const int g = find_graph_wg(edge_ptr, G, e < E ? e : E - 1);
     if (e >= E) return;
-    const int g = find_graph(edge_ptr, G, e);
     const int dst = node_ptr_pad[g] + (int)edge_index[(size_t)E + e];
     atomicAdd(&deg[dst], 1);
 }
@@ -124,8 +134,8 @@ __global__ void prep_fill_kernel(int G, int E, const long long* __restrict__ edg
                                  const int* __restrict__ node_ptr_pad, const int* __restrict__ row_beg,
                                  int* __restrict__ cursor, int4* __restrict__ csr) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const int g = find_graph_wg(edge_ptr, G, e < E ? e : E - 1);
     if (e >= E) return;
-    const int g = find_graph(edge_ptr, G, e);
     const int base = node_ptr_pad[g];
     const int src = base + (int)edge_index[e];
     const int dst = base + (int)edge_index[(size_t)E + e];
@@ -349,10 +359,12 @@ __device__ __forceinline__ void attention_block(const float* wl, const float* wg
                 ps += s[r];
             }
             psum = fmaf(psum, alpha, ps);
+            // obstacles 8q .. 8q+7 of this tile feed K-step group q: groups entirely beyond O carry p = 0
+            const int nq = min(4, (O - ot * 32 + 7) >> 3);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 acc[t] *= alpha;
-                mfma_tile(vo + t * kATile, s, acc[t], lane);
+                mfma_tile_q(vo + t * kATile, s, acc[t], lane, nq);
             }
             mx = nmx;
         }
@@ -471,6 +483,121 @@ __global__ __launch_bounds__(WAVES * 64) void pre_kernel(PreParams p) {
         load_vec<NT>(wl + L::bd, y, lane);
         linear_acc<NT, NT>(wl + L::wd_nc, aux, y, lane);
         store_row<NT>(p.o4 + (size_t)row * D, y, h);                          // DN
+    }
+}
+
+// =====================================================================================================
+// pre_resident_kernel: same arithmetic as pre_kernel, different residency.  When the three attention
+// blocks' weights (3 x 20 KB at d = 32) AND a graph's K/V operands for all three blocks (3 x 32 KB at
+// O <= 128) fit the 160 KB of LDS together, one 12-wave workgroup per CU keeps them resident: weights
+// are staged once per launch, K/V once per (workgroup, graph) -- instead of once per 128-edge tile and
+// phase -- and there is NO barrier inside a tile, so the three waves of a SIMD drift apart and overlap
+// each other's MFMA and VALU segments.  Work split: the padded tile space is cut into gridDim.x equal
+// contiguous shares (XCD-contiguous); inside a share waves pull 32-row tiles from an LDS counter.
+// Encoder / epilogue weights (22 KB) are read as MFMA A operands straight from global memory (L1/L2).
+// =====================================================================================================
+template <int D, bool EDGE>
+__global__ __launch_bounds__(768) void pre_resident_kernel(PreParams p) {
+    constexpr int NT = D / 32;
+    using AB = AttBlob<D>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* wl = lds;                                           // [3][AB::staged]
+    float* kvl = lds + 3 * AB::staged;                         // [3][kv_stride]
+    int* ctr = reinterpret_cast<int*>(kvl + 3 * (size_t)p.kv_stride);
+    const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
+    const int C = p.C;
+    const int total = p.ptr_pad_total[p.G] / 32;               // padded 32-row tiles actually in use
+    const int nb = gridDim.x >> 3;
+    const int wg = (blockIdx.x & 7) * nb + (blockIdx.x >> 3);   // XCD-contiguous order
+    const int share = (total + gridDim.x - 1) / gridDim.x;
+    int t0 = wg * share;
+    const int t1 = min(total, t0 + share);
+    if (t0 >= t1) return;
+    for (int b = 0; b < 3; ++b) stage(wl + b * AB::staged, p.att + (size_t)b * AB::size, AB::staged);
+    const EncBlob E = p.encb;
+    while (t0 < t1) {
+        const int g = p.tile_graph[t0];
+        const int seg_end = min(t1, p.ptr_pad_total[g + 1] / 32);
+        __syncthreads();                                       // previous graph's K/V no longer in use
+        stage(kvl, p.kv + (size_t)g * 3 * p.kv_stride, 3 * p.kv_stride);
+        if (threadIdx.x == 0) *ctr = t0;
+        __syncthreads();
+        const int nbase_pad = p.node_ptr_pad[g], nbase = p.node_ptr[g];
+        const int O = p.obs_ptr[g + 1] - p.obs_ptr[g];
+        while (true) {
+            int tile = 0;
+            if (lane == 0) tile = atomicAdd(ctr, 1);
+            tile = __builtin_amdgcn_readfirstlane(tile);
+            if (tile >= seg_end) break;
+            if (EDGE && p.tile_meta[tile] < 4) continue;       // tile of pure padding
+            const int row = tile * 32 + j;
+            f32x16 m[NT], aux[NT];
+            if constexpr (EDGE) {
+                const int4 rec = p.csr[row];
+                const int s = rec.x, t = rec.y;
+                const float* vs = p.v + (size_t)(nbase + (s >= 0 ? s - nbase_pad : 0)) * C;
+                const float* vt = p.v + (size_t)(nbase + (t >= 0 ? t - nbase_pad : 0)) * C;
+                auto getin = [&](int k) { return (k < C) ? vs[k] : ((k < 2 * C) ? vt[k - C] : 0.f); };
+                mlp2_in<NT>(p.enc + E.as0, E.ks0, p.enc + E.b0, p.enc + E.a0, p.enc + E.c0, getin, aux, lane);
+                mlp2_in<NT>(p.enc + E.as1, E.ks1, p.enc + E.b1, p.enc + E.a1, p.enc + E.c1, getin, m, lane);
+            } else {
+                const int local = row - nbase_pad;
+                const int ng = p.node_ptr[g + 1] - nbase;
+                const float* vr = p.v + (size_t)(nbase + (local < ng ? local : 0)) * C;
+                const float* gl = p.goal + (size_t)g * C;
+                auto getin_nc = [&](int k) {
+                    if (k >= 4 * C) return 0.f;
+                    const int part = k / C, c = k - part * C;
+                    const float x = vr[c], gg = gl[c];
+                    const float dlt = x - gg;
+                    return part == 0 ? x : (part == 1 ? gg : (part == 2 ? dlt * dlt : dlt));
+                };
+                auto getin_nf = [&](int k) { return (k < C) ? vr[k] : 0.f; };
+                mlp2_in<NT>(p.enc + E.as0, E.ks0, p.enc + E.b0, p.enc + E.a0, p.enc + E.c0, getin_nc, aux, lane);
+                mlp2_in<NT>(p.enc + E.as1, E.ks1, p.enc + E.b1, p.enc + E.a1, p.enc + E.c1, getin_nf, m, lane);
+            }
+            for (int b = 0; b < 3; ++b)
+                attention_block<D>(wl + b * AB::staged, p.att + (size_t)b * AB::size, kvl + (size_t)b * p.kv_stride, nullptr,
+                                   O, p.ot_max, p.ot_max, m, lane);
+            if constexpr (EDGE) {
+                using L = OutEBlob<D>;
+                f32x16 y[NT];
+                load_vec<NT>(p.out + L::b1, y, lane);
+                linear_acc<NT, NT>(p.out + L::w1d, m, y, lane);
+                linear_acc<NT, NT>(p.out + L::w1e, aux, y, lane);
+                store_tile<NT>(p.o0 + (size_t)tile * NT * kATile, y, lane);
+                load_vec<NT>(p.out + L::bp0, y, lane);
+                linear_acc<NT, NT>(p.out + L::wpc, m, y, lane);
+                store_tile<NT>(p.o1 + (size_t)tile * NT * kATile, y, lane);
+            } else {
+                using L = OutNBlob<D>;
+                const bool isgoal = (row == p.goal_node[g]);
+                f32x16 xi[NT], tmp[NT], y[NT];
+                load_vec<NT>(p.out + L::be, xi, lane);
+                linear_acc<NT, NT>(p.out + L::we_nc, aux, xi, lane);
+                linear_acc<NT, NT>(p.out + L::we_nf, m, xi, lane);
+                load_vec<NT>(p.out + L::weg, tmp, lane);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) xi[t] += isgoal ? tmp[t] : splat16(0.f);
+                store_row<NT>(p.o0 + (size_t)row * D, xi, h);
+                load_vec<NT>(p.out + L::wehg, tmp, lane);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) xi[t] += isgoal ? tmp[t] : splat16(0.f);
+                store_row<NT>(p.o1 + (size_t)row * D, xi, h);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) y[t] = splat16(0.f);
+                linear_acc<NT, NT>(p.out + L::wsrc, xi, y, lane);
+                store_row<NT>(p.o2 + (size_t)row * D, y, h);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) y[t] = splat16(0.f);
+                linear_acc<NT, NT>(p.out + L::wdst, xi, y, lane);
+                store_row<NT>(p.o3 + (size_t)row * D, y, h);
+                load_vec<NT>(p.out + L::bd, y, lane);
+                linear_acc<NT, NT>(p.out + L::wd_nc, aux, y, lane);
+                store_row<NT>(p.o4 + (size_t)row * D, y, h);
+            }
+        }
+        t0 = seg_end;
     }
 }
 
@@ -630,7 +757,7 @@ __global__ __launch_bounds__(256) void mp_node_kernel(MpNodeParams p) {
         load_vec<NT>(wl + L::bl, H, lane);
         linear_acc<NT, NT>(wl + L::wlx, x, H, lane);
         linear_acc<NT, NT>(wl + L::wla, ag, H, lane);
-        store_row<NT>(p.Hout + (size_t)t * D, H, h);
+        if (p.store_h) store_row<NT>(p.Hout + (size_t)t * D, H, h);
         load_row<NT>(p.R + (size_t)t * D, y, h);
         linear_acc<NT, NT>(wl + L::m1, H, y, lane);
         store_row<NT>(p.Xout + (size_t)t * D, y, h);
@@ -657,13 +784,25 @@ __global__ __launch_bounds__(256) void policy_kernel(PolicyParams p) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
     stage(wl, p.w, L::size);
     __syncthreads();
-    for (XcdWalk wk((p.n_tiles + 3) / 4); wk.valid(); wk.next()) {
+    XcdWalk wk((p.n_tiles + 3) / 4);
+    int4 rec_n = make_int4(-1, -1, -1, 0);
+    int g_n = -1;
+    auto fetch = [&](int grp) {
+        const int tl = grp * 4 + wave;
+        g_n = -1;
+        if (tl < p.n_tiles) {
+            g_n = p.etile_graph[tl];
+            rec_n = p.csr[tl * 32 + j];
+        }
+    };
+    if (wk.valid()) fetch(wk.cur);
+    while (wk.valid()) {
         const int tile = wk.cur * 4 + wave;
-        if (tile >= p.n_tiles) continue;
-        const int g = p.etile_graph[tile];
+        const int4 rec = rec_n;
+        const int g = __builtin_amdgcn_readfirstlane(g_n);
+        wk.next();
+        if (wk.valid()) fetch(wk.cur);
         if (g < 0) continue;
-        const int e = tile * 32 + j;
-        const int4 rec = p.csr[e];
         const int s = rec.x, t = rec.y;
         f32x16 hid[NT], a[NT], b[NT];
         load_tile_nt<NT>(p.PE + (size_t)tile * NT * kATile, hid, lane);
@@ -786,6 +925,18 @@ hipError_t launch_pre(int D, bool edge, int waves, const PreParams& p_in, int n_
     if (D == 64 && waves == 8) return edge ? launch_pre_t<64, true, 8>(p, n_wg, lds_bytes, st) : launch_pre_t<64, false, 8>(p, n_wg, lds_bytes, st);
     if (D == 64 && waves == 4) return edge ? launch_pre_t<64, true, 4>(p, n_wg, lds_bytes, st) : launch_pre_t<64, false, 4>(p, n_wg, lds_bytes, st);
     return hipErrorInvalidValue;
+}
+
+template <bool EDGE>
+static hipError_t launch_pre_resident_t(const PreParams& p, size_t lds_bytes, int n_cu, hipStream_t st) {
+    hipError_t e = set_lds(pre_resident_kernel<32, EDGE>, lds_bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((pre_resident_kernel<32, EDGE>), dim3(n_cu), dim3(768), lds_bytes, st, p);
+    LAUNCH_CHECK();
+    return hipSuccess;
+}
+hipError_t launch_pre_resident(bool edge, const PreParams& p, size_t lds_bytes, int n_cu, hipStream_t st) {
+    return edge ? launch_pre_resident_t<true>(p, lds_bytes, n_cu, st) : launch_pre_resident_t<false>(p, lds_bytes, n_cu, st);
 }
 
 static int grid_for(int n_tiles) {        // multiple of 8 (XcdWalk), at most 8 workgroups per CU

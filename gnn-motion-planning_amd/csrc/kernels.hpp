@@ -48,6 +48,10 @@ struct PreParams {
     int kv_stride, ot_max, ot_chunk;
     int wregion;             // floats reserved for the weight region of LDS
     int n_wg;                // workgroup tiles in the padded index space (set by launch_pre)
+    // resident variant only
+    const int* ptr_pad_total;   // node_ptr_pad or edge_ptr_pad [G+1] (the index space this launch tiles)
+    const int* tile_meta;       // per 32-edge tile (EDGE only)
+    int G;
     int use_obstacles;
     float *o0, *o1, *o2, *o3, *o4;
 };
@@ -65,6 +69,7 @@ struct MpNodeParams {
     const float *X, *R, *agg, *part_first, *part_last, *w;
     float *Hout, *Xout, *Aout, *Bout;
     int n_tiles;
+    int store_h;             // write h_i (only the last iteration's is ever consumed: debug tap)
 };
 
 struct PolicyParams {
@@ -100,6 +105,7 @@ hipError_t launch_sm_iter(int D, const SmParams& p, hipStream_t st);
 hipError_t launch_prep(const PrepParams& q, hipStream_t st);
 hipError_t launch_obs(int D, const ObsParams& p, int G, hipStream_t st);
 hipError_t launch_pre(int D, bool edge, int waves, const PreParams& p, int n_tiles32, size_t lds_bytes, hipStream_t st);
+hipError_t launch_pre_resident(bool edge, const PreParams& p, size_t lds_bytes, int n_cu, hipStream_t st);
 hipError_t launch_mp_edge(int D, const MpEdgeParams& p, hipStream_t st);
 hipError_t launch_mp_node(int D, const MpNodeParams& p, hipStream_t st);
 hipError_t launch_policy(int D, const PolicyParams& p, hipStream_t st);
