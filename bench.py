@@ -57,21 +57,28 @@ def cpu_baseline(env, n_nodes, k1, budget_s, seed0):
     from gnnmp.synth import ENVS, synth_graph
     from oracle import ref_cpu
     w = load_weights(ENVS[env]['ckpt'])
-    threads = torch.get_num_threads()
     graphs = [synth_graph(env, n_nodes, k1, seed=seed0 + i) for i in range(4)]
     run = lambda g: ref_cpu.explorer_forward(w, g['v'], g['goal'], g['obstacles'], g['edge_index'], 5,  # noqa: E731
                                              materialize=True)
-    run(graphs[0])                      # warm-up
-    n, t0 = 0, time.perf_counter()
-    while True:
-        run(graphs[n % len(graphs)])
-        n += 1
-        el = time.perf_counter() - t0
-        if el > budget_s or n >= 64:
-            break
-    return {'value': n / el, 'unit': 'graphs/s', 'cores': threads, 'kind': 'port',
-            'sample': '%d single-graph oracle forwards (%s N=%d k1=%d loop=5, materialising attention as '
-                      'model.py:178-179) in %.1f s on %d torch CPU threads' % (n, env, n_nodes, k1, el, threads)}
+    all_threads = torch.get_num_threads()
+    results = []
+    for threads in sorted({min(8, all_threads), all_threads}):      # 8 = the survey container's count; all = this host
+        torch.set_num_threads(threads)
+        run(graphs[0])                  # warm-up
+        n, t0 = 0, time.perf_counter()
+        while True:
+            run(graphs[n % len(graphs)])
+            n += 1
+            el = time.perf_counter() - t0
+            if el > budget_s / 2 or n >= 64:
+                break
+        results.append((n / el, threads, n, el))
+    torch.set_num_threads(all_threads)
+    best = max(results)
+    return {'value': best[0], 'unit': 'graphs/s', 'cores': best[1], 'kind': 'port',
+            'sample': 'single-graph oracle forwards (%s N=%d k1=%d loop=5, attention materialised as model.py:178-179): '
+                      % (env, n_nodes, k1) + '; '.join('%d calls in %.1f s on %d torch threads = %.2f graphs/s' %
+                                                        (r[2], r[3], r[1], r[0]) for r in results) + '; best reported'}
 
 
 def main():

@@ -496,8 +496,8 @@ bool carve(const gnnmp_explorer* h, const gnnmp_batch* b, Carve& c) {
     c.dense_ptr = take(sizeof(long long) * (c.G + 1));
     c.zero_beg = o;
     c.deg = take(sizeof(int) * c.Npad);
-    c.cursor = take(sizeof(int) * c.Npad);
     c.zero_end = o;
+    c.cursor = take(sizeof(int) * (size_t)(b->total_edges > 0 ? b->total_edges : 1));   // per-edge rank in its segment
     c.ff_beg = o;
     c.ntile_graph = take(sizeof(int) * (c.Npad / 32));
     c.etile_graph = take(sizeof(int) * (c.Epad / 32));

@@ -90,13 +90,13 @@ __device__ __forceinline__ int find_graph_wg(const int* __restrict__ ptr, int G,
 }
 
 __global__ void prep_count_kernel(int G, int E, const long long* __restrict__ edge_index, const int* __restrict__ edge_ptr,
-                                  const int* __restrict__ node_ptr_pad, int* __restrict__ deg) {
+                                  const int* __restrict__ node_ptr_pad, int* __restrict__ deg, int* __restrict__ rank) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     const int g = find_graph_wg(edge_ptr, G, e < E ? e : E - 1);
     if (e >= E) return;
     const int dst = node_ptr_pad[g] + (int)edge_index[(size_t)E + e];
-    atomicAdd(&deg[dst], 1);
-}
+    rank[e] = atomicAdd(&deg[dst], 1);        // arrival order inside the destination's segment (any order is fine:
+}                                             // max-aggregation is order-free and per-edge results do not depend on position)
 
 // one workgroup per graph: exclusive scan of deg over the graph's padded node range
 __global__ void prep_scan_kernel(const int* __restrict__ node_ptr_pad, const int* __restrict__ edge_ptr_pad,
@@ -132,14 +132,14 @@ __global__ void prep_scan_kernel(const int* __restrict__ node_ptr_pad, const int
 
 __global__ void prep_fill_kernel(int G, int E, const long long* __restrict__ edge_index, const int* __restrict__ edge_ptr,
                                  const int* __restrict__ node_ptr_pad, const int* __restrict__ row_beg,
-                                 int* __restrict__ cursor, int4* __restrict__ csr) {
+                                 const int* __restrict__ rank, int4* __restrict__ csr) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     const int g = find_graph_wg(edge_ptr, G, e < E ? e : E - 1);
     if (e >= E) return;
     const int base = node_ptr_pad[g];
     const int src = base + (int)edge_index[e];
     const int dst = base + (int)edge_index[(size_t)E + e];
-    const int pos = row_beg[dst] + atomicAdd(&cursor[dst], 1);
+    const int pos = row_beg[dst] + rank[e];
     csr[pos] = make_int4(src, dst, e, 0);      // one 16-byte record per edge: {source, target, caller column}
 }
 
@@ -871,7 +871,7 @@ hipError_t launch_prep(const PrepParams& q, hipStream_t st) {
     LAUNCH_CHECK();
     if (q.E > 0) {
         hipLaunchKernelGGL(prep_count_kernel, dim3((q.E + 255) / 256), dim3(256), 0, st, q.G, q.E, q.edge_index,
-                           q.edge_ptr, q.node_ptr_pad, q.deg);
+                           q.edge_ptr, q.node_ptr_pad, q.deg, q.cursor);
         LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(prep_scan_kernel, dim3(q.G), dim3(256), 0, st, q.node_ptr_pad, q.edge_ptr_pad, q.deg, q.row_beg,
