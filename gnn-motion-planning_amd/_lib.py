@@ -38,6 +38,12 @@ class SmoothBatch(ctypes.Structure):
 
 STAGES = ('prep', 'obs', 'node_pre', 'edge_pre', 'mp_edge', 'mp_node', 'policy')
 
+class GraphBuildBatch(ctypes.Structure):
+    _fields_ = [('n_graphs', ctypes.c_int32), ('total_nodes', ctypes.c_int32), ('k1_max', ctypes.c_int32),
+                ('config_size', ctypes.c_int32), ('v', ctypes.c_void_p), ('node_ptr', ctypes.c_void_p),
+                ('n_free', ctypes.c_void_p), ('k1', ctypes.c_void_p)]
+
+
 _lib = None
 
 
@@ -64,6 +70,8 @@ def lib():
     L.gnnmp_explorer_debug_tap.argtypes = [vp, ctypes.POINTER(Batch), ctypes.c_int, vp, vp, sz, vp]
     L.gnnmp_explorer_profile.argtypes = [vp, ctypes.c_int]
     L.gnnmp_explorer_profile_read.argtypes = [vp, ctypes.POINTER(ctypes.c_double), c_int64_p]
+    L.gnnmp_graph_workspace_bytes.argtypes = [ctypes.POINTER(GraphBuildBatch), ctypes.POINTER(sz)]
+    L.gnnmp_graph_build.argtypes = [ctypes.POINTER(GraphBuildBatch), vp, ctypes.c_int64, vp, vp, sz, vp]
     L.gnnmp_pack_a_tiles.restype = ctypes.c_int64
     L.gnnmp_pack_a_tiles.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp]
     L.gnnmp_pack_a_small.restype = ctypes.c_int64

@@ -924,3 +924,63 @@ extern "C" int gnnmp_smoother_forward(const gnnmp_smoother* h, const gnnmp_smoot
     HIP_TRY(launch_sm_final(b->total_path * C, p.scale, p.cur, out_path, st));
     return GNNMP_OK;
 }
+
+
+// =============================================================================================
+// device-side graph construction (create_data counterpart, eval_gnn.py:159-164)
+// =============================================================================================
+namespace {
+struct GbCarve { size_t nb_all, nb_free, zero_beg, cnt, cur, zero_end, off, ucnt, uoff, gtotal, bucket, total; };
+bool gb_carve(const gnnmp_graph_batch* b, GbCarve& c) {
+    if (b->n_graphs < 1 || b->total_nodes < 0 || b->k1_max < 1 || b->config_size < 1) return false;
+    if ((long long)4 * b->k1_max * b->total_nodes > 0x3fffffffLL) return false;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { const size_t r = o; o += (bytes + 255) & ~(size_t)255; return r; };
+    const size_t n = (size_t)(b->total_nodes > 0 ? b->total_nodes : 1);
+    c.nb_all = take(sizeof(int) * n * b->k1_max);
+    c.nb_free = take(sizeof(int) * n * b->k1_max);
+    c.zero_beg = o;
+    c.cnt = take(sizeof(int) * n);
+    c.cur = take(sizeof(int) * n);
+    c.zero_end = o;
+    c.off = take(sizeof(int) * n);
+    c.ucnt = take(sizeof(int) * n);
+    c.uoff = take(sizeof(int) * n);
+    c.gtotal = take(sizeof(int) * b->n_graphs);
+    c.bucket = take(sizeof(int) * n * 4 * b->k1_max);
+    c.total = o;
+    return true;
+}
+}  // namespace
+
+extern "C" int gnnmp_graph_workspace_bytes(const gnnmp_graph_batch* b, size_t* bytes) {
+    if (!b || !bytes) return GNNMP_ERR_NULL;
+    GbCarve c;
+    if (!gb_carve(b, c)) return GNNMP_ERR_ARG;
+    *bytes = c.total;
+    return GNNMP_OK;
+}
+
+extern "C" int gnnmp_graph_build(const gnnmp_graph_batch* b, int64_t* edge_index_out, int64_t out_cap,
+                                 int32_t* edge_ptr_out, void* ws, size_t ws_bytes, void* hip_stream) {
+    if (!b || !edge_index_out || !edge_ptr_out || !ws) return GNNMP_ERR_NULL;
+    if (!b->v || !b->node_ptr || !b->n_free || !b->k1) return GNNMP_ERR_NULL;
+    GbCarve c;
+    if (!gb_carve(b, c)) return GNNMP_ERR_ARG;
+    if (out_cap < (int64_t)4 * b->k1_max * b->total_nodes) return GNNMP_ERR_ARG;     // worst case: no duplicate at all
+    if (ws_bytes < c.total || (reinterpret_cast<uintptr_t>(ws) & 255)) return GNNMP_ERR_WORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    HIP_TRY(hipMemsetAsync(at<char>(ws, c.zero_beg), 0, c.zero_end - c.zero_beg, st));
+    GbParams p;
+    p.G = b->n_graphs; p.C = b->config_size; p.total_nodes = b->total_nodes; p.kmax = b->k1_max;
+    p.v = b->v; p.node_ptr = b->node_ptr; p.n_free = b->n_free; p.k1 = b->k1;
+    p.nb_all = at<int>(ws, c.nb_all); p.nb_free = at<int>(ws, c.nb_free);
+    p.cnt = at<int>(ws, c.cnt); p.cur = at<int>(ws, c.cur); p.off = at<int>(ws, c.off);
+    p.ucnt = at<int>(ws, c.ucnt); p.uoff = at<int>(ws, c.uoff); p.gtotal = at<int>(ws, c.gtotal);
+    p.bucket = at<int>(ws, c.bucket);
+    p.edge_ptr = edge_ptr_out;
+    p.edge_index = reinterpret_cast<long long*>(edge_index_out);
+    p.out_cap = out_cap;
+    if (b->total_nodes > 0) HIP_TRY(launch_graph_build(p, st));
+    return GNNMP_OK;
+}

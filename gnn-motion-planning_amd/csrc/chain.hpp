@@ -99,11 +99,20 @@ __device__ __forceinline__ void load_vec(const float* vec, f32x16 (&y)[NT], int 
 template <int NTO, class GetIn>
 __device__ __forceinline__ void linear_in(const float* Asmall, int ksteps, GetIn getin, f32x16 (&y)[NTO], int lane) {
     const int h = lane >> 5;
-    for (int st = 0; st < ksteps; ++st) {
-        const float b = getin(2 * st + h);
+    // inputs are gathered eight steps at a time so the (dependent, possibly global) loads behind getin
+    // are all in flight before the first MFMA needs one
+    for (int st0 = 0; st0 < ksteps; st0 += 8) {
+        float b[8];
 #pragma unroll
-        for (int ot = 0; ot < NTO; ++ot)
-            y[ot] = __builtin_amdgcn_mfma_f32_32x32x2f32(Asmall[(ot * ksteps + st) * 64 + lane], b, y[ot], 0, 0, 0);
+        for (int u = 0; u < 8; ++u) b[u] = getin(2 * (st0 + u) + h);      // getin returns 0 beyond the input width
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (st0 + u < ksteps) {
+#pragma unroll
+                for (int ot = 0; ot < NTO; ++ot)
+                    y[ot] = __builtin_amdgcn_mfma_f32_32x32x2f32(Asmall[(ot * ksteps + st0 + u) * 64 + lane], b[u], y[ot], 0, 0, 0);
+            }
+        }
     }
 }
 

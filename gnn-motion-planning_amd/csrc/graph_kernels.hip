@@ -1,0 +1,240 @@
+// graph_kernels.hip -- device-side construction of the planner's random geometric graph: the
+// counterpart of the reference's host-side create_data (eval_gnn.py:159-164):
+//
+//     edges = coalesce( kNN_k1(all nodes) + reversed + kNN_k1(free nodes only) + reversed )
+//
+// with knn_graph(x, k, loop=True) semantics (the point itself is one of its k neighbours; edge =
+// neighbour -> centre) and torch_sparse.coalesce semantics (columns sorted by (source, target),
+// duplicates dropped).  Batched over independent graphs; node ids stay graph-local.
+//
+//   gb_knn      one wave per (graph, node): k1 rounds of "next smallest (distance, index) after the last
+//               pick", distances in float64 from the fp32 coordinates (what the oracle's cdist does), ties
+//               broken by the lower index
+//   gb_count    every (centre, neighbour) pair contributes (nb -> c) and (c -> nb): histogram by source
+//   gb_scan     per graph: exclusive scan of the per-source counts
+//   gb_fill     drop targets into their source's bucket (arrival order)
+//   gb_unique   per source: sort its bucket, drop duplicates, count what is left
+//   gb_offsets  per graph scan of the unique counts; one workgroup then chains the graphs -> edge_ptr
+//   gb_write    emit [2, E] edge_index (int64, row 0 = source, row 1 = target) in coalesced order
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include "kernels.hpp"
+
+namespace gnnmp {
+
+__device__ __forceinline__ int gb_find(const int* __restrict__ ptr, int G, int x) {
+    int lo = 0, hi = G;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (ptr[mid] <= x) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// pass 0 = neighbours among all nodes, pass 1 = among the free nodes only (centres < n_free)
+__global__ __launch_bounds__(256) void gb_knn_kernel(GbParams p) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int node = blockIdx.x * 4 + wave;                // global node row
+    if (node >= p.total_nodes) return;
+    const int g = gb_find(p.node_ptr, p.G, node);
+    const int n0 = p.node_ptr[g], N = p.node_ptr[g + 1] - n0;
+    const int F = min(p.n_free[g], N);
+    const int i = node - n0;
+    const int C = p.C;
+    const float* xi = p.v + (size_t)node * C;
+    for (int pass = 0; pass < 2; ++pass) {
+        const int M = pass == 0 ? N : F;                   // candidate set size
+        int* out = (pass == 0 ? p.nb_all : p.nb_free) + (size_t)node * p.kmax;
+        const int k = min(p.k1[g], M);
+        if (pass == 1 && i >= F) {
+            for (int r = lane; r < p.kmax; r += 64) out[r] = -1;
+            continue;
+        }
+        double last_d = -1.0;
+        int last_i = -1;
+        for (int r = 0; r < p.kmax; ++r) {
+            int pick = -1;
+            if (r < k) {
+                double bd = INFINITY;
+                int bi = 0x7fffffff;
+                for (int c = lane; c < M; c += 64) {
+                    const float* xc = p.v + (size_t)(n0 + c) * C;
+                    double d = 0.0;
+                    for (int q = 0; q < C; ++q) {
+                        const double df = (double)xi[q] - (double)xc[q];
+                        d = fma(df, df, d);
+                    }
+                    const bool after = (d > last_d) || (d == last_d && c > last_i);      // strictly after the last pick
+                    if (after && (d < bd || (d == bd && c < bi))) { bd = d; bi = c; }
+                }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    const double od = __shfl_xor(bd, off, 64);
+                    const int oi = __shfl_xor(bi, off, 64);
+                    if (od < bd || (od == bd && oi < bi)) { bd = od; bi = oi; }
+                }
+                pick = bi;
+                last_d = bd;
+                last_i = bi;
+            }
+            if (lane == 0) out[r] = pick;
+        }
+    }
+}
+
+// iterate the (centre, neighbour) pairs of one node: calls f(src, dst) for both directions, both passes
+template <class F>
+__device__ __forceinline__ void gb_pairs(const GbParams& p, int node, int i, F f) {
+    for (int pass = 0; pass < 2; ++pass) {
+        const int* nb = (pass == 0 ? p.nb_all : p.nb_free) + (size_t)node * p.kmax;
+        for (int r = 0; r < p.kmax; ++r) {
+            const int a = nb[r];
+            if (a < 0) continue;
+            f(a, i);        // neighbour -> centre      (knn_graph)
+            f(i, a);        // reversed                 (edge_index.flip(0))
+        }
+    }
+}
+
+__global__ void gb_count_kernel(GbParams p) {
+    const int node = blockIdx.x * blockDim.x + threadIdx.x;
+    if (node >= p.total_nodes) return;
+    const int g = gb_find(p.node_ptr, p.G, node);
+    const int n0 = p.node_ptr[g];
+    gb_pairs(p, node, node - n0, [&](int s, int) { atomicAdd(&p.cnt[n0 + s], 1); });
+}
+
+__global__ void gb_scan_kernel(GbParams p, const int* __restrict__ in, int* __restrict__ out, int* __restrict__ total,
+                               const int* __restrict__ base) {
+    __shared__ int s[256];
+    __shared__ int carry;
+    const int g = blockIdx.x, tid = threadIdx.x;
+    const int n0 = p.node_ptr[g], n1 = p.node_ptr[g + 1];
+    if (tid == 0) carry = base ? base[g] : 0;
+    __syncthreads();
+    for (int b0 = n0; b0 < n1; b0 += 256) {
+        const int i = b0 + tid;
+        const int d = (i < n1) ? in[i] : 0;
+        s[tid] = d;
+        __syncthreads();
+        for (int off = 1; off < 256; off <<= 1) {
+            int a = 0;
+            if (tid >= off) a = s[tid - off];
+            __syncthreads();
+            s[tid] += a;
+            __syncthreads();
+        }
+        if (i < n1) out[i] = carry + s[tid] - d;
+        __syncthreads();
+        if (tid == 255) carry += s[255];
+        __syncthreads();
+    }
+    if (tid == 0 && total) total[g] = carry - (base ? base[g] : 0);
+}
+
+__global__ void gb_fill_kernel(GbParams p) {
+    const int node = blockIdx.x * blockDim.x + threadIdx.x;
+    if (node >= p.total_nodes) return;
+    const int g = gb_find(p.node_ptr, p.G, node);
+    const int n0 = p.node_ptr[g];
+    const int cap0 = 4 * p.kmax * n0;                       // start of this graph's candidate buckets (4 k N each)
+    gb_pairs(p, node, node - n0, [&](int s, int d) {
+        const int pos = cap0 + p.off[n0 + s] + atomicAdd(&p.cur[n0 + s], 1);
+        p.bucket[pos] = d;
+    });
+}
+
+// one thread per source: insertion sort of its bucket (a few dozen entries), then in-place unique
+__global__ void gb_unique_kernel(GbParams p) {
+    const int node = blockIdx.x * blockDim.x + threadIdx.x;
+    if (node >= p.total_nodes) return;
+    const int g = gb_find(p.node_ptr, p.G, node);
+    int* b = p.bucket + (size_t)4 * p.kmax * p.node_ptr[g] + p.off[node];
+    const int n = p.cnt[node];
+    for (int i = 1; i < n; ++i) {
+        const int x = b[i];
+        int j = i - 1;
+        while (j >= 0 && b[j] > x) { b[j + 1] = b[j]; --j; }
+        b[j + 1] = x;
+    }
+    int m = 0;
+    for (int i = 0; i < n; ++i)
+        if (i == 0 || b[i] != b[i - 1]) b[m++] = b[i];
+    p.ucnt[node] = m;
+}
+
+// chain the per-graph totals into edge_ptr (one workgroup)
+__global__ void gb_chain_kernel(int G, const int* __restrict__ total, int* __restrict__ edge_ptr) {
+    __shared__ int s[256];
+    __shared__ int carry;
+    const int tid = threadIdx.x;
+    if (tid == 0) { carry = 0; edge_ptr[0] = 0; }
+    __syncthreads();
+    for (int b0 = 0; b0 < G; b0 += 256) {
+        const int g = b0 + tid;
+        s[tid] = (g < G) ? total[g] : 0;
+        __syncthreads();
+        for (int off = 1; off < 256; off <<= 1) {
+            int a = 0;
+            if (tid >= off) a = s[tid - off];
+            __syncthreads();
+            s[tid] += a;
+            __syncthreads();
+        }
+        if (g < G) edge_ptr[g + 1] = carry + s[tid];
+        __syncthreads();
+        if (tid == 255) carry += s[255];
+        __syncthreads();
+    }
+}
+
+__global__ void gb_write_kernel(GbParams p) {
+    const int node = blockIdx.x * blockDim.x + threadIdx.x;
+    if (node >= p.total_nodes) return;
+    const int g = gb_find(p.node_ptr, p.G, node);
+    const int n0 = p.node_ptr[g];
+    const int* b = p.bucket + (size_t)4 * p.kmax * n0 + p.off[node];
+    const int m = p.ucnt[node];
+    const long long o = p.uoff[node];                       // already includes edge_ptr[g]
+    for (int i = 0; i < m; ++i) {
+        if (o + i < p.out_cap) {
+            p.edge_index[o + i] = node - n0;
+            p.edge_index[p.out_cap + o + i] = b[i];
+        }
+    }
+}
+
+#define LAUNCH_CHECK()                        \
+    do {                                      \
+        hipError_t _e = hipGetLastError();    \
+        if (_e != hipSuccess) return _e;      \
+    } while (0)
+
+hipError_t launch_graph_build(const GbParams& p, hipStream_t st) {
+    const int nb = (p.total_nodes + 255) / 256;
+    hipLaunchKernelGGL(gb_knn_kernel, dim3((p.total_nodes + 3) / 4), dim3(256), 0, st, p);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(gb_count_kernel, dim3(nb), dim3(256), 0, st, p);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(gb_scan_kernel, dim3(p.G), dim3(256), 0, st, p, (const int*)p.cnt, p.off, (int*)nullptr,
+                       (const int*)nullptr);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(gb_fill_kernel, dim3(nb), dim3(256), 0, st, p);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(gb_unique_kernel, dim3(nb), dim3(256), 0, st, p);
+    LAUNCH_CHECK();
+    // per-graph totals of unique edges, chained into edge_ptr, then final per-source offsets
+    hipLaunchKernelGGL(gb_scan_kernel, dim3(p.G), dim3(256), 0, st, p, (const int*)p.ucnt, p.uoff, p.gtotal,
+                       (const int*)nullptr);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(gb_chain_kernel, dim3(1), dim3(256), 0, st, p.G, (const int*)p.gtotal, p.edge_ptr);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(gb_scan_kernel, dim3(p.G), dim3(256), 0, st, p, (const int*)p.ucnt, p.uoff, (int*)nullptr,
+                       (const int*)p.edge_ptr);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(gb_write_kernel, dim3(nb), dim3(256), 0, st, p);
+    LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+}  // namespace gnnmp

@@ -102,6 +102,19 @@ hipError_t launch_sm_init(int n, float scale, const float* path, float* cur, hip
 hipError_t launch_sm_final(int n, float scale, const float* cur, float* out, hipStream_t st);
 hipError_t launch_sm_iter(int D, const SmParams& p, hipStream_t st);
 
+struct GbParams {
+    int G, C, total_nodes, kmax;
+    const float* v;
+    const int *node_ptr, *n_free, *k1;
+    int *nb_all, *nb_free;            // [total_nodes, kmax] neighbour ids (graph-local) or -1
+    int *cnt, *cur, *off, *ucnt, *uoff, *gtotal;
+    int* bucket;                      // [4 * kmax * total_nodes] targets grouped by source
+    int* edge_ptr;                    // out [G+1]
+    long long* edge_index;            // out [2, out_cap]
+    long long out_cap;
+};
+hipError_t launch_graph_build(const GbParams& p, hipStream_t st);
+
 hipError_t launch_prep(const PrepParams& q, hipStream_t st);
 hipError_t launch_obs(int D, const ObsParams& p, int G, hipStream_t st);
 hipError_t launch_pre(int D, bool edge, int waves, const PreParams& p, int n_tiles32, size_t lds_bytes, hipStream_t st);

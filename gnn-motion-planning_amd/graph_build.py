@@ -65,3 +65,38 @@ def create_data(free, collided, goal_state, k):
     k1 = k1_of(k, len(free))
     return {'goal': torch.tensor(np.asarray(goal_state), dtype=torch.float32), 'v': v,
             'labels': labels, 'edge_index': build_edges(v, len(free), k1)}
+
+
+# --------------------------------------------------------------------------------------------------
+# device-side construction (libgnnmp.so, csrc/graph_kernels.hip): same edge set, built on the GPU
+# --------------------------------------------------------------------------------------------------
+def build_edges_gpu(v, node_ptr, n_free, k1):
+    """Batched counterpart of :func:`build_edges` on the GPU.  ``v`` [sumN, C] float32 (cuda),
+    ``node_ptr`` [G+1] int32 (cuda), ``n_free`` / ``k1`` length-G sequences or int32 tensors.
+    Returns ``(edge_index [2, sumE] int64 with graph-local ids, edge_ptr [G+1] int32)`` on the device,
+    identical to coalescing each graph's kNN edges on the host."""
+    import ctypes
+    from . import _lib
+    dev = v.device
+    if dev.type != 'cuda':
+        raise RuntimeError('build_edges_gpu needs device tensors; use build_edges on the host')
+    G = int(node_ptr.numel() - 1)
+    as_i32 = lambda x: (x if torch.is_tensor(x) else torch.tensor(list(x))).to(device=dev, dtype=torch.int32).contiguous()  # noqa: E731
+    n_free_t, k1_t = as_i32(n_free), as_i32(k1)
+    kmax = int(k1_t.max().item()) if G else 1
+    v = v.float().contiguous()
+    total = int(v.shape[0])
+    b = _lib.GraphBuildBatch(G, total, max(kmax, 1), int(v.shape[1]), v.data_ptr(), node_ptr.data_ptr(),
+                             n_free_t.data_ptr(), k1_t.data_ptr())
+    need = ctypes.c_size_t()
+    _lib.check(_lib.lib().gnnmp_graph_workspace_bytes(ctypes.byref(b), ctypes.byref(need)), 'gnnmp_graph_workspace_bytes')
+    ws = torch.empty(need.value, dtype=torch.uint8, device=dev)
+    cap = 4 * max(kmax, 1) * max(total, 1)
+    out = torch.empty((2, cap), dtype=torch.int64, device=dev)
+    edge_ptr = torch.zeros(G + 1, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        st = torch.cuda.current_stream().cuda_stream
+        _lib.check(_lib.lib().gnnmp_graph_build(ctypes.byref(b), out.data_ptr(), cap, edge_ptr.data_ptr(), ws.data_ptr(),
+                                                ws.numel(), st), 'gnnmp_graph_build')
+    n_edges = int(edge_ptr[-1].item())               # one scalar read-back: the caller needs the size
+    return out[:, :n_edges].contiguous(), edge_ptr

@@ -87,6 +87,62 @@ def greedy_expand(P, v, env, state):
             P[end_b, end_a] = 0
 
 
+def greedy_expand_sparse(scores, edge_index, labels, v, env, state):
+    """Same decisions as ``_mask_policy`` + ``greedy_expand`` but on the per-edge scores (E numbers
+    instead of the dense N x N matrix): a max-heap over the live cells
+    ``P[a, b]`` with ``a`` explored, keyed so that ties break exactly like the dense row-major argmax
+    (position of ``a`` in the explored list, then column ``b``).  ``scores[e]`` is the score of column e
+    of ``edge_index`` = dense cell ``P[target, source]``."""
+    import heapq
+    explored, explored_edges = state['explored'], state['explored_edges']
+    src, dst = edge_index[0], edge_index[1]
+    coll = labels[:, 1] == 1
+    rows = {}                                            # target a -> {source b: score}
+    for e in range(src.shape[0]):
+        a, b, sc = int(dst[e]), int(src[e]), scores[e]
+        if a == b or sc == 0 or coll[a] or coll[b]:
+            continue
+        rows.setdefault(a, {})[b] = sc                   # later duplicate columns overwrite, like index_put
+    idx = np.array(explored_edges).reshape(2, -1)        # the reference's quirk (finding 0.6)
+    for a, b in zip(idx[0].tolist(), idx[1].tolist()):
+        if a in rows:
+            rows[a].pop(b, None)
+    is_explored = np.zeros(labels.shape[0], dtype=bool)
+    is_explored[explored] = True
+    heap = []
+
+    def push_row(pos, a):
+        for b, sc in rows.get(a, {}).items():
+            if not is_explored[b]:
+                heapq.heappush(heap, (-float(sc), pos, b, a))
+
+    for pos, a in enumerate(explored):
+        push_row(pos, a)
+    while heap:
+        neg, pos, end_b, end_a = heapq.heappop(heap)
+        live = rows.get(end_a, {})
+        if is_explored[end_b] or live.get(end_b) is None or float(live[end_b]) != -neg:
+            continue                                      # cell was zeroed since it was pushed
+        explored_edges.extend([[end_a, end_b], [end_b, end_a]])
+        if env._edge_fp(v[end_a], v[end_b]):
+            explored.append(end_b)
+            is_explored[end_b] = True
+            state['costs'][end_b] = state['costs'][end_a] + np.linalg.norm(v[end_a] - v[end_b])
+            state['prev'][end_b] = end_a
+            if env.in_goal_region(v[end_b]):
+                path, node = [end_b], end_b
+                while node != 0:
+                    node = state['prev'][node]
+                    path.append(node)
+                path.reverse()
+                return path
+            push_row(len(explored) - 1, end_b)
+        else:
+            live.pop(end_b, None)
+            rows.get(end_b, {}).pop(end_a, None)
+    return None
+
+
 def smooth_step(old_path, new_path, env):
     """``proposed_path_smootherv2`` (smoother.py:194-216): steer every interior waypoint at most RRT_EPS
     per round towards the network's proposal, keep the move only if both adjacent edges stay free
@@ -134,8 +190,10 @@ def model_smooth(model, free, collided, old_path, env, device, iters=5, trace=No
 
 @torch.no_grad()
 def explore(env, model, model_s, smooth=True, batch=500, t_max=1000, k=30, smoother='model', loop=5, device='cuda',
-            trace=None):
-    """Counterpart of ``explore`` (eval_gnn.py:168-276).  Returns the same result dict."""
+            trace=None, sparse=False):
+    """Counterpart of ``explore`` (eval_gnn.py:168-276).  Returns the same result dict.
+    ``sparse=True`` asks the model for per-edge scores (``edge_scores``) and runs the heap-based
+    frontier instead of pulling the dense N x N matrix to the host; decisions are identical."""
     c0 = env.collision_check_count
     t0 = time.time()
     forward = 0.
@@ -148,17 +206,24 @@ def explore(env, model, model_s, smooth=True, batch=500, t_max=1000, k=30, smoot
     while not success and (len(free) - 2) <= t_max:
         t1 = time.time()
         od = obs_data(env, free, collided, device)
-        P = model(goal=data['goal'].to(device), v=data['v'].to(device), labels=data['labels'].to(device),
+        kw = dict(goal=data['goal'].to(device), v=data['v'].to(device), labels=data['labels'].to(device),
                   edge_index=data['edge_index'].to(device), loop=loop, **od)
-        P = P.detach().cpu().numpy()                                # the implicit sync of eval_gnn.py:195
-        forward += time.time() - t1
-        if trace is not None:
-            ei = data['edge_index'].numpy()
-            trace.setdefault('forwards', []).append({'v': data['v'].numpy().copy(), 'edge_index': ei.copy(),
-                                                     'scores': P[ei[1], ei[0]].copy()})
-        P = _mask_policy(P, data['labels'].numpy(), state['explored'], state['explored_edges'])
+        ei = data['edge_index'].numpy()
         v = data['v'].numpy()
-        found = greedy_expand(P, v, env, state)
+        if sparse:
+            sc = model.edge_scores(**kw).detach().cpu().numpy()      # E floats instead of N^2
+            forward += time.time() - t1
+            if trace is not None:
+                trace.setdefault('forwards', []).append({'v': v.copy(), 'edge_index': ei.copy(), 'scores': sc.copy()})
+            found = greedy_expand_sparse(sc, ei, data['labels'].numpy(), v, env, state)
+        else:
+            P = model(**kw).detach().cpu().numpy()                   # the implicit sync of eval_gnn.py:195
+            forward += time.time() - t1
+            if trace is not None:
+                trace.setdefault('forwards', []).append({'v': v.copy(), 'edge_index': ei.copy(),
+                                                         'scores': P[ei[1], ei[0]].copy()})
+            P = _mask_policy(P, data['labels'].numpy(), state['explored'], state['explored_edges'])
+            found = greedy_expand(P, v, env, state)
         if found is not None:
             success, path = True, found
         if not success:

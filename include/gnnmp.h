@@ -13,6 +13,8 @@
  *       ModelSmoother.__init__ + load_state_dict              model_smoother.py:51-94, eval_gnn.py:102-104
  *   gnnmp_smoother_workspace_bytes / gnnmp_smoother_forward
  *       ModelSmoother.forward                                 model_smoother.py:104-142 (call smoother.py:243)
+ *   gnnmp_graph_workspace_bytes / gnnmp_graph_build
+ *       create_data's edge construction                       eval_gnn.py:159-164
  *
  * Conventions
  *   - plain C types only; every pointer in a batch / forward call is a DEVICE pointer unless the
@@ -178,6 +180,31 @@ int gnnmp_smoother_workspace_bytes(const gnnmp_smoother* h, const gnnmp_smooth_b
 /* out_path [total_path, C]: the new waypoints (end points copied through, model_smoother.py:139). */
 int gnnmp_smoother_forward(const gnnmp_smoother* h, const gnnmp_smooth_batch* batch, int loop,
                            float* out_path, void* workspace, size_t workspace_bytes, void* hip_stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Graph construction on the device   (create_data, eval_gnn.py:150-165; knn_graph :160,162; coalesce :164)
+ * ---------------------------------------------------------------------------------------- */
+/* Graph g owns node rows [node_ptr[g], node_ptr[g+1]) of v; its first n_free[g] rows are the
+ * collision-free samples; k1[g] = ceil(k * ln(n_free) / ln(100)) (eval_gnn.py:159) is computed by the
+ * caller.  The result is the reference's edge set: kNN_k1(all) + reversed + kNN_k1(free only) + reversed,
+ * self loops included, coalesced (sorted by (source, target), duplicates dropped), graph-local ids. */
+typedef struct {
+    int32_t n_graphs;
+    int32_t total_nodes;
+    int32_t k1_max;              /* >= max_g k1[g]                                            */
+    int32_t config_size;         /* C                                                         */
+    const float* v;              /* [total_nodes, C]                                          */
+    const int32_t* node_ptr;     /* [G+1]                                                     */
+    const int32_t* n_free;       /* [G]                                                       */
+    const int32_t* k1;           /* [G]                                                       */
+} gnnmp_graph_batch;
+
+int gnnmp_graph_workspace_bytes(const gnnmp_graph_batch* shape, size_t* bytes);
+/* edge_index_out: [2, out_cap] int64 with row stride out_cap (row 0 = source, row 1 = target); graph g's
+ * columns are [edge_ptr_out[g], edge_ptr_out[g+1]); out_cap >= 4 * k1_max * total_nodes (the no-duplicate
+ * worst case).  edge_ptr_out: [G+1] int32 (device). */
+int gnnmp_graph_build(const gnnmp_graph_batch* batch, int64_t* edge_index_out, int64_t out_cap,
+                      int32_t* edge_ptr_out, void* workspace, size_t workspace_bytes, void* hip_stream);
 
 /* ------------------------------------------------------------------------------------------
  * Host-only helpers exported for the CPU test-suite (no device needed)

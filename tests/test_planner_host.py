@@ -47,6 +47,11 @@ class ReplayExplorer:
         return P
 
 
+    def edge_scores(self, goal, v, labels, edge_index, loop, free, collided, obstacles):
+        P = self(goal, v, labels, edge_index, loop, free, collided, obstacles)
+        return P[edge_index[1], edge_index[0]]
+
+
 class ReplaySmoother:
     def __init__(self, rec):
         self.rec, self.i = rec, 0
@@ -69,14 +74,16 @@ def _env(r):
     return env
 
 
+@pytest.mark.parametrize('sparse', [False, True], ids=['dense', 'sparse_frontier'])
 @pytest.mark.parametrize('path', golden_files('planner_'), ids=os.path.basename)
-def test_planner_replay_matches_reference_trace(path):
+def test_planner_replay_matches_reference_trace(path, sparse):
     r = _load(path)
     env = _env(r)
     np.random.seed(int(r['seed']))
     torch.manual_seed(int(r['seed']))
     ex, sm = ReplayExplorer(r), ReplaySmoother(r)
-    res = planner.explore(env, ex, sm, True, batch=int(r['batch']), t_max=int(r['t_max']), k=int(r['k']), device='cpu')
+    res = planner.explore(env, ex, sm, True, batch=int(r['batch']), t_max=int(r['t_max']), k=int(r['k']), device='cpu',
+                          sparse=sparse)
     assert ex.i == int(r['n_forward']) and sm.i == int(r['n_smooth'])
     assert res['success'] == bool(r['success'])
     assert res['explored'] == r['explored'].tolist()

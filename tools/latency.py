@@ -1,0 +1,69 @@
+#!/usr/bin/env python
+"""Single-call latencies and other-config throughputs (informational; not the headline metric).
+Run on the GPU box:  python tools/latency.py"""
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, 'tests'))
+import torch  # noqa: E402
+import gnnmp  # noqa: E402
+from conftest import load_weights  # noqa: E402
+from gnnmp.synth import ENVS, synth_graph  # noqa: E402
+
+dev = torch.device('cuda:0')
+
+
+def model_for(env):
+    e = ENVS[env]
+    m = gnnmp.EncoderProcessDecoder(e['workspace'], e['C'], e['d'], e['S'])
+    m.load_state_dict(load_weights(e['ckpt']))
+    return m, e
+
+
+def timeit(fn, n=30, warm=5):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n
+
+
+def single(env, n, k):
+    m, e = model_for(env)
+    g = {kk: (v.to(dev) if torch.is_tensor(v) else v) for kk, v in synth_graph(env, n, k).items()}
+    dense = timeit(lambda: m(goal=g['goal'], loop=5, v=g['v'], obstacles=g['obstacles'], edge_index=g['edge_index']))
+    sparse = timeit(lambda: m.edge_scores(g['goal'], 5, g['v'], g['obstacles'], g['edge_index']))
+    b = m._single(g['goal'], g['v'], g['obstacles'], g['edge_index'])
+    fb = timeit(lambda: m.forward_batch(b, 5))
+    d2h = timeit(lambda: m(goal=g['goal'], loop=5, v=g['v'], obstacles=g['obstacles'], edge_index=g['edge_index']).cpu())
+    print('%-7s N=%-5d k1=%-3d E=%-7d single call: dense forward %.3f ms | sparse %.3f ms | prebuilt batch %.3f ms | '
+          'dense + .cpu() %.3f ms' % (env, n, k, g['edge_index'].shape[1], dense * 1e3, sparse * 1e3, fb * 1e3, d2h * 1e3))
+
+
+def batched(env, n, k, G, uniq=16):
+    m, e = model_for(env)
+    base = [synth_graph(env, n, k, seed=1234 + i) for i in range(uniq)]
+    b = gnnmp.GraphBatch.from_graphs([base[i % uniq] for i in range(G)], e['S'], dev)
+    m.profile(dev, True)
+    t = timeit(lambda: m.forward_batch(b, 5), n=10, warm=3)
+    prof = m.profile_read(dev)
+    print('%-7s N=%-5d k1=%-3d batch %-4d: %.3f ms/step = %.1f graphs/s   stages(ms/step): %s' %
+          (env, n, k, G, t * 1e3, G / t, {kk: round(v[0] / 13, 3) for kk, v in prof.items()}))
+
+
+if __name__ == '__main__':
+    single('maze2', 200, 6)        # BASELINE configs[0]
+    single('maze2', 1000, 8)
+    single('maze2', 1002, 41)      # the reference's default graph density (k=30 -> k1=41)
+    single('kuka7', 2000, 10)
+    batched('maze2', 200, 6, 256)
+    batched('kuka7', 2000, 10, 64)       # configs[2] shape (fp32 here)
+    batched('kuka14', 5000, 16, 32, uniq=4)     # configs[4] shape (fp32 here)
+    batched('ur5', 1000, 8, 256)
+    batched('snake7', 1000, 8, 256)
