@@ -12,7 +12,8 @@ c_int64_p = ctypes.POINTER(ctypes.c_int64)
 
 
 class ExplorerDims(ctypes.Structure):
-    _fields_ = [('config_size', ctypes.c_int32), ('embed_size', ctypes.c_int32), ('obs_size', ctypes.c_int32)]
+    _fields_ = [('config_size', ctypes.c_int32), ('embed_size', ctypes.c_int32), ('obs_size', ctypes.c_int32),
+                ('mlp_dtype', ctypes.c_int32)]          # 0 = fp32, 1 = bf16 MFMA operands (gnnmp.h)
 
 
 class Batch(ctypes.Structure):

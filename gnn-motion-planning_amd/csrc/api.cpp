@@ -92,7 +92,41 @@ struct Blob {          // host view of the caller's concatenated weights
 
 bool dims_ok(const gnnmp_explorer_dims& d) {
     return d.config_size >= 1 && d.config_size <= 64 && (d.embed_size == 32 || d.embed_size == 64) &&
-           d.obs_size >= 1 && d.obs_size <= 64;
+           d.obs_size >= 1 && d.obs_size <= 64 && (d.mlp_dtype == GNNMP_F32 || d.mlp_dtype == GNNMP_BF16);
+}
+
+// round-to-nearest-even fp32 -> bf16 (what v_cvt_pk_bf16_f32 does on the device)
+uint16_t to_bf16(float f) {
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);     // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+void pack_a_tiles_bf16(const float* w, int out_f, int ld, int col0, int n_in, float* dst_f) {
+    uint16_t* dst = reinterpret_cast<uint16_t*>(dst_f);
+    const int nto = out_f / 32, nti = n_in / 32;
+    for (int ot = 0; ot < nto; ++ot)
+        for (int it = 0; it < nti; ++it)
+            for (int m = 0; m < 2; ++m)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int t = 0; t < 8; ++t)
+                        dst[((size_t)((ot * nti + it) * 2 + m) * 64 + lane) * 8 + t] =
+                            to_bf16(w[(size_t)(32 * ot + (lane & 31)) * ld + col0 + 32 * it + phi(8 * m + t, lane >> 5)]);
+}
+
+void pack_a_small_bf16(const float* w, int out_f, int ld, int col0, int n_in, float* dst_f) {
+    uint16_t* dst = reinterpret_cast<uint16_t*>(dst_f);
+    const int nto = out_f / 32, ks = (n_in + 15) / 16;
+    for (int ot = 0; ot < nto; ++ot)
+        for (int st = 0; st < ks; ++st)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int t = 0; t < 8; ++t) {
+                    const int k = 16 * st + 8 * (lane >> 5) + t;
+                    dst[((size_t)(ot * ks + st) * 64 + lane) * 8 + t] =
+                        to_bf16(k < n_in ? w[(size_t)(32 * ot + (lane & 31)) * ld + col0 + k] : 0.f);
+                }
 }
 
 // dst <- a (+/-) b over a [D x n] column block of row-major matrices with leading dimension ld
@@ -226,57 +260,62 @@ extern "C" int gnnmp_explorer_manifest(const gnnmp_explorer_dims* dims, int inde
 
 namespace {
 
-template <int D>
+template <int D, int P>
 void pack_explorer(const Blob& B, const gnnmp_explorer_dims& dm, gnnmp_explorer* h, std::vector<float>& out) {
     const int C = dm.config_size, S = dm.obs_size;
-    h->enc_e = EncBlob::make(D, C, C);                         // K = 2C for both edge encoders
-    h->enc_n = EncBlob::make(D, 2 * C, (C + 1) / 2);           // node_code K = 4C, node_free_code K = C
-    h->obs = ObsBlob::make(D, (S + 1) / 2);
+    h->enc_e = EncBlob::make(P, D, 2 * C, 2 * C);              // both edge encoders read [v_src, v_dst]
+    h->enc_n = EncBlob::make(P, D, 4 * C, C);                  // node_code reads 4C numbers, node_free_code C
+    h->obs = ObsBlob::make(P, D, S);
     ExplorerOffsets& o = h->off;
     int cur = 0;
     auto take = [&](int n) { const int r = cur; cur += (n + 3) & ~3; return r; };
     o.enc_e = take(h->enc_e.size);
     o.enc_n = take(h->enc_n.size);
-    o.att_e = take(3 * AttBlob<D>::size);
-    o.att_n = take(3 * AttBlob<D>::size);
-    o.out_e = take(OutEBlob<D>::size);
-    o.out_n = take(OutNBlob<D>::size);
-    o.mpn = take(MpNBlob<D>::size);
-    o.mpn_last = take(MpNBlob<D>::size);
-    o.mpe = take(MpEBlob<D>::size);
-    o.pol = take(PolBlob<D>::size);
+    o.att_e = take(3 * AttBlob<D, P>::size);
+    o.att_n = take(3 * AttBlob<D, P>::size);
+    o.out_e = take(OutEBlob<D, P>::size);
+    o.out_n = take(OutNBlob<D, P>::size);
+    o.mpn = take(MpNBlob<D, P>::size);
+    o.mpn_last = take(MpNBlob<D, P>::size);
+    o.mpe = take(MpEBlob<D, P>::size);
+    o.pol = take(PolBlob<D, P>::size);
     o.obs_e = take(h->obs.size);
     o.obs_n = take(h->obs.size);
     o.total = cur;
     out.assign(cur, 0.f);
-    float* P = out.data();
+    float* PK = out.data();
     auto W = [&](const std::string& n) { return B.get(n); };
-    auto tiles = [&](const float* w, int ld, int col0, float* dst) { gnnmp_pack_a_tiles(w, D, ld, col0, D, dst); };
+    auto tiles = [&](const float* w, int ld, int col0, float* dst) {
+        if (P) pack_a_tiles_bf16(w, D, ld, col0, D, dst); else gnnmp_pack_a_tiles(w, D, ld, col0, D, dst);
+    };
+    auto small = [&](const float* w, int ld, int n_in, float* dst) {
+        if (P) pack_a_small_bf16(w, D, ld, 0, n_in, dst); else gnnmp_pack_a_small(w, D, ld, 0, n_in, dst);
+    };
     auto vec = [&](const float* b, float* dst) { gnnmp_pack_vec(b, D, dst); };
 
     // --- encoders on raw inputs
     auto enc = [&](const EncBlob& e, float* dst, const std::string& n0, int k0, const std::string& n1, int k1) {
-        gnnmp_pack_a_small(W(n0 + ".0.weight"), D, k0, 0, k0, dst + e.as0);
+        small(W(n0 + ".0.weight"), k0, k0, dst + e.as0);
         vec(W(n0 + ".0.bias"), dst + e.b0);
         tiles(W(n0 + ".2.weight"), D, 0, dst + e.a0);
         vec(W(n0 + ".2.bias"), dst + e.c0);
-        gnnmp_pack_a_small(W(n1 + ".0.weight"), D, k1, 0, k1, dst + e.as1);
+        small(W(n1 + ".0.weight"), k1, k1, dst + e.as1);
         vec(W(n1 + ".0.bias"), dst + e.b1);
         tiles(W(n1 + ".2.weight"), D, 0, dst + e.a1);
         vec(W(n1 + ".2.bias"), dst + e.c1);
     };
-    enc(h->enc_e, P + o.enc_e, "edge_code", 2 * C, "edge_free_code", 2 * C);
-    enc(h->enc_n, P + o.enc_n, "node_code", 4 * C, "node_free_code", C);
+    enc(h->enc_e, PK + o.enc_e, "edge_code", 2 * C, "edge_free_code", 2 * C);
+    enc(h->enc_n, PK + o.enc_n, "node_code", 4 * C, "node_free_code", C);
 
     // --- attention blocks (map side) and obstacle side
-    using A = AttBlob<D>;
+    using A = AttBlob<D, P>;
     for (int side = 0; side < 2; ++side) {
         const std::string sname = side == 0 ? "edge_attentions" : "node_attentions";
-        float* att = P + (side == 0 ? o.att_e : o.att_n);
-        float* ob = P + (side == 0 ? o.obs_e : o.obs_n);
+        float* att = PK + (side == 0 ? o.att_e : o.att_n);
+        float* ob = PK + (side == 0 ? o.obs_e : o.obs_n);
         const std::string oc = side == 0 ? "obs_edge_code" : "obs_node_code";
         const ObsBlob& L = h->obs;
-        gnnmp_pack_a_small(W(oc + ".0.weight"), D, S, 0, S, ob + L.as0);
+        small(W(oc + ".0.weight"), S, S, ob + L.as0);
         vec(W(oc + ".0.bias"), ob + L.b0);
         tiles(W(oc + ".2.weight"), D, 0, ob + L.a0);
         vec(W(oc + ".2.bias"), ob + L.c0);
@@ -324,8 +363,8 @@ void pack_explorer(const Blob& B, const gnnmp_explorer_dims& dm, gnnmp_explorer*
             wpt[(size_t)i * D + k] = p0[(size_t)i * 3 * D + D + k];
         }
     {
-        using L = OutEBlob<D>;
-        float* q = P + o.out_e;
+        using L = OutEBlob<D, P>;
+        float* q = PK + o.out_e;
         tiles(w1, 5 * D, 3 * D, q + L::w1d);
         tiles(w1, 5 * D, 4 * D, q + L::w1e);
         vec(W("process.lin_0.0.bias"), q + L::b1);
@@ -336,8 +375,8 @@ void pack_explorer(const Blob& B, const gnnmp_explorer_dims& dm, gnnmp_explorer*
     const float* wd = W("decoder.weight");      // [NC | H]            (model.py:143)
     const float* wl1 = W("process.lin_1.weight");   // [X | agg]       (model.py:36)
     {
-        using L = OutNBlob<D>;
-        float* q = P + o.out_n;
+        using L = OutNBlob<D, P>;
+        float* q = PK + o.out_n;
         tiles(we, 4 * D, 0, q + L::we_nc);
         tiles(we, 4 * D, D, q + L::we_nf);
         vec(W("encoder.bias"), q + L::be);
@@ -350,8 +389,8 @@ void pack_explorer(const Blob& B, const gnnmp_explorer_dims& dm, gnnmp_explorer*
         vec(W("decoder.bias"), q + L::bd);
     }
     for (int last = 0; last < 2; ++last) {
-        using L = MpNBlob<D>;
-        float* q = P + (last ? o.mpn_last : o.mpn);
+        using L = MpNBlob<D, P>;
+        float* q = PK + (last ? o.mpn_last : o.mpn);
         tiles(wl1, 2 * D, 0, q + L::wlx);
         tiles(wl1, 2 * D, D, q + L::wla);
         vec(W("process.lin_1.bias"), q + L::bl);
@@ -366,14 +405,14 @@ void pack_explorer(const Blob& B, const gnnmp_explorer_dims& dm, gnnmp_explorer*
         }
     }
     {
-        using L = MpEBlob<D>;
-        float* q = P + o.mpe;
+        using L = MpEBlob<D, P>;
+        float* q = PK + o.mpe;
         tiles(W("process.lin_0.2.weight"), D, 0, q + L::w2);
         vec(W("process.lin_0.2.bias"), q + L::b2);
     }
     {
-        using L = PolBlob<D>;
-        float* q = P + o.pol;
+        using L = PolBlob<D, P>;
+        float* q = PK + o.pol;
         tiles(W("policy.2.weight"), D, 0, q + L::w2);
         vec(W("policy.2.bias"), q + L::b2);
         vec(W("policy.4.weight"), q + L::w3);
@@ -398,8 +437,9 @@ extern "C" int gnnmp_explorer_create(gnnmp_explorer** out, const gnnmp_explorer_
     h->w_dev = nullptr;
     h->prof = new StageProf();
     std::vector<float> packed;
-    if (dims->embed_size == 32) pack_explorer<32>(B, *dims, h, packed);
-    else pack_explorer<64>(B, *dims, h, packed);
+    const int P = dims->mlp_dtype;
+    if (dims->embed_size == 32) { if (P) pack_explorer<32, 1>(B, *dims, h, packed); else pack_explorer<32, 0>(B, *dims, h, packed); }
+    else { if (P) pack_explorer<64, 1>(B, *dims, h, packed); else pack_explorer<64, 0>(B, *dims, h, packed); }
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) {
         int ncu = 0;
@@ -487,7 +527,7 @@ bool carve(const gnnmp_explorer* h, const gnnmp_batch* b, Carve& c) {
     c.Epad = round_up_i((int)ep, kPad);
     c.ot_max = (b->max_obstacles + 31) / 32;
     if (c.ot_max < 1) c.ot_max = 1;
-    c.kv_stride = 2 * c.ot_max * NT * 1024;
+    c.kv_stride = 2 * c.ot_max * NT * tile_unit(h->dims.mlp_dtype);
     size_t o = 0;
     auto take = [&](size_t bytes) { const size_t r = o; o += (bytes + 255) & ~(size_t)255; return r; };
     c.node_ptr_pad = take(sizeof(int) * (c.G + 1));
@@ -523,16 +563,29 @@ T* at(void* ws, size_t off) { return reinterpret_cast<T*>(static_cast<char*>(ws)
 // LDS plan of pre_kernel: weight region + K/V chunk region
 struct PrePlan { int waves, ot_chunk, wregion; size_t lds_bytes; };
 
-PrePlan plan_pre(int D, int ot_max, int enc_size, int out_size, bool use_obs) {
+int out_e_size(int D, int P) {
+    if (D == 32) return P ? OutEBlob<32, 1>::size : OutEBlob<32, 0>::size;
+    return P ? OutEBlob<64, 1>::size : OutEBlob<64, 0>::size;
+}
+int out_n_size(int D, int P) {
+    if (D == 32) return P ? OutNBlob<32, 1>::size : OutNBlob<32, 0>::size;
+    return P ? OutNBlob<64, 1>::size : OutNBlob<64, 0>::size;
+}
+int att_staged(int D, int P) {
+    if (D == 32) return P ? AttBlob<32, 1>::staged : AttBlob<32, 0>::staged;
+    return P ? AttBlob<64, 1>::staged : AttBlob<64, 0>::staged;
+}
+
+PrePlan plan_pre(int D, int P, int ot_max, int enc_size, int out_size, bool use_obs) {
     const int NT = D / 32;
-    const int att = (D == 32) ? AttBlob<32>::staged : AttBlob<64>::staged;
+    const int att = att_staged(D, P);
     int wr = enc_size > out_size ? enc_size : out_size;
     if (use_obs && att > wr) wr = att;
     wr = (wr + 3) & ~3;
     PrePlan p;
     p.wregion = wr;
     p.waves = (D == 32) ? 4 : 8;
-    const size_t per_tile = (size_t)2 * NT * 1024 * sizeof(float);
+    const size_t per_tile = (size_t)2 * NT * tile_unit(P) * sizeof(float);
     p.ot_chunk = 1;
     if (use_obs) {
         // prefer the highest workgroups-per-CU residency that still keeps a graph's whole K/V resident
@@ -571,7 +624,7 @@ extern "C" int gnnmp_explorer_forward(const gnnmp_explorer* h, const gnnmp_batch
     if (!carve(h, b, c)) return GNNMP_ERR_ARG;
     if (ws_bytes < c.total || (reinterpret_cast<uintptr_t>(ws) & 255)) return GNNMP_ERR_WORKSPACE;
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
-    const int D = h->dims.embed_size, C = h->dims.config_size;
+    const int D = h->dims.embed_size, C = h->dims.config_size, P = h->dims.mlp_dtype;
     const float* W = h->w_dev;
 
     StageProf* prof = h->prof;
@@ -605,7 +658,7 @@ extern "C" int gnnmp_explorer_forward(const gnnmp_explorer* h, const gnnmp_batch
         op.kv[0] = at<float>(ws, c.kv_n); op.kv[1] = at<float>(ws, c.kv_e);
         op.kv_stride = c.kv_stride; op.ot_max = c.ot_max;
         StageScope sc(prof, GNNMP_STAGE_OBS, st);
-        HIP_TRY(launch_obs(D, op, c.G, st));
+        HIP_TRY(launch_obs(D, P, op, c.G, st));
     }
 
     for (int edge = 0; edge < 2; ++edge) {
@@ -619,11 +672,10 @@ extern "C" int gnnmp_explorer_forward(const gnnmp_explorer* h, const gnnmp_batch
         p.encb = edge ? h->enc_e : h->enc_n;
         p.att = W + (edge ? h->off.att_e : h->off.att_n);
         p.out = W + (edge ? h->off.out_e : h->off.out_n);
-        p.out_size = edge ? (D == 32 ? OutEBlob<32>::size : OutEBlob<64>::size)
-                          : (D == 32 ? OutNBlob<32>::size : OutNBlob<64>::size);
+        p.out_size = edge ? out_e_size(D, P) : out_n_size(D, P);
         p.kv = at<float>(ws, edge ? c.kv_e : c.kv_n);
         p.kv_stride = c.kv_stride; p.ot_max = c.ot_max;
-        const PrePlan pl = plan_pre(D, c.ot_max, p.encb.size, p.out_size, use_obs);
+        const PrePlan pl = plan_pre(D, P, c.ot_max, p.encb.size, p.out_size, use_obs);
         p.ot_chunk = pl.ot_chunk; p.wregion = pl.wregion; p.use_obstacles = use_obs ? 1 : 0;
         if (edge) { p.o0 = at<float>(ws, c.Ke); p.o1 = at<float>(ws, c.PE); p.o2 = p.o3 = p.o4 = nullptr; }
         else {
@@ -636,12 +688,12 @@ extern "C" int gnnmp_explorer_forward(const gnnmp_explorer* h, const gnnmp_batch
         p.ptr_pad_total = edge ? q.edge_ptr_pad : q.node_ptr_pad;
         p.tile_meta = q.tile_meta;
         p.G = c.G;
-        const size_t res_bytes = ((size_t)3 * AttBlob<32>::staged + (size_t)3 * c.kv_stride) * sizeof(float) + 64;
-        if (D == 32 && use_obs && res_bytes <= 163840 && h->resident) {
-            HIP_TRY(launch_pre_resident(edge != 0, p, res_bytes, h->n_cu, st));
+        const size_t res_bytes = ((size_t)3 * att_staged(D, P) + (size_t)3 * c.kv_stride) * sizeof(float) + 64;
+        if ((D == 32 || P == 1) && use_obs && res_bytes <= 163840 && h->resident) {
+            HIP_TRY(launch_pre_resident(D, P, edge != 0, p, res_bytes, h->n_cu, st));
             continue;
         }
-        HIP_TRY(launch_pre(D, edge != 0, pl.waves, p, (edge ? c.Epad : c.Npad) / 32, pl.lds_bytes, st));
+        HIP_TRY(launch_pre(D, P, edge != 0, pl.waves, p, (edge ? c.Epad : c.Npad) / 32, pl.lds_bytes, st));
     }
 
     for (int it = 0; it < loop; ++it) {
@@ -655,7 +707,7 @@ extern "C" int gnnmp_explorer_forward(const gnnmp_explorer* h, const gnnmp_batch
             e.part_last = at<float>(ws, c.part_last);
             e.n_tiles = c.Epad / 32;
             StageScope sc(prof, GNNMP_STAGE_MP_EDGE, st);
-            HIP_TRY(launch_mp_edge(D, e, st));
+            HIP_TRY(launch_mp_edge(D, P, e, st));
         }
         MpNodeParams n;
         n.row_beg = q.row_beg; n.deg = q.deg; n.ntile_graph = q.ntile_graph;
@@ -666,7 +718,7 @@ extern "C" int gnnmp_explorer_forward(const gnnmp_explorer* h, const gnnmp_batch
         n.n_tiles = c.Npad / 32;
         n.store_h = last ? 1 : 0;
         StageScope sc(prof, GNNMP_STAGE_MP_NODE, st);
-        HIP_TRY(launch_mp_node(D, n, st));
+        HIP_TRY(launch_mp_node(D, P, n, st));
     }
 
     if (b->total_edges > 0) {
@@ -678,7 +730,7 @@ extern "C" int gnnmp_explorer_forward(const gnnmp_explorer* h, const gnnmp_batch
         p.scores = edge_scores; p.dense = dense;
         p.n_tiles = c.Epad / 32;
         StageScope sc(prof, GNNMP_STAGE_POLICY, st);
-        HIP_TRY(launch_policy(D, p, st));
+        HIP_TRY(launch_policy(D, P, p, st));
     }
     return GNNMP_OK;
 }

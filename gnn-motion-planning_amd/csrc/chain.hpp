@@ -40,6 +40,100 @@ __device__ __forceinline__ f32x16 splat16(float x) {
     return v;
 }
 
+// ---- precision of the MFMA operands.  P = 0: exact fp32 (v_mfma_f32_32x32x2_f32, 16 instructions per
+// 32x32x32 block).  P = 1: operands rounded to bf16 (RNE, v_cvt_pk_bf16_f32), fp32 accumulate
+// (v_mfma_f32_32x32x16_bf16, 2 instructions per block); everything outside the MFMA (bias, ReLU,
+// LayerNorm, softmax, residuals, max) stays fp32.  The accumulator layout is the same, so the chain
+// trick carries over: MFMA m of a block consumes the lane's registers 8m..8m+7 (8 bf16 per lane), and
+// the packed weights put W[i][phi(8m + t, lane>>5)] in slot t of lane (i, lane>>5).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+
+template <int P> struct Prec;
+template <> struct Prec<0> { static constexpr int TF = 1024; };      // floats of storage per 32x32 A tile
+template <> struct Prec<1> { static constexpr int TF = 512; };
+
+template <int P> struct BOp;                    // one 32-feature activation tile as MFMA B operand
+template <> struct BOp<0> {
+    f32x16 v;
+    __device__ __forceinline__ BOp() {}
+    __device__ __forceinline__ explicit BOp(const f32x16& x) : v(x) {}
+};
+template <> struct BOp<1> {
+    bf16x8 lo, hi;
+    __device__ __forceinline__ BOp() {}
+    __device__ __forceinline__ explicit BOp(const f32x16& x) {
+        f32x8 a, b;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { a[r] = x[r]; b[r] = x[8 + r]; }
+        lo = __builtin_convertvector(a, bf16x8);
+        hi = __builtin_convertvector(b, bf16x8);
+    }
+};
+
+template <int P>
+__device__ __forceinline__ void mfma_tile_p(const float* a, const BOp<P>& x, f32x16& acc, int lane) {
+    if constexpr (P == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(a + (q * 64 + lane) * 4);
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[c], x.v[q * 4 + c], acc, 0, 0, 0);
+        }
+    } else {
+        const bf16x8 w0 = *reinterpret_cast<const bf16x8*>(a + lane * 4);
+        const bf16x8 w1 = *reinterpret_cast<const bf16x8*>(a + (64 + lane) * 4);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, x.lo, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, x.hi, acc, 0, 0, 0);
+    }
+}
+
+// only K groups 0..nq-1 (8 obstacles each, 4 groups per tile) can be non-zero in x
+template <int P>
+__device__ __forceinline__ void mfma_tile_q_p(const float* a, const BOp<P>& x, f32x16& acc, int lane, int nq) {
+    if (nq >= 4) { mfma_tile_p<P>(a, x, acc, lane); return; }
+    if constexpr (P == 0) {
+        for (int q = 0; q < nq; ++q) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(a + (q * 64 + lane) * 4);
+            f32x4 xb;
+            switch (q) {
+                case 0: xb = f32x4{x.v[0], x.v[1], x.v[2], x.v[3]}; break;
+                case 1: xb = f32x4{x.v[4], x.v[5], x.v[6], x.v[7]}; break;
+                default: xb = f32x4{x.v[8], x.v[9], x.v[10], x.v[11]}; break;
+            }
+#pragma unroll
+            for (int cidx = 0; cidx < 4; ++cidx)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[cidx], xb[cidx], acc, 0, 0, 0);
+        }
+    } else {
+        const bf16x8 w0 = *reinterpret_cast<const bf16x8*>(a + lane * 4);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, x.lo, acc, 0, 0, 0);            // groups 0, 1
+        if (nq > 2) {
+            const bf16x8 w1 = *reinterpret_cast<const bf16x8*>(a + (64 + lane) * 4);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, x.hi, acc, 0, 0, 0);        // groups 2, 3
+        }
+    }
+}
+
+// y[ot] += sum_it A[ot][it] . x[it]      (A: [NTO][NTI][Prec<P>::TF] floats of storage)
+template <int P, int NTO, int NTI>
+__device__ __forceinline__ void linear_acc_p(const float* A, const f32x16 (&x)[NTI], f32x16 (&y)[NTO], int lane) {
+#pragma unroll
+    for (int it = 0; it < NTI; ++it) {
+        const BOp<P> xb(x[it]);
+#pragma unroll
+        for (int ot = 0; ot < NTO; ++ot)
+            mfma_tile_p<P>(A + (ot * NTI + it) * Prec<P>::TF, xb, y[ot], lane);
+    }
+}
+
+// first layer on raw inputs.  P = 0: Asmall [NTO][ceil(K/2)][64] floats, lane supplies in[2 st + h].
+// P = 1: Asmall [NTO][ceil(K/16)][64][8] bf16, lane supplies in[16 st + 8 h + t], t = 0..7.
+// `ksteps` is the step count of the chosen precision (EncBlob / ObsBlob carry it).
+template <int P, int NTO, class GetIn>
+__device__ __forceinline__ void linear_in_p(const float* Asmall, int ksteps, GetIn getin, f32x16 (&y)[NTO], int lane);
+
 // acc += A_tile . x   for one (out tile, in tile) pair; a points at the 1024-float A tile.
 __device__ __forceinline__ void mfma_tile(const float* a, const f32x16& x, f32x16& acc, int lane) {
 #pragma unroll
@@ -111,6 +205,26 @@ __device__ __forceinline__ void linear_in(const float* Asmall, int ksteps, GetIn
 #pragma unroll
                 for (int ot = 0; ot < NTO; ++ot)
                     y[ot] = __builtin_amdgcn_mfma_f32_32x32x2f32(Asmall[(ot * ksteps + st0 + u) * 64 + lane], b[u], y[ot], 0, 0, 0);
+            }
+        }
+    }
+}
+
+template <int P, int NTO, class GetIn>
+__device__ __forceinline__ void linear_in_p(const float* Asmall, int ksteps, GetIn getin, f32x16 (&y)[NTO], int lane) {
+    if constexpr (P == 0) {
+        linear_in<NTO>(Asmall, ksteps, getin, y, lane);
+    } else {
+        const int h = lane >> 5;
+        for (int st = 0; st < ksteps; ++st) {
+            f32x8 b;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) b[t] = getin(16 * st + 8 * h + t);      // getin returns 0 beyond the input width
+            const bf16x8 bb = __builtin_convertvector(b, bf16x8);
+#pragma unroll
+            for (int ot = 0; ot < NTO; ++ot) {
+                const bf16x8 w = *reinterpret_cast<const bf16x8*>(Asmall + ((ot * ksteps + st) * 64 + lane) * 4);
+                y[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, bb, y[ot], 0, 0, 0);
             }
         }
     }

@@ -200,27 +200,27 @@ __global__ void goal_kernel(int C, const float* __restrict__ v, const float* __r
 // shared pieces of the register-resident chains
 // =====================================================================================================
 // y = W2 . relu(W1s . in + b0) + c0          (Seq(Lin, ReLU, Lin) on raw inputs)
-template <int NT, class GetIn>
+template <int NT, int P, class GetIn>
 __device__ __forceinline__ void mlp2_in(const float* as0, int ks, const float* b0, const float* a0, const float* c0,
                                         GetIn getin, f32x16 (&y)[NT], int lane) {
     f32x16 hdn[NT];
     load_vec<NT>(b0, hdn, lane);
-    linear_in<NT>(as0, ks, getin, hdn, lane);
+    linear_in_p<P, NT>(as0, ks, getin, hdn, lane);
     relu_<NT>(hdn);
     load_vec<NT>(c0, y, lane);
-    linear_acc<NT, NT>(a0, hdn, y, lane);
+    linear_acc_p<P, NT, NT>(a0, hdn, y, lane);
 }
 
 // FeedForward (model.py:192-201): x <- LN(w_2 relu(w_1 x + b1) + b2 + x)
-template <int NT>
+template <int NT, int P>
 __device__ __forceinline__ void ffn_(const float* w1, const float* b1, const float* w2, const float* b2,
                                      const float* lng, const float* lnb, f32x16 (&x)[NT], int lane) {
     f32x16 hdn[NT], z[NT];
     load_vec<NT>(b1, hdn, lane);
-    linear_acc<NT, NT>(w1, x, hdn, lane);
+    linear_acc_p<P, NT, NT>(w1, x, hdn, lane);
     relu_<NT>(hdn);
     load_vec<NT>(b2, z, lane);
-    linear_acc<NT, NT>(w2, hdn, z, lane);
+    linear_acc_p<P, NT, NT>(w2, hdn, z, lane);
 #pragma unroll
     for (int t = 0; t < NT; ++t) x[t] += z[t];
     layer_norm_<NT>(x, lng, lnb, 1e-6f, lane);
@@ -233,9 +233,10 @@ __device__ __forceinline__ void ffn_(const float* w1, const float* b1, const flo
 // code = FFN_obs_b(code).
 // KV slab of (graph, block): Ko A-tiles [ot][ft][1024] then Vo A-tiles [ot][ft][1024] (stride ot_max).
 // =====================================================================================================
-template <int D>
+template <int D, int P>
 __global__ __launch_bounds__(256) void obs_kernel(ObsParams p) {
     constexpr int NT = D / 32;
+    constexpr int TF = Prec<P>::TF;
     const int g = blockIdx.x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
     const int o0 = p.obs_ptr[g], O = p.obs_ptr[g + 1] - o0;
@@ -250,47 +251,56 @@ __global__ __launch_bounds__(256) void obs_kernel(ObsParams p) {
             const float* orow = p.obstacles + (size_t)(o0 + (valid ? o : 0)) * p.S;
             const int S = p.S;
             f32x16 code[NT];
-            mlp2_in<NT>(W + L.as0, L.ks, W + L.b0, W + L.a0, W + L.c0,
+            mlp2_in<NT, P>(W + L.as0, L.ks, W + L.b0, W + L.a0, W + L.c0,
                         [&](int k) { return (k < S) ? orow[k] : 0.f; }, code, lane);
             for (int b = 0; b < 3; ++b) {
                 const float* Wb = W + L.blk0 + b * L.blk_stride;
                 f32x16 K[NT], V[NT];
 #pragma unroll
                 for (int t = 0; t < NT; ++t) { K[t] = splat16(0.f); V[t] = splat16(0.f); }
-                linear_acc<NT, NT>(Wb + L.wk, code, K, lane);
-                linear_acc<NT, NT>(Wb + L.wv, code, V, lane);
+                linear_acc_p<P, NT, NT>(Wb + L.wk, code, K, lane);
+                linear_acc_p<P, NT, NT>(Wb + L.wv, code, V, lane);
                 float* slab = kv_side + (size_t)(g * 3 + b) * p.kv_stride;
-                // Ko: A[i = obstacle][k = feature] -> tile (ot, ft) is exactly the register block
                 if (!valid) {
 #pragma unroll
                     for (int t = 0; t < NT; ++t) { K[t] = splat16(0.f); V[t] = splat16(0.f); }
                 }
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    float* kt = slab + (size_t)(ot * NT + t) * kATile;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        f32x4 a;
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) a[c] = K[t][q * 4 + c];
-                        *reinterpret_cast<f32x4*>(kt + (q * 64 + lane) * 4) = a;
-                    }
-                }
-                // Vo: A[i = feature][k = obstacle]: element V[o = 32 ot + j][f = 32 t + phi(r,h)] goes to
-                // lane' = phi(r,h) + 32 h', register r' with phi(r', h') = j
-                float* vbase = slab + (size_t)p.ot_max * NT * kATile;
+                float* vbase = slab + (size_t)p.ot_max * NT * TF;
+                // Vo is the A operand of P.V: A[i = feature][k = obstacle].  Element V[o = 32 ot + j][f = 32 t + phi(r,h)]
+                // belongs to lane' = phi(r,h) + 32 h' at register index r' where phi(r', h') = j
                 const int hp = (j >> 2) & 1, rp = (j & 3) + 4 * (j >> 3);
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
-                    float* vt = vbase + (size_t)(ot * NT + t) * kATile;
+                    float* kt = slab + (size_t)(ot * NT + t) * TF;
+                    float* vt = vbase + (size_t)(ot * NT + t) * TF;
+                    if constexpr (P == 0) {
+                        // Ko: A[i = obstacle][k = feature] -> tile (ot, ft) is exactly the register block
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int lp = phi(r, h) + 32 * hp;
-                        vt[((rp >> 2) * 64 + lp) * 4 + (rp & 3)] = V[t][r];
+                        for (int q = 0; q < 4; ++q) {
+                            f32x4 a;
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) a[c] = K[t][q * 4 + c];
+                            *reinterpret_cast<f32x4*>(kt + (q * 64 + lane) * 4) = a;
+                        }
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int lp = phi(r, h) + 32 * hp;
+                            vt[((rp >> 2) * 64 + lp) * 4 + (rp & 3)] = V[t][r];
+                        }
+                    } else {
+                        const BOp<1> kb(K[t]);                       // registers 0..7 -> MFMA 0, 8..15 -> MFMA 1
+                        *reinterpret_cast<bf16x8*>(kt + lane * 4) = kb.lo;
+                        *reinterpret_cast<bf16x8*>(kt + (64 + lane) * 4) = kb.hi;
+                        __bf16* vtb = reinterpret_cast<__bf16*>(vt);
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int lp = phi(r, h) + 32 * hp;
+                            vtb[((rp >> 3) * 64 + lp) * 8 + (rp & 7)] = (__bf16)V[t][r];
+                        }
                     }
                 }
                 if (b < 2)
-                    ffn_<NT>(Wb + L.fw1, Wb + L.fb1, Wb + L.fw2, Wb + L.fb2, Wb + L.lng, Wb + L.lnb, code, lane);
+                    ffn_<NT, P>(Wb + L.fw1, Wb + L.fb1, Wb + L.fw2, Wb + L.fb2, Wb + L.lng, Wb + L.lnb, code, lane);
             }
         }
     }
@@ -300,11 +310,12 @@ __global__ __launch_bounds__(256) void obs_kernel(ObsParams p) {
 // attention Block on the map rows held in registers (model.py:164-181 + map_feed :212-216).
 // wl: LDS copy of AttBlob<D>; kvl: LDS K/V chunk region; kvg: this (graph, block)'s slab in global.
 // =====================================================================================================
-template <int D>
+template <int D, int P>
 __device__ __forceinline__ void attention_block(const float* wl, const float* wg, float* kvl, const float* kvg, int O,
                                                 int ot_max, int ot_chunk, f32x16 (&m)[D / 32], int lane) {
     constexpr int NT = D / 32;
-    using L = AttBlob<D>;
+    constexpr int TF = Prec<P>::TF;
+    using L = AttBlob<D, P>;
     const int h = lane >> 5;
     const int OT = (O + 31) / 32;
     f32x16 Q[NT], acc[NT];
@@ -313,9 +324,9 @@ __device__ __forceinline__ void attention_block(const float* wl, const float* wg
         f32x16 Km[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) { Q[t] = splat16(0.f); Km[t] = splat16(0.f); acc[t] = splat16(0.f); }
-        linear_acc<NT, NT>(wl + L::wq, m, Q, lane);
-        linear_acc<NT, NT>(wl + L::wk, m, Km, lane);
-        linear_acc<NT, NT>(wl + L::wv, m, acc, lane);      // acc starts as 1 * V_self
+        linear_acc_p<P, NT, NT>(wl + L::wq, m, Q, lane);
+        linear_acc_p<P, NT, NT>(wl + L::wk, m, Km, lane);
+        linear_acc_p<P, NT, NT>(wl + L::wv, m, acc, lane);      // acc starts as 1 * V_self
         float l0 = 0.f;
 #pragma unroll
         for (int t = 0; t < NT; ++t)
@@ -327,21 +338,24 @@ __device__ __forceinline__ void attention_block(const float* wl, const float* wg
         psum = (h == 0) ? 1.0f : 0.0f;     // the self term exp(0) is counted once per row
     }
     const float cs = 1.4426950408889634f / sqrtf((float)D);
-    const int chunk_floats = ot_chunk * NT * kATile;
+    const int chunk_floats = ot_chunk * NT * TF;
+    BOp<P> qop[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) qop[t] = BOp<P>(Q[t]);
     for (int c0 = 0; c0 < OT; c0 += ot_chunk) {
         const int c1 = min(OT, c0 + ot_chunk);
         if (c0 > 0) {       // first chunk was staged together with the weights
             __syncthreads();
-            stage(kvl, kvg + (size_t)c0 * NT * kATile, (c1 - c0) * NT * kATile);
-            stage(kvl + chunk_floats, kvg + (size_t)(ot_max + c0) * NT * kATile, (c1 - c0) * NT * kATile);
+            stage(kvl, kvg + (size_t)c0 * NT * TF, (c1 - c0) * NT * TF);
+            stage(kvl + chunk_floats, kvg + (size_t)(ot_max + c0) * NT * TF, (c1 - c0) * NT * TF);
             __syncthreads();
         }
         for (int ot = c0; ot < c1; ++ot) {
-            const float* ko = kvl + (size_t)(ot - c0) * NT * kATile;
-            const float* vo = kvl + chunk_floats + (size_t)(ot - c0) * NT * kATile;
+            const float* ko = kvl + (size_t)(ot - c0) * NT * TF;
+            const float* vo = kvl + chunk_floats + (size_t)(ot - c0) * NT * TF;
             f32x16 s = splat16(0.f);
 #pragma unroll
-            for (int t = 0; t < NT; ++t) mfma_tile(ko + t * kATile, Q[t], s, lane);
+            for (int t = 0; t < NT; ++t) mfma_tile_p<P>(ko + t * TF, qop[t], s, lane);
             float tmax = -INFINITY;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -361,10 +375,11 @@ __device__ __forceinline__ void attention_block(const float* wl, const float* wg
             psum = fmaf(psum, alpha, ps);
             // obstacles 8q .. 8q+7 of this tile feed K-step group q: groups entirely beyond O carry p = 0
             const int nq = min(4, (O - ot * 32 + 7) >> 3);
+            const BOp<P> pop(s);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 acc[t] *= alpha;
-                mfma_tile_q(vo + t * kATile, s, acc[t], lane, nq);
+                mfma_tile_q_p<P>(vo + t * TF, pop, acc[t], lane, nq);
             }
             mx = nmx;
         }
@@ -373,15 +388,16 @@ __device__ __forceinline__ void attention_block(const float* wl, const float* wg
 #pragma unroll
     for (int t = 0; t < NT; ++t) m[t] = acc[t] * inv + m[t];         // value mix + residual
     layer_norm_<NT>(m, wg + L::ln1g, wg + L::ln1b, 1e-6f, lane);        // vectors: global (L1/L2 hits)
-    ffn_<NT>(wl + L::w1, wg + L::b1, wl + L::w2, wg + L::b2, wg + L::ln2g, wg + L::ln2b, m, lane);
+    ffn_<NT, P>(wl + L::w1, wg + L::b1, wl + L::w2, wg + L::b2, wg + L::ln2g, wg + L::ln2b, m, lane);
 }
 
 // =====================================================================================================
 // pre_kernel: encoders + 3 attention blocks + loop-invariant epilogue, one 32-row tile per wave.
 // =====================================================================================================
-template <int D, bool EDGE, int WAVES>
+template <int D, int P, bool EDGE, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void pre_kernel(PreParams p) {
     constexpr int NT = D / 32;
+    constexpr int TF = Prec<P>::TF;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* wl = lds;
     float* kvl = lds + p.wregion;
@@ -408,8 +424,8 @@ __global__ __launch_bounds__(WAVES * 64) void pre_kernel(PreParams p) {
         const float* vs = p.v + (size_t)(nbase + (s >= 0 ? s - nbase_pad : 0)) * C;
         const float* vt = p.v + (size_t)(nbase + (t >= 0 ? t - nbase_pad : 0)) * C;
         auto getin = [&](int k) { return (k < C) ? vs[k] : ((k < 2 * C) ? vt[k - C] : 0.f); };
-        mlp2_in<NT>(wl + E.as0, E.ks0, wl + E.b0, wl + E.a0, wl + E.c0, getin, aux, lane);   // edge_code
-        mlp2_in<NT>(wl + E.as1, E.ks1, wl + E.b1, wl + E.a1, wl + E.c1, getin, m, lane);     // edge_free_code
+        mlp2_in<NT, P>(wl + E.as0, E.ks0, wl + E.b0, wl + E.a0, wl + E.c0, getin, aux, lane);   // edge_code
+        mlp2_in<NT, P>(wl + E.as1, E.ks1, wl + E.b1, wl + E.a1, wl + E.c1, getin, m, lane);     // edge_free_code
     } else {
         const int local = row - nbase_pad;
         const int ng = p.node_ptr[g + 1] - nbase;
@@ -423,24 +439,24 @@ __global__ __launch_bounds__(WAVES * 64) void pre_kernel(PreParams p) {
             return part == 0 ? x : (part == 1 ? gg : (part == 2 ? dlt * dlt : dlt));
         };
         auto getin_nf = [&](int k) { return (k < C) ? vr[k] : 0.f; };
-        mlp2_in<NT>(wl + E.as0, E.ks0, wl + E.b0, wl + E.a0, wl + E.c0, getin_nc, aux, lane);  // node_code
-        mlp2_in<NT>(wl + E.as1, E.ks1, wl + E.b1, wl + E.a1, wl + E.c1, getin_nf, m, lane);    // node_free_code
+        mlp2_in<NT, P>(wl + E.as0, E.ks0, wl + E.b0, wl + E.a0, wl + E.c0, getin_nc, aux, lane);  // node_code
+        mlp2_in<NT, P>(wl + E.as1, E.ks1, wl + E.b1, wl + E.a1, wl + E.c1, getin_nf, m, lane);    // node_free_code
     }
 
     if (p.use_obstacles) {
         const int O = p.obs_ptr[g + 1] - p.obs_ptr[g];
         const int OT = (O + 31) / 32;
-        const int chunk_floats = p.ot_chunk * NT * kATile;
+        const int chunk_floats = p.ot_chunk * NT * TF;
         for (int b = 0; b < 3; ++b) {
             const float* kvg = p.kv + (size_t)(g * 3 + b) * p.kv_stride;
             __syncthreads();
-            const float* attg = p.att + (size_t)b * AttBlob<D>::size;
-            stage(wl, attg, AttBlob<D>::staged);
+            const float* attg = p.att + (size_t)b * AttBlob<D, P>::size;
+            stage(wl, attg, AttBlob<D, P>::staged);
             const int c1 = min(OT, p.ot_chunk);
-            stage(kvl, kvg, c1 * NT * kATile);
-            stage(kvl + chunk_floats, kvg + (size_t)p.ot_max * NT * kATile, c1 * NT * kATile);
+            stage(kvl, kvg, c1 * NT * TF);
+            stage(kvl + chunk_floats, kvg + (size_t)p.ot_max * NT * TF, c1 * NT * TF);
             __syncthreads();
-            attention_block<D>(wl, attg, kvl, kvg, O, p.ot_max, p.ot_chunk, m, lane);
+            attention_block<D, P>(wl, attg, kvl, kvg, O, p.ot_max, p.ot_chunk, m, lane);
         }
     }
 
@@ -448,22 +464,22 @@ __global__ __launch_bounds__(WAVES * 64) void pre_kernel(PreParams p) {
     stage(wl, p.out, p.out_size);
     __syncthreads();
     if constexpr (EDGE) {
-        using L = OutEBlob<D>;
+        using L = OutEBlob<D, P>;
         f32x16 y[NT];
         load_vec<NT>(wl + L::b1, y, lane);
-        linear_acc<NT, NT>(wl + L::w1d, m, y, lane);
-        linear_acc<NT, NT>(wl + L::w1e, aux, y, lane);
+        linear_acc_p<P, NT, NT>(wl + L::w1d, m, y, lane);
+        linear_acc_p<P, NT, NT>(wl + L::w1e, aux, y, lane);
         store_tile<NT>(p.o0 + (size_t)tile * NT * kATile, y, lane);          // K_e
         load_vec<NT>(wl + L::bp0, y, lane);
-        linear_acc<NT, NT>(wl + L::wpc, m, y, lane);
+        linear_acc_p<P, NT, NT>(wl + L::wpc, m, y, lane);
         store_tile<NT>(p.o1 + (size_t)tile * NT * kATile, y, lane);          // PE_e
     } else {
-        using L = OutNBlob<D>;
+        using L = OutNBlob<D, P>;
         const bool isgoal = (row == p.goal_node[g]);
         f32x16 xi[NT], tmp[NT], y[NT];
         load_vec<NT>(wl + L::be, xi, lane);
-        linear_acc<NT, NT>(wl + L::we_nc, aux, xi, lane);
-        linear_acc<NT, NT>(wl + L::we_nf, m, xi, lane);
+        linear_acc_p<P, NT, NT>(wl + L::we_nc, aux, xi, lane);
+        linear_acc_p<P, NT, NT>(wl + L::we_nf, m, xi, lane);
         load_vec<NT>(wl + L::weg, tmp, lane);
 #pragma unroll
         for (int t = 0; t < NT; ++t) xi[t] += isgoal ? tmp[t] : splat16(0.f);
@@ -474,14 +490,14 @@ __global__ __launch_bounds__(WAVES * 64) void pre_kernel(PreParams p) {
         store_row<NT>(p.o1 + (size_t)row * D, xi, h);                         // X_0
 #pragma unroll
         for (int t = 0; t < NT; ++t) y[t] = splat16(0.f);
-        linear_acc<NT, NT>(wl + L::wsrc, xi, y, lane);
+        linear_acc_p<P, NT, NT>(wl + L::wsrc, xi, y, lane);
         store_row<NT>(p.o2 + (size_t)row * D, y, h);                          // A_0
 #pragma unroll
         for (int t = 0; t < NT; ++t) y[t] = splat16(0.f);
-        linear_acc<NT, NT>(wl + L::wdst, xi, y, lane);
+        linear_acc_p<P, NT, NT>(wl + L::wdst, xi, y, lane);
         store_row<NT>(p.o3 + (size_t)row * D, y, h);                          // B_0
         load_vec<NT>(wl + L::bd, y, lane);
-        linear_acc<NT, NT>(wl + L::wd_nc, aux, y, lane);
+        linear_acc_p<P, NT, NT>(wl + L::wd_nc, aux, y, lane);
         store_row<NT>(p.o4 + (size_t)row * D, y, h);                          // DN
     }
 }
@@ -496,10 +512,10 @@ __global__ __launch_bounds__(WAVES * 64) void pre_kernel(PreParams p) {
 // contiguous shares (XCD-contiguous); inside a share waves pull 32-row tiles from an LDS counter.
 // Encoder / epilogue weights (22 KB) are read as MFMA A operands straight from global memory (L1/L2).
 // =====================================================================================================
-template <int D, bool EDGE>
-__global__ __launch_bounds__(768) void pre_resident_kernel(PreParams p) {
+template <int D, int P, bool EDGE, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void pre_resident_kernel(PreParams p) {
     constexpr int NT = D / 32;
-    using AB = AttBlob<D>;
+    using AB = AttBlob<D, P>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* wl = lds;                                           // [3][AB::staged]
     float* kvl = lds + 3 * AB::staged;                         // [3][kv_stride]
@@ -538,8 +554,8 @@ __global__ __launch_bounds__(768) void pre_resident_kernel(PreParams p) {
                 const float* vs = p.v + (size_t)(nbase + (s >= 0 ? s - nbase_pad : 0)) * C;
                 const float* vt = p.v + (size_t)(nbase + (t >= 0 ? t - nbase_pad : 0)) * C;
                 auto getin = [&](int k) { return (k < C) ? vs[k] : ((k < 2 * C) ? vt[k - C] : 0.f); };
-                mlp2_in<NT>(p.enc + E.as0, E.ks0, p.enc + E.b0, p.enc + E.a0, p.enc + E.c0, getin, aux, lane);
-                mlp2_in<NT>(p.enc + E.as1, E.ks1, p.enc + E.b1, p.enc + E.a1, p.enc + E.c1, getin, m, lane);
+                mlp2_in<NT, P>(p.enc + E.as0, E.ks0, p.enc + E.b0, p.enc + E.a0, p.enc + E.c0, getin, aux, lane);
+                mlp2_in<NT, P>(p.enc + E.as1, E.ks1, p.enc + E.b1, p.enc + E.a1, p.enc + E.c1, getin, m, lane);
             } else {
                 const int local = row - nbase_pad;
                 const int ng = p.node_ptr[g + 1] - nbase;
@@ -553,29 +569,29 @@ __global__ __launch_bounds__(768) void pre_resident_kernel(PreParams p) {
                     return part == 0 ? x : (part == 1 ? gg : (part == 2 ? dlt * dlt : dlt));
                 };
                 auto getin_nf = [&](int k) { return (k < C) ? vr[k] : 0.f; };
-                mlp2_in<NT>(p.enc + E.as0, E.ks0, p.enc + E.b0, p.enc + E.a0, p.enc + E.c0, getin_nc, aux, lane);
-                mlp2_in<NT>(p.enc + E.as1, E.ks1, p.enc + E.b1, p.enc + E.a1, p.enc + E.c1, getin_nf, m, lane);
+                mlp2_in<NT, P>(p.enc + E.as0, E.ks0, p.enc + E.b0, p.enc + E.a0, p.enc + E.c0, getin_nc, aux, lane);
+                mlp2_in<NT, P>(p.enc + E.as1, E.ks1, p.enc + E.b1, p.enc + E.a1, p.enc + E.c1, getin_nf, m, lane);
             }
             for (int b = 0; b < 3; ++b)
-                attention_block<D>(wl + b * AB::staged, p.att + (size_t)b * AB::size, kvl + (size_t)b * p.kv_stride, nullptr,
+                attention_block<D, P>(wl + b * AB::staged, p.att + (size_t)b * AB::size, kvl + (size_t)b * p.kv_stride, nullptr,
                                    O, p.ot_max, p.ot_max, m, lane);
             if constexpr (EDGE) {
-                using L = OutEBlob<D>;
+                using L = OutEBlob<D, P>;
                 f32x16 y[NT];
                 load_vec<NT>(p.out + L::b1, y, lane);
-                linear_acc<NT, NT>(p.out + L::w1d, m, y, lane);
-                linear_acc<NT, NT>(p.out + L::w1e, aux, y, lane);
+                linear_acc_p<P, NT, NT>(p.out + L::w1d, m, y, lane);
+                linear_acc_p<P, NT, NT>(p.out + L::w1e, aux, y, lane);
                 store_tile<NT>(p.o0 + (size_t)tile * NT * kATile, y, lane);
                 load_vec<NT>(p.out + L::bp0, y, lane);
-                linear_acc<NT, NT>(p.out + L::wpc, m, y, lane);
+                linear_acc_p<P, NT, NT>(p.out + L::wpc, m, y, lane);
                 store_tile<NT>(p.o1 + (size_t)tile * NT * kATile, y, lane);
             } else {
-                using L = OutNBlob<D>;
+                using L = OutNBlob<D, P>;
                 const bool isgoal = (row == p.goal_node[g]);
                 f32x16 xi[NT], tmp[NT], y[NT];
                 load_vec<NT>(p.out + L::be, xi, lane);
-                linear_acc<NT, NT>(p.out + L::we_nc, aux, xi, lane);
-                linear_acc<NT, NT>(p.out + L::we_nf, m, xi, lane);
+                linear_acc_p<P, NT, NT>(p.out + L::we_nc, aux, xi, lane);
+                linear_acc_p<P, NT, NT>(p.out + L::we_nf, m, xi, lane);
                 load_vec<NT>(p.out + L::weg, tmp, lane);
 #pragma unroll
                 for (int t = 0; t < NT; ++t) xi[t] += isgoal ? tmp[t] : splat16(0.f);
@@ -586,14 +602,14 @@ __global__ __launch_bounds__(768) void pre_resident_kernel(PreParams p) {
                 store_row<NT>(p.o1 + (size_t)row * D, xi, h);
 #pragma unroll
                 for (int t = 0; t < NT; ++t) y[t] = splat16(0.f);
-                linear_acc<NT, NT>(p.out + L::wsrc, xi, y, lane);
+                linear_acc_p<P, NT, NT>(p.out + L::wsrc, xi, y, lane);
                 store_row<NT>(p.o2 + (size_t)row * D, y, h);
 #pragma unroll
                 for (int t = 0; t < NT; ++t) y[t] = splat16(0.f);
-                linear_acc<NT, NT>(p.out + L::wdst, xi, y, lane);
+                linear_acc_p<P, NT, NT>(p.out + L::wdst, xi, y, lane);
                 store_row<NT>(p.o3 + (size_t)row * D, y, h);
                 load_vec<NT>(p.out + L::bd, y, lane);
-                linear_acc<NT, NT>(p.out + L::wd_nc, aux, y, lane);
+                linear_acc_p<P, NT, NT>(p.out + L::wd_nc, aux, y, lane);
                 store_row<NT>(p.o4 + (size_t)row * D, y, h);
             }
         }
@@ -624,11 +640,11 @@ struct XcdWalk {
 // segmented max over runs of equal destination.  Complete segments go to agg[dst]; segments cut by
 // the tile boundary go to part_first / part_last and are merged by mp_node.
 // =====================================================================================================
-template <int D>
+template <int D, int P>
 __global__ __launch_bounds__(256) void mp_edge_kernel(MpEdgeParams p) {
     constexpr int NT = D / 32;
     constexpr int LD = D + 1;
-    using L = MpEBlob<D>;
+    using L = MpEBlob<D, P>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* wl = lds;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
@@ -668,7 +684,7 @@ __global__ __launch_bounds__(256) void mp_edge_kernel(MpEdgeParams p) {
         relu_<NT>(hid);
         f32x16 M[NT];
         load_vec<NT>(wl + L::b2, M, lane);
-        linear_acc<NT, NT>(wl + L::w2, hid, M, lane);
+        linear_acc_p<P, NT, NT>(wl + L::w2, hid, M, lane);
         // transpose through this wave's LDS scratch: scr[edge j][feature]
 #pragma unroll
         for (int tt = 0; tt < NT; ++tt)
@@ -718,10 +734,10 @@ __global__ __launch_bounds__(256) void mp_edge_kernel(MpEdgeParams p) {
 // mp_node: per 32-node tile: agg (merge partial maxima; 0 for empty), H = Wlx X + Wla agg + bl,
 // Y = R + M1 H, A' = M2 Y, B' = M3 Y.
 // =====================================================================================================
-template <int D>
+template <int D, int P>
 __global__ __launch_bounds__(256) void mp_node_kernel(MpNodeParams p) {
     constexpr int NT = D / 32;
-    using L = MpNBlob<D>;
+    using L = MpNBlob<D, P>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* wl = lds;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
@@ -755,19 +771,19 @@ __global__ __launch_bounds__(256) void mp_node_kernel(MpNodeParams p) {
         }
         f32x16 H[NT], y[NT], z[NT];
         load_vec<NT>(wl + L::bl, H, lane);
-        linear_acc<NT, NT>(wl + L::wlx, x, H, lane);
-        linear_acc<NT, NT>(wl + L::wla, ag, H, lane);
+        linear_acc_p<P, NT, NT>(wl + L::wlx, x, H, lane);
+        linear_acc_p<P, NT, NT>(wl + L::wla, ag, H, lane);
         if (p.store_h) store_row<NT>(p.Hout + (size_t)t * D, H, h);
         load_row<NT>(p.R + (size_t)t * D, y, h);
-        linear_acc<NT, NT>(wl + L::m1, H, y, lane);
+        linear_acc_p<P, NT, NT>(wl + L::m1, H, y, lane);
         store_row<NT>(p.Xout + (size_t)t * D, y, h);
 #pragma unroll
         for (int tt = 0; tt < NT; ++tt) z[tt] = splat16(0.f);
-        linear_acc<NT, NT>(wl + L::m2, y, z, lane);
+        linear_acc_p<P, NT, NT>(wl + L::m2, y, z, lane);
         store_row<NT>(p.Aout + (size_t)t * D, z, h);
 #pragma unroll
         for (int tt = 0; tt < NT; ++tt) z[tt] = splat16(0.f);
-        linear_acc<NT, NT>(wl + L::m3, y, z, lane);
+        linear_acc_p<P, NT, NT>(wl + L::m3, y, z, lane);
         store_row<NT>(p.Bout + (size_t)t * D, z, h);
     }
 }
@@ -775,10 +791,10 @@ __global__ __launch_bounds__(256) void mp_node_kernel(MpNodeParams p) {
 // =====================================================================================================
 // policy: score_e = w3 . relu(W2 relu(PS[src] - PT[dst] + PE_e) + b2)
 // =====================================================================================================
-template <int D>
+template <int D, int P>
 __global__ __launch_bounds__(256) void policy_kernel(PolicyParams p) {
     constexpr int NT = D / 32;
-    using L = PolBlob<D>;
+    using L = PolBlob<D, P>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* wl = lds;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
@@ -813,7 +829,7 @@ __global__ __launch_bounds__(256) void policy_kernel(PolicyParams p) {
         relu_<NT>(hid);
         f32x16 y[NT], w3[NT];
         load_vec<NT>(wl + L::b2, y, lane);
-        linear_acc<NT, NT>(wl + L::w2, hid, y, lane);
+        linear_acc_p<P, NT, NT>(wl + L::w2, hid, y, lane);
         relu_<NT>(y);
         load_vec<NT>(wl + L::w3, w3, lane);
         float sc = 0.f;
@@ -897,46 +913,55 @@ static hipError_t set_lds(K kernel, size_t bytes) {
                                (int)bytes);
 }
 
-template <int D>
+template <int D, int P>
 static hipError_t launch_obs_t(const ObsParams& p, int G, hipStream_t st) {
-    hipLaunchKernelGGL(obs_kernel<D>, dim3(G), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((obs_kernel<D, P>), dim3(G), dim3(256), 0, st, p);
     LAUNCH_CHECK();
     return hipSuccess;
 }
-hipError_t launch_obs(int D, const ObsParams& p, int G, hipStream_t st) {
-    return D == 32 ? launch_obs_t<32>(p, G, st) : launch_obs_t<64>(p, G, st);
+hipError_t launch_obs(int D, int P, const ObsParams& p, int G, hipStream_t st) {
+    if (D == 32) return P ? launch_obs_t<32, 1>(p, G, st) : launch_obs_t<32, 0>(p, G, st);
+    return P ? launch_obs_t<64, 1>(p, G, st) : launch_obs_t<64, 0>(p, G, st);
 }
 
-template <int D, bool EDGE, int WAVES>
+template <int D, int P, bool EDGE, int WAVES>
 static hipError_t launch_pre_t(const PreParams& p, int n_wg, size_t lds_bytes, hipStream_t st) {
-    hipError_t e = set_lds(pre_kernel<D, EDGE, WAVES>, lds_bytes);
+    hipError_t e = set_lds(pre_kernel<D, P, EDGE, WAVES>, lds_bytes);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((pre_kernel<D, EDGE, WAVES>), dim3(n_wg), dim3(WAVES * 64), lds_bytes, st, p);
+    hipLaunchKernelGGL((pre_kernel<D, P, EDGE, WAVES>), dim3(n_wg), dim3(WAVES * 64), lds_bytes, st, p);
     LAUNCH_CHECK();
     return hipSuccess;
 }
-hipError_t launch_pre(int D, bool edge, int waves, const PreParams& p_in, int n_tiles32, size_t lds_bytes, hipStream_t st) {
+template <int D, int P>
+static hipError_t launch_pre_dp(bool edge, int waves, const PreParams& p, int n_wg, size_t lds_bytes, hipStream_t st) {
+    if (waves == 4) return edge ? launch_pre_t<D, P, true, 4>(p, n_wg, lds_bytes, st) : launch_pre_t<D, P, false, 4>(p, n_wg, lds_bytes, st);
+    if (waves == 8) return edge ? launch_pre_t<D, P, true, 8>(p, n_wg, lds_bytes, st) : launch_pre_t<D, P, false, 8>(p, n_wg, lds_bytes, st);
+    return hipErrorInvalidValue;
+}
+hipError_t launch_pre(int D, int P, bool edge, int waves, const PreParams& p_in, int n_tiles32, size_t lds_bytes, hipStream_t st) {
     int n_wg = n_tiles32 / waves;
     PreParams p = p_in;
     p.n_wg = n_wg;
     n_wg = (n_wg + 7) & ~7;
-    if (D == 32 && waves == 4) return edge ? launch_pre_t<32, true, 4>(p, n_wg, lds_bytes, st) : launch_pre_t<32, false, 4>(p, n_wg, lds_bytes, st);
-    if (D == 32 && waves == 8) return edge ? launch_pre_t<32, true, 8>(p, n_wg, lds_bytes, st) : launch_pre_t<32, false, 8>(p, n_wg, lds_bytes, st);
-    if (D == 64 && waves == 8) return edge ? launch_pre_t<64, true, 8>(p, n_wg, lds_bytes, st) : launch_pre_t<64, false, 8>(p, n_wg, lds_bytes, st);
-    if (D == 64 && waves == 4) return edge ? launch_pre_t<64, true, 4>(p, n_wg, lds_bytes, st) : launch_pre_t<64, false, 4>(p, n_wg, lds_bytes, st);
+    if (D == 32) return P ? launch_pre_dp<32, 1>(edge, waves, p, n_wg, lds_bytes, st) : launch_pre_dp<32, 0>(edge, waves, p, n_wg, lds_bytes, st);
+    if (D == 64) return P ? launch_pre_dp<64, 1>(edge, waves, p, n_wg, lds_bytes, st) : launch_pre_dp<64, 0>(edge, waves, p, n_wg, lds_bytes, st);
     return hipErrorInvalidValue;
 }
 
-template <bool EDGE>
+template <int D, int P, bool EDGE, int WAVES>
 static hipError_t launch_pre_resident_t(const PreParams& p, size_t lds_bytes, int n_cu, hipStream_t st) {
-    hipError_t e = set_lds(pre_resident_kernel<32, EDGE>, lds_bytes);
+    hipError_t e = set_lds(pre_resident_kernel<D, P, EDGE, WAVES>, lds_bytes);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((pre_resident_kernel<32, EDGE>), dim3(n_cu), dim3(768), lds_bytes, st, p);
+    hipLaunchKernelGGL((pre_resident_kernel<D, P, EDGE, WAVES>), dim3(n_cu), dim3(WAVES * 64), lds_bytes, st, p);
     LAUNCH_CHECK();
     return hipSuccess;
 }
-hipError_t launch_pre_resident(bool edge, const PreParams& p, size_t lds_bytes, int n_cu, hipStream_t st) {
-    return edge ? launch_pre_resident_t<true>(p, lds_bytes, n_cu, st) : launch_pre_resident_t<false>(p, lds_bytes, n_cu, st);
+// d = 32: 12 waves (3 per SIMD, <= 168 VGPRs); d = 64 (bf16 operands only -- fp32 weights do not fit): 8 waves
+hipError_t launch_pre_resident(int D, int P, bool edge, const PreParams& p, size_t lds_bytes, int n_cu, hipStream_t st) {
+    if (D == 32 && P == 0) return edge ? launch_pre_resident_t<32, 0, true, 12>(p, lds_bytes, n_cu, st) : launch_pre_resident_t<32, 0, false, 12>(p, lds_bytes, n_cu, st);
+    if (D == 32 && P == 1) return edge ? launch_pre_resident_t<32, 1, true, 12>(p, lds_bytes, n_cu, st) : launch_pre_resident_t<32, 1, false, 12>(p, lds_bytes, n_cu, st);
+    if (D == 64 && P == 1) return edge ? launch_pre_resident_t<64, 1, true, 8>(p, lds_bytes, n_cu, st) : launch_pre_resident_t<64, 1, false, 8>(p, lds_bytes, n_cu, st);
+    return hipErrorInvalidValue;
 }
 
 static int grid_for(int n_tiles) {        // multiple of 8 (XcdWalk), at most 8 workgroups per CU
@@ -945,43 +970,46 @@ static int grid_for(int n_tiles) {        // multiple of 8 (XcdWalk), at most 8 
     return groups < 256 * 8 ? groups : 256 * 8;
 }
 
-template <int D>
+template <int D, int P>
 static hipError_t launch_mp_edge_t(const MpEdgeParams& p, hipStream_t st) {
-    const size_t lds = (size_t)(((MpEBlob<D>::size + 3) & ~3) + 4 * 32 * (D + 1)) * sizeof(float);
-    hipError_t e = set_lds(mp_edge_kernel<D>, lds);
+    const size_t lds = (size_t)(((MpEBlob<D, P>::size + 3) & ~3) + 4 * 32 * (D + 1)) * sizeof(float);
+    hipError_t e = set_lds(mp_edge_kernel<D, P>, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(mp_edge_kernel<D>, dim3(grid_for(p.n_tiles)), dim3(256), lds, st, p);
+    hipLaunchKernelGGL((mp_edge_kernel<D, P>), dim3(grid_for(p.n_tiles)), dim3(256), lds, st, p);
     LAUNCH_CHECK();
     return hipSuccess;
 }
-hipError_t launch_mp_edge(int D, const MpEdgeParams& p, hipStream_t st) {
-    return D == 32 ? launch_mp_edge_t<32>(p, st) : launch_mp_edge_t<64>(p, st);
+hipError_t launch_mp_edge(int D, int P, const MpEdgeParams& p, hipStream_t st) {
+    if (D == 32) return P ? launch_mp_edge_t<32, 1>(p, st) : launch_mp_edge_t<32, 0>(p, st);
+    return P ? launch_mp_edge_t<64, 1>(p, st) : launch_mp_edge_t<64, 0>(p, st);
 }
 
-template <int D>
+template <int D, int P>
 static hipError_t launch_mp_node_t(const MpNodeParams& p, hipStream_t st) {
-    const size_t lds = (size_t)MpNBlob<D>::size * sizeof(float);
-    hipError_t e = set_lds(mp_node_kernel<D>, lds);
+    const size_t lds = (size_t)MpNBlob<D, P>::size * sizeof(float);
+    hipError_t e = set_lds(mp_node_kernel<D, P>, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(mp_node_kernel<D>, dim3(grid_for(p.n_tiles)), dim3(256), lds, st, p);
+    hipLaunchKernelGGL((mp_node_kernel<D, P>), dim3(grid_for(p.n_tiles)), dim3(256), lds, st, p);
     LAUNCH_CHECK();
     return hipSuccess;
 }
-hipError_t launch_mp_node(int D, const MpNodeParams& p, hipStream_t st) {
-    return D == 32 ? launch_mp_node_t<32>(p, st) : launch_mp_node_t<64>(p, st);
+hipError_t launch_mp_node(int D, int P, const MpNodeParams& p, hipStream_t st) {
+    if (D == 32) return P ? launch_mp_node_t<32, 1>(p, st) : launch_mp_node_t<32, 0>(p, st);
+    return P ? launch_mp_node_t<64, 1>(p, st) : launch_mp_node_t<64, 0>(p, st);
 }
 
-template <int D>
+template <int D, int P>
 static hipError_t launch_policy_t(const PolicyParams& p, hipStream_t st) {
-    const size_t lds = (size_t)PolBlob<D>::size * sizeof(float);
-    hipError_t e = set_lds(policy_kernel<D>, lds);
+    const size_t lds = (size_t)PolBlob<D, P>::size * sizeof(float);
+    hipError_t e = set_lds(policy_kernel<D, P>, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(policy_kernel<D>, dim3(grid_for(p.n_tiles)), dim3(256), lds, st, p);
+    hipLaunchKernelGGL((policy_kernel<D, P>), dim3(grid_for(p.n_tiles)), dim3(256), lds, st, p);
     LAUNCH_CHECK();
     return hipSuccess;
 }
-hipError_t launch_policy(int D, const PolicyParams& p, hipStream_t st) {
-    return D == 32 ? launch_policy_t<32>(p, st) : launch_policy_t<64>(p, st);
+hipError_t launch_policy(int D, int P, const PolicyParams& p, hipStream_t st) {
+    if (D == 32) return P ? launch_policy_t<32, 1>(p, st) : launch_policy_t<32, 0>(p, st);
+    return P ? launch_policy_t<64, 1>(p, st) : launch_policy_t<64, 0>(p, st);
 }
 
 hipError_t launch_unpad_rows(int G, int total_nodes, int D, const int* node_ptr, const int* node_ptr_pad,

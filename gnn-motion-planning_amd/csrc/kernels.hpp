@@ -116,12 +116,12 @@ struct GbParams {
 hipError_t launch_graph_build(const GbParams& p, hipStream_t st);
 
 hipError_t launch_prep(const PrepParams& q, hipStream_t st);
-hipError_t launch_obs(int D, const ObsParams& p, int G, hipStream_t st);
-hipError_t launch_pre(int D, bool edge, int waves, const PreParams& p, int n_tiles32, size_t lds_bytes, hipStream_t st);
-hipError_t launch_pre_resident(bool edge, const PreParams& p, size_t lds_bytes, int n_cu, hipStream_t st);
-hipError_t launch_mp_edge(int D, const MpEdgeParams& p, hipStream_t st);
-hipError_t launch_mp_node(int D, const MpNodeParams& p, hipStream_t st);
-hipError_t launch_policy(int D, const PolicyParams& p, hipStream_t st);
+hipError_t launch_obs(int D, int P, const ObsParams& p, int G, hipStream_t st);
+hipError_t launch_pre(int D, int P, bool edge, int waves, const PreParams& p, int n_tiles32, size_t lds_bytes, hipStream_t st);
+hipError_t launch_pre_resident(int D, int P, bool edge, const PreParams& p, size_t lds_bytes, int n_cu, hipStream_t st);
+hipError_t launch_mp_edge(int D, int P, const MpEdgeParams& p, hipStream_t st);
+hipError_t launch_mp_node(int D, int P, const MpNodeParams& p, hipStream_t st);
+hipError_t launch_policy(int D, int P, const PolicyParams& p, hipStream_t st);
 hipError_t launch_unpad_rows(int G, int total_nodes, int D, const int* node_ptr, const int* node_ptr_pad,
                              const float* src, float* dst, hipStream_t st);
 hipError_t launch_zero_dense(float* dense, const long long* n_ptr, hipStream_t st);

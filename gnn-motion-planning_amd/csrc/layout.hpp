@@ -13,16 +13,21 @@ constexpr int kRowsPerWave = 32;
 // feature (within a 32-feature tile) held by accumulator register r of a lane in half-wave h
 __host__ __device__ constexpr int phi(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
-__host__ __device__ constexpr int tile_floats(int D) { return (D / 32) * (D / 32) * 1024; }   // one DxD matrix
+// P = operand precision of the packed matrices: 0 = fp32 (1024 floats per 32x32 tile), 1 = bf16 (512 floats
+// of storage per tile: 2 MFMAs x 64 lanes x 8 bf16).  Vectors (bias, LayerNorm) are always fp32.
+__host__ __device__ constexpr int tile_unit(int P) { return P ? 512 : 1024; }
+__host__ __device__ constexpr int tile_floats(int D, int P = 0) { return (D / 32) * (D / 32) * tile_unit(P); }   // one DxD matrix
 __host__ __device__ constexpr int vec_floats(int D) { return (D / 32) * 32; }                 // one D-vector
-__host__ __device__ constexpr int small_floats(int D, int ksteps) { return (D / 32) * ksteps * 64; }
+// first layers on K raw inputs: fp32 -> ceil(K/2) steps of 64 floats; bf16 -> ceil(K/16) steps of 64 x 8 bf16
+__host__ __device__ constexpr int small_steps(int K, int P) { return P ? (K + 15) / 16 : (K + 1) / 2; }
+__host__ __device__ constexpr int small_floats(int D, int ksteps, int P = 0) { return (D / 32) * ksteps * (P ? 256 : 64); }
 
 // One attention Block (model.py:204-218).  The five DxD matrices come first and are what gets staged
 // into LDS (`staged` floats); the six D-vectors behind them are read straight from global memory
 // (768 B at d = 32: keeping them out of LDS is what lets three workgroups share a CU at O <= 128).
-template <int D>
+template <int D, int P = 0>
 struct AttBlob {
-    static constexpr int T = tile_floats(D), V = vec_floats(D);
+    static constexpr int T = tile_floats(D, P), V = vec_floats(D);
     static constexpr int wq = 0, wk = T, wv = 2 * T, w1 = 3 * T, w2 = 4 * T, staged = 5 * T;
     static constexpr int ln1g = 5 * T, ln1b = 5 * T + V, b1 = 5 * T + 2 * V, b2 = 5 * T + 3 * V, ln2g = 5 * T + 4 * V,
                          ln2b = 5 * T + 5 * V, size = 5 * T + 6 * V;
@@ -32,16 +37,18 @@ struct AttBlob {
 // edge_free_code): [As0][b0][A0][c0][As1][b1][A1][c1]
 struct EncBlob {
     int as0, b0, a0, c0, as1, b1, a1, c1, size, ks0, ks1;
-    __host__ __device__ static EncBlob make(int D, int ks0, int ks1) {
+    // K0 / K1: raw input widths of the two encoders
+    __host__ __device__ static EncBlob make(int P, int D, int K0, int K1) {
         EncBlob e;
-        const int T = tile_floats(D), V = vec_floats(D);
+        const int T = tile_floats(D, P), V = vec_floats(D);
+        const int ks0 = small_steps(K0, P), ks1 = small_steps(K1, P);
         int o = 0;
         e.ks0 = ks0; e.ks1 = ks1;
-        e.as0 = o; o += small_floats(D, ks0);
+        e.as0 = o; o += small_floats(D, ks0, P);
         e.b0 = o; o += V;
         e.a0 = o; o += T;
         e.c0 = o; o += V;
-        e.as1 = o; o += small_floats(D, ks1);
+        e.as1 = o; o += small_floats(D, ks1, P);
         e.b1 = o; o += V;
         e.a1 = o; o += T;
         e.c1 = o; o += V;
@@ -52,17 +59,17 @@ struct EncBlob {
 
 // Edge epilogue: K_e = W1d.EF + W1e.EC + b1 (message first-layer edge constant),
 //                PE  = Wpc.EF + bp0        (policy first-layer edge constant)
-template <int D>
+template <int D, int P = 0>
 struct OutEBlob {
-    static constexpr int T = tile_floats(D), V = vec_floats(D);
+    static constexpr int T = tile_floats(D, P), V = vec_floats(D);
     static constexpr int w1d = 0, w1e = T, b1 = 2 * T, wpc = 2 * T + V, bp0 = 3 * T + V, size = 3 * T + 2 * V;
 };
 
 // Node epilogue: XI = We_nc.NC + We_nf.NF + be (+ weg on the goal row); X0 = XI (+ wehg on the goal
 // row); A0 = Wsrc.X0; B0 = Wdst.X0; DN = Wd_nc.NC + bd
-template <int D>
+template <int D, int P = 0>
 struct OutNBlob {
-    static constexpr int T = tile_floats(D), V = vec_floats(D);
+    static constexpr int T = tile_floats(D, P), V = vec_floats(D);
     static constexpr int we_nc = 0, we_nf = T, be = 2 * T, weg = 2 * T + V, wehg = 2 * T + 2 * V, wsrc = 2 * T + 3 * V,
                          wdst = 3 * T + 3 * V, wd_nc = 4 * T + 3 * V, bd = 5 * T + 3 * V, size = 5 * T + 4 * V;
 };
@@ -70,21 +77,21 @@ struct OutNBlob {
 // Node update of one message-passing iteration: H = Wlx.X + Wla.agg + bl; Y = R + M1.H;
 // A' = M2.Y; B' = M3.Y.   (loop body: R = XI, M1 = Weh, M2 = Wsrc, M3 = Wdst;
 //                          after the last iteration: R = DN, M1 = Wdh, M2 = Wpa+Wpb, M3 = Wpb)
-template <int D>
+template <int D, int P = 0>
 struct MpNBlob {
-    static constexpr int T = tile_floats(D), V = vec_floats(D);
+    static constexpr int T = tile_floats(D, P), V = vec_floats(D);
     static constexpr int wlx = 0, wla = T, bl = 2 * T, m1 = 2 * T + V, m2 = 3 * T + V, m3 = 4 * T + V, size = 5 * T + V;
 };
 
-template <int D>
+template <int D, int P = 0>
 struct MpEBlob {   // message second layer
-    static constexpr int T = tile_floats(D), V = vec_floats(D);
+    static constexpr int T = tile_floats(D, P), V = vec_floats(D);
     static constexpr int w2 = 0, b2 = T, size = T + V;
 };
 
-template <int D>
+template <int D, int P = 0>
 struct PolBlob {   // policy.2 and policy.4
-    static constexpr int T = tile_floats(D), V = vec_floats(D);
+    static constexpr int T = tile_floats(D, P), V = vec_floats(D);
     static constexpr int w2 = 0, b2 = T, w3 = T + V, size = T + 2 * V;
 };
 
@@ -93,12 +100,13 @@ struct ObsBlob {
     int as0, b0, a0, c0, blk0, blk_stride, size, ks;
     // inside a block:
     int wk, wv, fw1, fb1, fw2, fb2, lng, lnb;
-    __host__ __device__ static ObsBlob make(int D, int ks) {
+    __host__ __device__ static ObsBlob make(int P, int D, int K) {
         ObsBlob e;
-        const int T = tile_floats(D), V = vec_floats(D);
+        const int T = tile_floats(D, P), V = vec_floats(D);
+        const int ks = small_steps(K, P);
         int o = 0;
         e.ks = ks;
-        e.as0 = o; o += small_floats(D, ks);
+        e.as0 = o; o += small_floats(D, ks, P);
         e.b0 = o; o += V;
         e.a0 = o; o += T;
         e.c0 = o; o += V;

@@ -94,6 +94,9 @@ class EncoderProcessDecoder(nn.Module):
         self.value = Seq(Lin(d, d), ReLU(), Lin(d, d), ReLU(), Lin(d, 1))
         self.node_free = Lin(d, 1)
         self.edge_free = Lin(d, 1)
+        # precision of the MFMA operands: 'fp32' (exact, the reference's precision) or 'bf16' (BASELINE configs[2],
+        # [4]: bf16 operands, fp32 accumulate); not a constructor argument so the reference signature is kept
+        self.mlp_dtype = 'fp32'
         self._handle = None
         self._handle_key = None
         self._ws = None
@@ -115,7 +118,9 @@ class EncoderProcessDecoder(nn.Module):
             pass
 
     def _dims(self):
-        return _lib.ExplorerDims(self.config_size, self.embed_size, self.obs_size)
+        if self.mlp_dtype not in ('fp32', 'bf16'):
+            raise ValueError("mlp_dtype must be 'fp32' or 'bf16'")
+        return _lib.ExplorerDims(self.config_size, self.embed_size, self.obs_size, 1 if self.mlp_dtype == 'bf16' else 0)
 
     def _apply(self, fn, *a, **k):          # .to() / .float() / .cuda(): parameters are replaced
         self._drop_handle()
@@ -128,13 +133,13 @@ class EncoderProcessDecoder(nn.Module):
             self._manifest = _lib.manifest('explorer', self._dims())
             sd = self.state_dict(keep_vars=True)
             self._wt = [sd[n] for n, _ in self._manifest]
-        key = (str(device), tuple(t._version for t in self._wt))
+        key = (str(device), self.mlp_dtype, tuple(t._version for t in self._wt))
         if self._handle is not None and key == self._handle_key:
             return self._handle
         self._drop_handle()
         sd = self.state_dict(keep_vars=True)
         self._wt = [sd[n] for n, _ in self._manifest]
-        key = (str(device), tuple(t._version for t in self._wt))
+        key = (str(device), self.mlp_dtype, tuple(t._version for t in self._wt))
         parts = []
         for (n, numel), t in zip(self._manifest, self._wt):
             t = t.detach().to('cpu', torch.float32).contiguous().reshape(-1)

@@ -57,11 +57,15 @@ int gnnmp_abi_version(void);
  * Explorer   (EncoderProcessDecoder, model.py:48-150)
  * ---------------------------------------------------------------------------------------- */
 typedef struct gnnmp_explorer gnnmp_explorer;   /* opaque */
+enum { GNNMP_F32 = 0, GNNMP_BF16 = 1 };
 
 typedef struct {
     int32_t config_size;   /* C  (model.py:49 config_size)                                    */
     int32_t embed_size;    /* d  (embed_size): 32 or 64 (every shipped checkpoint)             */
     int32_t obs_size;      /* S  (obs_size): obstacles are viewed as [-1, S] (model.py:126)   */
+    int32_t mlp_dtype;     /* GNNMP_F32 (exact fp32 MFMA, the reference's precision) or GNNMP_BF16:
+                              MFMA operands rounded to bf16, fp32 accumulate, fp32 everywhere else
+                              (BASELINE configs[2], [4]); inputs and outputs stay fp32 either way */
 } gnnmp_explorer_dims;
 
 /* Manifest of the state_dict tensors forward() actually uses (142 of the 200 keys), in the
