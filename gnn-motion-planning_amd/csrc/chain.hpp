@@ -74,13 +74,16 @@ template <> struct BOp<1> {
 template <int P>
 __device__ __forceinline__ void mfma_tile_p(const float* a, const BOp<P>& x, f32x16& acc, int lane) {
     if constexpr (P == 0) {
+        // all four 16-byte operand reads of the tile are issued before the first MFMA, so only the first
+        // MFMA of a 16-instruction block can wait on LDS
+        f32x4 w[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 w = *reinterpret_cast<const f32x4*>(a + (q * 64 + lane) * 4);
+        for (int q = 0; q < 4; ++q) w[q] = *reinterpret_cast<const f32x4*>(a + (q * 64 + lane) * 4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
 #pragma unroll
             for (int c = 0; c < 4; ++c)
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[c], x.v[q * 4 + c], acc, 0, 0, 0);
-        }
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[q][c], x.v[q * 4 + c], acc, 0, 0, 0);
     } else {
         const bf16x8 w0 = *reinterpret_cast<const bf16x8*>(a + lane * 4);
         const bf16x8 w1 = *reinterpret_cast<const bf16x8*>(a + (64 + lane) * 4);
