@@ -201,7 +201,10 @@ __device__ __forceinline__ void linear_in(const float* Asmall, int ksteps, GetIn
     for (int st0 = 0; st0 < ksteps; st0 += 8) {
         float b[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) b[u] = getin(2 * (st0 + u) + h);      // getin returns 0 beyond the input width
+        for (int u = 0; u < 8; ++u) {
+            b[u] = 0.f;
+            if (st0 + u < ksteps) b[u] = getin(2 * (st0 + u) + h);        // wave-uniform guard; getin is 0 beyond the width
+        }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             if (st0 + u < ksteps) {

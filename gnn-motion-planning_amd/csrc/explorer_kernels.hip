@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256) void obs_kernel(ObsParams p) {
             const int S = p.S;
             f32x16 code[NT];
             mlp2_in<NT, P>(W + L.as0, L.ks, W + L.b0, W + L.a0, W + L.c0,
-                        [&](int k) { return (k < S) ? orow[k] : 0.f; }, code, lane);
+                        [&](int k) { const bool ok = k < S; const float x = orow[ok ? k : 0]; return ok ? x : 0.f; }, code, lane);
             for (int b = 0; b < 3; ++b) {
                 const float* Wb = W + L.blk0 + b * L.blk_stride;
                 f32x16 K[NT], V[NT];
@@ -356,31 +356,36 @@ __device__ __forceinline__ void attention_block(const float* wl, const float* wg
             f32x16 s = splat16(0.f);
 #pragma unroll
             for (int t = 0; t < NT; ++t) mfma_tile_p<P>(ko + t * TF, qop[t], s, lane);
-            float tmax = -INFINITY;
+            // fp32 MFMA and VALU share the SIMD's issue time (tools/microbench/mfma_chain.hip), so every VALU
+            // instruction here costs MFMA throughput: mask only the one partial tile, fold the scale into an
+            // fma, and skip the accumulator rescale while the running maximum does not move.
+            if ((ot + 1) * 32 > O) {                     // wave-uniform: only the last tile can hold padding obstacles
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const bool ok = (ot * 32 + phi(r, h)) < O;
-                s[r] = ok ? s[r] : -INFINITY;
-                tmax = fmaxf(tmax, s[r]);
+                for (int r = 0; r < 16; ++r) s[r] = ((ot * 32 + phi(r, h)) < O) ? s[r] : -INFINITY;
             }
+            float tmax = s[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, s[r]);
             tmax = fmaxf(tmax, xhalf(tmax));
             const float nmx = fmaxf(mx, tmax);
-            const float alpha = __builtin_amdgcn_exp2f((mx - nmx) * cs);
+            const float off = -nmx * cs;
             float ps = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                s[r] = __builtin_amdgcn_exp2f((s[r] - nmx) * cs);
+                s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], cs, off));
                 ps += s[r];
             }
-            psum = fmaf(psum, alpha, ps);
-            // obstacles 8q .. 8q+7 of this tile feed K-step group q: groups entirely beyond O carry p = 0
             const int nq = min(4, (O - ot * 32 + 7) >> 3);
             const BOp<P> pop(s);
+            if (__builtin_amdgcn_ballot_w64(nmx != mx) != 0) {      // some row's maximum moved: rescale (alpha = 1 elsewhere)
+                const float alpha = __builtin_amdgcn_exp2f((mx - nmx) * cs);
+                psum *= alpha;
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                acc[t] *= alpha;
-                mfma_tile_q_p<P>(vo + t * TF, pop, acc[t], lane, nq);
+                for (int t = 0; t < NT; ++t) acc[t] *= alpha;
             }
+            psum += ps;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) mfma_tile_q_p<P>(vo + t * TF, pop, acc[t], lane, nq);
             mx = nmx;
         }
     }
@@ -423,7 +428,12 @@ __global__ __launch_bounds__(WAVES * 64) void pre_kernel(PreParams p) {
         const int s = rec.x, t = rec.y;
         const float* vs = p.v + (size_t)(nbase + (s >= 0 ? s - nbase_pad : 0)) * C;
         const float* vt = p.v + (size_t)(nbase + (t >= 0 ? t - nbase_pad : 0)) * C;
-        auto getin = [&](int k) { return (k < C) ? vs[k] : ((k < 2 * C) ? vt[k - C] : 0.f); };
+        auto getin = [&](int k) {                           // [v_src, v_dst], branch-free
+            const bool ok = k < 2 * C;
+            const float* base = (k < C) ? vs : vt - C;
+            const float x = base[ok ? k : C];
+            return ok ? x : 0.f;
+        };
         mlp2_in<NT, P>(wl + E.as0, E.ks0, wl + E.b0, wl + E.a0, wl + E.c0, getin, aux, lane);   // edge_code
         mlp2_in<NT, P>(wl + E.as1, E.ks1, wl + E.b1, wl + E.a1, wl + E.c1, getin, m, lane);     // edge_free_code
     } else {
@@ -431,14 +441,16 @@ __global__ __launch_bounds__(WAVES * 64) void pre_kernel(PreParams p) {
         const int ng = p.node_ptr[g + 1] - nbase;
         const float* vr = p.v + (size_t)(nbase + (local < ng ? local : 0)) * C;
         const float* gl = p.goal + (size_t)g * C;
-        auto getin_nc = [&](int k) {                      // [v, goal, (v-goal)^2, v-goal]  model.py:119
-            if (k >= 4 * C) return 0.f;
-            const int part = k / C, c = k - part * C;
+        auto getin_nc = [&](int k) {                        // [v, goal, (v-goal)^2, v-goal]  model.py:119, branch-free
+            const bool ok = k < 4 * C;
+            const int kk = ok ? k : 0;
+            const int part = kk / C, c = kk - part * C;
             const float x = vr[c], gg = gl[c];
             const float dlt = x - gg;
-            return part == 0 ? x : (part == 1 ? gg : (part == 2 ? dlt * dlt : dlt));
+            const float val = part == 0 ? x : (part == 1 ? gg : (part == 2 ? dlt * dlt : dlt));
+            return ok ? val : 0.f;
         };
-        auto getin_nf = [&](int k) { return (k < C) ? vr[k] : 0.f; };
+        auto getin_nf = [&](int k) { const bool ok = k < C; const float x = vr[ok ? k : 0]; return ok ? x : 0.f; };
         mlp2_in<NT, P>(wl + E.as0, E.ks0, wl + E.b0, wl + E.a0, wl + E.c0, getin_nc, aux, lane);  // node_code
         mlp2_in<NT, P>(wl + E.as1, E.ks1, wl + E.b1, wl + E.a1, wl + E.c1, getin_nf, m, lane);    // node_free_code
     }
@@ -553,7 +565,14 @@ __global__ __launch_bounds__(WAVES * 64) void pre_resident_kernel(PreParams p) {
                 const int s = rec.x, t = rec.y;
                 const float* vs = p.v + (size_t)(nbase + (s >= 0 ? s - nbase_pad : 0)) * C;
                 const float* vt = p.v + (size_t)(nbase + (t >= 0 ? t - nbase_pad : 0)) * C;
-                auto getin = [&](int k) { return (k < C) ? vs[k] : ((k < 2 * C) ? vt[k - C] : 0.f); };
+                // [v_src, v_dst]; branch-free: one clamped load + select (a divergent lambda would cost far more
+                // VALU/SALU issue time than the handful of MFMAs it feeds)
+                auto getin = [&](int k) {
+                    const bool ok = k < 2 * C;
+                    const float* base = (k < C) ? vs : vt - C;
+                    const float x = base[ok ? k : C];
+                    return ok ? x : 0.f;
+                };
                 mlp2_in<NT, P>(p.enc + E.as0, E.ks0, p.enc + E.b0, p.enc + E.a0, p.enc + E.c0, getin, aux, lane);
                 mlp2_in<NT, P>(p.enc + E.as1, E.ks1, p.enc + E.b1, p.enc + E.a1, p.enc + E.c1, getin, m, lane);
             } else {
@@ -561,14 +580,16 @@ __global__ __launch_bounds__(WAVES * 64) void pre_resident_kernel(PreParams p) {
                 const int ng = p.node_ptr[g + 1] - nbase;
                 const float* vr = p.v + (size_t)(nbase + (local < ng ? local : 0)) * C;
                 const float* gl = p.goal + (size_t)g * C;
-                auto getin_nc = [&](int k) {
-                    if (k >= 4 * C) return 0.f;
-                    const int part = k / C, c = k - part * C;
+                auto getin_nc = [&](int k) {                        // [v, goal, (v-goal)^2, v-goal]  model.py:119, branch-free
+                    const bool ok = k < 4 * C;
+                    const int kk = ok ? k : 0;
+                    const int part = kk / C, c = kk - part * C;
                     const float x = vr[c], gg = gl[c];
                     const float dlt = x - gg;
-                    return part == 0 ? x : (part == 1 ? gg : (part == 2 ? dlt * dlt : dlt));
+                    const float val = part == 0 ? x : (part == 1 ? gg : (part == 2 ? dlt * dlt : dlt));
+                    return ok ? val : 0.f;
                 };
-                auto getin_nf = [&](int k) { return (k < C) ? vr[k] : 0.f; };
+                auto getin_nf = [&](int k) { const bool ok = k < C; const float x = vr[ok ? k : 0]; return ok ? x : 0.f; };
                 mlp2_in<NT, P>(p.enc + E.as0, E.ks0, p.enc + E.b0, p.enc + E.a0, p.enc + E.c0, getin_nc, aux, lane);
                 mlp2_in<NT, P>(p.enc + E.as1, E.ks1, p.enc + E.b1, p.enc + E.a1, p.enc + E.c1, getin_nf, m, lane);
             }
