@@ -100,3 +100,22 @@ def build_edges_gpu(v, node_ptr, n_free, k1):
                                                 ws.numel(), st), 'gnnmp_graph_build')
     n_edges = int(edge_ptr[-1].item())               # one scalar read-back: the caller needs the size
     return out[:, :n_edges].contiguous(), edge_ptr
+
+
+def create_data_gpu(free, collided, goal_state, k, device):
+    """:func:`create_data` with the edge construction on the GPU (identical edge_index); ``v`` and
+    ``edge_index`` are returned on ``device`` so the explorer can consume them without a host round trip."""
+    import numpy as np
+    vf = torch.tensor(np.asarray(free), dtype=torch.float32).reshape(len(free), -1)
+    C = vf.shape[1]
+    vc = torch.tensor(np.asarray(collided), dtype=torch.float32).reshape(-1, C)
+    v = torch.cat((vf, vc), dim=0)
+    labels = torch.zeros(v.shape[0], 3)
+    labels[:len(free), 0] = 1
+    labels[len(free):, 1] = 1
+    labels[1, 2] = 1
+    vd = v.to(device)
+    ptr = torch.tensor([0, v.shape[0]], dtype=torch.int32, device=device)
+    ei, _ = build_edges_gpu(vd, ptr, [len(free)], [k1_of(k, len(free))])
+    return {'goal': torch.tensor(np.asarray(goal_state), dtype=torch.float32), 'v': v, 'labels': labels,
+            'edge_index': ei, 'v_dev': vd}

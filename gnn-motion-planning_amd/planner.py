@@ -18,7 +18,7 @@ from copy import deepcopy
 import numpy as np
 import torch
 
-from .graph_build import create_data
+from .graph_build import create_data, create_data_gpu
 
 
 def path_cost(path):
@@ -190,10 +190,11 @@ def model_smooth(model, free, collided, old_path, env, device, iters=5, trace=No
 
 @torch.no_grad()
 def explore(env, model, model_s, smooth=True, batch=500, t_max=1000, k=30, smoother='model', loop=5, device='cuda',
-            trace=None, sparse=False):
+            trace=None, sparse=False, gpu_graph=False):
     """Counterpart of ``explore`` (eval_gnn.py:168-276).  Returns the same result dict.
     ``sparse=True`` asks the model for per-edge scores (``edge_scores``) and runs the heap-based
-    frontier instead of pulling the dense N x N matrix to the host; decisions are identical."""
+    frontier instead of pulling the dense N x N matrix to the host; decisions are identical.
+    ``gpu_graph=True`` builds the kNN graph on the device (graph_kernels.hip; same edge_index)."""
     c0 = env.collision_check_count
     t0 = time.time()
     forward = 0.
@@ -202,13 +203,15 @@ def explore(env, model, model_s, smooth=True, batch=500, t_max=1000, k=30, smoot
     collided = collided[:len(free)]
     free = [env.init_state] + [env.goal_state] + list(free)
     state = {'explored': [0], 'explored_edges': [[0, 0]], 'costs': {0: 0.}, 'prev': {0: 0}}
-    data = create_data(free, collided, env.goal_state, k)
+    make_data = (lambda f, c: create_data_gpu(f, c, env.goal_state, k, device)) if gpu_graph else \
+        (lambda f, c: create_data(f, c, env.goal_state, k))
+    data = make_data(free, collided)
     while not success and (len(free) - 2) <= t_max:
         t1 = time.time()
         od = obs_data(env, free, collided, device)
-        kw = dict(goal=data['goal'].to(device), v=data['v'].to(device), labels=data['labels'].to(device),
+        kw = dict(goal=data['goal'].to(device), v=data.get('v_dev', data['v']).to(device), labels=data['labels'].to(device),
                   edge_index=data['edge_index'].to(device), loop=loop, **od)
-        ei = data['edge_index'].numpy()
+        ei = data['edge_index'].cpu().numpy()
         v = data['v'].numpy()
         if sparse:
             sc = model.edge_scores(**kw).detach().cpu().numpy()      # E floats instead of N^2
@@ -234,7 +237,7 @@ def explore(env, model, model_s, smooth=True, batch=500, t_max=1000, k=30, smoot
             new_free, new_coll = env.sample_n_points(batch, need_negative=True)
             free = free + list(new_free)
             collided = (collided + list(new_coll))[:len(free)]
-            data = create_data(free, collided, env.goal_state, k)
+            data = make_data(free, collided)
     c_explore = env.collision_check_count - c0
     c1 = env.collision_check_count
     t1 = time.time()

@@ -210,6 +210,39 @@ def planner_cases(sds):
     planner_case(eg, env, 7, sds['maze2'], sd_s, batch=40, t_max=200, k=8, seed=77)
 
 
+def eval_set_case(n_problems=12):
+    """The reference's eval_gnn defaults (batch=500, t_max=500, k=30 -> N ~ 1002, k1 = 41, E ~ 56 k, smoothing on)
+    on the first problems of mazes_hard.npz, seed 1234 -- the setting of the notebook's published run
+    (main.ipynb:57-61).  Records the problem definitions (data) and the per-problem outcomes."""
+    from environment import MazeEnv
+    from config import set_random_seed
+    eg = load_patched_eval_gnn()
+    env = MazeEnv(dim=2, map_file='maze_files/mazes_hard.npz')
+    sd_e = torch.load(os.path.join(REF, 'data', 'weights', 'weights_maze.pt'), map_location='cpu')
+    sd_s = torch.load(os.path.join(REF, 'data', 'weights', 'smooth_2d_attv3.pt'), map_location='cpu')
+    m = ref_model.EncoderProcessDecoder(2, 2, 32, 2)
+    m.load_state_dict(sd_e, strict=True)
+    ms = ref_smoother.ModelSmoother(workspace_size=2, config_size=2, embed_size=128, obs_size=6)
+    ms.load_state_dict(sd_s, strict=True)
+    m.eval(); ms.eval()
+    set_random_seed(1234)
+    rows, explored_n = [], []
+    import time as _t
+    t0 = _t.time()
+    for idx in range(n_problems):
+        env.init_new_problem(idx)
+        r = eg.explore(env, m, ms, True, batch=500, t_max=500, k=30)
+        rows.append([int(r['success']), eg.path_cost(r['path']), eg.path_cost(r['smooth_path']), r['c_explore'],
+                     r['c_smooth'], len(r['path']), len(r['explored'])])
+        print('  problem %d: success=%d c_explore=%d c_smooth=%d explored=%d (%.1f s)' %
+              (idx, r['success'], r['c_explore'], r['c_smooth'], len(r['explored']), _t.time() - t0))
+    np.savez_compressed(os.path.join(OUT, 'evalset_mazehard_first%d.npz' % n_problems),
+                        maps=env.maps[:n_problems].copy(), init_states=env.init_states[:n_problems].copy(),
+                        goal_states=env.goal_states[:n_problems].copy(), seed=1234, batch=500, t_max=500, k=30,
+                        rows=np.array(rows, dtype=np.float64),
+                        columns=np.array(['success', 'path_cost', 'smooth_cost', 'c_explore', 'c_smooth', 'path_len', 'explored']))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -233,11 +266,15 @@ def main():
     smoother_case('smooth_2d_attv3', 2, 1.0, P=30, F=500, Co=500, loop=1)
     smoother_case('smooth_14d_attv3', 14, 1.0, P=7, F=40, Co=3, loop=3)
     planner_cases(sds)
+    eval_set_case()
 
 
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'planner':
         torch.set_num_threads(8)
         planner_cases({'maze2': save_weights('weights_maze')})
+    elif len(sys.argv) > 1 and sys.argv[1] == 'evalset':
+        torch.set_num_threads(8)
+        eval_set_case()
     else:
         main()

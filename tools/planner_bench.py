@@ -1,0 +1,65 @@
+#!/usr/bin/env python
+"""Whole-planner throughput on 2-D maze problems (informational; the headline metric is bench.py).
+
+The GNN forwards run on the GPU; sampling, graph construction (host or device), the greedy frontier loop
+and every collision check run on ONE host core in this process -- exactly the split north_star
+describes.  Problems come from tests/golden/evalset_*.npz (the first problems of the reference's
+mazes_hard.npz), cycled.  Prints one JSON line."""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, 'tests'))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import gnnmp  # noqa: E402
+from conftest import golden_files, load_weights  # noqa: E402
+from gnnmp import planner  # noqa: E402
+from gnnmp.maze2d import Maze2D  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--problems', type=int, default=48)
+    ap.add_argument('--sparse', action='store_true', help='sparse frontier on per-edge scores instead of the dense N x N matrix')
+    ap.add_argument('--gpu-graph', action='store_true', help='build the kNN graph on the device')
+    ap.add_argument('--batch', type=int, default=500)
+    ap.add_argument('--k', type=int, default=30)
+    a = ap.parse_args()
+    with np.load(golden_files('evalset_')[0]) as f:
+        maps, init, goal = f['maps'], f['init_states'], f['goal_states']
+    env = Maze2D(maps, init, goal)
+    dev = 'cuda:0'
+    m = gnnmp.EncoderProcessDecoder(2, 2, 32, 2)
+    m.load_state_dict(load_weights('weights_maze'))
+    ms = gnnmp.ModelSmoother(workspace_size=2, config_size=2, embed_size=128, obs_size=6)
+    ms.load_state_dict(load_weights('smooth_2d_attv3'))
+    np.random.seed(1234)
+    torch.manual_seed(1234)
+    env.init_new_problem(0)
+    planner.explore(env, m, ms, True, batch=a.batch, t_max=500, k=a.k, device=dev, sparse=a.sparse, gpu_graph=a.gpu_graph)     # warm-up
+    tot = dict(success=0, forward=0.0, total=0.0, explore=0.0, c_explore=0, c_smooth=0)
+    t0 = time.perf_counter()
+    for i in range(a.problems):
+        env.init_new_problem(i % maps.shape[0])
+        r = planner.explore(env, m, ms, True, batch=a.batch, t_max=500, k=a.k, device=dev, sparse=a.sparse,
+                            gpu_graph=a.gpu_graph)
+        tot['success'] += int(r['success']); tot['forward'] += r['forward']; tot['total'] += r['total']
+        tot['explore'] += r['total_explore']; tot['c_explore'] += r['c_explore']; tot['c_smooth'] += r['c_smooth']
+    wall = time.perf_counter() - t0
+    n = a.problems
+    print(json.dumps({'problems': n, 'success': tot['success'], 'problems_per_s': round(n / wall, 3),
+                      's_per_problem': round(wall / n, 4), 'gnn_forward_s_per_problem': round(tot['forward'] / n, 5),
+                      'host_s_per_problem': round((tot['total'] - tot['forward']) / n, 4),
+                      'collision_checks_explore': round(tot['c_explore'] / n, 2),
+                      'collision_checks_total': round((tot['c_explore'] + tot['c_smooth']) / n, 2),
+                      'host_cores_used': 1, 'graph_build': 'device' if a.gpu_graph else 'host', 'frontier': 'sparse heap' if a.sparse else 'dense N x N (reference form)',
+                      'config': 'maze2 hard, batch=%d, k=%d, smoothing on' % (a.batch, a.k)}))
+
+
+if __name__ == '__main__':
+    main()
