@@ -26,6 +26,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_FP32_TFLOPS = 157.3      # MI355X fp32 matrix = vector peak (MI355X_MICROARCH.md)
+PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA peak
 PEAK_HBM_GBS = 8000.0
 
 
@@ -91,6 +92,8 @@ def main():
     ap.add_argument('--nodes', type=int, default=1000)
     ap.add_argument('--k1', type=int, default=8)
     ap.add_argument('--loop', type=int, default=5)
+    ap.add_argument('--mlp-dtype', default='fp32', choices=['fp32', 'bf16'],
+                    help="MFMA operand precision; the headline metric is fp32 (bf16 = BASELINE configs[2]/[4] mode)")
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--pcie-steps', type=int, default=5, help='extra steps timed incl. H2D/D2H (0 = skip)')
@@ -111,15 +114,18 @@ def main():
 
     import gnnmp
     from conftest import load_weights
-    from gnnmp.synth import ENVS, synth_graph
+    from gnnmp.synth import ENVS, synth_batch_gpu
     e = ENVS[args.env]
     G = args.graphs
     uniq = G if args.unique <= 0 else min(G, args.unique)
-    base = [synth_graph(args.env, args.nodes, args.k1, seed=1234 + rank * G + i) for i in range(uniq)]
+    # same node / obstacle draws as synth_graph(seed = 1234 + rank * G + i); the kNN edge lists are built by the
+    # device graph builder (bit-identical to the host builder) so start-up takes seconds instead of half a minute
+    base = synth_batch_gpu(args.env, args.nodes, args.k1, uniq, dev, seed0=1234 + rank * G)
     graphs = [base[i % uniq] for i in range(G)]
     batch = gnnmp.GraphBatch.from_graphs(graphs, e['S'], dev)
     model = gnnmp.EncoderProcessDecoder(e['workspace'], e['C'], e['d'], e['S'])
     model.load_state_dict(load_weights(e['ckpt']), strict=True)
+    model.mlp_dtype = args.mlp_dtype
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -190,8 +196,8 @@ def main():
         checksum = float(sum(o[:int(s.item())].double().sum().item() for o, s in zip(out, sizes)))
 
     if rank == 0:
-        Ns = [g['v'].shape[0] for g in graphs]
-        Es = [g['edge_index'].shape[1] for g in graphs]
+        Ns = [int(g['v'].shape[0]) for g in graphs]
+        Es = [int(g['edge_index'].shape[1]) for g in graphs]
         Os = [g['obstacles'].reshape(-1, e['S']).shape[0] for g in graphs]
         flops_batch = sum(algorithmic_flops(n, m, o, e['C'], e['d'], e['S'], args.loop) for n, m, o in zip(Ns, Es, Os))
         bytes_batch = sum(algorithmic_bytes(n, m, o, e['C'], e['S']) for n, m, o in zip(Ns, Es, Os))
@@ -199,6 +205,7 @@ def main():
         ep_ms, ep_n = prof['edge_pre']
         ep_avg_ms = ep_ms / max(ep_n, 1)
         achieved = ep_flops / (ep_avg_ms * 1e-3) / 1e12 if ep_avg_ms > 0 else 0.0
+        peak = PEAK_FP32_TFLOPS if args.mlp_dtype == 'fp32' else PEAK_BF16_TFLOPS
         traffic = None
         tpath = os.path.join(REPO, 'profiles', 'edge_pre_traffic.json')
         if os.path.exists(tpath):
@@ -206,6 +213,9 @@ def main():
                 traffic = json.load(open(tpath)).get('hbm_bytes_per_launch')
             except Exception:
                 traffic = None
+        cfg_name = 'BASELINE configs[1]' if (args.env, args.nodes, args.k1, G, args.mlp_dtype) == ('maze2', 1000, 8, 256, 'fp32') \
+            else ('BASELINE configs[2] shape' if (args.env, args.nodes, args.k1, args.mlp_dtype) == ('kuka7', 2000, 10, 'bf16')
+                  else 'custom workload')
         ms_step = elapsed / args.steps * 1e3
         value = world * G * args.steps / elapsed
         stages = {k: round(v[0] / max(args.steps, 1), 4) for k, v in prof.items()}
@@ -213,11 +223,11 @@ def main():
             'metric': 'RGG graphs/sec (GNN explorer forward), 1000-node k=8',
             'value': round(value, 2), 'unit': 'graphs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(ms_step, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'BASELINE configs[1]: %s, batch of %d problems per GPU, %d-node k1=%d RGGs '
-                                   '(mean E=%.0f, O=%d), loop=%d, use_obstacles, real %s checkpoint, fp32, sparse '
-                                   'per-edge scores' % (args.env, G, args.nodes, args.k1, sum(Es) / len(Es), Os[0],
-                                                        args.loop, e['ckpt']),
+            'dtype': 'f32' if args.mlp_dtype == 'fp32' else 'bf16', 'data': 'synthetic',
+            'config': {'workload': '%s: %s, batch of %d problems per GPU, %d-node k1=%d RGGs '
+                                   '(mean E=%.0f, O=%d), loop=%d, use_obstacles, real %s checkpoint, %s, sparse '
+                                   'per-edge scores' % (cfg_name, args.env, G, args.nodes, args.k1, sum(Es) / len(Es), Os[0],
+                                                        args.loop, e['ckpt'], args.mlp_dtype),
                        'graphs_per_gpu': G, 'parallelism': 'problem-sharded x%d' % world,
                        'whole_forward': {'algorithmic_TFLOPs': round(flops_batch * args.steps / elapsed / 1e12, 2),
                                          'algorithmic_GBs': round(bytes_batch * args.steps / elapsed / 1e9, 3),
@@ -226,9 +236,9 @@ def main():
                        'stage_ms_per_step': stages, 'result_checksum': checksum,
                        'pcie_inclusive_graphs_per_s_per_gpu': None if e2e is None else round(e2e, 1),
                        'dense_output_graphs_per_s_per_gpu': None if dense_rate is None else round(dense_rate, 1)},
-            'roofline': {'kernel': 'pre_kernel<%d,EDGE> (edge encoders + 3 obstacle-attention blocks)' % e['d'],
-                         'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_FP32_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': round(achieved / PEAK_FP32_TFLOPS, 4), 'traffic': traffic,
+            'roofline': {'kernel': 'pre_resident_kernel<%d,%s,EDGE> (edge encoders + 3 obstacle-attention blocks)' % (e['d'], args.mlp_dtype),
+                         'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
+                         'frac': round(achieved / peak, 4), 'traffic': traffic if args.mlp_dtype == 'fp32' else None,
                          'launch_ms': round(ep_avg_ms, 4), 'algorithmic_flops_per_launch': ep_flops},
         }
         if world == 1 and not args.no_cpu_baseline:

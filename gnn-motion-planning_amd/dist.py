@@ -57,3 +57,22 @@ def gather_problem_results(rows, group=None):
     k = rows.shape[1] if rows.dim() == 2 else 0
     parts = gather_variable(rows.reshape(-1), group)
     return torch.cat([p.reshape(-1, k) for p in parts], dim=0) if k else torch.cat(parts)
+
+
+def run_mixed(problems, models, loop=5):
+    """Score a mixed set of planning problems (BASELINE configs[3]: maze / snake / ur5 / kuka together).
+    Each problem is a dict with ``env`` (family key into ``models``) plus ``v, goal, obstacles, edge_index``;
+    problems are bucketed per family -- one batched forward per family, since every family has its own
+    (C, d, S) and weights -- and the per-edge scores come back in the caller's problem order."""
+    from .batch import GraphBatch
+    buckets = {}
+    for i, p in enumerate(problems):
+        buckets.setdefault(p['env'], []).append(i)
+    out = [None] * len(problems)
+    for env, idxs in buckets.items():
+        m = models[env]
+        dev = problems[idxs[0]]['v'].device
+        b = GraphBatch.from_graphs([problems[i] for i in idxs], m.obs_size, dev)
+        for i, sc in zip(idxs, b.split_edges(m.forward_batch(b, loop))):
+            out[i] = sc
+    return out

@@ -52,3 +52,36 @@ def synth_graph(env, n_nodes, k1, seed=1234, n_obs=None):
         obstacles = torch.stack((half, base), dim=1).float()          # [O, 2, 3] like kuka_env.py:98
     return {'v': v, 'goal': v[1].clone(), 'obstacles': obstacles,
             'edge_index': build_edges(v, n_free, k1), 'n_free': n_free}
+
+
+def synth_batch_gpu(env, n_nodes, k1, n_graphs, device, seed0=1234, n_obs=None):
+    """``n_graphs`` synthetic graphs (seeds ``seed0 + i``) with the SAME node / obstacle draws as
+    :func:`synth_graph`, but with the kNN edge construction done in one batched call on the GPU
+    (graph_kernels.hip; bit-identical edge_index to the host builder, tests/test_graph_build_gpu.py).
+    Returns a list of graph dicts whose tensors live on ``device``."""
+    from .graph_build import build_edges_gpu
+    e = ENVS[env]
+    vs, obs = [], []
+    for i in range(n_graphs):
+        gen = torch.Generator().manual_seed(int(seed0 + i))
+        lim = torch.tensor(e['lim'], dtype=torch.float64)
+        vs.append(((torch.rand(n_nodes, e['C'], generator=gen, dtype=torch.float64) * 2 - 1) * lim).float())
+        if e['obs'] == 'grid':
+            O = 116 if n_obs is None else n_obs
+            cells = torch.randperm(225, generator=gen)[:O].sort().values
+            obs.append((torch.stack((cells // 15, cells % 15), dim=1).to(torch.float64) / 15 - 0.5).float())
+        else:
+            O = 5 if n_obs is None else n_obs
+            half = torch.rand(O, 3, generator=gen, dtype=torch.float64) * 0.25 + 0.05
+            base = torch.rand(O, 3, generator=gen, dtype=torch.float64) * 2 - 1
+            obs.append(torch.stack((half, base), dim=1).float())
+    v_all = torch.cat(vs).to(device)
+    ptr = (torch.arange(n_graphs + 1, dtype=torch.int64) * n_nodes).to(torch.int32).to(device)
+    ei, eptr = build_edges_gpu(v_all, ptr, [n_nodes // 2] * n_graphs, [k1] * n_graphs)
+    eptr = eptr.cpu().tolist()
+    out = []
+    for i in range(n_graphs):
+        vd = v_all[i * n_nodes:(i + 1) * n_nodes]
+        out.append({'v': vd, 'goal': vd[1].clone(), 'obstacles': obs[i].to(device),
+                    'edge_index': ei[:, eptr[i]:eptr[i + 1]], 'n_free': n_nodes // 2})
+    return out

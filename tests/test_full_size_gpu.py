@@ -1,0 +1,67 @@
+"""BASELINE configs[1] at FULL size (256 problems x 1000-node k=8 RGGs on one GPU), checked through
+size-independent properties: problems are independent, so (a) any graph scored inside the 256-batch equals
+the same graph scored alone, bit for bit; (b) two runs give identical bytes (no order-dependent atomics in
+the results); (c) the dense blocks are exactly the scatter of the sparse scores; (d) sampled graphs agree with
+the CPU oracle within the fp32 bar; plus the mixed-environment batching helper of configs[3]."""
+import pytest
+import torch
+
+from conftest import load_weights
+import gnnmp
+from gnnmp.synth import ENVS, synth_batch_gpu, synth_graph
+from oracle import ref_cpu
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def test_cfg2_full_batch_properties():
+    G, N, K1 = 256, 1000, 8
+    graphs = synth_batch_gpu('maze2', N, K1, G, DEV)
+    m = gnnmp.EncoderProcessDecoder(2, 2, 32, 2)
+    m.load_state_dict(load_weights('weights_maze'))
+    b = gnnmp.GraphBatch.from_graphs(graphs, 2, DEV)
+    s1 = m.forward_batch(b, 5).clone()
+    s2 = m.forward_batch(b, 5)
+    assert torch.equal(s1, s2)                                           # (b) deterministic
+    parts = b.split_edges(s1)
+    w = load_weights('weights_maze')
+    for i in (0, 97, 255):
+        g = graphs[i]
+        alone = m.edge_scores(g['goal'], 5, g['v'], g['obstacles'], g['edge_index'])
+        assert torch.equal(alone, parts[i])                              # (a) batch == per graph
+        # the device-built graph equals the host builder's for the same seed
+        host = synth_graph('maze2', N, K1, seed=1234 + i)
+        assert torch.equal(g['edge_index'].cpu(), host['edge_index']) and torch.equal(g['v'].cpu(), host['v'])
+        ref = ref_cpu.explorer_forward(w, host['v'], host['goal'], host['obstacles'], host['edge_index'], 5)
+        assert torch.allclose(parts[i].cpu(), ref, rtol=1e-5, atol=2e-5)   # (d) fp32 bar
+    sub = gnnmp.GraphBatch.from_graphs(graphs[:8], 2, DEV)
+    sc, dense = m.forward_batch(sub, 5, dense=True)
+    off = 0
+    for g, p in zip(graphs[:8], sub.split_edges(sc)):
+        P = dense[off:off + N * N].view(N, N)
+        ei = g['edge_index']
+        assert torch.equal(P[ei[1], ei[0]], p)                           # (c) dense == scatter of sparse
+        assert int((P != 0).sum()) <= ei.shape[1]
+        off += N * N
+
+
+def test_mixed_environment_set():
+    """configs[3]: maze / snake / ur5 / kuka problems in one job -- bucketed per environment family (each
+    family has its own (C, d, S) and checkpoint), results returned in the caller's problem order."""
+    from gnnmp.dist import run_mixed
+    order = ['maze2', 'kuka7', 'ur5', 'snake7', 'kuka7', 'maze2', 'ur5']
+    problems = [dict(env=env, **{k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in
+                                 synth_graph(env, 90 + 10 * i, 5, seed=40 + i).items()}) for i, env in enumerate(order)]
+    models = {}
+    for env in set(order):
+        e = ENVS[env]
+        mm = gnnmp.EncoderProcessDecoder(e['workspace'], e['C'], e['d'], e['S'])
+        mm.load_state_dict(load_weights(e['ckpt']))
+        models[env] = mm
+    scores = run_mixed(problems, models, loop=4)
+    assert len(scores) == len(problems)
+    for p, s in zip(problems, scores):
+        ref = ref_cpu.explorer_forward(load_weights(ENVS[p['env']]['ckpt']), p['v'].cpu(), p['goal'].cpu(),
+                                       p['obstacles'].cpu(), p['edge_index'].cpu(), 4)
+        assert torch.allclose(s.cpu(), ref, rtol=1e-5, atol=2e-5), p['env']
