@@ -25,7 +25,8 @@ class Batch(ctypes.Structure):
 
 
 class SmootherDims(ctypes.Structure):
-    _fields_ = [('config_size', ctypes.c_int32), ('embed_size', ctypes.c_int32), ('scale', ctypes.c_float)]
+    _fields_ = [('config_size', ctypes.c_int32), ('embed_size', ctypes.c_int32), ('scale', ctypes.c_float),
+                ('mlp_dtype', ctypes.c_int32)]
 
 
 class SmoothBatch(ctypes.Structure):

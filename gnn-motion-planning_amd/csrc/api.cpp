@@ -785,7 +785,7 @@ std::vector<Entry> smoother_manifest(const gnnmp_smoother_dims& d) {
 
 bool sm_dims_ok(const gnnmp_smoother_dims& d) {
     return d.config_size >= 1 && d.config_size <= 29 && (d.embed_size == 32 || d.embed_size == 64 || d.embed_size == 128) &&
-           d.scale > 0.f;
+           d.scale > 0.f && (d.mlp_dtype == GNNMP_F32 || d.mlp_dtype == GNNMP_BF16);
 }
 
 }  // namespace
@@ -827,9 +827,13 @@ extern "C" int gnnmp_smoother_create(gnnmp_smoother** out, const gnnmp_smoother_
     h->dims = *dims;
     h->device = device;
     h->w_dev = nullptr;
-    h->L = SmLayout::make(D, C);
+    const int PR = dims->mlp_dtype;
+    h->L = SmLayout::make(PR, D, C);
     const SmLayout& L = h->L;
     std::vector<float> P(L.total, 0.f);
+    auto ptiles = [&](const float* w, int out_f, int ld, float* dst) {
+        if (PR) pack_a_tiles_bf16(w, out_f, ld, 0, D, dst); else gnnmp_pack_a_tiles(w, out_f, ld, 0, D, dst);
+    };
     auto W = [&](const std::string& n) { return B.get(n); };
     // fold eval-mode BatchNorm (eps 1e-5) into node_code.0:  y = (W x + b - mean) * g + beta,  g = gamma / sqrt(var + eps)
     {
@@ -842,10 +846,10 @@ extern "C" int gnnmp_smoother_create(gnnmp_smoother** out, const gnnmp_smoother_
             for (int k = 0; k < K; ++k) wf[(size_t)i * K + k] = w0[(size_t)i * K + k] * g;
             bf[i] = (b0[i] - mu[i]) * g + be[i];
         }
-        gnnmp_pack_a_small(wf.data(), D, K, 0, K, P.data() + L.as0);
+        if (PR) pack_a_small_bf16(wf.data(), D, K, 0, K, P.data() + L.as0); else gnnmp_pack_a_small(wf.data(), D, K, 0, K, P.data() + L.as0);
         gnnmp_pack_vec(bf.data(), D, P.data() + L.b0);
     }
-    gnnmp_pack_a_tiles(W("node_code.3.weight"), D, D, 0, D, P.data() + L.w3);
+    ptiles(W("node_code.3.weight"), D, D, P.data() + L.w3);
     gnnmp_pack_vec(W("node_code.3.bias"), D, P.data() + L.b3);
     {
         const float* w1 = W("process.lin_0.0.weight");      // [x_j - x_i | x_j | x_i]  model_smoother.py:37
@@ -856,15 +860,15 @@ extern "C" int gnnmp_smoother_create(gnnmp_smoother** out, const gnnmp_smoother_
                 ws[(size_t)i * D + k] = a + b;
                 wd[(size_t)i * D + k] = c - a;
             }
-        gnnmp_pack_a_tiles(ws.data(), D, D, 0, D, P.data() + L.wsrc);
-        gnnmp_pack_a_tiles(wd.data(), D, D, 0, D, P.data() + L.wdst);
+        ptiles(ws.data(), D, D, P.data() + L.wsrc);
+        ptiles(wd.data(), D, D, P.data() + L.wdst);
         gnnmp_pack_vec(W("process.lin_0.0.bias"), D, P.data() + L.b00);
     }
-    gnnmp_pack_a_tiles(W("process.lin_0.2.weight"), D, D, 0, D, P.data() + L.w02);
+    ptiles(W("process.lin_0.2.weight"), D, D, P.data() + L.w02);
     gnnmp_pack_vec(W("process.lin_0.2.bias"), D, P.data() + L.b02);
-    gnnmp_pack_a_tiles(W("process.lin_1.0.weight"), D, D, 0, D, P.data() + L.w10);
+    ptiles(W("process.lin_1.0.weight"), D, D, P.data() + L.w10);
     gnnmp_pack_vec(W("process.lin_1.0.bias"), D, P.data() + L.b10);
-    gnnmp_pack_a_tiles(W("process.lin_1.2.weight"), D, D, 0, D, P.data() + L.w12);
+    ptiles(W("process.lin_1.2.weight"), D, D, P.data() + L.w12);
     gnnmp_pack_vec(W("process.lin_1.2.bias"), D, P.data() + L.b12);
     {
         std::vector<float> ws((size_t)32 * D, 0.f), bs(32, 0.f);
@@ -873,7 +877,7 @@ extern "C" int gnnmp_smoother_create(gnnmp_smoother** out, const gnnmp_smoother_
             for (int k = 0; k < D; ++k) ws[(size_t)i * D + k] = w[(size_t)i * D + k];
             bs[i] = b[i];
         }
-        gnnmp_pack_a_tiles(ws.data(), 32, D, 0, D, P.data() + L.ws);
+        ptiles(ws.data(), 32, D, P.data() + L.ws);
         gnnmp_pack_vec(bs.data(), 32, P.data() + L.bs);
     }
     hipError_t e = hipSetDevice(device);
@@ -971,7 +975,7 @@ extern "C" int gnnmp_smoother_forward(const gnnmp_smoother* h, const gnnmp_smoot
     HIP_TRY(launch_sm_init(b->total_path * C, p.scale, b->path, p.cur, st));
     for (int it = 0; it < loop; ++it) {
         HIP_TRY(hipMemsetAsync(at<char>(ws, c.ff_beg), 0xFF, c.ff_end - c.ff_beg, st));
-        HIP_TRY(launch_sm_iter(D, p, st));
+        HIP_TRY(launch_sm_iter(D, h->dims.mlp_dtype, p, st));
     }
     HIP_TRY(launch_sm_final(b->total_path * C, p.scale, p.cur, out_path, st));
     return GNNMP_OK;

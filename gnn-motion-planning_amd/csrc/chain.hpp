@@ -137,46 +137,6 @@ __device__ __forceinline__ void linear_acc_p(const float* A, const f32x16 (&x)[N
 template <int P, int NTO, class GetIn>
 __device__ __forceinline__ void linear_in_p(const float* Asmall, int ksteps, GetIn getin, f32x16 (&y)[NTO], int lane);
 
-// acc += A_tile . x   for one (out tile, in tile) pair; a points at the 1024-float A tile.
-__device__ __forceinline__ void mfma_tile(const float* a, const f32x16& x, f32x16& acc, int lane) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const f32x4 w = *reinterpret_cast<const f32x4*>(a + (q * 64 + lane) * 4);
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[c], x[q * 4 + c], acc, 0, 0, 0);
-    }
-}
-
-// same, but only the first nq (1..4) groups of four K steps: the remaining K indices are known to
-// carry exact zeros in x (masked softmax weights of padding obstacles), so skipping them is bit-exact
-__device__ __forceinline__ void mfma_tile_q(const float* a, const f32x16& x, f32x16& acc, int lane, int nq) {
-    if (nq >= 4) { mfma_tile(a, x, acc, lane); return; }
-    for (int q = 0; q < nq; ++q) {
-        const f32x4 w = *reinterpret_cast<const f32x4*>(a + (q * 64 + lane) * 4);
-        // x[q*4 + c] with runtime q: select through a small switch to keep the vector in registers
-        f32x4 xb;
-        switch (q) {
-            case 0: xb = f32x4{x[0], x[1], x[2], x[3]}; break;
-            case 1: xb = f32x4{x[4], x[5], x[6], x[7]}; break;
-            default: xb = f32x4{x[8], x[9], x[10], x[11]}; break;
-        }
-#pragma unroll
-        for (int cidx = 0; cidx < 4; ++cidx)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[cidx], xb[cidx], acc, 0, 0, 0);
-    }
-}
-
-// y[ot] += sum_it A[ot][it] . x[it]      (A: [NTO][NTI][1024] floats, LDS or global)
-template <int NTO, int NTI>
-__device__ __forceinline__ void linear_acc(const float* A, const f32x16 (&x)[NTI], f32x16 (&y)[NTO], int lane) {
-#pragma unroll
-    for (int it = 0; it < NTI; ++it)
-#pragma unroll
-        for (int ot = 0; ot < NTO; ++ot)
-            mfma_tile(A + (ot * NTI + it) * kATile, x[it], y[ot], lane);
-}
-
 // per-feature vector in register order: vec[(t*2 + h)*16 + r]
 template <int NT>
 __device__ __forceinline__ void load_vec(const float* vec, f32x16 (&y)[NT], int lane) {

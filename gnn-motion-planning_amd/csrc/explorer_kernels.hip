@@ -239,7 +239,9 @@ __global__ __launch_bounds__(256) void obs_kernel(ObsParams p) {
     constexpr int TF = Prec<P>::TF;
     const int g = blockIdx.x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
-    const int o0 = p.obs_ptr[g], O = p.obs_ptr[g + 1] - o0;
+    // max_obstacles is a caller promise; clamp so a too-small value truncates the obstacle set instead of
+    // writing past the K/V slab (documented in gnnmp.h)
+    const int o0 = p.obs_ptr[g], O = min(p.obs_ptr[g + 1] - o0, p.ot_max * 32);
     const int OT = (O + 31) / 32;
     for (int side = 0; side < 2; ++side) {
         const float* W = p.w[side];
@@ -456,7 +458,7 @@ __global__ __launch_bounds__(WAVES * 64) void pre_kernel(PreParams p) {
     }
 
     if (p.use_obstacles) {
-        const int O = p.obs_ptr[g + 1] - p.obs_ptr[g];
+        const int O = min(p.obs_ptr[g + 1] - p.obs_ptr[g], p.ot_max * 32);
         const int OT = (O + 31) / 32;
         const int chunk_floats = p.ot_chunk * NT * TF;
         for (int b = 0; b < 3; ++b) {
@@ -551,7 +553,7 @@ __global__ __launch_bounds__(WAVES * 64) void pre_resident_kernel(PreParams p) {
         if (threadIdx.x == 0) *ctr = t0;
         __syncthreads();
         const int nbase_pad = p.node_ptr_pad[g], nbase = p.node_ptr[g];
-        const int O = p.obs_ptr[g + 1] - p.obs_ptr[g];
+        const int O = min(p.obs_ptr[g + 1] - p.obs_ptr[g], p.ot_max * 32);
         while (true) {
             int tile = 0;
             if (lane == 0) tile = atomicAdd(ctr, 1);

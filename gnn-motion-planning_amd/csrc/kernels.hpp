@@ -100,7 +100,7 @@ struct SmParams {
 
 hipError_t launch_sm_init(int n, float scale, const float* path, float* cur, hipStream_t st);
 hipError_t launch_sm_final(int n, float scale, const float* cur, float* out, hipStream_t st);
-hipError_t launch_sm_iter(int D, const SmParams& p, hipStream_t st);
+hipError_t launch_sm_iter(int D, int P, const SmParams& p, hipStream_t st);
 
 struct GbParams {
     int G, C, total_nodes, kmax;

@@ -129,12 +129,12 @@ struct SmLayout {
     int w10, b10, w12, b12;          // process.lin_1
     int ws, bs;                      // smooth_node, out features padded to 32
     int total;
-    __host__ __device__ static SmLayout make(int D, int C) {
+    __host__ __device__ static SmLayout make(int P, int D, int C) {
         SmLayout L;
-        const int T = tile_floats(D), V = vec_floats(D);
+        const int T = tile_floats(D, P), V = vec_floats(D);
         int o = 0;
-        L.ks = (C + 3 + 1) / 2;
-        L.as0 = o; o += small_floats(D, L.ks);
+        L.ks = small_steps(C + 3, P);
+        L.as0 = o; o += small_floats(D, L.ks, P);
         L.b0 = o; o += V;
         L.w3 = o; o += T;
         L.b3 = o; o += V;
@@ -147,7 +147,7 @@ struct SmLayout {
         L.b10 = o; o += V;
         L.w12 = o; o += T;
         L.b12 = o; o += V;
-        L.ws = o; o += (D / 32) * 1024;
+        L.ws = o; o += (D / 32) * tile_unit(P);
         L.bs = o; o += 32;
         L.total = o;
         return L;

@@ -203,21 +203,21 @@ __device__ __forceinline__ SmNodeIn sm_node_in(const SmParams& p, int b, int n) 
 }
 
 // x = node_code.3( relu( BN_eval( node_code.0(in) ) ) ) with BN folded into node_code.0 at pack time
-template <int NT>
+template <int NT, int P>
 __device__ __forceinline__ void sm_node_code(const SmParams& p, const SmNodeIn& in, f32x16 (&x)[NT], int lane) {
     const float* W = p.w;
     f32x16 hdn[NT];
     load_vec<NT>(W + p.L.b0, hdn, lane);
-    linear_in<NT>(W + p.L.as0, p.L.ks, in, hdn, lane);
+    linear_in_p<P, NT>(W + p.L.as0, p.L.ks, in, hdn, lane);
     relu_<NT>(hdn);
     load_vec<NT>(W + p.L.b3, x, lane);
-    linear_acc<NT, NT>(W + p.L.w3, hdn, x, lane);
+    linear_acc_p<P, NT, NT>(W + p.L.w3, hdn, x, lane);
 }
 
 // ---------------------------------------------------------------------------------------------------
 // messages: one wave per 32-edge tile
 // ---------------------------------------------------------------------------------------------------
-template <int D>
+template <int D, int P>
 __global__ __launch_bounds__(256) void sm_msg_kernel(SmParams p) {
     constexpr int NT = D / 32;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
@@ -234,25 +234,25 @@ __global__ __launch_bounds__(256) void sm_msg_kernel(SmParams p) {
     load_vec<NT>(W + p.L.b00, z, lane);
     {
         f32x16 x[NT];
-        sm_node_code<NT>(p, sm_node_in(p, b, dst), x, lane);          // x_i (target)
-        linear_acc<NT, NT>(W + p.L.wdst, x, z, lane);                  // (W_c - W_a) x_i
+        sm_node_code<NT, P>(p, sm_node_in(p, b, dst), x, lane);          // x_i (target)
+        linear_acc_p<P, NT, NT>(W + p.L.wdst, x, z, lane);                  // (W_c - W_a) x_i
     }
     {
         f32x16 x[NT];
-        sm_node_code<NT>(p, sm_node_in(p, b, src), x, lane);          // x_j (source)
-        linear_acc<NT, NT>(W + p.L.wsrc, x, z, lane);                  // (W_a + W_b) x_j
+        sm_node_code<NT, P>(p, sm_node_in(p, b, src), x, lane);          // x_j (source)
+        linear_acc_p<P, NT, NT>(W + p.L.wsrc, x, z, lane);                  // (W_a + W_b) x_j
     }
     relu_<NT>(z);
     f32x16 m[NT];
     load_vec<NT>(W + p.L.b02, m, lane);
-    linear_acc<NT, NT>(W + p.L.w02, z, m, lane);
+    linear_acc_p<P, NT, NT>(W + p.L.w02, z, m, lane);
     store_row<NT>(p.msg + (size_t)e * D, m, h);
 }
 
 // ---------------------------------------------------------------------------------------------------
 // path-node update: one wave per 32 path nodes
 // ---------------------------------------------------------------------------------------------------
-template <int D>
+template <int D, int P>
 __global__ __launch_bounds__(256) void sm_node_kernel(SmParams p) {
     constexpr int NT = D / 32;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
@@ -261,9 +261,9 @@ __global__ __launch_bounds__(256) void sm_node_kernel(SmParams p) {
     const int b = p.ptile_prob[tile];
     if (b < 0) return;
     const int poff = sm_poff(p.path_ptr, b);
-    const int p0 = p.path_ptr[b], P = p.path_ptr[b + 1] - p0;
+    const int p0 = p.path_ptr[b], PN = p.path_ptr[b + 1] - p0;
     const int n = tile * 32 + j - poff;                  // local path index
-    const bool valid = n < P;
+    const bool valid = n < PN;
     const float* W = p.w;
     f32x16 S[NT];
 #pragma unroll
@@ -281,21 +281,21 @@ __global__ __launch_bounds__(256) void sm_node_kernel(SmParams p) {
     {
         f32x16 hdn[NT];
         load_vec<NT>(W + p.L.b10, hdn, lane);
-        linear_acc<NT, NT>(W + p.L.w10, S, hdn, lane);
+        linear_acc_p<P, NT, NT>(W + p.L.w10, S, hdn, lane);
         relu_<NT>(hdn);
         load_vec<NT>(W + p.L.b12, y, lane);
-        linear_acc<NT, NT>(W + p.L.w12, hdn, y, lane);
+        linear_acc_p<P, NT, NT>(W + p.L.w12, hdn, y, lane);
     }
     {
         f32x16 x[NT];
-        sm_node_code<NT>(p, sm_node_in(p, b, valid ? n : 0), x, lane);
+        sm_node_code<NT, P>(p, sm_node_in(p, b, valid ? n : 0), x, lane);
 #pragma unroll
         for (int t = 0; t < NT; ++t) y[t] += x[t];        // h = x + lin_1(S)      model_smoother.py:34
     }
     f32x16 o[1];
     load_vec<1>(W + p.L.bs, o, lane);
-    linear_acc<1, NT>(W + p.L.ws, y, o, lane);            // smooth_node (out features padded to 32)
-    if (valid && n >= 1 && n <= P - 2) {                  // path[1:-1] = ...       model_smoother.py:139
+    linear_acc_p<P, 1, NT>(W + p.L.ws, y, o, lane);            // smooth_node (out features padded to 32)
+    if (valid && n >= 1 && n <= PN - 2) {                  // path[1:-1] = ...       model_smoother.py:139
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int f = phi(r, h);
@@ -325,25 +325,25 @@ hipError_t launch_sm_final(int n, float scale, const float* cur, float* out, hip
     return hipSuccess;
 }
 
-template <int D>
+template <int D, int P>
 static hipError_t launch_sm_iter_t(const SmParams& p, hipStream_t st) {
     hipLaunchKernelGGL(sm_knn_kernel, dim3((p.total_path + 3) / 4), dim3(256), 0, st, p);
     LAUNCH_CHECK();
     const size_t lds = (size_t)2 * p.cand_cap * sizeof(int);
     hipLaunchKernelGGL(sm_edges_kernel, dim3(p.B), dim3(256), lds, st, p);
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(sm_msg_kernel<D>, dim3((p.n_etiles + 3) / 4), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((sm_msg_kernel<D, P>), dim3((p.n_etiles + 3) / 4), dim3(256), 0, st, p);
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(sm_node_kernel<D>, dim3((p.n_ptiles + 3) / 4), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((sm_node_kernel<D, P>), dim3((p.n_ptiles + 3) / 4), dim3(256), 0, st, p);
     LAUNCH_CHECK();
     return hipSuccess;
 }
 
-hipError_t launch_sm_iter(int D, const SmParams& p, hipStream_t st) {
+hipError_t launch_sm_iter(int D, int P, const SmParams& p, hipStream_t st) {
     switch (D) {
-        case 32: return launch_sm_iter_t<32>(p, st);
-        case 64: return launch_sm_iter_t<64>(p, st);
-        case 128: return launch_sm_iter_t<128>(p, st);
+        case 32: return P ? launch_sm_iter_t<32, 1>(p, st) : launch_sm_iter_t<32, 0>(p, st);
+        case 64: return P ? launch_sm_iter_t<64, 1>(p, st) : launch_sm_iter_t<64, 0>(p, st);
+        case 128: return P ? launch_sm_iter_t<128, 1>(p, st) : launch_sm_iter_t<128, 0>(p, st);
     }
     return hipErrorInvalidValue;
 }

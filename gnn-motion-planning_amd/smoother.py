@@ -71,6 +71,7 @@ class ModelSmoother(nn.Module):
         self.node_pos = Lin(C, d)
         self.encoder = Lin(d * 2, d)
         self.decoder = Lin(d * 2, d)
+        self.mlp_dtype = 'fp32'            # or 'bf16': MFMA operands only (see EncoderProcessDecoder.mlp_dtype)
         self._handle = None
         self._handle_key = None
         self._manifest = None
@@ -95,14 +96,16 @@ class ModelSmoother(nn.Module):
         return super()._apply(fn, *a, **k)
 
     def _dims(self):
-        return _lib.SmootherDims(self.config_size, self.embed_size, float(self.scale))
+        if self.mlp_dtype not in ('fp32', 'bf16'):
+            raise ValueError("mlp_dtype must be 'fp32' or 'bf16'")
+        return _lib.SmootherDims(self.config_size, self.embed_size, float(self.scale), 1 if self.mlp_dtype == 'bf16' else 0)
 
     def _native(self, device):
         if self._manifest is None:
             self._manifest = _lib.manifest('smoother', self._dims())
         sd = self.state_dict(keep_vars=True)
         wt = [sd[n] for n, _ in self._manifest]
-        key = (str(device), float(self.scale), tuple(t._version for t in wt))
+        key = (str(device), float(self.scale), self.mlp_dtype, tuple(t._version for t in wt))
         if self._handle is not None and key == self._handle_key:
             return self._handle
         self._drop_handle()

@@ -87,13 +87,16 @@ int gnnmp_explorer_destroy(gnnmp_explorer* h);
  * columns [edge_ptr[g], edge_ptr[g+1]) of edge_index and rows [obs_ptr[g], obs_ptr[g+1]) of
  * obstacles.  edge_index holds GRAPH-LOCAL node ids (what each problem's create_data produced),
  * row 0 = message source j, row 1 = message target i (PyG flow source_to_target); any order,
- * duplicates allowed (each column is scored independently). */
+ * duplicates allowed (each column is scored independently).  Node ids must lie in [0, N_g): like
+ * the reference's tensor indexing, out-of-range ids are not checked on the device. */
 typedef struct {
     int32_t n_graphs;            /* G >= 1                                                    */
     int32_t total_nodes;         /* sum_g N_g                                                 */
     int32_t total_edges;         /* sum_g E_g                                                 */
     int32_t total_obstacles;     /* sum_g O_g (may be 0)                                      */
-    int32_t max_obstacles;       /* >= max_g O_g (upper bound is fine; sizes the K/V slabs)   */
+    int32_t max_obstacles;       /* >= max_g O_g (upper bound is fine; sizes the K/V slabs); a graph with
+                                    more obstacles than this is scored against its first max_obstacles
+                                    (rounded up to 32) only                                    */
     const float* v;              /* [total_nodes, C]                                          */
     const float* goal;           /* [G, C]                                                    */
     const float* obstacles;      /* [total_obstacles, S]                                      */
@@ -151,6 +154,7 @@ typedef struct {
     int32_t config_size;   /* C                                                               */
     int32_t embed_size;    /* d (128 in every shipped checkpoint; 32/64/128 supported)         */
     float scale;           /* ModelSmoother(scale=...) (model_smoother.py:51, str2name.py:40)   */
+    int32_t mlp_dtype;     /* GNNMP_F32 or GNNMP_BF16 (MFMA operands only, as for the explorer)   */
 } gnnmp_smoother_dims;
 
 int gnnmp_smoother_manifest(const gnnmp_smoother_dims* dims, int index,

@@ -115,3 +115,46 @@ def explorer_forward_bf16(w, v, goal, obstacles, edge_index, loop, use_obstacles
     h1 = F.relu(A[s] - B[t] + pe_)
     h2 = F.relu(lin(h1, w['policy.2.weight'], w['policy.2.bias']))
     return (h2 * w['policy.4.weight'].view(1, -1)).sum(-1)
+
+
+@torch.no_grad()
+def smoother_forward_bf16(w, path, free, collided, edge_index, loop=1, scale=1.0):
+    """bf16-operand emulation of the smoother kernels' formulation (BatchNorm folded into node_code.0 in fp32,
+    lin_0 split into (W_a + W_b) x_j + (W_c - W_a) x_i, ordered fp32 sum of the messages)."""
+    from .ref_cpu import coalesce
+    path = path / scale
+    free = free / scale
+    collided = collided / scale
+    P = path.shape[0]
+    d = w['node_code.3.bias'].shape[0]
+    nodes = torch.cat((path, free, collided), dim=0)
+    n = nodes.shape[0]
+    g = w['node_code.1.weight'] / torch.sqrt(w['node_code.1.running_var'] + 1e-5)
+    w0 = w['node_code.0.weight'] * g.unsqueeze(1)
+    b0 = (w['node_code.0.bias'] - w['node_code.1.running_mean']) * g + w['node_code.1.bias']
+    w1 = w['process.lin_0.0.weight']
+    wsrc, wdst = w1[:, :d] + w1[:, d:2 * d], w1[:, 2 * d:] - w1[:, :d]
+    for _ in range(loop):
+        ne = knn(nodes[P:], path, 10).flip(0)
+        ne[0, :] = ne[0, :] + P
+        ei = coalesce(torch.cat((edge_index, ne), dim=-1), n)
+        ei = ei[:, ei[1] < P]
+        info = nodes.new_zeros(n, 3)
+        info[:P, 0] = 1
+        info[P:P + free.shape[0], 1] = 1
+        info[P + free.shape[0]:, 2] = 1
+        x = lin(F.relu(lin(torch.cat((nodes, info), dim=-1), w0, b0)), w['node_code.3.weight'], w['node_code.3.bias'])
+        s, t = ei[0], ei[1]
+        z = F.relu(lin(x[t], wdst) + lin(x[s], wsrc) + w['process.lin_0.0.bias'])
+        msg = lin(z, w['process.lin_0.2.weight'], w['process.lin_0.2.bias'])
+        S = x.new_zeros(P, d)
+        for e in range(ei.shape[1]):                      # coalesced order: fp32 sequential sum per target
+            S[t[e]] = S[t[e]] + msg[e]
+        hh = x[:P] + lin(F.relu(lin(S, w['process.lin_1.0.weight'], w['process.lin_1.0.bias'])),
+                         w['process.lin_1.2.weight'], w['process.lin_1.2.bias'])
+        new = lin(hh, w['smooth_node.weight'], w['smooth_node.bias'])
+        path = path.clone()
+        path[1:-1] = new[1:-1]
+        nodes = nodes.clone()
+        nodes[:P] = path
+    return path * scale
