@@ -92,7 +92,8 @@ struct Blob {          // host view of the caller's concatenated weights
 
 bool dims_ok(const gnnmp_explorer_dims& d) {
     return d.config_size >= 1 && d.config_size <= 64 && (d.embed_size == 32 || d.embed_size == 64) &&
-           d.obs_size >= 1 && d.obs_size <= 64 && (d.mlp_dtype == GNNMP_F32 || d.mlp_dtype == GNNMP_BF16);
+           d.obs_size >= 1 && d.obs_size <= 64 &&
+           (d.mlp_dtype == GNNMP_F32 || d.mlp_dtype == GNNMP_BF16 || d.mlp_dtype == GNNMP_BF16X3);
 }
 
 // round-to-nearest-even fp32 -> bf16 (what v_cvt_pk_bf16_f32 does on the device)
@@ -114,6 +115,47 @@ void pack_a_tiles_bf16(const float* w, int out_f, int ld, int col0, int n_in, fl
                     for (int t = 0; t < 8; ++t)
                         dst[((size_t)((ot * nti + it) * 2 + m) * 64 + lane) * 8 + t] =
                             to_bf16(w[(size_t)(32 * ot + (lane & 31)) * ld + col0 + 32 * it + phi(8 * m + t, lane >> 5)]);
+}
+
+// bf16x3: every fp32 weight as three bf16 pieces w = w0 + w1 + w2 (exact for normal numbers)
+void split3(float w, uint16_t (&pc)[3]) {
+    float r = w;
+    for (int i = 0; i < 3; ++i) {
+        pc[i] = to_bf16(r);
+        uint32_t u = (uint32_t)pc[i] << 16;
+        float f;
+        std::memcpy(&f, &u, 4);
+        r -= f;
+    }
+}
+
+void pack_a_tiles_bf16x3(const float* w, int out_f, int ld, int col0, int n_in, float* dst_f) {
+    uint16_t* dst = reinterpret_cast<uint16_t*>(dst_f);
+    const int nto = out_f / 32, nti = n_in / 32;
+    for (int ot = 0; ot < nto; ++ot)
+        for (int it = 0; it < nti; ++it)
+            for (int m = 0; m < 2; ++m)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int t = 0; t < 8; ++t) {
+                        uint16_t pc[3];
+                        split3(w[(size_t)(32 * ot + (lane & 31)) * ld + col0 + 32 * it + phi(8 * m + t, lane >> 5)], pc);
+                        for (int q = 0; q < 3; ++q)
+                            dst[(((size_t)(ot * nti + it) * 3 + q) * 2 + m) * 512 + lane * 8 + t] = pc[q];
+                    }
+}
+
+void pack_a_small_bf16x3(const float* w, int out_f, int ld, int col0, int n_in, float* dst_f) {
+    uint16_t* dst = reinterpret_cast<uint16_t*>(dst_f);
+    const int nto = out_f / 32, ks = (n_in + 15) / 16;
+    for (int ot = 0; ot < nto; ++ot)
+        for (int st = 0; st < ks; ++st)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int t = 0; t < 8; ++t) {
+                    const int k = 16 * st + 8 * (lane >> 5) + t;
+                    uint16_t pc[3];
+                    split3(k < n_in ? w[(size_t)(32 * ot + (lane & 31)) * ld + col0 + k] : 0.f, pc);
+                    for (int q = 0; q < 3; ++q) dst[(((size_t)(ot * ks + st) * 3 + q) * 64 + lane) * 8 + t] = pc[q];
+                }
 }
 
 void pack_a_small_bf16(const float* w, int out_f, int ld, int col0, int n_in, float* dst_f) {
@@ -286,10 +328,14 @@ void pack_explorer(const Blob& B, const gnnmp_explorer_dims& dm, gnnmp_explorer*
     float* PK = out.data();
     auto W = [&](const std::string& n) { return B.get(n); };
     auto tiles = [&](const float* w, int ld, int col0, float* dst) {
-        if (P) pack_a_tiles_bf16(w, D, ld, col0, D, dst); else gnnmp_pack_a_tiles(w, D, ld, col0, D, dst);
+        if (P == 2) pack_a_tiles_bf16x3(w, D, ld, col0, D, dst);
+        else if (P == 1) pack_a_tiles_bf16(w, D, ld, col0, D, dst);
+        else gnnmp_pack_a_tiles(w, D, ld, col0, D, dst);
     };
     auto small = [&](const float* w, int ld, int n_in, float* dst) {
-        if (P) pack_a_small_bf16(w, D, ld, 0, n_in, dst); else gnnmp_pack_a_small(w, D, ld, 0, n_in, dst);
+        if (P == 2) pack_a_small_bf16x3(w, D, ld, 0, n_in, dst);
+        else if (P == 1) pack_a_small_bf16(w, D, ld, 0, n_in, dst);
+        else gnnmp_pack_a_small(w, D, ld, 0, n_in, dst);
     };
     auto vec = [&](const float* b, float* dst) { gnnmp_pack_vec(b, D, dst); };
 
@@ -438,8 +484,15 @@ extern "C" int gnnmp_explorer_create(gnnmp_explorer** out, const gnnmp_explorer_
     h->prof = new StageProf();
     std::vector<float> packed;
     const int P = dims->mlp_dtype;
-    if (dims->embed_size == 32) { if (P) pack_explorer<32, 1>(B, *dims, h, packed); else pack_explorer<32, 0>(B, *dims, h, packed); }
-    else { if (P) pack_explorer<64, 1>(B, *dims, h, packed); else pack_explorer<64, 0>(B, *dims, h, packed); }
+    if (dims->embed_size == 32) {
+        if (P == 2) pack_explorer<32, 2>(B, *dims, h, packed);
+        else if (P == 1) pack_explorer<32, 1>(B, *dims, h, packed);
+        else pack_explorer<32, 0>(B, *dims, h, packed);
+    } else {
+        if (P == 2) pack_explorer<64, 2>(B, *dims, h, packed);
+        else if (P == 1) pack_explorer<64, 1>(B, *dims, h, packed);
+        else pack_explorer<64, 0>(B, *dims, h, packed);
+    }
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) {
         int ncu = 0;
@@ -563,18 +616,10 @@ T* at(void* ws, size_t off) { return reinterpret_cast<T*>(static_cast<char*>(ws)
 // LDS plan of pre_kernel: weight region + K/V chunk region
 struct PrePlan { int waves, ot_chunk, wregion; size_t lds_bytes; };
 
-int out_e_size(int D, int P) {
-    if (D == 32) return P ? OutEBlob<32, 1>::size : OutEBlob<32, 0>::size;
-    return P ? OutEBlob<64, 1>::size : OutEBlob<64, 0>::size;
-}
-int out_n_size(int D, int P) {
-    if (D == 32) return P ? OutNBlob<32, 1>::size : OutNBlob<32, 0>::size;
-    return P ? OutNBlob<64, 1>::size : OutNBlob<64, 0>::size;
-}
-int att_staged(int D, int P) {
-    if (D == 32) return P ? AttBlob<32, 1>::staged : AttBlob<32, 0>::staged;
-    return P ? AttBlob<64, 1>::staged : AttBlob<64, 0>::staged;
-}
+// blob sizes by (d, precision): T = (d/32)^2 * tile_unit(P), V = d
+int out_e_size(int D, int P) { return 3 * tile_floats(D, P) + 2 * vec_floats(D); }
+int out_n_size(int D, int P) { return 5 * tile_floats(D, P) + 4 * vec_floats(D); }
+int att_staged(int D, int P) { return 5 * tile_floats(D, P); }
 
 PrePlan plan_pre(int D, int P, int ot_max, int enc_size, int out_size, bool use_obs) {
     const int NT = D / 32;
@@ -689,7 +734,7 @@ extern "C" int gnnmp_explorer_forward(const gnnmp_explorer* h, const gnnmp_batch
         p.tile_meta = q.tile_meta;
         p.G = c.G;
         const size_t res_bytes = ((size_t)3 * att_staged(D, P) + (size_t)3 * c.kv_stride) * sizeof(float) + 64;
-        if ((D == 32 || P == 1) && use_obs && res_bytes <= 163840 && h->resident) {
+        if (((D == 32 && P == 0) || P == 1) && use_obs && res_bytes <= 163840 && h->resident) {
             HIP_TRY(launch_pre_resident(D, P, edge != 0, p, res_bytes, h->n_cu, st));
             continue;
         }

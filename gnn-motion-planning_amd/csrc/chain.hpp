@@ -52,6 +52,12 @@ typedef float f32x8 __attribute__((ext_vector_type(8)));
 template <int P> struct Prec;
 template <> struct Prec<0> { static constexpr int TF = 1024; };      // floats of storage per 32x32 A tile
 template <> struct Prec<1> { static constexpr int TF = 512; };
+// P = 2 ("bf16x3"): fp32-class results from the bf16 matrix pipe.  Every fp32 operand is split exactly into
+// three bf16 pieces x = x0 + x1 + x2 (8 mantissa bits each); a product keeps the six piece pairs with
+// i + j <= 2 (dropped terms are <= 2^-24 of the leading one) and all of them accumulate in the same fp32
+// accumulator, smallest first.  A 32x32x32 block costs 12 bf16 MFMAs (384 matrix-pipe cycles) instead of 16
+// fp32 MFMAs (1024 cycles on the VECTOR pipe), and the matrix pipe overlaps with VALU work.
+template <> struct Prec<2> { static constexpr int TF = 1536; };     // 3 pieces x 512
 
 template <int P> struct BOp;                    // one 32-feature activation tile as MFMA B operand
 template <> struct BOp<0> {
@@ -71,6 +77,25 @@ template <> struct BOp<1> {
     }
 };
 
+template <> struct BOp<2> {
+    bf16x8 lo[3], hi[3];
+    __device__ __forceinline__ BOp() {}
+    __device__ __forceinline__ explicit BOp(const f32x16& x) {
+        f32x8 a, b;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { a[r] = x[r]; b[r] = x[8 + r]; }
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) {
+            lo[pc] = __builtin_convertvector(a, bf16x8);
+            hi[pc] = __builtin_convertvector(b, bf16x8);
+            if (pc < 2) {                                  // exact residual: a - float(bf16(a)) is representable
+                a -= __builtin_convertvector(lo[pc], f32x8);
+                b -= __builtin_convertvector(hi[pc], f32x8);
+            }
+        }
+    }
+};
+
 template <int P>
 __device__ __forceinline__ void mfma_tile_p(const float* a, const BOp<P>& x, f32x16& acc, int lane) {
     if constexpr (P == 0) {
@@ -84,11 +109,24 @@ __device__ __forceinline__ void mfma_tile_p(const float* a, const BOp<P>& x, f32
 #pragma unroll
             for (int c = 0; c < 4; ++c)
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[q][c], x.v[q * 4 + c], acc, 0, 0, 0);
-    } else {
+    } else if constexpr (P == 1) {
         const bf16x8 w0 = *reinterpret_cast<const bf16x8*>(a + lane * 4);
         const bf16x8 w1 = *reinterpret_cast<const bf16x8*>(a + (64 + lane) * 4);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, x.lo, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, x.hi, acc, 0, 0, 0);
+    } else {
+        // weight piece pw of K half m sits at a + ((pw*2 + m)*64 + lane)*4; pairs (weight piece, x piece), smallest first
+        bf16x8 w[3][2];
+#pragma unroll
+        for (int pw = 0; pw < 3; ++pw)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) w[pw][m] = *reinterpret_cast<const bf16x8*>(a + ((pw * 2 + m) * 64 + lane) * 4);
+        constexpr int PW[6] = {2, 0, 1, 1, 0, 0}, PX[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[PW[t]][0], x.lo[PX[t]], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[PW[t]][1], x.hi[PX[t]], acc, 0, 0, 0);
+        }
     }
 }
 
@@ -109,12 +147,23 @@ __device__ __forceinline__ void mfma_tile_q_p(const float* a, const BOp<P>& x, f
             for (int cidx = 0; cidx < 4; ++cidx)
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[cidx], xb[cidx], acc, 0, 0, 0);
         }
-    } else {
+    } else if constexpr (P == 1) {
         const bf16x8 w0 = *reinterpret_cast<const bf16x8*>(a + lane * 4);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, x.lo, acc, 0, 0, 0);            // groups 0, 1
         if (nq > 2) {
             const bf16x8 w1 = *reinterpret_cast<const bf16x8*>(a + (64 + lane) * 4);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, x.hi, acc, 0, 0, 0);        // groups 2, 3
+        }
+    } else {
+        constexpr int PW[6] = {2, 0, 1, 1, 0, 0}, PX[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {
+            const bf16x8 w0 = *reinterpret_cast<const bf16x8*>(a + ((PW[t] * 2) * 64 + lane) * 4);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, x.lo[PX[t]], acc, 0, 0, 0);
+            if (nq > 2) {
+                const bf16x8 w1 = *reinterpret_cast<const bf16x8*>(a + ((PW[t] * 2 + 1) * 64 + lane) * 4);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, x.hi[PX[t]], acc, 0, 0, 0);
+            }
         }
     }
 }
@@ -180,7 +229,7 @@ template <int P, int NTO, class GetIn>
 __device__ __forceinline__ void linear_in_p(const float* Asmall, int ksteps, GetIn getin, f32x16 (&y)[NTO], int lane) {
     if constexpr (P == 0) {
         linear_in<NTO>(Asmall, ksteps, getin, y, lane);
-    } else {
+    } else if constexpr (P == 1) {
         const int h = lane >> 5;
         for (int st = 0; st < ksteps; ++st) {
             f32x8 b;
@@ -192,6 +241,28 @@ __device__ __forceinline__ void linear_in_p(const float* Asmall, int ksteps, Get
                 const bf16x8 w = *reinterpret_cast<const bf16x8*>(Asmall + ((ot * ksteps + st) * 64 + lane) * 4);
                 y[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, bb, y[ot], 0, 0, 0);
             }
+        }
+    } else {
+        // Asmall: [NTO][ksteps][3 pieces][64][8] bf16
+        const int h = lane >> 5;
+        for (int st = 0; st < ksteps; ++st) {
+            f32x8 b;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) b[t] = getin(16 * st + 8 * h + t);
+            bf16x8 xb[3];
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) {
+                xb[pc] = __builtin_convertvector(b, bf16x8);
+                if (pc < 2) b -= __builtin_convertvector(xb[pc], f32x8);
+            }
+            constexpr int PW[6] = {2, 0, 1, 1, 0, 0}, PX[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+            for (int ot = 0; ot < NTO; ++ot)
+#pragma unroll
+                for (int t = 0; t < 6; ++t) {
+                    const bf16x8 w = *reinterpret_cast<const bf16x8*>(Asmall + (((ot * ksteps + st) * 3 + PW[t]) * 64 + lane) * 4);
+                    y[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, xb[PX[t]], y[ot], 0, 0, 0);
+                }
         }
     }
 }

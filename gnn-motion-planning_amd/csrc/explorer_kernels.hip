@@ -289,7 +289,7 @@ __global__ __launch_bounds__(256) void obs_kernel(ObsParams p) {
                             const int lp = phi(r, h) + 32 * hp;
                             vt[((rp >> 2) * 64 + lp) * 4 + (rp & 3)] = V[t][r];
                         }
-                    } else {
+                    } else if constexpr (P == 1) {
                         const BOp<1> kb(K[t]);                       // registers 0..7 -> MFMA 0, 8..15 -> MFMA 1
                         *reinterpret_cast<bf16x8*>(kt + lane * 4) = kb.lo;
                         *reinterpret_cast<bf16x8*>(kt + (64 + lane) * 4) = kb.hi;
@@ -298,6 +298,25 @@ __global__ __launch_bounds__(256) void obs_kernel(ObsParams p) {
                         for (int r = 0; r < 16; ++r) {
                             const int lp = phi(r, h) + 32 * hp;
                             vtb[((rp >> 3) * 64 + lp) * 8 + (rp & 7)] = (__bf16)V[t][r];
+                        }
+                    } else {
+                        const BOp<2> kb(K[t]);                       // three exact bf16 pieces of every key
+                        __bf16* vtb = reinterpret_cast<__bf16*>(vt);
+#pragma unroll
+                        for (int pc = 0; pc < 3; ++pc) {
+                            *reinterpret_cast<bf16x8*>(kt + ((pc * 2) * 64 + lane) * 4) = kb.lo[pc];
+                            *reinterpret_cast<bf16x8*>(kt + ((pc * 2 + 1) * 64 + lane) * 4) = kb.hi[pc];
+                        }
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int lp = phi(r, h) + 32 * hp;
+                            float res = V[t][r];
+#pragma unroll
+                            for (int pc = 0; pc < 3; ++pc) {
+                                const __bf16 piece = (__bf16)res;
+                                vtb[((pc * 2 + (rp >> 3)) * 64 + lp) * 8 + (rp & 7)] = piece;
+                                res -= (float)piece;
+                            }
                         }
                     }
                 }
@@ -942,9 +961,20 @@ static hipError_t launch_obs_t(const ObsParams& p, int G, hipStream_t st) {
     LAUNCH_CHECK();
     return hipSuccess;
 }
+// precision dispatch: P = 0 fp32, 1 bf16, 2 bf16x3
+#define GNNMP_DISPATCH_DP(D_, P_, CALL)                                                     \
+    do {                                                                                     \
+        if ((D_) == 32 && (P_) == 0) { constexpr int DD = 32, PP = 0; return CALL; }         \
+        if ((D_) == 32 && (P_) == 1) { constexpr int DD = 32, PP = 1; return CALL; }         \
+        if ((D_) == 32 && (P_) == 2) { constexpr int DD = 32, PP = 2; return CALL; }         \
+        if ((D_) == 64 && (P_) == 0) { constexpr int DD = 64, PP = 0; return CALL; }         \
+        if ((D_) == 64 && (P_) == 1) { constexpr int DD = 64, PP = 1; return CALL; }         \
+        if ((D_) == 64 && (P_) == 2) { constexpr int DD = 64, PP = 2; return CALL; }         \
+        return hipErrorInvalidValue;                                                         \
+    } while (0)
+
 hipError_t launch_obs(int D, int P, const ObsParams& p, int G, hipStream_t st) {
-    if (D == 32) return P ? launch_obs_t<32, 1>(p, G, st) : launch_obs_t<32, 0>(p, G, st);
-    return P ? launch_obs_t<64, 1>(p, G, st) : launch_obs_t<64, 0>(p, G, st);
+    GNNMP_DISPATCH_DP(D, P, (launch_obs_t<DD, PP>(p, G, st)));
 }
 
 template <int D, int P, bool EDGE, int WAVES>
@@ -966,9 +996,7 @@ hipError_t launch_pre(int D, int P, bool edge, int waves, const PreParams& p_in,
     PreParams p = p_in;
     p.n_wg = n_wg;
     n_wg = (n_wg + 7) & ~7;
-    if (D == 32) return P ? launch_pre_dp<32, 1>(edge, waves, p, n_wg, lds_bytes, st) : launch_pre_dp<32, 0>(edge, waves, p, n_wg, lds_bytes, st);
-    if (D == 64) return P ? launch_pre_dp<64, 1>(edge, waves, p, n_wg, lds_bytes, st) : launch_pre_dp<64, 0>(edge, waves, p, n_wg, lds_bytes, st);
-    return hipErrorInvalidValue;
+    GNNMP_DISPATCH_DP(D, P, (launch_pre_dp<DD, PP>(edge, waves, p, n_wg, lds_bytes, st)));
 }
 
 template <int D, int P, bool EDGE, int WAVES>
@@ -1003,8 +1031,7 @@ static hipError_t launch_mp_edge_t(const MpEdgeParams& p, hipStream_t st) {
     return hipSuccess;
 }
 hipError_t launch_mp_edge(int D, int P, const MpEdgeParams& p, hipStream_t st) {
-    if (D == 32) return P ? launch_mp_edge_t<32, 1>(p, st) : launch_mp_edge_t<32, 0>(p, st);
-    return P ? launch_mp_edge_t<64, 1>(p, st) : launch_mp_edge_t<64, 0>(p, st);
+    GNNMP_DISPATCH_DP(D, P, (launch_mp_edge_t<DD, PP>(p, st)));
 }
 
 template <int D, int P>
@@ -1017,8 +1044,7 @@ static hipError_t launch_mp_node_t(const MpNodeParams& p, hipStream_t st) {
     return hipSuccess;
 }
 hipError_t launch_mp_node(int D, int P, const MpNodeParams& p, hipStream_t st) {
-    if (D == 32) return P ? launch_mp_node_t<32, 1>(p, st) : launch_mp_node_t<32, 0>(p, st);
-    return P ? launch_mp_node_t<64, 1>(p, st) : launch_mp_node_t<64, 0>(p, st);
+    GNNMP_DISPATCH_DP(D, P, (launch_mp_node_t<DD, PP>(p, st)));
 }
 
 template <int D, int P>
@@ -1031,8 +1057,7 @@ static hipError_t launch_policy_t(const PolicyParams& p, hipStream_t st) {
     return hipSuccess;
 }
 hipError_t launch_policy(int D, int P, const PolicyParams& p, hipStream_t st) {
-    if (D == 32) return P ? launch_policy_t<32, 1>(p, st) : launch_policy_t<32, 0>(p, st);
-    return P ? launch_policy_t<64, 1>(p, st) : launch_policy_t<64, 0>(p, st);
+    GNNMP_DISPATCH_DP(D, P, (launch_policy_t<DD, PP>(p, st)));
 }
 
 hipError_t launch_unpad_rows(int G, int total_nodes, int D, const int* node_ptr, const int* node_ptr_pad,

@@ -14,13 +14,16 @@ constexpr int kRowsPerWave = 32;
 __host__ __device__ constexpr int phi(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
 // P = operand precision of the packed matrices: 0 = fp32 (1024 floats per 32x32 tile), 1 = bf16 (512 floats
-// of storage per tile: 2 MFMAs x 64 lanes x 8 bf16).  Vectors (bias, LayerNorm) are always fp32.
-__host__ __device__ constexpr int tile_unit(int P) { return P ? 512 : 1024; }
+// of storage per tile: 2 MFMAs x 64 lanes x 8 bf16), 2 = bf16x3 (three bf16 pieces per fp32 weight, 1536 floats:
+// [piece][K half][lane][8]).  Vectors (bias, LayerNorm) are always fp32.
+__host__ __device__ constexpr int tile_unit(int P) { return P == 0 ? 1024 : (P == 1 ? 512 : 1536); }
 __host__ __device__ constexpr int tile_floats(int D, int P = 0) { return (D / 32) * (D / 32) * tile_unit(P); }   // one DxD matrix
 __host__ __device__ constexpr int vec_floats(int D) { return (D / 32) * 32; }                 // one D-vector
 // first layers on K raw inputs: fp32 -> ceil(K/2) steps of 64 floats; bf16 -> ceil(K/16) steps of 64 x 8 bf16
 __host__ __device__ constexpr int small_steps(int K, int P) { return P ? (K + 15) / 16 : (K + 1) / 2; }
-__host__ __device__ constexpr int small_floats(int D, int ksteps, int P = 0) { return (D / 32) * ksteps * (P ? 256 : 64); }
+__host__ __device__ constexpr int small_floats(int D, int ksteps, int P = 0) {
+    return (D / 32) * ksteps * (P == 0 ? 64 : (P == 1 ? 256 : 768));
+}
 
 // One attention Block (model.py:204-218).  The five DxD matrices come first and are what gets staged
 // into LDS (`staged` floats); the six D-vectors behind them are read straight from global memory

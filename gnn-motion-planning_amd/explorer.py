@@ -118,9 +118,10 @@ class EncoderProcessDecoder(nn.Module):
             pass
 
     def _dims(self):
-        if self.mlp_dtype not in ('fp32', 'bf16'):
-            raise ValueError("mlp_dtype must be 'fp32' or 'bf16'")
-        return _lib.ExplorerDims(self.config_size, self.embed_size, self.obs_size, 1 if self.mlp_dtype == 'bf16' else 0)
+        modes = {'fp32': 0, 'bf16': 1, 'bf16x3': 2}
+        if self.mlp_dtype not in modes:
+            raise ValueError("mlp_dtype must be 'fp32', 'bf16' or 'bf16x3'")
+        return _lib.ExplorerDims(self.config_size, self.embed_size, self.obs_size, modes[self.mlp_dtype])
 
     def _apply(self, fn, *a, **k):          # .to() / .float() / .cuda(): parameters are replaced
         self._drop_handle()

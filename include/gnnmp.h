@@ -57,7 +57,7 @@ int gnnmp_abi_version(void);
  * Explorer   (EncoderProcessDecoder, model.py:48-150)
  * ---------------------------------------------------------------------------------------- */
 typedef struct gnnmp_explorer gnnmp_explorer;   /* opaque */
-enum { GNNMP_F32 = 0, GNNMP_BF16 = 1 };
+enum { GNNMP_F32 = 0, GNNMP_BF16 = 1, GNNMP_BF16X3 = 2 };
 
 typedef struct {
     int32_t config_size;   /* C  (model.py:49 config_size)                                    */
@@ -65,7 +65,10 @@ typedef struct {
     int32_t obs_size;      /* S  (obs_size): obstacles are viewed as [-1, S] (model.py:126)   */
     int32_t mlp_dtype;     /* GNNMP_F32 (exact fp32 MFMA, the reference's precision) or GNNMP_BF16:
                               MFMA operands rounded to bf16, fp32 accumulate, fp32 everywhere else
-                              (BASELINE configs[2], [4]); inputs and outputs stay fp32 either way */
+                              (BASELINE configs[2], [4]); or GNNMP_BF16X3: every fp32 operand split exactly
+                              into three bf16 pieces, six piece products per MAC on the bf16 matrix pipe,
+                              fp32 accumulate -> fp32-class results (explorer only).  Inputs and outputs
+                              stay fp32 in every mode */
 } gnnmp_explorer_dims;
 
 /* Manifest of the state_dict tensors forward() actually uses (142 of the 200 keys), in the
