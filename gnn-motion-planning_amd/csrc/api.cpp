@@ -529,6 +529,13 @@ extern "C" int gnnmp_explorer_destroy(gnnmp_explorer* h) {
 extern "C" int gnnmp_explorer_profile(gnnmp_explorer* h, int enable) {
     if (!h) return GNNMP_ERR_NULL;
     h->prof->on = enable != 0;
+    // create the events up front so that no hipEventCreate lands inside a timed region
+    if (h->prof->on)
+        while (h->prof->pool.size() < 2048) {
+            hipEvent_t e = nullptr;
+            HIP_TRY(hipEventCreate(&e));
+            h->prof->pool.push_back(e);
+        }
     return GNNMP_OK;
 }
 
