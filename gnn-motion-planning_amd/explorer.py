@@ -198,6 +198,34 @@ class EncoderProcessDecoder(nn.Module):
                 dn.data_ptr() if dense else None, ws.data_ptr(), ws.numel(), st), 'gnnmp_explorer_forward')
         return (scores, dn) if dense else scores
 
+    def capture(self, batch, loop):
+        """Capture one forward over ``batch`` into a HIP graph (the C-ABI forward allocates nothing and never
+        synchronises).  Returns ``(graph, scores)``: after writing new problem data of the SAME shape into the
+        batch's tensors in place, ``graph.replay()`` refreshes ``scores``.  Removes the per-kernel launch
+        overhead of the ~25-launch sequence for latency-sensitive single-problem use."""
+        dev = batch.v.device
+        h = self._native(dev)
+        cb = self._cbatch(batch)
+        ws = self._workspace(h, cb, dev)
+        scores = torch.empty(batch.total_edges, dtype=torch.float32, device=dev)
+        use_obs = 1 if self.use_obstacles else 0
+        fwd = _lib.lib().gnnmp_explorer_forward
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            _lib.check(fwd(h, ctypes.byref(cb), int(loop), use_obs, scores.data_ptr(), None, ws.data_ptr(), ws.numel(),
+                           side.cuda_stream), 'gnnmp_explorer_forward')
+            side.synchronize()
+            graph.capture_begin()
+            rc = fwd(h, ctypes.byref(cb), int(loop), use_obs, scores.data_ptr(), None, ws.data_ptr(), ws.numel(),
+                     torch.cuda.current_stream(dev).cuda_stream)
+            graph.capture_end()
+        _lib.check(rc, 'gnnmp_explorer_forward (capture)')
+        torch.cuda.current_stream(dev).wait_stream(side)
+        graph._gnnmp_keepalive = (batch, ws, cb)         # the graph holds raw pointers into these
+        return graph, scores
+
     def profile(self, device, enable=True):
         """Switch per-stage HIP-event timing on/off for this module's handle on ``device``."""
         _lib.check(_lib.lib().gnnmp_explorer_profile(self._native(torch.device(device)), 1 if enable else 0),

@@ -1,0 +1,43 @@
+"""The product path has no CPU / PyTorch fallback: it fails loudly without the HIP library, and the package
+never imports the oracle (test infrastructure)."""
+import glob
+import os
+import re
+
+import pytest
+import torch
+
+import gnnmp
+from gnnmp import _lib
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_constructors_raise_without_the_library(monkeypatch):
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, 'LIB_PATH', os.path.join(REPO, 'does', 'not', 'exist', 'libgnnmp.so'))
+    with pytest.raises(RuntimeError, match='libgnnmp.so not found'):
+        gnnmp.EncoderProcessDecoder(2, 2, 32, 2)
+    with pytest.raises(RuntimeError, match='libgnnmp.so not found'):
+        gnnmp.ModelSmoother(2, 2, 6, 128)
+
+
+def test_cpu_tensors_are_refused():
+    m = gnnmp.EncoderProcessDecoder(2, 2, 32, 2)
+    v = torch.rand(8, 2)
+    ei = torch.tensor([[0, 1], [1, 0]])
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        m(goal=v[1], loop=1, v=v, obstacles=torch.rand(3, 2), edge_index=ei)
+    s = gnnmp.ModelSmoother(2, 2, 6, 128)
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        s(path=v[:4], free=v, collided=v, edge_index=ei, loop=1)
+
+
+def test_package_never_imports_the_oracle_or_the_reference():
+    pkg = os.path.join(REPO, 'gnn-motion-planning_amd')
+    for path in glob.glob(os.path.join(pkg, '**', '*.py'), recursive=True) + [os.path.join(REPO, 'gnnmp.py')]:
+        src = open(path).read()
+        assert not re.search(r'^\s*(from|import)\s+oracle\b', src, flags=re.M), path
+        assert '/root/reference' not in src, path
+    for path in [os.path.join(REPO, 'bench.py'), os.path.join(REPO, '__graft_entry__.py')]:
+        assert '/root/reference' not in open(path).read(), path

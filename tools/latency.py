@@ -42,8 +42,11 @@ def single(env, n, k):
     b = m._single(g['goal'], g['v'], g['obstacles'], g['edge_index'])
     fb = timeit(lambda: m.forward_batch(b, 5))
     d2h = timeit(lambda: m(goal=g['goal'], loop=5, v=g['v'], obstacles=g['obstacles'], edge_index=g['edge_index']).cpu())
+    graph, _ = m.capture(b, 5)
+    rep = timeit(graph.replay)
     print('%-7s N=%-5d k1=%-3d E=%-7d single call: dense forward %.3f ms | sparse %.3f ms | prebuilt batch %.3f ms | '
-          'dense + .cpu() %.3f ms' % (env, n, k, g['edge_index'].shape[1], dense * 1e3, sparse * 1e3, fb * 1e3, d2h * 1e3))
+          'dense + .cpu() %.3f ms | hipGraph replay %.3f ms' % (env, n, k, g['edge_index'].shape[1], dense * 1e3, sparse * 1e3,
+                                                               fb * 1e3, d2h * 1e3, rep * 1e3))
 
 
 def batched(env, n, k, G, uniq=16):
