@@ -169,15 +169,27 @@ __device__ __forceinline__ void mfma_tile_q_p(const float* a, const BOp<P>& x, f
 }
 
 // y[ot] += sum_it A[ot][it] . x[it]      (A: [NTO][NTI][Prec<P>::TF] floats of storage)
+// operand form: the B operands were prepared once (conversion / 3-way split) and feed several matrices
 template <int P, int NTO, int NTI>
-__device__ __forceinline__ void linear_acc_p(const float* A, const f32x16 (&x)[NTI], f32x16 (&y)[NTO], int lane) {
+__device__ __forceinline__ void linear_acc_ops(const float* A, const BOp<P> (&xb)[NTI], f32x16 (&y)[NTO], int lane) {
 #pragma unroll
-    for (int it = 0; it < NTI; ++it) {
-        const BOp<P> xb(x[it]);
+    for (int it = 0; it < NTI; ++it)
 #pragma unroll
         for (int ot = 0; ot < NTO; ++ot)
-            mfma_tile_p<P>(A + (ot * NTI + it) * Prec<P>::TF, xb, y[ot], lane);
-    }
+            mfma_tile_p<P>(A + (ot * NTI + it) * Prec<P>::TF, xb[it], y[ot], lane);
+}
+
+template <int P, int NT>
+__device__ __forceinline__ void make_ops(const f32x16 (&x)[NT], BOp<P> (&xb)[NT]) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) xb[t] = BOp<P>(x[t]);
+}
+
+template <int P, int NTO, int NTI>
+__device__ __forceinline__ void linear_acc_p(const float* A, const f32x16 (&x)[NTI], f32x16 (&y)[NTO], int lane) {
+    BOp<P> xb[NTI];
+    make_ops<P, NTI>(x, xb);
+    linear_acc_ops<P, NTO, NTI>(A, xb, y, lane);
 }
 
 // first layer on raw inputs.  P = 0: Asmall [NTO][ceil(K/2)][64] floats, lane supplies in[2 st + h].

@@ -345,9 +345,11 @@ __device__ __forceinline__ void attention_block(const float* wl, const float* wg
         f32x16 Km[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) { Q[t] = splat16(0.f); Km[t] = splat16(0.f); acc[t] = splat16(0.f); }
-        linear_acc_p<P, NT, NT>(wl + L::wq, m, Q, lane);
-        linear_acc_p<P, NT, NT>(wl + L::wk, m, Km, lane);
-        linear_acc_p<P, NT, NT>(wl + L::wv, m, acc, lane);      // acc starts as 1 * V_self
+        BOp<P> mop[NT];                                         // one conversion / split of m feeds Wq, Wk and Wv
+        make_ops<P, NT>(m, mop);
+        linear_acc_ops<P, NT, NT>(wl + L::wq, mop, Q, lane);
+        linear_acc_ops<P, NT, NT>(wl + L::wk, mop, Km, lane);
+        linear_acc_ops<P, NT, NT>(wl + L::wv, mop, acc, lane);  // acc starts as 1 * V_self
         float l0 = 0.f;
 #pragma unroll
         for (int t = 0; t < NT; ++t)
@@ -499,12 +501,14 @@ __global__ __launch_bounds__(WAVES * 64) void pre_kernel(PreParams p) {
     if constexpr (EDGE) {
         using L = OutEBlob<D, P>;
         f32x16 y[NT];
+        BOp<P> mop[NT];
+        make_ops<P, NT>(m, mop);
         load_vec<NT>(wl + L::b1, y, lane);
-        linear_acc_p<P, NT, NT>(wl + L::w1d, m, y, lane);
+        linear_acc_ops<P, NT, NT>(wl + L::w1d, mop, y, lane);
         linear_acc_p<P, NT, NT>(wl + L::w1e, aux, y, lane);
         store_tile<NT>(p.o0 + (size_t)tile * NT * kATile, y, lane);          // K_e
         load_vec<NT>(wl + L::bp0, y, lane);
-        linear_acc_p<P, NT, NT>(wl + L::wpc, m, y, lane);
+        linear_acc_ops<P, NT, NT>(wl + L::wpc, mop, y, lane);
         store_tile<NT>(p.o1 + (size_t)tile * NT * kATile, y, lane);          // PE_e
     } else {
         using L = OutNBlob<D, P>;
@@ -620,12 +624,14 @@ __global__ __launch_bounds__(WAVES * 64) void pre_resident_kernel(PreParams p) {
             if constexpr (EDGE) {
                 using L = OutEBlob<D, P>;
                 f32x16 y[NT];
+                BOp<P> mop[NT];
+                make_ops<P, NT>(m, mop);
                 load_vec<NT>(p.out + L::b1, y, lane);
-                linear_acc_p<P, NT, NT>(p.out + L::w1d, m, y, lane);
+                linear_acc_ops<P, NT, NT>(p.out + L::w1d, mop, y, lane);
                 linear_acc_p<P, NT, NT>(p.out + L::w1e, aux, y, lane);
                 store_tile<NT>(p.o0 + (size_t)tile * NT * kATile, y, lane);
                 load_vec<NT>(p.out + L::bp0, y, lane);
-                linear_acc_p<P, NT, NT>(p.out + L::wpc, m, y, lane);
+                linear_acc_ops<P, NT, NT>(p.out + L::wpc, mop, y, lane);
                 store_tile<NT>(p.o1 + (size_t)tile * NT * kATile, y, lane);
             } else {
                 using L = OutNBlob<D, P>;
