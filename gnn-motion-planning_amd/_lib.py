@@ -46,6 +46,13 @@ class GraphBuildBatch(ctypes.Structure):
                 ('n_free', ctypes.c_void_p), ('k1', ctypes.c_void_p)]
 
 
+class MazeBatch(ctypes.Structure):
+    _fields_ = [('n_problems', ctypes.c_int32), ('total_nodes', ctypes.c_int32), ('total_edges', ctypes.c_int32),
+                ('width', ctypes.c_int32), ('v', ctypes.c_void_p), ('node_ptr', ctypes.c_void_p),
+                ('edge_ptr', ctypes.c_void_p), ('n_free', ctypes.c_void_p), ('edge_index', ctypes.c_void_p),
+                ('scores', ctypes.c_void_p), ('maps', ctypes.c_void_p), ('goal_states', ctypes.c_void_p)]
+
+
 _lib = None
 
 
@@ -74,6 +81,8 @@ def lib():
     L.gnnmp_explorer_profile_read.argtypes = [vp, ctypes.POINTER(ctypes.c_double), c_int64_p]
     L.gnnmp_graph_workspace_bytes.argtypes = [ctypes.POINTER(GraphBuildBatch), ctypes.POINTER(sz)]
     L.gnnmp_graph_build.argtypes = [ctypes.POINTER(GraphBuildBatch), vp, ctypes.c_int64, vp, vp, sz, vp]
+    L.gnnmp_maze_explore_workspace_bytes.argtypes = [ctypes.POINTER(MazeBatch), ctypes.POINTER(sz)]
+    L.gnnmp_maze_explore.argtypes = [ctypes.POINTER(MazeBatch), vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
     L.gnnmp_pack_a_tiles.restype = ctypes.c_int64
     L.gnnmp_pack_a_tiles.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp]
     L.gnnmp_pack_a_small.restype = ctypes.c_int64

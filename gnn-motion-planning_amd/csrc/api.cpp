@@ -1092,3 +1092,57 @@ extern "C" int gnnmp_graph_build(const gnnmp_graph_batch* b, int64_t* edge_index
     if (b->total_nodes > 0) HIP_TRY(launch_graph_build(p, st));
     return GNNMP_OK;
 }
+
+
+// =============================================================================================
+// device-side explore stage for 2-D mazes (eval_gnn.py:198-233 + environment/maze_env.py:270-326)
+// =============================================================================================
+namespace {
+struct MzCarve { size_t in_ptr, cnt, in_eid, pos, prev, alive, total; };
+bool mz_carve(const gnnmp_maze_batch* b, MzCarve& c) {
+    if (b->n_problems < 1 || b->total_nodes < 0 || b->total_edges < 0 || b->width < 1) return false;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { const size_t r = o; o += (bytes + 255) & ~(size_t)255; return r; };
+    const size_t n = (size_t)b->total_nodes + b->n_problems + 1, e = (size_t)(b->total_edges > 0 ? b->total_edges : 1);
+    c.in_ptr = take(sizeof(int) * n);
+    c.cnt = take(sizeof(int) * n);
+    c.in_eid = take(sizeof(int) * e);
+    c.pos = take(sizeof(int) * n);
+    c.prev = take(sizeof(int) * n);
+    c.alive = take(e);
+    c.total = o;
+    return true;
+}
+}  // namespace
+
+extern "C" int gnnmp_maze_explore_workspace_bytes(const gnnmp_maze_batch* b, size_t* bytes) {
+    if (!b || !bytes) return GNNMP_ERR_NULL;
+    MzCarve c;
+    if (!mz_carve(b, c)) return GNNMP_ERR_ARG;
+    *bytes = c.total;
+    return GNNMP_OK;
+}
+
+extern "C" int gnnmp_maze_explore(const gnnmp_maze_batch* b, int32_t* success, int32_t* n_explored, int32_t* explored,
+                                  int32_t* n_pairs, int32_t* explored_edges, int32_t* path_len, int32_t* path,
+                                  int64_t* checks, void* ws, size_t ws_bytes, void* hip_stream) {
+    if (!b || !success || !n_explored || !explored || !n_pairs || !explored_edges || !path_len || !path || !checks || !ws)
+        return GNNMP_ERR_NULL;
+    if (!b->v || !b->node_ptr || !b->edge_ptr || !b->n_free || !b->maps || !b->goal_states) return GNNMP_ERR_NULL;
+    if (b->total_edges > 0 && (!b->edge_index || !b->scores)) return GNNMP_ERR_NULL;
+    MzCarve c;
+    if (!mz_carve(b, c)) return GNNMP_ERR_ARG;
+    if (ws_bytes < c.total || (reinterpret_cast<uintptr_t>(ws) & 255)) return GNNMP_ERR_WORKSPACE;
+    MazeParams p;
+    p.B = b->n_problems; p.total_edges = b->total_edges; p.w = b->width;
+    p.v = b->v; p.node_ptr = b->node_ptr; p.edge_ptr = b->edge_ptr; p.n_free = b->n_free;
+    p.edge_index = reinterpret_cast<const long long*>(b->edge_index); p.scores = b->scores;
+    p.maps = b->maps; p.goal_states = b->goal_states;
+    p.in_ptr = at<int>(ws, c.in_ptr); p.cnt = at<int>(ws, c.cnt); p.in_eid = at<int>(ws, c.in_eid);
+    p.pos = at<int>(ws, c.pos); p.prev = at<int>(ws, c.prev); p.alive = at<unsigned char>(ws, c.alive);
+    p.success = success; p.n_explored = n_explored; p.explored = explored; p.n_pairs = n_pairs;
+    p.explored_edges = explored_edges; p.path_len = path_len; p.path = path;
+    p.checks = reinterpret_cast<long long*>(checks);
+    HIP_TRY(launch_maze_explore(p, static_cast<hipStream_t>(hip_stream)));
+    return GNNMP_OK;
+}

@@ -115,6 +115,20 @@ struct GbParams {
 };
 hipError_t launch_graph_build(const GbParams& p, hipStream_t st);
 
+struct MazeParams {
+    int B, total_edges, w;
+    const float* v;                       // [sumN, 2]
+    const int *node_ptr, *edge_ptr, *n_free;
+    const long long* edge_index;          // [2, sumE] graph-local
+    const float* scores;                  // [sumE]
+    const double *maps, *goal_states;     // [B, w, w], [B, 2]
+    int *in_ptr, *cnt, *in_eid, *pos, *prev;
+    unsigned char* alive;
+    int *success, *n_explored, *explored, *n_pairs, *explored_edges, *path_len, *path;
+    long long* checks;
+};
+hipError_t launch_maze_explore(const MazeParams& p, hipStream_t st);
+
 hipError_t launch_prep(const PrepParams& q, hipStream_t st);
 hipError_t launch_obs(int D, int P, const ObsParams& p, int G, hipStream_t st);
 hipError_t launch_pre(int D, int P, bool edge, int waves, const PreParams& p, int n_tiles32, size_t lds_bytes, hipStream_t st);

@@ -1,0 +1,202 @@
+// maze_kernels.hip -- device-side explore stage for 2-D maze problems (SURVEY.md section 8(f) ranks 1 + 3):
+// the reference's greedy best-edge expansion (eval_gnn.py:198-233) together with MazeEnv's grid collision
+// checker (environment/maze_env.py:270-326), one wavefront per planning problem, so a batch of problems runs
+// the whole explore stage without a host round trip per step.
+//
+// Decisions are the reference's, exactly:
+//   * dense-matrix semantics on the per-edge scores: cell P[a][b] = score of edge (b -> a); diagonal, collided
+//     rows / columns and exact zeros are invisible; the next cell is the maximum over explored rows a, first
+//     maximum in (position of a in the explored list, column b) order;
+//   * a free edge adds b to the tree and kills column b; a blocked edge kills cells (a, b) and (b, a);
+//   * collision queries replicate numpy's float32 arithmetic on the float32 node rows bit for bit (no fma
+//     contraction: explicit __f*_rn), count one check per in-bounds configuration query, short-circuit left
+//     to right, bisect while the end cells are > 1 grid step apart and the L1 distance exceeds RRT_EPS;
+//   * goal test in float64 against the float64 goal state, then one more query.
+// Scope: one explorer forward per problem with a fresh tree (the reference's defaults batch = t_max = 500 give
+// exactly that); resample rounds stay on the host path (planner.explore).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include "kernels.hpp"
+
+namespace gnnmp {
+
+namespace {
+
+struct MazeCtx {
+    const double* map;      // [w, w] occupancy (1 = obstacle), row-major map[x][y]
+    int w;
+    long long checks;
+};
+
+__device__ __forceinline__ int maze_cell(float x, int w) {        // ((x + 1.0) * w / 2.0).astype(int), clipped at w-1
+    const float t = __fdiv_rn(__fmul_rn(__fadd_rn(x, 1.0f), (float)w), 2.0f);
+    int c = (int)t;
+    return c > w - 1 ? w - 1 : c;
+}
+
+__device__ __forceinline__ bool maze_valid(float x, float y) { return x >= -1.0f && x <= 1.0f && y >= -1.0f && y <= 1.0f; }
+
+__device__ __forceinline__ bool maze_state_fp(MazeCtx& m, float x, float y) {
+    if (!maze_valid(x, y)) return false;
+    m.checks += 1;
+    return m.map[maze_cell(x, m.w) * m.w + maze_cell(y, m.w)] == 0.0;
+}
+
+// iterative form of the recursive bisection (left half first, stop at the first blocked midpoint)
+__device__ bool maze_segment_fp(MazeCtx& m, float ax, float ay, float bx, float by) {
+    float sx0[48], sy0[48], sx1[48], sy1[48];
+    int sp = 0;
+    sx0[0] = ax; sy0[0] = ay; sx1[0] = bx; sy1[0] = by; sp = 1;
+    while (sp > 0) {
+        --sp;
+        const float lx = sx0[sp], ly = sy0[sp], rx = sx1[sp], ry = sy1[sp];
+        const int dc = abs(maze_cell(lx, m.w) - maze_cell(rx, m.w)) + abs(maze_cell(ly, m.w) - maze_cell(ry, m.w));
+        const float l1 = __fadd_rn(fabsf(__fsub_rn(lx, rx)), fabsf(__fsub_rn(ly, ry)));
+        if (dc > 1 && l1 > 0.05f) {
+            const float mx = __fdiv_rn(__fadd_rn(lx, rx), 2.0f), my = __fdiv_rn(__fadd_rn(ly, ry), 2.0f);
+            if (!maze_state_fp(m, mx, my)) return false;
+            if (sp + 2 > 48) return false;                       // cannot happen: depth <= ~8 for RRT_EPS = 0.05
+            sx0[sp] = mx; sy0[sp] = my; sx1[sp] = rx; sy1[sp] = ry; ++sp;      // right half second ...
+            sx0[sp] = lx; sy0[sp] = ly; sx1[sp] = mx; sy1[sp] = my; ++sp;      // ... left half first
+        }
+    }
+    return true;
+}
+
+__device__ bool maze_edge_fp(MazeCtx& m, float ax, float ay, float bx, float by) {
+    if (!maze_valid(ax, ay) || !maze_valid(bx, by)) return false;
+    if (!maze_state_fp(m, ax, ay)) return false;
+    if (!maze_state_fp(m, bx, by)) return false;
+    return maze_segment_fp(m, ax, ay, bx, by);
+}
+
+}  // namespace
+
+// one wave per problem
+__global__ __launch_bounds__(64) void maze_explore_kernel(MazeParams p) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int n0 = p.node_ptr[b], N = p.node_ptr[b + 1] - n0;
+    const int e0 = p.edge_ptr[b], E = p.edge_ptr[b + 1] - e0;
+    const int F = p.n_free[b];
+    const long long* src = p.edge_index + e0;
+    const long long* dst = p.edge_index + (size_t)p.total_edges + e0;
+    const float* sc = p.scores + e0;
+    const float* v = p.v + (size_t)n0 * 2;
+    int* in_ptr = p.in_ptr + n0 + b;              // [N + 1] per problem
+    int* cnt = p.cnt + n0;
+    int* in_eid = p.in_eid + e0;
+    unsigned char* alive = p.alive + e0;
+    int* pos = p.pos + n0;                        // position in the explored list or -1
+    int* explored = p.explored + n0;
+    int* prev = p.prev + n0;
+    int* ee = p.explored_edges + 2 * ((size_t)2 * e0 + b);      // [2E + 1] (a, b) pairs per problem
+
+    // ---- CSR by target + live cells
+    for (int i = lane; i < N; i += 64) { cnt[i] = 0; pos[i] = -1; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    for (int e = lane; e < E; e += 64) {
+        const int s = (int)src[e], t = (int)dst[e];
+        const bool ok = s != t && sc[e] != 0.0f && s < F && t < F;        // diagonal, zeros, collided rows / columns
+        alive[e] = ok ? 1 : 0;
+        atomicAdd(&cnt[t], 1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+        int run = 0;
+        for (int i = 0; i < N; ++i) { in_ptr[i] = run; run += cnt[i]; cnt[i] = 0; }
+        in_ptr[N] = run;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    for (int e = lane; e < E; e += 64) {
+        const int t = (int)dst[e];
+        in_eid[in_ptr[t] + atomicAdd(&cnt[t], 1)] = e;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+
+    MazeCtx m;
+    m.map = p.maps + (size_t)b * p.w * p.w;
+    m.w = p.w;
+    m.checks = 0;
+    const double gx = p.goal_states[2 * b], gy = p.goal_states[2 * b + 1];
+    int n_expl = 1, n_pairs = 1, success = 0, path_len = 0;
+    if (lane == 0) { explored[0] = 0; pos[0] = 0; prev[0] = 0; ee[0] = 0; ee[1] = 0; }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+
+    while (true) {
+        // ---- argmax over live cells of explored rows: key (value desc, row position asc, column asc)
+        float bv = -INFINITY;
+        int bp = 0x7fffffff, bb = 0x7fffffff, be = -1;
+        for (int i = 0; i < n_expl; ++i) {
+            const int a = explored[i];
+            for (int q = in_ptr[a] + lane; q < in_ptr[a + 1]; q += 64) {
+                const int e = in_eid[q];
+                if (!alive[e]) continue;
+                const int s = (int)src[e];
+                if (pos[s] >= 0) continue;                                 // column already explored
+                const float val = sc[e];
+                if (val > bv || (val == bv && (i < bp || (i == bp && s < bb)))) { bv = val; bp = i; bb = s; be = e; }
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float ov = __shfl_xor(bv, off, 64);
+            const int op = __shfl_xor(bp, off, 64), ob = __shfl_xor(bb, off, 64), oe = __shfl_xor(be, off, 64);
+            const bool take = (oe >= 0) && (be < 0 || ov > bv || (ov == bv && (op < bp || (op == bp && ob < bb))));
+            if (take) { bv = ov; bp = op; bb = ob; be = oe; }
+        }
+        if (be < 0) break;                                                 // nothing left on the frontier
+        const int a = explored[bp], nb = bb;
+        int free_edge = 0, goal = 0;
+        if (lane == 0) {
+            ee[2 * n_pairs] = a; ee[2 * n_pairs + 1] = nb;
+            ee[2 * n_pairs + 2] = nb; ee[2 * n_pairs + 3] = a;
+            free_edge = maze_edge_fp(m, v[2 * a], v[2 * a + 1], v[2 * nb], v[2 * nb + 1]) ? 1 : 0;
+            if (free_edge) {
+                explored[n_expl] = nb; pos[nb] = n_expl; prev[nb] = a;
+                const double dx = fabs(gx - (double)v[2 * nb]), dy = fabs(gy - (double)v[2 * nb + 1]);
+                const double d = sqrt(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)));
+                if (d < 0.05) goal = maze_state_fp(m, v[2 * nb], v[2 * nb + 1]) ? 1 : 0;
+            } else {
+                alive[be] = 0;                                             // cell (a, nb)
+                for (int q = in_ptr[nb]; q < in_ptr[nb + 1]; ++q)          // cell (nb, a): edge a -> nb
+                    if ((int)src[in_eid[q]] == a) alive[in_eid[q]] = 0;
+            }
+        }
+        n_pairs += 2;
+        free_edge = __shfl(free_edge, 0, 64);
+        goal = __shfl(goal, 0, 64);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        if (free_edge) {
+            ++n_expl;
+            if (goal) { success = 1; break; }
+        }
+    }
+    if (lane == 0) {
+        if (success) {                                                     // back-track prev[] to the start node
+            int node = explored[n_expl - 1], len = 0;
+            int* path = p.path + n0;
+            while (true) { path[len++] = node; if (node == 0) break; node = prev[node]; }
+            for (int i = 0; i < len / 2; ++i) { const int t = path[i]; path[i] = path[len - 1 - i]; path[len - 1 - i] = t; }
+            path_len = len;
+        }
+        p.success[b] = success;
+        p.n_explored[b] = n_expl;
+        p.n_pairs[b] = n_pairs;
+        p.path_len[b] = path_len;
+        p.checks[b] = m.checks;
+    }
+}
+
+hipError_t launch_maze_explore(const MazeParams& p, hipStream_t st) {
+    if (p.B <= 0) return hipSuccess;
+    hipLaunchKernelGGL(maze_explore_kernel, dim3(p.B), dim3(64), 0, st, p);
+    return hipGetLastError();
+}
+
+}  // namespace gnnmp

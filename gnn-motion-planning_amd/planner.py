@@ -278,3 +278,79 @@ def eval_gnn(env, indexes, model, model_s, seed=1234, smooth=True, batch=500, t_
     total_time_explore = sum(s[6] for s in sol)
     return (n_success, collision, running_time, solution_cost, total_time, paths, smooth_paths, collision_explore,
             total_time_explore)
+
+
+# --------------------------------------------------------------------------------------------------
+# batched explore stage with everything but the sampling on the device (2-D mazes)
+# --------------------------------------------------------------------------------------------------
+@torch.no_grad()
+def explore_maze_batch(problems, model, device, batch=500, k=30, loop=5):
+    """Explore stage of many 2-D maze problems at once: sampling on the host (the reference's numpy RNG
+    stream, one problem after the other), then -- in ONE pass on the device -- kNN graphs
+    (graph_kernels.hip), explorer forward (batched), greedy expansion + collision checks
+    (maze_kernels.hip).  ``problems``: list of dicts(map [w, w], init_state, goal_state).
+    Covers the reference's default single-forward case (batch == t_max); returns one
+    result dict per problem with the explore-stage fields of ``explore``."""
+    import ctypes
+    from . import _lib
+    from .batch import GraphBatch
+    from .graph_build import build_edges_gpu, k1_of
+    from .maze2d import Maze2D
+    envs, vs, n_free, k1s = [], [], [], []
+    for pr in problems:
+        env = Maze2D(np.asarray(pr['map'])[None], np.asarray(pr['init_state'])[None], np.asarray(pr['goal_state'])[None])
+        env.init_new_problem(0)
+        free, coll = env.sample_n_points(batch, need_negative=True)
+        coll = coll[:len(free)]
+        free = [env.init_state] + [env.goal_state] + list(free)
+        vf = torch.tensor(np.asarray(free), dtype=torch.float32)
+        vc = torch.tensor(np.asarray(coll), dtype=torch.float32).reshape(-1, 2)
+        envs.append(env)
+        vs.append(torch.cat((vf, vc), dim=0))
+        n_free.append(len(free))
+        k1s.append(k1_of(k, len(free)))
+    B = len(problems)
+    ptr = torch.zeros(B + 1, dtype=torch.int64)
+    ptr[1:] = torch.tensor([x.shape[0] for x in vs]).cumsum(0)
+    node_ptr = ptr.to(torch.int32).to(device)
+    v = torch.cat(vs).to(device)
+    ei, edge_ptr = build_edges_gpu(v, node_ptr, n_free, k1s)
+    obs = [torch.tensor(np.asarray(e.obstacles), dtype=torch.float32).reshape(-1, 2) for e in envs]
+    optr = torch.zeros(B + 1, dtype=torch.int64)
+    optr[1:] = torch.tensor([o.shape[0] for o in obs]).cumsum(0)
+    goals = torch.tensor(np.asarray([e.goal_state for e in envs]), dtype=torch.float32).to(device)
+    gb = GraphBatch(v, goals, torch.cat(obs).to(device), ei, node_ptr, edge_ptr, optr.to(torch.int32).to(device),
+                    max(o.shape[0] for o in obs))
+    scores = model.forward_batch(gb, loop)
+    w = int(np.asarray(problems[0]['map']).shape[0])
+    maps = torch.tensor(np.asarray([np.asarray(pr['map'], dtype=np.float64) for pr in problems])).to(device)
+    goal64 = torch.tensor(np.asarray([e.goal_state for e in envs], dtype=np.float64)).to(device)
+    nf = torch.tensor(n_free, dtype=torch.int32, device=device)
+    total_n, total_e = int(v.shape[0]), int(ei.shape[1])
+    mb = _lib.MazeBatch(B, total_n, total_e, w, v.data_ptr(), node_ptr.data_ptr(), edge_ptr.data_ptr(), nf.data_ptr(),
+                        ei.data_ptr(), scores.data_ptr(), maps.data_ptr(), goal64.data_ptr())
+    need = ctypes.c_size_t()
+    _lib.check(_lib.lib().gnnmp_maze_explore_workspace_bytes(ctypes.byref(mb), ctypes.byref(need)), 'maze ws')
+    ws = torch.empty(need.value, dtype=torch.uint8, device=device)
+    i32 = lambda n: torch.zeros(n, dtype=torch.int32, device=device)      # noqa: E731
+    success, n_expl, expl, n_pairs, ee, plen, path = i32(B), i32(B), i32(total_n), i32(B), i32(2 * (2 * total_e + B)), \
+        i32(B), i32(total_n)
+    checks = torch.zeros(B, dtype=torch.int64, device=device)
+    with torch.cuda.device(device):
+        st = torch.cuda.current_stream().cuda_stream
+        _lib.check(_lib.lib().gnnmp_maze_explore(ctypes.byref(mb), success.data_ptr(), n_expl.data_ptr(), expl.data_ptr(),
+                                                 n_pairs.data_ptr(), ee.data_ptr(), plen.data_ptr(), path.data_ptr(),
+                                                 checks.data_ptr(), ws.data_ptr(), ws.numel(), st), 'gnnmp_maze_explore')
+    success, n_expl, n_pairs, plen, checks = (t.cpu().tolist() for t in (success, n_expl, n_pairs, plen, checks))
+    expl, ee, path = expl.cpu().numpy(), ee.cpu().numpy(), path.cpu().numpy()
+    nptr, eptr = ptr.tolist(), edge_ptr.cpu().tolist()
+    out = []
+    for b in range(B):
+        o = 2 * (2 * eptr[b] + b)
+        nodes = path[nptr[b]:nptr[b] + plen[b]]
+        # sampling cost the host b*... checks already (rejection sampling); the device count is the greedy loop's
+        out.append({'success': bool(success[b]), 'explored': expl[nptr[b]:nptr[b] + n_expl[b]].tolist(),
+                    'explored_edges': ee[o:o + 2 * n_pairs[b]].reshape(-1, 2).tolist(),
+                    'c_explore': envs[b].collision_check_count + int(checks[b]),
+                    'path': [vs[b][i].numpy() for i in nodes], 'free': None, 'env': envs[b], 'v': vs[b]})
+    return out

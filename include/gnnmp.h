@@ -15,6 +15,8 @@
  *       ModelSmoother.forward                                 model_smoother.py:104-142 (call smoother.py:243)
  *   gnnmp_graph_workspace_bytes / gnnmp_graph_build
  *       create_data's edge construction                       eval_gnn.py:159-164
+ *   gnnmp_maze_explore_workspace_bytes / gnnmp_maze_explore
+ *       explore()'s greedy loop + MazeEnv._edge_fp            eval_gnn.py:198-233, environment/maze_env.py:270-326
  *
  * Conventions
  *   - plain C types only; every pointer in a batch / forward call is a DEVICE pointer unless the
@@ -216,6 +218,33 @@ int gnnmp_graph_workspace_bytes(const gnnmp_graph_batch* shape, size_t* bytes);
  * worst case).  edge_ptr_out: [G+1] int32 (device). */
 int gnnmp_graph_build(const gnnmp_graph_batch* batch, int64_t* edge_index_out, int64_t out_cap,
                       int32_t* edge_ptr_out, void* workspace, size_t workspace_bytes, void* hip_stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Explore stage on the device for 2-D maze problems
+ *   (greedy best-edge expansion eval_gnn.py:198-233 + MazeEnv collision checker maze_env.py:270-326)
+ * ---------------------------------------------------------------------------------------- */
+/* Problem b: node rows [node_ptr[b], node_ptr[b+1]) of v (float32 [.,2]; the first n_free[b] rows are the free
+ * samples, row 0 = start, row 1 = goal sample), edge columns [edge_ptr[b], ...) of edge_index (graph-local ids)
+ * with their explorer scores, its width x width occupancy map (float64, 1 = obstacle, map[x][y]) and float64
+ * goal state.  One explorer forward per problem, fresh search tree (the reference's default batch = t_max). */
+typedef struct {
+    int32_t n_problems, total_nodes, total_edges, width;
+    const float* v;
+    const int32_t *node_ptr, *edge_ptr, *n_free;
+    const int64_t* edge_index;
+    const float* scores;
+    const double* maps;          /* [B, width, width]                                         */
+    const double* goal_states;   /* [B, 2]                                                    */
+} gnnmp_maze_batch;
+
+int gnnmp_maze_explore_workspace_bytes(const gnnmp_maze_batch* shape, size_t* bytes);
+/* Outputs (device): success [B]; n_explored [B] and explored [total_nodes] (explored node ids in order, problem b
+ * at node_ptr[b]); n_pairs [B] and explored_edges [2 * (2 * total_edges + B)] ((a, b) pairs in order, starting
+ * with the reference's initial [0, 0]; problem b at int offset 2 * (2 * edge_ptr[b] + b)); path_len [B] and
+ * path [total_nodes] (node ids start -> goal); checks [B] = collision-check count of the explore stage. */
+int gnnmp_maze_explore(const gnnmp_maze_batch* batch, int32_t* success, int32_t* n_explored, int32_t* explored,
+                       int32_t* n_pairs, int32_t* explored_edges, int32_t* path_len, int32_t* path, int64_t* checks,
+                       void* workspace, size_t workspace_bytes, void* hip_stream);
 
 /* ------------------------------------------------------------------------------------------
  * Host-only helpers exported for the CPU test-suite (no device needed)

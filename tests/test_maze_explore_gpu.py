@@ -1,0 +1,80 @@
+"""Explore stage fully on the device for 2-D mazes (maze_kernels.hip: greedy best-edge expansion + grid
+collision checker, one wavefront per problem; graphs from graph_kernels.hip; batched explorer forward) against
+the outcomes of the reference planner at its default configuration (tests/golden/evalset_*.npz) and against the
+host counterpart (planner.explore) decision by decision."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_files, load_weights
+import gnnmp
+from gnnmp import planner
+from gnnmp.maze2d import Maze2D
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _models():
+    m = gnnmp.EncoderProcessDecoder(2, 2, 32, 2)
+    m.load_state_dict(load_weights('weights_maze'))
+    return m
+
+
+def test_device_explore_matches_reference_outcomes():
+    with np.load(golden_files('evalset_')[0]) as f:
+        r = {k: f[k] for k in f.files}
+    n = r['rows'].shape[0]
+    problems = [dict(map=r['maps'][i], init_state=r['init_states'][i], goal_state=r['goal_states'][i]) for i in range(n)]
+    np.random.seed(int(r['seed']))
+    torch.manual_seed(int(r['seed']))
+    res = planner.explore_maze_batch(problems, _models(), DEV, batch=int(r['batch']), k=int(r['k']))
+    ref = r['rows']
+    got_c = [x['c_explore'] for x in res]
+    print('\nc_explore device %s\n          ref    %s' % (got_c, ref[:, 3].astype(int).tolist()))
+    assert [int(x['success']) for x in res] == ref[:, 0].astype(int).tolist()
+    assert got_c == ref[:, 3].astype(int).tolist()                        # collision checks of the explore stage
+    assert [len(x['explored']) for x in res] == ref[:, 6].astype(int).tolist()
+    assert [len(x['path']) for x in res] == ref[:, 5].astype(int).tolist()
+    assert np.allclose([planner.path_cost(x['path']) for x in res], ref[:, 1], rtol=0, atol=1e-9)
+
+
+def test_device_explore_equals_host_counterpart_step_by_step():
+    """Same problems through planner.explore (host frontier + host collision checker): identical explored
+    order, identical explored_edges list (incl. the initial [0, 0]), identical path."""
+    with np.load(golden_files('evalset_')[0]) as f:
+        r = {k: f[k] for k in f.files}
+    idx = [0, 3, 5]
+    m = _models()
+    ms = gnnmp.ModelSmoother(workspace_size=2, config_size=2, embed_size=128, obs_size=6)
+    ms.load_state_dict(load_weights('smooth_2d_attv3'))
+    problems = [dict(map=r['maps'][i], init_state=r['init_states'][i], goal_state=r['goal_states'][i]) for i in idx]
+    np.random.seed(7)
+    dev_res = planner.explore_maze_batch(problems, m, DEV, batch=300, k=20)
+    np.random.seed(7)
+    # the host path samples problem by problem in the same order -> same numpy stream
+    host = []
+    envs = []
+    for i in idx:
+        env = Maze2D(r['maps'][i][None], r['init_states'][i][None], r['goal_states'][i][None])
+        env.init_new_problem(0)
+        envs.append(env)
+    # sample first for all (like the batched path), then run the host greedy loops on the same samples
+    samples = []
+    for env in envs:
+        free, coll = env.sample_n_points(300, need_negative=True)
+        samples.append((free, coll[:len(free)]))
+    for env, (free, coll), d in zip(envs, samples, dev_res):
+        free = [env.init_state] + [env.goal_state] + list(free)
+        data = planner.create_data(free, coll, env.goal_state, 20)
+        od = planner.obs_data(env, free, coll, DEV)
+        sc = m.edge_scores(goal=data['goal'].to(DEV), v=data['v'].to(DEV), edge_index=data['edge_index'].to(DEV), loop=5,
+                           obstacles=od['obstacles']).cpu().numpy()
+        state = {'explored': [0], 'explored_edges': [[0, 0]], 'costs': {0: 0.}, 'prev': {0: 0}}
+        path = planner.greedy_expand_sparse(sc, data['edge_index'].numpy(), data['labels'].numpy(), data['v'].numpy(), env, state)
+        assert d['explored'] == state['explored']
+        assert d['explored_edges'] == state['explored_edges']
+        assert d['success'] == (path is not None)
+        if path is not None:
+            assert [tuple(x) for x in d['path']] == [tuple(data['v'][j].numpy()) for j in path]
+        assert d['c_explore'] == env.collision_check_count
