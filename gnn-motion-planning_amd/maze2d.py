@@ -73,6 +73,34 @@ class Maze2D:
                     rejected.append(s)
         return (free, rejected) if need_negative else free
 
+    def sample_n_points_fast(self, n, need_negative=False):
+        """Same samples, same collision-check count and same final state of the global numpy RNG as
+        :meth:`sample_n_points`, but vectorised: draws are made in blocks, classified with one grid lookup,
+        and the generator is then rewound and advanced by exactly the number of draws the one-by-one loop
+        would have consumed (two doubles per attempt)."""
+        state = np.random.get_state()
+        block = max(2 * n, 64)
+        while True:
+            pts = np.random.uniform(-LIMITS, LIMITS, (block, 2))
+            w = self.width
+            cells = ((pts + 1.0) * w / 2.0).astype(int)
+            cells[cells > w - 1] = w - 1
+            free_mask = self.map[cells[:, 0], cells[:, 1]] == 0
+            idx = np.flatnonzero(free_mask)
+            if idx.size >= n:
+                used = int(idx[n - 1]) + 1
+                break
+            np.random.set_state(state)
+            block *= 2
+        np.random.set_state(state)
+        pts = np.random.uniform(-LIMITS, LIMITS, (used, 2))          # consume exactly `used` attempts
+        free_mask = free_mask[:used]
+        self.collision_check_count += used
+        free = [pts[i] for i in np.flatnonzero(free_mask)]
+        if not need_negative:
+            return free
+        return free, [pts[i] for i in np.flatnonzero(~free_mask)]
+
     # ------------------------------------------------------------------ geometry
     def distance(self, a, b):
         d = np.abs(b - a)

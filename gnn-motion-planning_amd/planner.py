@@ -300,7 +300,7 @@ def explore_maze_batch(problems, model, device, batch=500, k=30, loop=5):
     for pr in problems:
         env = Maze2D(np.asarray(pr['map'])[None], np.asarray(pr['init_state'])[None], np.asarray(pr['goal_state'])[None])
         env.init_new_problem(0)
-        free, coll = env.sample_n_points(batch, need_negative=True)
+        free, coll = env.sample_n_points_fast(batch, need_negative=True)      # same stream as sample_n_points
         coll = coll[:len(free)]
         free = [env.init_state] + [env.goal_state] + list(free)
         vf = torch.tensor(np.asarray(free), dtype=torch.float32)

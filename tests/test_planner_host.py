@@ -122,3 +122,22 @@ def test_legacy_index_quirk_is_reproduced():
         expect[a, b] = 0
     assert np.array_equal(P, expect)
     assert P[0, 2] == 1.0          # the (0, 2) edge itself is NOT masked: that is the reference's behaviour
+
+
+def test_fast_sampler_is_stream_identical():
+    """Vectorised rejection sampling == the one-by-one loop: same samples, same rejected samples, same check
+    count, same state of the global numpy generator afterwards (so later problems see the same stream)."""
+    r = _load(golden_files('planner_mazehard_2')[0])
+    for n in (1, 37, 500):
+        a, b = _env(r), _env(r)
+        np.random.seed(99)
+        fa, ra = a.sample_n_points(n, need_negative=True)
+        nxt_a = np.random.uniform()
+        np.random.seed(99)
+        fb, rb = b.sample_n_points_fast(n, need_negative=True)
+        nxt_b = np.random.uniform()
+        assert len(fa) == len(fb) == n and len(ra) == len(rb)
+        assert all(np.array_equal(x, y) for x, y in zip(fa, fb))
+        assert all(np.array_equal(x, y) for x, y in zip(ra, rb))
+        assert a.collision_check_count == b.collision_check_count
+        assert nxt_a == nxt_b

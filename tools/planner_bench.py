@@ -27,6 +27,8 @@ def main():
     ap.add_argument('--problems', type=int, default=48)
     ap.add_argument('--sparse', action='store_true', help='sparse frontier on per-edge scores instead of the dense N x N matrix')
     ap.add_argument('--gpu-graph', action='store_true', help='build the kNN graph on the device')
+    ap.add_argument('--device-explore', action='store_true',
+                    help='explore stage of ALL problems in one device pass (graphs, forward, greedy loop, collision checks)')
     ap.add_argument('--batch', type=int, default=500)
     ap.add_argument('--k', type=int, default=30)
     a = ap.parse_args()
@@ -38,6 +40,24 @@ def main():
     m.load_state_dict(load_weights('weights_maze'))
     ms = gnnmp.ModelSmoother(workspace_size=2, config_size=2, embed_size=128, obs_size=6)
     ms.load_state_dict(load_weights('smooth_2d_attv3'))
+    if a.device_explore:
+        probs = [dict(map=maps[i % maps.shape[0]], init_state=init[i % maps.shape[0]], goal_state=goal[i % maps.shape[0]])
+                 for i in range(a.problems)]
+        np.random.seed(1234)
+        planner.explore_maze_batch(probs[:4], m, dev, batch=a.batch, k=a.k)          # warm-up
+        np.random.seed(1234)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = planner.explore_maze_batch(probs, m, dev, batch=a.batch, k=a.k)
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        print(json.dumps({'problems': a.problems, 'success': sum(int(x['success']) for x in res), 'stage': 'explore only (no smoothing)',
+                          'problems_per_s': round(a.problems / wall, 2), 's_per_problem': round(wall / a.problems, 5),
+                          'collision_checks_explore': round(sum(x['c_explore'] for x in res) / a.problems, 2),
+                          'host_cores_used': 1, 'host_work': 'rejection sampling only (vectorised, same numpy stream)',
+                          'device_work': 'kNN graphs, explorer forward, greedy frontier, collision checks',
+                          'config': 'maze2 hard, batch=%d, k=%d' % (a.batch, a.k)}))
+        return
     np.random.seed(1234)
     torch.manual_seed(1234)
     env.init_new_problem(0)
