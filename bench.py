@@ -109,7 +109,9 @@ def main():
             raise SystemExit('launch with torch.distributed.run --nproc-per-node %d for --gpus %d' % (args.gpus, args.gpus))
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
-    if world > 1:
+    # GNNMP_BENCH_FORCE_DIST=1 exercises the RCCL code path (init, barrier, all_reduce, all_gather) with one rank
+    use_dist = world > 1 or os.environ.get('GNNMP_BENCH_FORCE_DIST') == '1'
+    if use_dist:
         dist.init_process_group('nccl', device_id=dev)
 
     import gnnmp
@@ -129,7 +131,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -145,7 +147,7 @@ def main():
     elapsed = time.perf_counter() - t0
     prof = model.profile_read(dev)
     model.profile(dev, False)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -184,7 +186,7 @@ def main():
 
     # final result gather (the only collective of the job): per-rank edge scores -> every rank
     checksum = float(scores.double().sum().item())
-    if world > 1:
+    if use_dist:
         n = torch.tensor([scores.numel()], dtype=torch.int64, device=dev)
         sizes = [torch.zeros_like(n) for _ in range(world)]
         dist.all_gather(sizes, n)
@@ -245,7 +247,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(args.env, args.nodes, args.k1, args.cpu_seconds, 1234)
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
