@@ -386,6 +386,80 @@ __device__ __forceinline__ void load_tile_nt(const float* tile_base, f32x16 (&x)
         }
 }
 
+// ---- precision-dependent storage of the per-edge tiles (K_e, PE) and of the gathered node rows (A, B):
+//      fp32 in the exact and bf16x3 modes; bf16 (RNE) in the bf16 mode, where these values feed bf16 MFMA
+//      operands anyway and the message-passing kernels are bandwidth-bound.  Tile image in bf16:
+//      [NT][2][64 lanes][8 bf16]; row image: [N, D] bf16 row-major.
+template <int P, int NT>
+__device__ __forceinline__ void store_tile_p(float* tile_base_f32_units, const f32x16 (&x)[NT], int lane) {
+    if constexpr (P != 1) {
+        store_tile<NT>(tile_base_f32_units, x, lane);
+    } else {
+        __bf16* base = reinterpret_cast<__bf16*>(tile_base_f32_units);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const BOp<1> b(x[t]);
+            *reinterpret_cast<bf16x8*>(base + ((t * 2 + 0) * 64 + lane) * 8) = b.lo;
+            *reinterpret_cast<bf16x8*>(base + ((t * 2 + 1) * 64 + lane) * 8) = b.hi;
+        }
+    }
+}
+
+template <int P, int NT>
+__device__ __forceinline__ void load_tile_nt_p(const float* tile_base_f32_units, f32x16 (&x)[NT], int lane) {
+    if constexpr (P != 1) {
+        load_tile_nt<NT>(tile_base_f32_units, x, lane);
+    } else {
+        const __bf16* base = reinterpret_cast<const __bf16*>(tile_base_f32_units);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const bf16x8 lo = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(base + ((t * 2 + 0) * 64 + lane) * 8));
+            const bf16x8 hi = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(base + ((t * 2 + 1) * 64 + lane) * 8));
+            const f32x8 a = __builtin_convertvector(lo, f32x8), b = __builtin_convertvector(hi, f32x8);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) { x[t][r] = a[r]; x[t][8 + r] = b[r]; }
+        }
+    }
+}
+
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+// row_base: start of the row in ELEMENTS of the storage type (caller multiplies the row index by D)
+template <int P, int NT>
+__device__ __forceinline__ void store_row_p(float* array_f32_units, size_t row, const f32x16 (&x)[NT], int h) {
+    if constexpr (P != 1) {
+        store_row<NT>(array_f32_units + row * (NT * 32), x, h);
+    } else {
+        __bf16* base = reinterpret_cast<__bf16*>(array_f32_units) + row * (NT * 32);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 a;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) a[c] = x[t][q * 4 + c];
+                *reinterpret_cast<bf16x4*>(base + t * 32 + q * 8 + h * 4) = __builtin_convertvector(a, bf16x4);
+            }
+    }
+}
+
+template <int P, int NT>
+__device__ __forceinline__ void load_row_p(const float* array_f32_units, size_t row, f32x16 (&x)[NT], int h) {
+    if constexpr (P != 1) {
+        load_row<NT>(array_f32_units + row * (NT * 32), x, h);
+    } else {
+        const __bf16* base = reinterpret_cast<const __bf16*>(array_f32_units) + row * (NT * 32);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 a = __builtin_convertvector(*reinterpret_cast<const bf16x4*>(base + t * 32 + q * 8 + h * 4), f32x4);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) x[t][q * 4 + c] = a[c];
+            }
+    }
+}
+
 // cooperative global -> LDS copy by the whole workgroup (n multiple of 4 floats, 16-B aligned).
 // Uses the gfx950 LDS-DMA path (global_load_lds_dwordx4): every wave issues all of its 1-KiB pieces
 // back to back with no VGPR round trip, so the L2 latency is paid once per phase instead of once

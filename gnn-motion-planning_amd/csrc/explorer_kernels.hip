@@ -23,6 +23,9 @@
 
 namespace gnnmp {
 
+// floats of storage per 32-edge x 32-feature tile of the per-edge intermediates (bf16 in the bf16 mode)
+#define kETile (P == 1 ? 512 : 1024)
+
 // =====================================================================================================
 // prep: padded index spaces + CSR by destination
 // =====================================================================================================
@@ -506,10 +509,10 @@ __global__ __launch_bounds__(WAVES * 64) void pre_kernel(PreParams p) {
         load_vec<NT>(wl + L::b1, y, lane);
         linear_acc_ops<P, NT, NT>(wl + L::w1d, mop, y, lane);
         linear_acc_p<P, NT, NT>(wl + L::w1e, aux, y, lane);
-        store_tile<NT>(p.o0 + (size_t)tile * NT * kATile, y, lane);          // K_e
+        store_tile_p<P, NT>(p.o0 + (size_t)tile * NT * kETile, y, lane);     // K_e
         load_vec<NT>(wl + L::bp0, y, lane);
         linear_acc_ops<P, NT, NT>(wl + L::wpc, mop, y, lane);
-        store_tile<NT>(p.o1 + (size_t)tile * NT * kATile, y, lane);          // PE_e
+        store_tile_p<P, NT>(p.o1 + (size_t)tile * NT * kETile, y, lane);     // PE_e
     } else {
         using L = OutNBlob<D, P>;
         const bool isgoal = (row == p.goal_node[g]);
@@ -528,11 +531,11 @@ __global__ __launch_bounds__(WAVES * 64) void pre_kernel(PreParams p) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) y[t] = splat16(0.f);
         linear_acc_p<P, NT, NT>(wl + L::wsrc, xi, y, lane);
-        store_row<NT>(p.o2 + (size_t)row * D, y, h);                          // A_0
+        store_row_p<P, NT>(p.o2, (size_t)row, y, h);                           // A_0
 #pragma unroll
         for (int t = 0; t < NT; ++t) y[t] = splat16(0.f);
         linear_acc_p<P, NT, NT>(wl + L::wdst, xi, y, lane);
-        store_row<NT>(p.o3 + (size_t)row * D, y, h);                          // B_0
+        store_row_p<P, NT>(p.o3, (size_t)row, y, h);                           // B_0
         load_vec<NT>(wl + L::bd, y, lane);
         linear_acc_p<P, NT, NT>(wl + L::wd_nc, aux, y, lane);
         store_row<NT>(p.o4 + (size_t)row * D, y, h);                          // DN
@@ -629,10 +632,10 @@ __global__ __launch_bounds__(WAVES * 64) void pre_resident_kernel(PreParams p) {
                 load_vec<NT>(p.out + L::b1, y, lane);
                 linear_acc_ops<P, NT, NT>(p.out + L::w1d, mop, y, lane);
                 linear_acc_p<P, NT, NT>(p.out + L::w1e, aux, y, lane);
-                store_tile<NT>(p.o0 + (size_t)tile * NT * kATile, y, lane);
+                store_tile_p<P, NT>(p.o0 + (size_t)tile * NT * kETile, y, lane);
                 load_vec<NT>(p.out + L::bp0, y, lane);
                 linear_acc_ops<P, NT, NT>(p.out + L::wpc, mop, y, lane);
-                store_tile<NT>(p.o1 + (size_t)tile * NT * kATile, y, lane);
+                store_tile_p<P, NT>(p.o1 + (size_t)tile * NT * kETile, y, lane);
             } else {
                 using L = OutNBlob<D, P>;
                 const bool isgoal = (row == p.goal_node[g]);
@@ -651,11 +654,11 @@ __global__ __launch_bounds__(WAVES * 64) void pre_resident_kernel(PreParams p) {
 #pragma unroll
                 for (int t = 0; t < NT; ++t) y[t] = splat16(0.f);
                 linear_acc_p<P, NT, NT>(p.out + L::wsrc, xi, y, lane);
-                store_row<NT>(p.o2 + (size_t)row * D, y, h);
+                store_row_p<P, NT>(p.o2, (size_t)row, y, h);
 #pragma unroll
                 for (int t = 0; t < NT; ++t) y[t] = splat16(0.f);
                 linear_acc_p<P, NT, NT>(p.out + L::wdst, xi, y, lane);
-                store_row<NT>(p.o3 + (size_t)row * D, y, h);
+                store_row_p<P, NT>(p.o3, (size_t)row, y, h);
                 load_vec<NT>(p.out + L::bd, y, lane);
                 linear_acc_p<P, NT, NT>(p.out + L::wd_nc, aux, y, lane);
                 store_row<NT>(p.o4 + (size_t)row * D, y, h);
@@ -721,12 +724,10 @@ __global__ __launch_bounds__(256) void mp_edge_kernel(MpEdgeParams p) {
         if (wk.valid()) fetch(wk.cur);
         if (meta < 4) continue;                            // unused or empty tile (wave-uniform)
         const int s = rec.x, t = rec.y;
-        const float* ar = p.A + (size_t)(s >= 0 ? s : 0) * D;
-        const float* br = p.B + (size_t)(t >= 0 ? t : 0) * D;
         f32x16 hid[NT], a[NT], b[NT];
-        load_tile_nt<NT>(p.Ke + (size_t)tile * NT * kATile, hid, lane);
-        load_row<NT>(ar, a, h);
-        load_row<NT>(br, b, h);
+        load_tile_nt_p<P, NT>(p.Ke + (size_t)tile * NT * kETile, hid, lane);
+        load_row_p<P, NT>(p.A, (size_t)(s >= 0 ? s : 0), a, h);
+        load_row_p<P, NT>(p.B, (size_t)(t >= 0 ? t : 0), b, h);
 #pragma unroll
         for (int tt = 0; tt < NT; ++tt) hid[tt] += a[tt] + b[tt];
         relu_<NT>(hid);
@@ -828,11 +829,11 @@ __global__ __launch_bounds__(256) void mp_node_kernel(MpNodeParams p) {
 #pragma unroll
         for (int tt = 0; tt < NT; ++tt) z[tt] = splat16(0.f);
         linear_acc_p<P, NT, NT>(wl + L::m2, y, z, lane);
-        store_row<NT>(p.Aout + (size_t)t * D, z, h);
+        store_row_p<P, NT>(p.Aout, (size_t)t, z, h);
 #pragma unroll
         for (int tt = 0; tt < NT; ++tt) z[tt] = splat16(0.f);
         linear_acc_p<P, NT, NT>(wl + L::m3, y, z, lane);
-        store_row<NT>(p.Bout + (size_t)t * D, z, h);
+        store_row_p<P, NT>(p.Bout, (size_t)t, z, h);
     }
 }
 
@@ -869,9 +870,9 @@ __global__ __launch_bounds__(256) void policy_kernel(PolicyParams p) {
         if (g < 0) continue;
         const int s = rec.x, t = rec.y;
         f32x16 hid[NT], a[NT], b[NT];
-        load_tile_nt<NT>(p.PE + (size_t)tile * NT * kATile, hid, lane);
-        load_row<NT>(p.PS + (size_t)(s >= 0 ? s : 0) * D, a, h);
-        load_row<NT>(p.PT + (size_t)(t >= 0 ? t : 0) * D, b, h);
+        load_tile_nt_p<P, NT>(p.PE + (size_t)tile * NT * kETile, hid, lane);
+        load_row_p<P, NT>(p.PS, (size_t)(s >= 0 ? s : 0), a, h);
+        load_row_p<P, NT>(p.PT, (size_t)(t >= 0 ? t : 0), b, h);
 #pragma unroll
         for (int tt = 0; tt < NT; ++tt) hid[tt] += a[tt] - b[tt];
         relu_<NT>(hid);

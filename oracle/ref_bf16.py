@@ -97,10 +97,11 @@ def explorer_forward_bf16(w, v, goal, obstacles, edge_index, loop, use_obstacles
     xi[gi] = xi[gi] + weg
     x = xi.clone()
     x[gi] = x[gi] + wehg
-    A, B = lin(x, wsrc), lin(x, wdst)
+    # A, B, K_e, PE (and the policy's node terms) are STORED in bf16 in this mode (chain.hpp store_*_p)
+    A, B = r(lin(x, wsrc)), r(lin(x, wdst))
     dn = lin(nc, wd[:, :d]) + w['decoder.bias']
-    ke = lin(ef, w1[:, 3 * d:4 * d]) + lin(ec, w1[:, 4 * d:]) + w['process.lin_0.0.bias']
-    pe_ = lin(ef, p0[:, 2 * d:]) + w['policy.0.bias']
+    ke = r(lin(ef, w1[:, 3 * d:4 * d]) + lin(ec, w1[:, 4 * d:]) + w['process.lin_0.0.bias'])
+    pe_ = r(lin(ef, p0[:, 2 * d:]) + w['policy.0.bias'])
     for it in range(loop):
         hid = F.relu(A[s] + B[t] + ke)
         msg = lin(hid, w['process.lin_0.2.weight'], w['process.lin_0.2.bias'])
@@ -108,10 +109,10 @@ def explorer_forward_bf16(w, v, goal, obstacles, edge_index, loop, use_obstacles
         h = lin(x, wl1[:, :d]) + lin(agg, wl1[:, d:]) + w['process.lin_1.bias']
         if it < loop - 1:
             x = xi + lin(h, we[:, 3 * d:])
-            A, B = lin(x, wsrc), lin(x, wdst)
+            A, B = r(lin(x, wsrc)), r(lin(x, wdst))
         else:
             dec = dn + lin(h, wd[:, d:])
-            A, B = lin(dec, wps), lin(dec, wpt)
+            A, B = r(lin(dec, wps)), r(lin(dec, wpt))
     h1 = F.relu(A[s] - B[t] + pe_)
     h2 = F.relu(lin(h1, w['policy.2.weight'], w['policy.2.bias']))
     return (h2 * w['policy.4.weight'].view(1, -1)).sum(-1)
