@@ -742,37 +742,36 @@ __global__ __launch_bounds__(256) void mp_edge_kernel(MpEdgeParams p) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // segment ends as a wave-uniform bit mask (valid edges are a prefix of the tile, pads carry -1):
+        // the walk below is 32 x (LDS read, max, one scalar bit test) plus one flush per segment
         const int td = t;                                  // lanes j and j+32 hold the same value
+        const int td_next = __shfl_down(td, 1, 64);
+        const unsigned endmask = (unsigned)__ballot(td >= 0 && (j == 31 || td_next != td));
+        const int last_jj = 31 - __builtin_clz(endmask);  // meta >= 4: at least one valid edge
 #pragma unroll
         for (int fc = 0; fc < (D + 63) / 64; ++fc) {
             const int f = fc * 64 + lane;
             const bool fok = f < D;
             float run = -INFINITY;
-            int cur = __builtin_amdgcn_readlane(td, 0);
             bool first = true;
-            auto flush = [&](bool last) {
-                if (cur < 0) return;
-                const bool closed = !((first && (meta & 1)) || (last && (meta & 2)));
-                if (fok) {
-                    if (closed) p.agg[(size_t)cur * D + f] = run;
-                    else {
-                        if (first) p.part_first[(size_t)tile * D + f] = run;
-                        if (last) p.part_last[(size_t)tile * D + f] = run;
-                    }
-                }
-            };
 #pragma unroll
             for (int jj = 0; jj < 32; ++jj) {
-                const int dj = __builtin_amdgcn_readlane(td, jj);
-                if (dj != cur) {
-                    flush(dj < 0);
+                if (fok) run = fmaxf(run, scr[jj * LD + f]);
+                if ((endmask >> jj) & 1u) {
+                    const int dj = __builtin_amdgcn_readlane(td, jj);
+                    const bool last = jj == last_jj;
+                    const bool closed = !((first && (meta & 1)) || (last && (meta & 2)));
+                    if (fok) {
+                        if (closed) p.agg[(size_t)dj * D + f] = run;
+                        else {
+                            if (first) p.part_first[(size_t)tile * D + f] = run;
+                            if (last) p.part_last[(size_t)tile * D + f] = run;
+                        }
+                    }
                     first = false;
-                    cur = dj;
                     run = -INFINITY;
                 }
-                if (fok) run = fmaxf(run, scr[jj * LD + f]);
             }
-            flush(true);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();

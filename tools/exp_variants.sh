@@ -1,0 +1,7 @@
+#!/bin/bash
+# perf experiments on the GPU box: stage times of the headline workload and of the cfg-3 shape
+cd $GRAFT_REPO_ROOT
+show() { tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d['value'],1), d['config']['stage_ms_per_step'], d['config']['result_checksum'])"; }
+timeout 300 python bench.py --no-cpu-baseline --pcie-steps 0 --dense-steps 0 2>&1 | show
+timeout 300 python bench.py --no-cpu-baseline --pcie-steps 0 --dense-steps 0 --env kuka7 --nodes 2000 --k1 10 --graphs 64 2>&1 | show
+timeout 300 python bench.py --no-cpu-baseline --pcie-steps 0 --dense-steps 0 --env kuka7 --nodes 2000 --k1 10 --graphs 64 --mlp-dtype bf16 2>&1 | show
