@@ -83,6 +83,7 @@ def lib():
     L.gnnmp_graph_build.argtypes = [ctypes.POINTER(GraphBuildBatch), vp, ctypes.c_int64, vp, vp, sz, vp]
     L.gnnmp_maze_explore_workspace_bytes.argtypes = [ctypes.POINTER(MazeBatch), ctypes.POINTER(sz)]
     L.gnnmp_maze_explore.argtypes = [ctypes.POINTER(MazeBatch), vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
+    L.gnnmp_maze_steer.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, vp, vp, vp, vp, vp, vp, vp, vp]
     L.gnnmp_pack_a_tiles.restype = ctypes.c_int64
     L.gnnmp_pack_a_tiles.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp]
     L.gnnmp_pack_a_small.restype = ctypes.c_int64

@@ -1146,3 +1146,18 @@ extern "C" int gnnmp_maze_explore(const gnnmp_maze_batch* b, int32_t* success, i
     HIP_TRY(launch_maze_explore(p, static_cast<hipStream_t>(hip_stream)));
     return GNNMP_OK;
 }
+
+extern "C" int gnnmp_maze_steer(int32_t n_problems, int32_t total_path, int32_t width, const double* maps,
+                                const int32_t* path_ptr, const float* old_path, const float* new_path, float* out_path,
+                                float* tmp, int64_t* checks, void* hip_stream) {
+    if (!maps || !path_ptr || !checks) return GNNMP_ERR_NULL;
+    if (n_problems < 1 || total_path < 0 || width < 1) return GNNMP_ERR_ARG;
+    if (total_path > 0 && (!old_path || !new_path || !out_path || !tmp)) return GNNMP_ERR_NULL;
+    if (out_path == old_path || out_path == new_path) return GNNMP_ERR_ARG;
+    MazeSteerParams p;
+    p.B = n_problems; p.w = width; p.maps = maps; p.path_ptr = path_ptr;
+    p.old_path = old_path; p.new_path = new_path; p.out_path = out_path; p.tmp = tmp;
+    p.checks = reinterpret_cast<long long*>(checks);
+    HIP_TRY(launch_maze_steer(p, static_cast<hipStream_t>(hip_stream)));
+    return GNNMP_OK;
+}

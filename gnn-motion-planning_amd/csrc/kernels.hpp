@@ -129,6 +129,17 @@ struct MazeParams {
 };
 hipError_t launch_maze_explore(const MazeParams& p, hipStream_t st);
 
+// collision-checked steering of the smoothing stage (smoother.py:194-216) for 2-D mazes
+struct MazeSteerParams {
+    int B, w;
+    const double* maps;                   // [B, w, w]
+    const int* path_ptr;                  // [B + 1]
+    const float *old_path, *new_path;     // [sumP, 2]
+    float *out_path, *tmp;                // [sumP, 2]
+    long long* checks;                    // [B], incremented
+};
+hipError_t launch_maze_steer(const MazeSteerParams& p, hipStream_t st);
+
 hipError_t launch_prep(const PrepParams& q, hipStream_t st);
 hipError_t launch_obs(int D, int P, const ObsParams& p, int G, hipStream_t st);
 hipError_t launch_pre(int D, int P, bool edge, int waves, const PreParams& p, int n_tiles32, size_t lds_bytes, hipStream_t st);

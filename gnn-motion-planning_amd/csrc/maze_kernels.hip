@@ -9,7 +9,7 @@
 //     maximum in (position of a in the explored list, column b) order;
 //   * a free edge adds b to the tree and kills column b; a blocked edge kills cells (a, b) and (b, a);
 //   * collision queries replicate numpy's float32 arithmetic on the float32 node rows bit for bit (no fma
-//     contraction: explicit __f*_rn), count one check per in-bounds configuration query, short-circuit left
+//     contraction: every operation rounded on its own (contraction off)), count one check per in-bounds configuration query, short-circuit left
 //     to right, bisect while the end cells are > 1 grid step apart and the L1 distance exceeds RRT_EPS;
 //   * goal test in float64 against the float64 goal state, then one more query.
 // Scope: one explorer forward per problem with a fresh tree (the reference's defaults batch = t_max = 500 give
@@ -18,9 +18,20 @@
 #include <math.h>
 #include "kernels.hpp"
 
+// numpy evaluates every float32 operation on its own: no fused multiply-add anywhere in this file (hipcc's default
+// is -ffp-contract=fast-honor-pragmas, and HIP's __fmul_rn / __fadd_rn are plain operators that WOULD be fused;
+// __fsqrt_rn is the approximate native square root), so the rounded operations are spelled out here.
+#pragma clang fp contract(off)
+
 namespace gnnmp {
 
 namespace {
+
+__device__ __forceinline__ float f_add(float x, float y) { return x + y; }
+__device__ __forceinline__ float f_sub(float x, float y) { return x - y; }
+__device__ __forceinline__ float f_mul(float x, float y) { return x * y; }
+__device__ __forceinline__ float f_div(float x, float y) { return x / y; }        // correctly rounded (hipcc default)
+__device__ __forceinline__ float f_sqrt(float x) { return __builtin_sqrtf(x); }   // correctly rounded (hipcc default)
 
 struct MazeCtx {
     const double* map;      // [w, w] occupancy (1 = obstacle), row-major map[x][y]
@@ -29,7 +40,7 @@ struct MazeCtx {
 };
 
 __device__ __forceinline__ int maze_cell(float x, int w) {        // ((x + 1.0) * w / 2.0).astype(int), clipped at w-1
-    const float t = __fdiv_rn(__fmul_rn(__fadd_rn(x, 1.0f), (float)w), 2.0f);
+    const float t = f_div(f_mul(f_add(x, 1.0f), (float)w), 2.0f);
     int c = (int)t;
     return c > w - 1 ? w - 1 : c;
 }
@@ -51,9 +62,9 @@ __device__ bool maze_segment_fp(MazeCtx& m, float ax, float ay, float bx, float 
         --sp;
         const float lx = sx0[sp], ly = sy0[sp], rx = sx1[sp], ry = sy1[sp];
         const int dc = abs(maze_cell(lx, m.w) - maze_cell(rx, m.w)) + abs(maze_cell(ly, m.w) - maze_cell(ry, m.w));
-        const float l1 = __fadd_rn(fabsf(__fsub_rn(lx, rx)), fabsf(__fsub_rn(ly, ry)));
+        const float l1 = f_add(fabsf(f_sub(lx, rx)), fabsf(f_sub(ly, ry)));
         if (dc > 1 && l1 > 0.05f) {
-            const float mx = __fdiv_rn(__fadd_rn(lx, rx), 2.0f), my = __fdiv_rn(__fadd_rn(ly, ry), 2.0f);
+            const float mx = f_div(f_add(lx, rx), 2.0f), my = f_div(f_add(ly, ry), 2.0f);
             if (!maze_state_fp(m, mx, my)) return false;
             if (sp + 2 > 48) return false;                       // cannot happen: depth <= ~8 for RRT_EPS = 0.05
             sx0[sp] = mx; sy0[sp] = my; sx1[sp] = rx; sy1[sp] = ry; ++sp;      // right half second ...
@@ -159,7 +170,7 @@ __global__ __launch_bounds__(64) void maze_explore_kernel(MazeParams p) {
             if (free_edge) {
                 explored[n_expl] = nb; pos[nb] = n_expl; prev[nb] = a;
                 const double dx = fabs(gx - (double)v[2 * nb]), dy = fabs(gy - (double)v[2 * nb + 1]);
-                const double d = sqrt(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)));
+                const double d = sqrt(dx * dx + dy * dy);                  // no contraction: see the pragma above
                 if (d < 0.05) goal = maze_state_fp(m, v[2 * nb], v[2 * nb + 1]) ? 1 : 0;
             } else {
                 alive[be] = 0;                                             // cell (a, nb)
@@ -191,6 +202,80 @@ __global__ __launch_bounds__(64) void maze_explore_kernel(MazeParams p) {
         p.path_len[b] = path_len;
         p.checks[b] = m.checks;
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Steering of the smoothing stage: proposed_path_smootherv2 (smoother.py:194-216).  Every interior waypoint
+// moves at most RRT_EPS per round towards the network's proposal and keeps the move only if both adjacent
+// edges stay free (left neighbour already updated, right one not); at most K = ceil(max distance / RRT_EPS)
+// rounds, early exit once the accepted waypoints sit on their targets.  The waypoints are numpy float32 arrays
+// in the reference, so every operation below is the explicitly rounded float32 one (no fma contraction):
+//   norm(x)     = sqrt(x0*x0 + x1*x1)       (np.linalg.norm: sqrt(dot) / sqrt(add.reduce(x*x)))
+//   interpolate = a + (b - a) * (RRT_EPS / dist), python-float constants weak-cast to float32 (NEP 50)
+// One wavefront per problem; the walk itself is sequential (lane 0), like the reference's.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float maze_norm2(float dx, float dy) {
+    return f_sqrt(f_add(f_mul(dx, dx), f_mul(dy, dy)));
+}
+
+__global__ __launch_bounds__(64) void maze_steer_kernel(MazeSteerParams p) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int p0 = p.path_ptr[b], P = p.path_ptr[b + 1] - p0;
+    const float* oldp = p.old_path + (size_t)p0 * 2;
+    const float* newp = p.new_path + (size_t)p0 * 2;
+    float* cur = p.out_path + (size_t)p0 * 2;
+    float* nxt = p.tmp + (size_t)p0 * 2;
+    // K = int(ceil((norm(old - new, axis=-1) / RRT_EPS).max()))
+    float mx = 0.0f;
+    for (int i = lane; i < P; i += 64) {
+        const float n = maze_norm2(f_sub(oldp[2 * i], newp[2 * i]), f_sub(oldp[2 * i + 1], newp[2 * i + 1]));
+        mx = fmaxf(mx, f_div(n, 0.05f));
+        cur[2 * i] = oldp[2 * i];
+        cur[2 * i + 1] = oldp[2 * i + 1];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    const int K = (int)ceilf(mx);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    if (lane != 0 || P < 3) return;
+    MazeCtx m;
+    m.map = p.maps + (size_t)b * p.w * p.w;
+    m.w = p.w;
+    m.checks = 0;
+    for (int r = 0; r < K; ++r) {
+        float diff = 0.0f;
+        nxt[0] = cur[0]; nxt[1] = cur[1];
+        nxt[2 * (P - 1)] = cur[2 * (P - 1)]; nxt[2 * (P - 1) + 1] = cur[2 * (P - 1) + 1];
+        for (int i = 1; i < P - 1; ++i) {
+            const float ox = cur[2 * i], oy = cur[2 * i + 1], tx = newp[2 * i], ty = newp[2 * i + 1];
+            const float dist = maze_norm2(f_sub(ox, tx), f_sub(oy, ty));
+            float cx = tx, cy = ty;
+            if (!(dist < 0.05f)) {
+                const float ratio = f_div(0.05f, dist);
+                cx = f_add(ox, f_mul(f_sub(tx, ox), ratio));
+                cy = f_add(oy, f_mul(f_sub(ty, oy), ratio));
+            }
+            // nxt[i-1] is this round's value, the right neighbour still last round's
+            const bool ok = maze_edge_fp(m, nxt[2 * (i - 1)], nxt[2 * (i - 1) + 1], cx, cy) &&
+                            maze_edge_fp(m, cur[2 * (i + 1)], cur[2 * (i + 1) + 1], cx, cy);
+            if (ok) {
+                nxt[2 * i] = cx; nxt[2 * i + 1] = cy;
+                diff = f_add(diff, maze_norm2(f_sub(cx, tx), f_sub(cy, ty)));
+            } else {
+                nxt[2 * i] = ox; nxt[2 * i + 1] = oy;
+            }
+        }
+        for (int i = 0; i < 2 * P; ++i) cur[i] = nxt[i];
+        if (diff < 1e-5f) break;
+    }
+    p.checks[b] += m.checks;
+}
+
+hipError_t launch_maze_steer(const MazeSteerParams& p, hipStream_t st) {
+    if (p.B <= 0) return hipSuccess;
+    hipLaunchKernelGGL(maze_steer_kernel, dim3(p.B), dim3(64), 0, st, p);
+    return hipGetLastError();
 }
 
 hipError_t launch_maze_explore(const MazeParams& p, hipStream_t st) {

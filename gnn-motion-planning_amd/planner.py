@@ -284,13 +284,15 @@ def eval_gnn(env, indexes, model, model_s, seed=1234, smooth=True, batch=500, t_
 # batched explore stage with everything but the sampling on the device (2-D mazes)
 # --------------------------------------------------------------------------------------------------
 @torch.no_grad()
-def explore_maze_batch(problems, model, device, batch=500, k=30, loop=5):
-    """Explore stage of many 2-D maze problems at once: sampling on the host (the reference's numpy RNG
+def explore_maze_batch(problems, model, device, batch=500, k=30, loop=5, model_s=None, smooth_iters=5):
+    """Many 2-D maze problems at once: sampling on the host (the reference's numpy RNG
     stream, one problem after the other), then -- in ONE pass on the device -- kNN graphs
     (graph_kernels.hip), explorer forward (batched), greedy expansion + collision checks
-    (maze_kernels.hip).  ``problems``: list of dicts(map [w, w], init_state, goal_state).
+    (maze_kernels.hip) and, when ``model_s`` is given, the smoothing stage of the solved problems
+    (smoother.py:233-246: ``smooth_iters`` x (batched smoother forward, collision-checked steering on
+    the device)).  ``problems``: list of dicts(map [w, w], init_state, goal_state).
     Covers the reference's default single-forward case (batch == t_max); returns one
-    result dict per problem with the explore-stage fields of ``explore``."""
+    result dict per problem with the fields of ``explore`` (``smooth_path`` / ``c_smooth`` with ``model_s``)."""
     import ctypes
     from . import _lib
     from .batch import GraphBatch
@@ -344,6 +346,10 @@ def explore_maze_batch(problems, model, device, batch=500, k=30, loop=5):
     success, n_expl, n_pairs, plen, checks = (t.cpu().tolist() for t in (success, n_expl, n_pairs, plen, checks))
     expl, ee, path = expl.cpu().numpy(), ee.cpu().numpy(), path.cpu().numpy()
     nptr, eptr = ptr.tolist(), edge_ptr.cpu().tolist()
+    smoothed = {}
+    if model_s is not None and any(success):
+        smoothed = _smooth_maze_batch(model_s, [b for b in range(B) if success[b]], v, nptr, n_free, path, plen, maps, w,
+                                      smooth_iters, device)
     out = []
     for b in range(B):
         o = 2 * (2 * eptr[b] + b)
@@ -352,5 +358,49 @@ def explore_maze_batch(problems, model, device, batch=500, k=30, loop=5):
         out.append({'success': bool(success[b]), 'explored': expl[nptr[b]:nptr[b] + n_expl[b]].tolist(),
                     'explored_edges': ee[o:o + 2 * n_pairs[b]].reshape(-1, 2).tolist(),
                     'c_explore': envs[b].collision_check_count + int(checks[b]),
-                    'path': [vs[b][i].numpy() for i in nodes], 'free': None, 'env': envs[b], 'v': vs[b]})
+                    'path': [vs[b][i].numpy() for i in nodes], 'free': None, 'env': envs[b], 'v': vs[b],
+                    'n_free': n_free[b]})
+        if model_s is not None:
+            sp, cs = smoothed.get(b, ([], 0))
+            out[-1].update(smooth_path=sp, c_smooth=cs)
     return out
+
+
+def _smooth_maze_batch(model_s, sel, v, nptr, n_free, path, plen, maps, w, iters, device):
+    """Smoothing stage of the solved problems ``sel`` entirely on the device: per iteration one batched
+    smoother forward (loop = 1) and one ``gnnmp_maze_steer`` launch; one D2H copy at the end.
+    Samples handed to the network: the first 500 free and 500 collided points (smoother.py:52-64)."""
+    from . import _lib
+    from .smoother import SmoothBatch
+    total_n = int(v.shape[0])
+    v_ext = torch.cat((v, torch.zeros(1, 2, device=device)))          # row total_n: the reference's zero filler row
+    widx, fidx, cidx, eis, pc, fc, cc, ec = [], [], [], [], [], [], [], []
+    for b in sel:
+        nb = nptr[b + 1] - nptr[b]
+        widx.append(path[nptr[b]:nptr[b] + plen[b]].astype(np.int64) + nptr[b])
+        nf, nc = min(n_free[b], 500), min(nb - n_free[b], 500)
+        fidx.append(np.arange(nf, dtype=np.int64) + nptr[b] if nf else np.array([total_n], dtype=np.int64))
+        cidx.append(np.arange(nc, dtype=np.int64) + nptr[b] + n_free[b] if nc else np.array([total_n], dtype=np.int64))
+        eis.append(chain_edge_index(plen[b]))
+        pc.append(plen[b]); fc.append(len(fidx[-1])); cc.append(len(cidx[-1])); ec.append(eis[-1].shape[1])
+    take = lambda parts: v_ext[torch.from_numpy(np.concatenate(parts)).to(device)]      # noqa: E731
+    sb = SmoothBatch.from_device(take(widx), take(fidx), take(cidx), torch.cat(eis, dim=1).to(device), pc, fc, cc, ec)
+    maps_sel = maps[torch.tensor(sel, device=device)].contiguous()
+    checks = torch.zeros(len(sel), dtype=torch.int64, device=device)
+    tmp = torch.empty_like(sb.path)
+    L = _lib.lib()
+    with torch.cuda.device(device):
+        st = torch.cuda.current_stream().cuda_stream
+        for _ in range(iters):
+            new = model_s.forward_batch(sb, 1)
+            out = torch.empty_like(sb.path)
+            _lib.check(L.gnnmp_maze_steer(len(sel), int(sb.path.shape[0]), w, maps_sel.data_ptr(), sb.path_ptr.data_ptr(),
+                                          sb.path.data_ptr(), new.data_ptr(), out.data_ptr(), tmp.data_ptr(),
+                                          checks.data_ptr(), st), 'gnnmp_maze_steer')
+            sb.path = out
+    final, checks = sb.path.cpu().numpy(), checks.cpu().tolist()
+    res, o = {}, 0
+    for i, b in enumerate(sel):
+        res[b] = ([final[o + q].copy() for q in range(plen[b])], int(checks[i]))
+        o += plen[b]
+    return res

@@ -41,6 +41,28 @@ class SmoothBatch:
         self.max_edges = max(e.shape[1] for e in edge_indexes)
         self.path_counts = [t.shape[0] for t in paths]
 
+    @classmethod
+    def from_device(cls, path, free, collided, edge_index, path_counts, free_counts, coll_counts, edge_counts):
+        """Batch over tensors that already live on the device (no host copies): ``path`` [sum P, C], ``free``,
+        ``collided`` float32, ``edge_index`` [2, sum E] int64 with problem-local ids; ``*_counts`` host lists."""
+        dev = path.device
+
+        def prefix(counts):
+            p = torch.zeros(len(counts) + 1, dtype=torch.int64)
+            p[1:] = torch.tensor(counts, dtype=torch.int64).cumsum(0)
+            return p.to(torch.int32).to(dev)
+        sb = cls.__new__(cls)
+        sb.n = len(path_counts)
+        sb.path, sb.free, sb.collided, sb.edge_index = path.contiguous(), free.contiguous(), collided.contiguous(), \
+            edge_index.contiguous()
+        sb.path_ptr, sb.free_ptr, sb.coll_ptr, sb.edge_ptr = prefix(path_counts), prefix(free_counts), \
+            prefix(coll_counts), prefix(edge_counts)
+        sb.max_path = max(path_counts)
+        sb.max_samples = max(f + c for f, c in zip(free_counts, coll_counts))
+        sb.max_edges = max(edge_counts)
+        sb.path_counts = list(path_counts)
+        return sb
+
 
 class ModelSmoother(nn.Module):
     """``ModelSmoother(workspace_size, config_size, obs_size, embed_size, scale=1.)``

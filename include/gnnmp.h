@@ -15,6 +15,8 @@
  *       ModelSmoother.forward                                 model_smoother.py:104-142 (call smoother.py:243)
  *   gnnmp_graph_workspace_bytes / gnnmp_graph_build
  *       create_data's edge construction                       eval_gnn.py:159-164
+ *   gnnmp_maze_steer
+ *       proposed_path_smootherv2 (steering of the smoothing stage)  smoother.py:194-216
  *   gnnmp_maze_explore_workspace_bytes / gnnmp_maze_explore
  *       explore()'s greedy loop + MazeEnv._edge_fp            eval_gnn.py:198-233, environment/maze_env.py:270-326
  *
@@ -245,6 +247,15 @@ int gnnmp_maze_explore_workspace_bytes(const gnnmp_maze_batch* shape, size_t* by
 int gnnmp_maze_explore(const gnnmp_maze_batch* batch, int32_t* success, int32_t* n_explored, int32_t* explored,
                        int32_t* n_pairs, int32_t* explored_edges, int32_t* path_len, int32_t* path, int64_t* checks,
                        void* workspace, size_t workspace_bytes, void* hip_stream);
+
+/* Collision-checked steering of the smoothing stage for 2-D mazes: proposed_path_smootherv2 (smoother.py:194-216)
+ * with MazeEnv's checker (maze_env.py:270-326), batched.  Problem b owns waypoints [path_ptr[b], path_ptr[b+1])
+ * of old_path / new_path (float32 [.,2]: the current path and the smoother network's proposal, smoother.py:243-245).
+ * out_path receives the steered path (may NOT alias old_path / new_path); tmp: [total_path, 2] float32 scratch;
+ * checks [B] (int64) is INCREMENTED by the collision checks spent.  All pointers are device pointers. */
+int gnnmp_maze_steer(int32_t n_problems, int32_t total_path, int32_t width, const double* maps, const int32_t* path_ptr,
+                     const float* old_path, const float* new_path, float* out_path, float* tmp, int64_t* checks,
+                     void* hip_stream);
 
 /* ------------------------------------------------------------------------------------------
  * Host-only helpers exported for the CPU test-suite (no device needed)

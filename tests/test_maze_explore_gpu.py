@@ -78,3 +78,60 @@ def test_device_explore_equals_host_counterpart_step_by_step():
         if path is not None:
             assert [tuple(x) for x in d['path']] == [tuple(data['v'][j].numpy()) for j in path]
         assert d['c_explore'] == env.collision_check_count
+
+
+def _smoother():
+    ms = gnnmp.ModelSmoother(workspace_size=2, config_size=2, embed_size=128, obs_size=6)
+    ms.load_state_dict(load_weights('smooth_2d_attv3'))
+    return ms
+
+
+def test_device_smoothing_matches_reference_outcomes():
+    """Whole planner on the device (explore + 5 x (smoother forward, collision-checked steering)): per-problem
+    collision-check counts of BOTH stages and the smoothed path cost against the reference planner's own run."""
+    with np.load(golden_files('evalset_')[0]) as f:
+        r = {k: f[k] for k in f.files}
+    n = r['rows'].shape[0]
+    problems = [dict(map=r['maps'][i], init_state=r['init_states'][i], goal_state=r['goal_states'][i]) for i in range(n)]
+    np.random.seed(int(r['seed']))
+    torch.manual_seed(int(r['seed']))
+    res = planner.explore_maze_batch(problems, _models(), DEV, batch=int(r['batch']), k=int(r['k']), model_s=_smoother())
+    ref = r['rows']
+    c_s = [x['c_smooth'] for x in res]
+    cost = [planner.path_cost(x['smooth_path']) for x in res]
+    print('\nc_smooth device %s\n         ref    %s' % (c_s, ref[:, 4].astype(int).tolist()))
+    print('smooth cost device %s\n            ref    %s' % (np.round(cost, 5).tolist(), np.round(ref[:, 2], 5).tolist()))
+    assert [x['c_explore'] for x in res] == ref[:, 3].astype(int).tolist()
+    # same bar as the host-steered planner (tests/test_planner_evalset_gpu.py): identical steering decisions unless a
+    # proposal sits within fp32 noise of the RRT_EPS threshold
+    assert np.allclose(cost, ref[:, 2], rtol=1e-3, atol=1e-3)
+    assert np.abs(np.array(c_s) - ref[:, 4]).max() <= 0.03 * ref[:, 4].max()
+
+
+def test_device_smoothing_equals_host_steering_bitwise():
+    """Device steering against planner.model_smooth (host steering with the Maze2D checker, same GPU smoother
+    network): identical waypoints bit for bit and identical collision-check counts, on real solved problems and
+    on a batch with a two-waypoint path (nothing to steer)."""
+    with np.load(golden_files('evalset_')[0]) as f:
+        r = {k: f[k] for k in f.files}
+    idx = [0, 2, 4, 8, 9]
+    m, ms = _models(), _smoother()
+    problems = [dict(map=r['maps'][i], init_state=r['init_states'][i], goal_state=r['goal_states'][i]) for i in idx]
+    np.random.seed(11)
+    res = planner.explore_maze_batch(problems, m, DEV, batch=400, k=25, model_s=ms)
+    for d in res:
+        if not d['success']:
+            continue
+        env = d['env']
+        v = d['v'].numpy()
+        # the samples the batched path handed to the smoother: free rows first (init, goal, samples), then collided
+        n_free = d['n_free']
+        free = [x for x in v[:n_free]]
+        coll = [x for x in v[n_free:]]
+        c0 = env.collision_check_count
+        host = planner.model_smooth(ms, free, coll, [p.copy() for p in d['path']], env, DEV)
+        c_host = env.collision_check_count - c0
+        assert len(host) == len(d['smooth_path'])
+        assert all(np.array_equal(a, b) for a, b in zip(host, d['smooth_path'])), \
+            np.abs(np.array(host) - np.array(d['smooth_path'])).max()
+        assert c_host == d['c_smooth']

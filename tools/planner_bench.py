@@ -29,6 +29,8 @@ def main():
     ap.add_argument('--gpu-graph', action='store_true', help='build the kNN graph on the device')
     ap.add_argument('--device-explore', action='store_true',
                     help='explore stage of ALL problems in one device pass (graphs, forward, greedy loop, collision checks)')
+    ap.add_argument('--device-smooth', action='store_true',
+                    help='with --device-explore: the smoothing stage too (batched smoother forwards + steering on the device)')
     ap.add_argument('--batch', type=int, default=500)
     ap.add_argument('--k', type=int, default=30)
     a = ap.parse_args()
@@ -44,19 +46,26 @@ def main():
         probs = [dict(map=maps[i % maps.shape[0]], init_state=init[i % maps.shape[0]], goal_state=goal[i % maps.shape[0]])
                  for i in range(a.problems)]
         np.random.seed(1234)
-        planner.explore_maze_batch(probs[:4], m, dev, batch=a.batch, k=a.k)          # warm-up
+        sm = ms if a.device_smooth else None
+        planner.explore_maze_batch(probs[:4], m, dev, batch=a.batch, k=a.k, model_s=sm)          # warm-up
         np.random.seed(1234)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        res = planner.explore_maze_batch(probs, m, dev, batch=a.batch, k=a.k)
+        res = planner.explore_maze_batch(probs, m, dev, batch=a.batch, k=a.k, model_s=sm)
         torch.cuda.synchronize()
         wall = time.perf_counter() - t0
-        print(json.dumps({'problems': a.problems, 'success': sum(int(x['success']) for x in res), 'stage': 'explore only (no smoothing)',
-                          'problems_per_s': round(a.problems / wall, 2), 's_per_problem': round(wall / a.problems, 5),
-                          'collision_checks_explore': round(sum(x['c_explore'] for x in res) / a.problems, 2),
-                          'host_cores_used': 1, 'host_work': 'rejection sampling only (vectorised, same numpy stream)',
-                          'device_work': 'kNN graphs, explorer forward, greedy frontier, collision checks',
-                          'config': 'maze2 hard, batch=%d, k=%d' % (a.batch, a.k)}))
+        out = {'problems': a.problems, 'success': sum(int(x['success']) for x in res),
+               'stage': 'explore + smoothing (whole planner)' if sm else 'explore only (no smoothing)',
+               'problems_per_s': round(a.problems / wall, 2), 's_per_problem': round(wall / a.problems, 5),
+               'collision_checks_explore': round(sum(x['c_explore'] for x in res) / a.problems, 2),
+               'host_cores_used': 1, 'host_work': 'rejection sampling only (vectorised, same numpy stream)',
+               'device_work': 'kNN graphs, explorer forward, greedy frontier, collision checks' +
+                              (', 5 x (smoother forward, steering)' if sm else ''),
+               'config': 'maze2 hard, batch=%d, k=%d' % (a.batch, a.k)}
+        if sm:
+            out['collision_checks_total'] = round(sum(x['c_explore'] + x['c_smooth'] for x in res) / a.problems, 2)
+            out['path_cost'] = round(float(np.mean([planner.path_cost(x['smooth_path']) for x in res if x['success']])), 4)
+        print(json.dumps(out))
         return
     np.random.seed(1234)
     torch.manual_seed(1234)
