@@ -7,13 +7,13 @@
 // neighbour -> centre) and torch_sparse.coalesce semantics (columns sorted by (source, target),
 // duplicates dropped).  Batched over independent graphs; node ids stay graph-local.
 //
-//   gb_knn      one wave per (graph, node): k1 rounds of "next smallest (distance, index) after the last
-//               pick", distances in float64 from the fp32 coordinates (what the oracle's cdist does), ties
-//               broken by the lower index
+//   gb_knn      one wave per (graph, node): k1 rounds of "next smallest (distance, index)", distances in
+//               float64 from the fp32 coordinates (what the oracle's cdist does), ties broken by the lower
+//               index; graphs up to 2048 nodes keep the candidate distances in registers
 //   gb_count    every (centre, neighbour) pair contributes (nb -> c) and (c -> nb): histogram by source
 //   gb_scan     per graph: exclusive scan of the per-source counts
 //   gb_fill     drop targets into their source's bucket (arrival order)
-//   gb_unique   per source: sort its bucket, drop duplicates, count what is left
+//   gb_unique   one wave per source: rank-sort its bucket in LDS, drop duplicates, count what is left
 //   gb_offsets  per graph scan of the unique counts; one workgroup then chains the graphs -> edge_ptr
 //   gb_write    emit [2, E] edge_index (int64, row 0 = source, row 1 = target) in coalesced order
 #include <hip/hip_runtime.h>
@@ -29,6 +29,51 @@ __device__ __forceinline__ int gb_find(const int* __restrict__ ptr, int G, int x
         if (ptr[mid] <= x) lo = mid; else hi = mid;
     }
     return lo;
+}
+
+// Selection with the candidate distances held in registers (T per lane, graphs up to 64 T nodes): distances are
+// computed once per pass, then each of the k rounds is a register scan + a wave argmin over (distance, index),
+// and the winner is retired.  Same order as the general path: ascending distance, ties by the lower index.
+template <int T>
+__device__ __forceinline__ void gb_knn_cached(const GbParams& p, const float* __restrict__ xi, int n0, int M, int k,
+                                              int* __restrict__ out, int lane) {
+    const int C = p.C;
+    double dist[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const int c = t * 64 + lane;
+        double d = INFINITY;
+        if (c < M) {
+            const float* xc = p.v + (size_t)(n0 + c) * C;
+            d = 0.0;
+            for (int q = 0; q < C; ++q) {
+                const double df = (double)xi[q] - (double)xc[q];
+                d = fma(df, df, d);
+            }
+        }
+        dist[t] = d;
+    }
+    for (int r = 0; r < p.kmax; ++r) {
+        int pick = -1;
+        if (r < k) {
+            double bd = INFINITY;
+            int bi = 0x7fffffff;
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+                if (dist[t] < bd) { bd = dist[t]; bi = t * 64 + lane; }      // ascending t = ascending index per lane
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const double od = __shfl_xor(bd, off, 64);
+                const int oi = __shfl_xor(bi, off, 64);
+                if (od < bd || (od == bd && oi < bi)) { bd = od; bi = oi; }
+            }
+            pick = bi;
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+                if (t * 64 + lane == bi) dist[t] = INFINITY;
+        }
+        if (lane == 0) out[r] = pick;
+    }
 }
 
 // pass 0 = neighbours among all nodes, pass 1 = among the free nodes only (centres < n_free)
@@ -50,6 +95,10 @@ __global__ __launch_bounds__(256) void gb_knn_kernel(GbParams p) {
             for (int r = lane; r < p.kmax; r += 64) out[r] = -1;
             continue;
         }
+        if (M <= 1024) { gb_knn_cached<16>(p, xi, n0, M, k, out, lane); continue; }
+        if (M <= 2048) { gb_knn_cached<32>(p, xi, n0, M, k, out, lane); continue; }
+        // general path (any graph size): every round recomputes the distances and takes the smallest
+        // (distance, index) strictly after the previous pick
         double last_d = -1.0;
         int last_i = -1;
         for (int r = 0; r < p.kmax; ++r) {
@@ -144,23 +193,57 @@ __global__ void gb_fill_kernel(GbParams p) {
     });
 }
 
-// one thread per source: insertion sort of its bucket (a few dozen entries), then in-place unique
-__global__ void gb_unique_kernel(GbParams p) {
-    const int node = blockIdx.x * blockDim.x + threadIdx.x;
+// one wave per source: rank sort of its bucket through LDS (n compares per entry, no dependent global traffic), then
+// unique + compaction back into the bucket.  Buckets beyond the wave's LDS share (hubs that are the neighbour of
+// very many nodes) fall back to an in-place insertion sort by lane 0.
+__global__ __launch_bounds__(256) void gb_unique_kernel(GbParams p, int cap) {
+    extern __shared__ int gb_lds[];                          // [4 waves][2][cap]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int node = blockIdx.x * 4 + wave;
     if (node >= p.total_nodes) return;
     const int g = gb_find(p.node_ptr, p.G, node);
     int* b = p.bucket + (size_t)4 * p.kmax * p.node_ptr[g] + p.off[node];
     const int n = p.cnt[node];
-    for (int i = 1; i < n; ++i) {
-        const int x = b[i];
-        int j = i - 1;
-        while (j >= 0 && b[j] > x) { b[j + 1] = b[j]; --j; }
-        b[j + 1] = x;
+    if (n > cap) {
+        if (lane == 0) {
+            for (int i = 1; i < n; ++i) {
+                const int x = b[i];
+                int j = i - 1;
+                while (j >= 0 && b[j] > x) { b[j + 1] = b[j]; --j; }
+                b[j + 1] = x;
+            }
+            int m = 0;
+            for (int i = 0; i < n; ++i)
+                if (i == 0 || b[i] != b[i - 1]) b[m++] = b[i];
+            p.ucnt[node] = m;
+        }
+        return;
     }
+    int* key = gb_lds + (size_t)wave * 2 * cap;
+    int* srt = key + cap;
+    for (int c = lane; c < n; c += 64) key[c] = b[c];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    for (int c = lane; c < n; c += 64) {
+        const int x = key[c];
+        int rank = 0;
+        for (int y = 0; y < n; ++y) {
+            const int ky = key[y];
+            rank += (ky < x) || (ky == x && y < c);
+        }
+        srt[rank] = x;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
     int m = 0;
-    for (int i = 0; i < n; ++i)
-        if (i == 0 || b[i] != b[i - 1]) b[m++] = b[i];
-    p.ucnt[node] = m;
+    for (int base = 0; base < n; base += 64) {
+        const int c = base + lane;
+        const bool keep = c < n && (c == 0 || srt[c - 1] != srt[c]);
+        const unsigned long long mask = __ballot(keep);
+        if (keep) b[m + __builtin_popcountll(mask & ((1ull << lane) - 1ull))] = srt[c];
+        m += __builtin_popcountll(mask);
+    }
+    if (lane == 0) p.ucnt[node] = m;
 }
 
 // chain the per-graph totals into edge_ptr (one workgroup)
@@ -221,7 +304,12 @@ hipError_t launch_graph_build(const GbParams& p, hipStream_t st) {
     LAUNCH_CHECK();
     hipLaunchKernelGGL(gb_fill_kernel, dim3(nb), dim3(256), 0, st, p);
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(gb_unique_kernel, dim3(nb), dim3(256), 0, st, p);
+    {
+        int cap = 8 * p.kmax < 256 ? 256 : 8 * p.kmax;       // entries per wave held in LDS (typical bucket: <= 4 k1)
+        if (cap > 3072) cap = 3072;
+        hipLaunchKernelGGL(gb_unique_kernel, dim3((p.total_nodes + 3) / 4), dim3(256), (size_t)4 * 2 * cap * sizeof(int), st,
+                           p, cap);
+    }
     LAUNCH_CHECK();
     // per-graph totals of unique edges, chained into edge_ptr, then final per-source offsets
     hipLaunchKernelGGL(gb_scan_kernel, dim3(p.G), dim3(256), 0, st, p, (const int*)p.ucnt, p.uoff, p.gtotal,

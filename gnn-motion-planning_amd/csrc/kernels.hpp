@@ -123,6 +123,8 @@ struct MazeParams {
     const float* scores;                  // [sumE]
     const double *maps, *goal_states;     // [B, w, w], [B, 2]
     int *in_ptr, *cnt, *in_eid, *pos, *prev;
+    float* rb_val;                        // cached best live cell per explored row (value, column, edge id)
+    int *rb_src, *rb_eid;
     unsigned char* alive;
     int *success, *n_explored, *explored, *n_pairs, *explored_edges, *path_len, *path;
     long long* checks;

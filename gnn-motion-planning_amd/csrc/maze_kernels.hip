@@ -33,11 +33,28 @@ __device__ __forceinline__ float f_mul(float x, float y) { return x * y; }
 __device__ __forceinline__ float f_div(float x, float y) { return x / y; }        // correctly rounded (hipcc default)
 __device__ __forceinline__ float f_sqrt(float x) { return __builtin_sqrtf(x); }   // correctly rounded (hipcc default)
 
+constexpr int kMazeLdsCells = 4096;      // maps up to 64 x 64 are staged into LDS as bytes
+
 struct MazeCtx {
-    const double* map;      // [w, w] occupancy (1 = obstacle), row-major map[x][y]
+    const double* map;          // [w, w] occupancy (1 = obstacle), row-major map[x][y]
+    const unsigned char* occ;   // LDS copy (1 = obstacle) or nullptr for maps beyond kMazeLdsCells
     int w;
     long long checks;
 };
+
+// all lanes of the wave: stage the problem's map into LDS
+__device__ __forceinline__ void maze_ctx_init(MazeCtx& m, const double* map, int w, unsigned char* lds, int lane) {
+    m.map = map;
+    m.w = w;
+    m.checks = 0;
+    m.occ = nullptr;
+    if (w * w <= kMazeLdsCells) {
+        for (int i = lane; i < w * w; i += 64) lds[i] = map[i] == 0.0 ? 0 : 1;
+        m.occ = lds;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
 
 __device__ __forceinline__ int maze_cell(float x, int w) {        // ((x + 1.0) * w / 2.0).astype(int), clipped at w-1
     const float t = f_div(f_mul(f_add(x, 1.0f), (float)w), 2.0f);
@@ -50,7 +67,8 @@ __device__ __forceinline__ bool maze_valid(float x, float y) { return x >= -1.0f
 __device__ __forceinline__ bool maze_state_fp(MazeCtx& m, float x, float y) {
     if (!maze_valid(x, y)) return false;
     m.checks += 1;
-    return m.map[maze_cell(x, m.w) * m.w + maze_cell(y, m.w)] == 0.0;
+    const int idx = maze_cell(x, m.w) * m.w + maze_cell(y, m.w);
+    return m.occ ? m.occ[idx] == 0 : m.map[idx] == 0.0;
 }
 
 // iterative form of the recursive bisection (left half first, stop at the first blocked midpoint)
@@ -114,10 +132,21 @@ __global__ __launch_bounds__(64) void maze_explore_kernel(MazeParams p) {
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
-    if (lane == 0) {
-        int run = 0;
-        for (int i = 0; i < N; ++i) { in_ptr[i] = run; run += cnt[i]; cnt[i] = 0; }
-        in_ptr[N] = run;
+    {
+        int run = 0;                                                       // wave-wide exclusive scan, 64 rows a time
+        for (int base = 0; base < N; base += 64) {
+            const int i = base + lane;
+            const int c = i < N ? cnt[i] : 0;
+            int incl = c;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int t = __shfl_up(incl, off, 64);
+                if (lane >= off) incl += t;
+            }
+            if (i < N) { in_ptr[i] = run + incl - c; cnt[i] = 0; }
+            run += __shfl(incl, 63, 64);
+        }
+        if (lane == 0) in_ptr[N] = run;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
@@ -128,36 +157,63 @@ __global__ __launch_bounds__(64) void maze_explore_kernel(MazeParams p) {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
 
+    __shared__ unsigned char occ_lds[kMazeLdsCells];
     MazeCtx m;
-    m.map = p.maps + (size_t)b * p.w * p.w;
-    m.w = p.w;
-    m.checks = 0;
+    maze_ctx_init(m, p.maps + (size_t)b * p.w * p.w, p.w, occ_lds, lane);
     const double gx = p.goal_states[2 * b], gy = p.goal_states[2 * b + 1];
     int n_expl = 1, n_pairs = 1, success = 0, path_len = 0;
     if (lane == 0) { explored[0] = 0; pos[0] = 0; prev[0] = 0; ee[0] = 0; ee[1] = 0; }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
 
+    // Cached best live cell of every explored row i: (value, column, edge id), first maximum in column order.
+    // A row's best only changes when that very cell dies -- its column gets explored, or the edge is found
+    // blocked -- so a step rescans one to three rows instead of the whole frontier.
+    float* rb_val = p.rb_val + n0;
+    int* rb_src = p.rb_src + n0;
+    int* rb_eid = p.rb_eid + n0;
+    auto rescan = [&](int i) {
+        const int a = explored[i];
+        float bv = -INFINITY;
+        int bb = 0x7fffffff, be = -1;
+        for (int q = in_ptr[a] + lane; q < in_ptr[a + 1]; q += 64) {
+            const int e = in_eid[q];
+            if (!alive[e]) continue;
+            const int s = (int)src[e];
+            if (pos[s] >= 0) continue;                                     // column already explored
+            const float val = sc[e];
+            if (val > bv || (val == bv && s < bb)) { bv = val; bb = s; be = e; }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float ov = __shfl_xor(bv, off, 64);
+            const int ob = __shfl_xor(bb, off, 64), oe = __shfl_xor(be, off, 64);
+            if (oe >= 0 && (be < 0 || ov > bv || (ov == bv && ob < bb))) { bv = ov; bb = ob; be = oe; }
+        }
+        if (lane == 0) { rb_val[i] = bv; rb_src[i] = bb; rb_eid[i] = be; }
+    };
+    auto sync = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    };
+    rescan(0);
+    sync();
+
     while (true) {
-        // ---- argmax over live cells of explored rows: key (value desc, row position asc, column asc)
+        // ---- argmax over the cached row maxima: key (value desc, row position asc); the column is the row's own
         float bv = -INFINITY;
         int bp = 0x7fffffff, bb = 0x7fffffff, be = -1;
-        for (int i = 0; i < n_expl; ++i) {
-            const int a = explored[i];
-            for (int q = in_ptr[a] + lane; q < in_ptr[a + 1]; q += 64) {
-                const int e = in_eid[q];
-                if (!alive[e]) continue;
-                const int s = (int)src[e];
-                if (pos[s] >= 0) continue;                                 // column already explored
-                const float val = sc[e];
-                if (val > bv || (val == bv && (i < bp || (i == bp && s < bb)))) { bv = val; bp = i; bb = s; be = e; }
-            }
+        for (int i = lane; i < n_expl; i += 64) {
+            const int e = rb_eid[i];
+            if (e < 0) continue;
+            const float val = rb_val[i];
+            if (val > bv || (val == bv && i < bp)) { bv = val; bp = i; bb = rb_src[i]; be = e; }
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             const float ov = __shfl_xor(bv, off, 64);
             const int op = __shfl_xor(bp, off, 64), ob = __shfl_xor(bb, off, 64), oe = __shfl_xor(be, off, 64);
-            const bool take = (oe >= 0) && (be < 0 || ov > bv || (ov == bv && (op < bp || (op == bp && ob < bb))));
+            const bool take = (oe >= 0) && (be < 0 || ov > bv || (ov == bv && op < bp));
             if (take) { bv = ov; bp = op; bb = ob; be = oe; }
         }
         if (be < 0) break;                                                 // nothing left on the frontier
@@ -181,12 +237,24 @@ __global__ __launch_bounds__(64) void maze_explore_kernel(MazeParams p) {
         n_pairs += 2;
         free_edge = __shfl(free_edge, 0, 64);
         goal = __shfl(goal, 0, 64);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-        __builtin_amdgcn_wave_barrier();
+        sync();
         if (free_edge) {
             ++n_expl;
             if (goal) { success = 1; break; }
+            // column nb is gone: every row whose cached best sat in it looks again; the new row is scanned
+            for (int base = 0; base < n_expl - 1; base += 64) {
+                const int i = base + lane;
+                unsigned long long stale = __ballot(i < n_expl - 1 && rb_eid[i] >= 0 && rb_src[i] == nb);
+                while (stale) {
+                    rescan(base + __builtin_ctzll(stale));
+                    stale &= stale - 1;
+                }
+            }
+            rescan(n_expl - 1);
+        } else {
+            rescan(bp);                                                    // cell (a, nb) died
         }
+        sync();
     }
     if (lane == 0) {
         if (success) {                                                     // back-track prev[] to the start node
@@ -236,13 +304,10 @@ __global__ __launch_bounds__(64) void maze_steer_kernel(MazeSteerParams p) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
     const int K = (int)ceilf(mx);
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    if (lane != 0 || P < 3) return;
+    __shared__ unsigned char occ_lds[kMazeLdsCells];
     MazeCtx m;
-    m.map = p.maps + (size_t)b * p.w * p.w;
-    m.w = p.w;
-    m.checks = 0;
+    maze_ctx_init(m, p.maps + (size_t)b * p.w * p.w, p.w, occ_lds, lane);      // includes the fence + barrier
+    if (lane != 0 || P < 3) return;
     for (int r = 0; r < K; ++r) {
         float diff = 0.0f;
         nxt[0] = cur[0]; nxt[1] = cur[1];

@@ -74,10 +74,15 @@ class Maze2D:
         return (free, rejected) if need_negative else free
 
     def sample_n_points_fast(self, n, need_negative=False):
+        """List form of :meth:`sample_n_points_arrays` (same return type as :meth:`sample_n_points`)."""
+        free, rej = self.sample_n_points_arrays(n)
+        return (list(free), list(rej)) if need_negative else list(free)
+
+    def sample_n_points_arrays(self, n):
         """Same samples, same collision-check count and same final state of the global numpy RNG as
         :meth:`sample_n_points`, but vectorised: draws are made in blocks, classified with one grid lookup,
         and the generator is then rewound and advanced by exactly the number of draws the one-by-one loop
-        would have consumed (two doubles per attempt)."""
+        would have consumed (two doubles per attempt).  Returns (free [n, 2], rejected [m, 2]) float64."""
         state = np.random.get_state()
         block = max(2 * n, 64)
         while True:
@@ -96,10 +101,7 @@ class Maze2D:
         pts = np.random.uniform(-LIMITS, LIMITS, (used, 2))          # consume exactly `used` attempts
         free_mask = free_mask[:used]
         self.collision_check_count += used
-        free = [pts[i] for i in np.flatnonzero(free_mask)]
-        if not need_negative:
-            return free
-        return free, [pts[i] for i in np.flatnonzero(~free_mask)]
+        return pts[free_mask], pts[~free_mask]
 
     # ------------------------------------------------------------------ geometry
     def distance(self, a, b):

@@ -284,7 +284,7 @@ def eval_gnn(env, indexes, model, model_s, seed=1234, smooth=True, batch=500, t_
 # batched explore stage with everything but the sampling on the device (2-D mazes)
 # --------------------------------------------------------------------------------------------------
 @torch.no_grad()
-def explore_maze_batch(problems, model, device, batch=500, k=30, loop=5, model_s=None, smooth_iters=5):
+def explore_maze_batch(problems, model, device, batch=500, k=30, loop=5, model_s=None, smooth_iters=5, timings=None):
     """Many 2-D maze problems at once: sampling on the host (the reference's numpy RNG
     stream, one problem after the other), then -- in ONE pass on the device -- kNN graphs
     (graph_kernels.hip), explorer forward (batched), greedy expansion + collision checks
@@ -292,8 +292,18 @@ def explore_maze_batch(problems, model, device, batch=500, k=30, loop=5, model_s
     (smoother.py:233-246: ``smooth_iters`` x (batched smoother forward, collision-checked steering on
     the device)).  ``problems``: list of dicts(map [w, w], init_state, goal_state).
     Covers the reference's default single-forward case (batch == t_max); returns one
-    result dict per problem with the fields of ``explore`` (``smooth_path`` / ``c_smooth`` with ``model_s``)."""
+    result dict per problem with the fields of ``explore`` (``smooth_path`` / ``c_smooth`` with ``model_s``).
+    ``timings``: optional dict that receives wall-clock seconds per stage (adds device syncs)."""
     import ctypes
+
+    def mark(name, t_prev):
+        if timings is None:
+            return t_prev
+        torch.cuda.synchronize()
+        now = time.perf_counter()
+        timings[name] = timings.get(name, 0.) + now - t_prev
+        return now
+    tm = time.perf_counter()
     from . import _lib
     from .batch import GraphBatch
     from .graph_build import build_edges_gpu, k1_of
@@ -302,21 +312,23 @@ def explore_maze_batch(problems, model, device, batch=500, k=30, loop=5, model_s
     for pr in problems:
         env = Maze2D(np.asarray(pr['map'])[None], np.asarray(pr['init_state'])[None], np.asarray(pr['goal_state'])[None])
         env.init_new_problem(0)
-        free, coll = env.sample_n_points_fast(batch, need_negative=True)      # same stream as sample_n_points
-        coll = coll[:len(free)]
-        free = [env.init_state] + [env.goal_state] + list(free)
-        vf = torch.tensor(np.asarray(free), dtype=torch.float32)
-        vc = torch.tensor(np.asarray(coll), dtype=torch.float32).reshape(-1, 2)
+        free, coll = env.sample_n_points_arrays(batch)                        # same stream as sample_n_points
+        coll = coll[:len(free)]                                               # eval_gnn.py:182 (before init / goal join)
+        nf = len(free) + 2
+        vrows = np.concatenate((np.asarray(env.init_state, dtype=np.float64).reshape(1, 2),
+                                np.asarray(env.goal_state, dtype=np.float64).reshape(1, 2), free, coll)).astype(np.float32)
         envs.append(env)
-        vs.append(torch.cat((vf, vc), dim=0))
-        n_free.append(len(free))
-        k1s.append(k1_of(k, len(free)))
+        vs.append(torch.from_numpy(vrows))
+        n_free.append(nf)
+        k1s.append(k1_of(k, nf))
+    tm = mark('host_sampling', tm)
     B = len(problems)
     ptr = torch.zeros(B + 1, dtype=torch.int64)
     ptr[1:] = torch.tensor([x.shape[0] for x in vs]).cumsum(0)
     node_ptr = ptr.to(torch.int32).to(device)
     v = torch.cat(vs).to(device)
     ei, edge_ptr = build_edges_gpu(v, node_ptr, n_free, k1s)
+    tm = mark('graph_build', tm)
     obs = [torch.tensor(np.asarray(e.obstacles), dtype=torch.float32).reshape(-1, 2) for e in envs]
     optr = torch.zeros(B + 1, dtype=torch.int64)
     optr[1:] = torch.tensor([o.shape[0] for o in obs]).cumsum(0)
@@ -324,6 +336,7 @@ def explore_maze_batch(problems, model, device, batch=500, k=30, loop=5, model_s
     gb = GraphBatch(v, goals, torch.cat(obs).to(device), ei, node_ptr, edge_ptr, optr.to(torch.int32).to(device),
                     max(o.shape[0] for o in obs))
     scores = model.forward_batch(gb, loop)
+    tm = mark('explorer_forward', tm)
     w = int(np.asarray(problems[0]['map']).shape[0])
     maps = torch.tensor(np.asarray([np.asarray(pr['map'], dtype=np.float64) for pr in problems])).to(device)
     goal64 = torch.tensor(np.asarray([e.goal_state for e in envs], dtype=np.float64)).to(device)
@@ -344,25 +357,34 @@ def explore_maze_batch(problems, model, device, batch=500, k=30, loop=5, model_s
                                                  n_pairs.data_ptr(), ee.data_ptr(), plen.data_ptr(), path.data_ptr(),
                                                  checks.data_ptr(), ws.data_ptr(), ws.numel(), st), 'gnnmp_maze_explore')
     success, n_expl, n_pairs, plen, checks = (t.cpu().tolist() for t in (success, n_expl, n_pairs, plen, checks))
-    expl, ee, path = expl.cpu().numpy(), ee.cpu().numpy(), path.cpu().numpy()
     nptr, eptr = ptr.tolist(), edge_ptr.cpu().tolist()
+    # the pair list has room for 2E + 1 pairs per problem but holds a few hundred: compact it on the device
+    ee_off = np.zeros(B + 1, dtype=np.int64)
+    ee_off[1:] = np.cumsum([2 * n for n in n_pairs])
+    take = np.concatenate([np.arange(2 * (2 * eptr[b] + b), 2 * (2 * eptr[b] + b) + 2 * n_pairs[b], dtype=np.int64)
+                           for b in range(B)])
+    ee = ee[torch.from_numpy(take).to(device)].cpu().numpy()
+    expl, path = expl.cpu().numpy(), path.cpu().numpy()
+    tm = mark('greedy_explore', tm)
     smoothed = {}
     if model_s is not None and any(success):
         smoothed = _smooth_maze_batch(model_s, [b for b in range(B) if success[b]], v, nptr, n_free, path, plen, maps, w,
                                       smooth_iters, device)
+        tm = mark('smoothing', tm)
     out = []
+    vs_np = [x.numpy() for x in vs]
     for b in range(B):
-        o = 2 * (2 * eptr[b] + b)
         nodes = path[nptr[b]:nptr[b] + plen[b]]
-        # sampling cost the host b*... checks already (rejection sampling); the device count is the greedy loop's
-        out.append({'success': bool(success[b]), 'explored': expl[nptr[b]:nptr[b] + n_expl[b]].tolist(),
-                    'explored_edges': ee[o:o + 2 * n_pairs[b]].reshape(-1, 2).tolist(),
+        # results stay numpy arrays (explored [n], explored_edges [m, 2], path [P, 2]): building Python lists for
+        # hundreds of problems costs more than the device pass itself
+        out.append({'success': bool(success[b]), 'explored': expl[nptr[b]:nptr[b] + n_expl[b]],
+                    'explored_edges': ee[ee_off[b]:ee_off[b + 1]].reshape(-1, 2),
                     'c_explore': envs[b].collision_check_count + int(checks[b]),
-                    'path': [vs[b][i].numpy() for i in nodes], 'free': None, 'env': envs[b], 'v': vs[b],
-                    'n_free': n_free[b]})
+                    'path': vs_np[b][nodes], 'free': None, 'env': envs[b], 'v': vs[b], 'n_free': n_free[b]})
         if model_s is not None:
-            sp, cs = smoothed.get(b, ([], 0))
+            sp, cs = smoothed.get(b, (np.zeros((0, 2), dtype=np.float32), 0))
             out[-1].update(smooth_path=sp, c_smooth=cs)
+    mark('results', tm)
     return out
 
 
@@ -401,6 +423,6 @@ def _smooth_maze_batch(model_s, sel, v, nptr, n_free, path, plen, maps, w, iters
     final, checks = sb.path.cpu().numpy(), checks.cpu().tolist()
     res, o = {}, 0
     for i, b in enumerate(sel):
-        res[b] = ([final[o + q].copy() for q in range(plen[b])], int(checks[i]))
+        res[b] = (final[o:o + plen[b]], int(checks[i]))
         o += plen[b]
     return res

@@ -92,3 +92,16 @@ def test_feeds_the_explorer():
     s = m.edge_scores(g['goal'].to(DEV), 5, g['v'].to(DEV), g['obstacles'].to(DEV), ei).cpu()
     ref = ref_cpu.explorer_forward(load_weights('weights_maze'), g['v'], g['goal'], g['obstacles'], g['edge_index'], 5)
     assert torch.allclose(s, ref, rtol=1e-5, atol=2e-5)
+
+
+def test_hub_bucket_beyond_lds_share_and_large_graphs():
+    """(a) a hub that is the nearest neighbour of every other node: its per-source bucket (N entries) exceeds the
+    wave's LDS share in gb_unique (cap = 256 at k1 = 2) and takes the in-place fallback; (b) graphs of 1500 and
+    2500 nodes: the 32-per-lane register cache and the general recomputing path of gb_knn."""
+    gen = torch.Generator().manual_seed(21)
+    x = torch.randn(600, 7, generator=gen)
+    x = x / x.norm(dim=1, keepdim=True)            # points on the unit sphere: pairwise ~ sqrt(2), hub at distance 1
+    x[5] = 0.0
+    _check([x, torch.rand(50, 7, generator=gen)], [400, 20], [2, 3])
+    _check([torch.rand(1500, 2, generator=gen) * 2 - 1], [700], [5])
+    _check([torch.rand(2500, 3, generator=gen) * 2 - 1], [1200], [4])

@@ -72,8 +72,8 @@ def test_device_explore_equals_host_counterpart_step_by_step():
                            obstacles=od['obstacles']).cpu().numpy()
         state = {'explored': [0], 'explored_edges': [[0, 0]], 'costs': {0: 0.}, 'prev': {0: 0}}
         path = planner.greedy_expand_sparse(sc, data['edge_index'].numpy(), data['labels'].numpy(), data['v'].numpy(), env, state)
-        assert d['explored'] == state['explored']
-        assert d['explored_edges'] == state['explored_edges']
+        assert d['explored'].tolist() == state['explored']
+        assert d['explored_edges'].tolist() == state['explored_edges']
         assert d['success'] == (path is not None)
         if path is not None:
             assert [tuple(x) for x in d['path']] == [tuple(data['v'][j].numpy()) for j in path]
@@ -129,7 +129,7 @@ def test_device_smoothing_equals_host_steering_bitwise():
         free = [x for x in v[:n_free]]
         coll = [x for x in v[n_free:]]
         c0 = env.collision_check_count
-        host = planner.model_smooth(ms, free, coll, [p.copy() for p in d['path']], env, DEV)
+        host = planner.model_smooth(ms, free, coll, [p.copy() for p in d['path']], env, DEV)      # list of float32 rows
         c_host = env.collision_check_count - c0
         assert len(host) == len(d['smooth_path'])
         assert all(np.array_equal(a, b) for a, b in zip(host, d['smooth_path'])), \

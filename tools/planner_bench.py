@@ -54,6 +54,9 @@ def main():
         res = planner.explore_maze_batch(probs, m, dev, batch=a.batch, k=a.k, model_s=sm)
         torch.cuda.synchronize()
         wall = time.perf_counter() - t0
+        tms = {}
+        np.random.seed(1234)
+        planner.explore_maze_batch(probs, m, dev, batch=a.batch, k=a.k, model_s=sm, timings=tms)     # second pass with syncs
         out = {'problems': a.problems, 'success': sum(int(x['success']) for x in res),
                'stage': 'explore + smoothing (whole planner)' if sm else 'explore only (no smoothing)',
                'problems_per_s': round(a.problems / wall, 2), 's_per_problem': round(wall / a.problems, 5),
@@ -61,7 +64,8 @@ def main():
                'host_cores_used': 1, 'host_work': 'rejection sampling only (vectorised, same numpy stream)',
                'device_work': 'kNN graphs, explorer forward, greedy frontier, collision checks' +
                               (', 5 x (smoother forward, steering)' if sm else ''),
-               'config': 'maze2 hard, batch=%d, k=%d' % (a.batch, a.k)}
+               'config': 'maze2 hard, batch=%d, k=%d' % (a.batch, a.k),
+               'stage_ms_per_problem': {k_: round(1e3 * v_ / a.problems, 4) for k_, v_ in tms.items()}}
         if sm:
             out['collision_checks_total'] = round(sum(x['c_explore'] + x['c_smooth'] for x in res) / a.problems, 2)
             out['path_cost'] = round(float(np.mean([planner.path_cost(x['smooth_path']) for x in res if x['success']])), 4)
