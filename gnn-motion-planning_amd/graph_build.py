@@ -91,14 +91,22 @@ def build_edges_gpu(v, node_ptr, n_free, k1):
     need = ctypes.c_size_t()
     _lib.check(_lib.lib().gnnmp_graph_workspace_bytes(ctypes.byref(b), ctypes.byref(need)), 'gnnmp_graph_workspace_bytes')
     ws = torch.empty(need.value, dtype=torch.uint8, device=dev)
-    cap = 4 * max(kmax, 1) * max(total, 1)
-    out = torch.empty((2, cap), dtype=torch.int64, device=dev)
+    # 4 k1 N columns is the no-duplicate worst case; kNN graphs coalesce to ~1.4 k1 N, so start with 1.7 k1 N and
+    # repeat with the exact size in the rare case that was not enough (the kernels never write past `cap` and
+    # edge_ptr always reports the true total)
+    worst = 4 * max(kmax, 1) * max(total, 1)
+    cap = min(worst, int(1.7 * max(kmax, 1) * max(total, 1)) + 4096)
     edge_ptr = torch.zeros(G + 1, dtype=torch.int32, device=dev)
-    with torch.cuda.device(dev):
-        st = torch.cuda.current_stream().cuda_stream
-        _lib.check(_lib.lib().gnnmp_graph_build(ctypes.byref(b), out.data_ptr(), cap, edge_ptr.data_ptr(), ws.data_ptr(),
-                                                ws.numel(), st), 'gnnmp_graph_build')
-    n_edges = int(edge_ptr[-1].item())               # one scalar read-back: the caller needs the size
+    while True:
+        out = torch.empty((2, cap), dtype=torch.int64, device=dev)
+        with torch.cuda.device(dev):
+            st = torch.cuda.current_stream().cuda_stream
+            _lib.check(_lib.lib().gnnmp_graph_build(ctypes.byref(b), out.data_ptr(), cap, edge_ptr.data_ptr(), ws.data_ptr(),
+                                                    ws.numel(), st), 'gnnmp_graph_build')
+        n_edges = int(edge_ptr[-1].item())           # one scalar read-back: the caller needs the size
+        if n_edges <= cap:
+            break
+        cap = n_edges
     return out[:, :n_edges].contiguous(), edge_ptr
 
 

@@ -21,6 +21,41 @@ RRT_EPS = 5e-2                       # environment/env_config.py:3
 LIMITS = np.array([1.0, 1.0])        # environment/env_config.py:5 (first two entries)
 
 
+class AttemptStream:
+    """Look-ahead over the global numpy RNG for a SEQUENCE of problems sampled back to back: attempts are drawn in
+    large blocks and handed out in order, so consumers see exactly the values one-by-one ``uniform_sample`` calls
+    would have produced; :meth:`close` puts the global generator into the state it would have had (rewind to the
+    start, advance by the attempts actually consumed).  Saves the per-problem get_state / set_state round trips
+    (~0.2 ms each) of :meth:`Maze2D.sample_n_points_arrays`."""
+
+    def __init__(self, block=1 << 15):
+        self._state0 = np.random.get_state()
+        self._block = block
+        self._buf = np.zeros((0, 2))
+        self._pos = 0
+        self.consumed = 0
+
+    def peek(self, m):
+        """The next m attempts [m, 2] (not yet consumed)."""
+        while self._buf.shape[0] - self._pos < m:
+            fresh = np.random.uniform(-LIMITS, LIMITS, (max(self._block, m), 2))
+            self._buf = np.concatenate((self._buf[self._pos:], fresh))
+            self._pos = 0
+        return self._buf[self._pos:self._pos + m]
+
+    def consume(self, m):
+        self._pos += m
+        self.consumed += m
+
+    def close(self):
+        np.random.set_state(self._state0)
+        left = self.consumed
+        while left > 0:                                       # two doubles per attempt, same order as the draws above
+            step = min(left, 1 << 20)
+            np.random.uniform(-LIMITS, LIMITS, (step, 2))
+            left -= step
+
+
 class Maze2D:
     RRT_EPS = RRT_EPS
 
@@ -100,6 +135,25 @@ class Maze2D:
         np.random.set_state(state)
         pts = np.random.uniform(-LIMITS, LIMITS, (used, 2))          # consume exactly `used` attempts
         free_mask = free_mask[:used]
+        self.collision_check_count += used
+        return pts[free_mask], pts[~free_mask]
+
+    def sample_n_points_stream(self, stream, n):
+        """:meth:`sample_n_points_arrays` on an :class:`AttemptStream` shared by consecutive problems."""
+        w = self.width
+        m = max(2 * n, 64)
+        while True:
+            pts = stream.peek(m)
+            cells = ((pts + 1.0) * w / 2.0).astype(int)
+            cells[cells > w - 1] = w - 1
+            free_mask = self.map[cells[:, 0], cells[:, 1]] == 0
+            idx = np.flatnonzero(free_mask)
+            if idx.size >= n:
+                used = int(idx[n - 1]) + 1
+                break
+            m *= 2
+        pts, free_mask = pts[:used], free_mask[:used]
+        stream.consume(used)
         self.collision_check_count += used
         return pts[free_mask], pts[~free_mask]
 

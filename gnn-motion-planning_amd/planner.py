@@ -307,12 +307,13 @@ def explore_maze_batch(problems, model, device, batch=500, k=30, loop=5, model_s
     from . import _lib
     from .batch import GraphBatch
     from .graph_build import build_edges_gpu, k1_of
-    from .maze2d import Maze2D
+    from .maze2d import AttemptStream, Maze2D
     envs, vs, n_free, k1s = [], [], [], []
+    stream = AttemptStream()
     for pr in problems:
         env = Maze2D(np.asarray(pr['map'])[None], np.asarray(pr['init_state'])[None], np.asarray(pr['goal_state'])[None])
         env.init_new_problem(0)
-        free, coll = env.sample_n_points_arrays(batch)                        # same stream as sample_n_points
+        free, coll = env.sample_n_points_stream(stream, batch)                # same stream as sample_n_points
         coll = coll[:len(free)]                                               # eval_gnn.py:182 (before init / goal join)
         nf = len(free) + 2
         vrows = np.concatenate((np.asarray(env.init_state, dtype=np.float64).reshape(1, 2),
@@ -321,6 +322,7 @@ def explore_maze_batch(problems, model, device, batch=500, k=30, loop=5, model_s
         vs.append(torch.from_numpy(vrows))
         n_free.append(nf)
         k1s.append(k1_of(k, nf))
+    stream.close()                                                            # global RNG: as if sampled one by one
     tm = mark('host_sampling', tm)
     B = len(problems)
     ptr = torch.zeros(B + 1, dtype=torch.int64)

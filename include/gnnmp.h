@@ -216,8 +216,10 @@ typedef struct {
 
 int gnnmp_graph_workspace_bytes(const gnnmp_graph_batch* shape, size_t* bytes);
 /* edge_index_out: [2, out_cap] int64 with row stride out_cap (row 0 = source, row 1 = target); graph g's
- * columns are [edge_ptr_out[g], edge_ptr_out[g+1]); out_cap >= 4 * k1_max * total_nodes (the no-duplicate
- * worst case).  edge_ptr_out: [G+1] int32 (device). */
+ * columns are [edge_ptr_out[g], edge_ptr_out[g+1]).  4 * k1_max * total_nodes columns always suffice (the
+ * no-duplicate worst case); with a smaller out_cap the columns beyond it are not written while edge_ptr_out
+ * still reports the true totals, so a caller may try an estimate and repeat with edge_ptr_out[G] columns.
+ * edge_ptr_out: [G+1] int32 (device). */
 int gnnmp_graph_build(const gnnmp_graph_batch* batch, int64_t* edge_index_out, int64_t out_cap,
                       int32_t* edge_ptr_out, void* workspace, size_t workspace_bytes, void* hip_stream);
 

@@ -105,3 +105,15 @@ def test_hub_bucket_beyond_lds_share_and_large_graphs():
     _check([x, torch.rand(50, 7, generator=gen)], [400, 20], [2, 3])
     _check([torch.rand(1500, 2, generator=gen) * 2 - 1], [700], [5])
     _check([torch.rand(2500, 3, generator=gen) * 2 - 1], [1200], [4])
+
+
+def test_small_capacity_is_retried(monkeypatch):
+    """Far fewer columns than needed on the first try (duplicate-free worst case: k1 = 1 gives only self loops, so make
+    the estimate too small by shrinking it): the builder repeats with the exact size and returns the same edges."""
+    import builtins
+    gen = torch.Generator().manual_seed(4)
+    vs = [torch.rand(1500, 2, generator=gen), torch.rand(400, 2, generator=gen)]       # ~20 k columns, first try: 4112
+    real_int = builtins.int
+    # force the first estimate down to a handful of columns
+    monkeypatch.setattr(graph_build, 'int', lambda x: 16 if isinstance(x, float) else real_int(x), raising=False)
+    _check(vs, [700, 200], [8, 6])

@@ -141,3 +141,31 @@ def test_fast_sampler_is_stream_identical():
         assert all(np.array_equal(x, y) for x, y in zip(ra, rb))
         assert a.collision_check_count == b.collision_check_count
         assert nxt_a == nxt_b
+
+
+def test_attempt_stream_equals_one_by_one_sampling():
+    """The shared look-ahead sampler hands consecutive problems exactly the samples (free and rejected), check
+    counts and final global-RNG state of the reference's one-by-one rejection loop."""
+    from gnnmp.maze2d import AttemptStream, Maze2D
+    rng = np.random.RandomState(3)
+    maps = (rng.rand(4, 15, 15) < 0.35).astype(np.float64)
+    maps[:, 7, 7] = 0
+    z = np.zeros((4, 2))
+    ref = []
+    np.random.seed(99)
+    for i in range(4):
+        env = Maze2D(maps, z, z)
+        env.init_new_problem(i)
+        free, rej = env.sample_n_points(40 + 10 * i, need_negative=True)
+        ref.append((np.array(free), np.array(rej).reshape(-1, 2), env.collision_check_count))
+    tail_ref = np.random.uniform(size=3)
+    np.random.seed(99)
+    st = AttemptStream(block=64)                    # small block: forces refills in the middle of a problem
+    for i in range(4):
+        env = Maze2D(maps, z, z)
+        env.init_new_problem(i)
+        free, rej = env.sample_n_points_stream(st, 40 + 10 * i)
+        assert np.array_equal(free, ref[i][0]) and np.array_equal(rej, ref[i][1])
+        assert env.collision_check_count == ref[i][2]
+    st.close()
+    assert np.array_equal(np.random.uniform(size=3), tail_ref)
