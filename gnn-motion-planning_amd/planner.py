@@ -280,6 +280,42 @@ def eval_gnn(env, indexes, model, model_s, seed=1234, smooth=True, batch=500, t_
             total_time_explore)
 
 
+def eval_gnn_device(env, indexes, model, model_s, seed=1234, batch=500, k=30, device='cuda', loop=5, chunk=512,
+                    rows_out=None):
+    """:func:`eval_gnn` for 2-D maze environments with the planner itself on the device
+    (:func:`explore_maze_batch`, ``chunk`` problems per device pass): same return tuple as ``eval_gnn``
+    (eval_gnn.py:96-145), same per-problem decisions and collision-check counts as the one-by-one loop at the
+    reference's default configuration (smoothing on, batch == t_max: one explorer forward per problem).
+    The time entries are the batch wall time spread evenly over the problems of a chunk.  ``rows_out``: optional
+    list that receives one (success, path cost, smoothed cost, c_explore, c_smooth, path length, explored) per problem."""
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    indexes = list(indexes)
+    sol, paths, smooth_paths = [], [], []
+    for c0 in range(0, len(indexes), chunk):
+        idx = indexes[c0:c0 + chunk]
+        problems = [dict(map=env.maps[i], init_state=env.init_states[i], goal_state=env.goal_states[i]) for i in idx]
+        tm = {}
+        t0 = time.perf_counter()
+        res = explore_maze_batch(problems, model, device, batch=batch, k=k, loop=loop, model_s=model_s, timings=tm)
+        wall = (time.perf_counter() - t0) / len(idx)
+        t_explore = wall - tm.get('smoothing', 0.) / len(idx)
+        for r in res:
+            paths.append(r['path'] if r['success'] else [])
+            smooth_paths.append(r['smooth_path'] if r['success'] else [])
+            sol.append((r['success'], path_cost(paths[-1]), path_cost(smooth_paths[-1]), r['c_explore'], r['c_smooth'],
+                        wall, t_explore))
+            if rows_out is not None:
+                rows_out.append(sol[-1][:5] + (len(paths[-1]), len(r['explored'])))
+    n_success = sum(s[0] for s in sol)
+    collision_explore = float(np.mean([s[3] for s in sol]))
+    collision = float(np.mean([s[3] + s[4] for s in sol]))
+    running_time = float(sum(s[5] for s in sol if s[0])) / max(n_success, 1)
+    solution_cost = float(sum(s[2] for s in sol if s[0])) / max(n_success, 1)
+    return (n_success, collision, running_time, solution_cost, sum(s[5] for s in sol), paths, smooth_paths,
+            collision_explore, sum(s[6] for s in sol))
+
+
 # --------------------------------------------------------------------------------------------------
 # batched explore stage with everything but the sampling on the device (2-D mazes)
 # --------------------------------------------------------------------------------------------------

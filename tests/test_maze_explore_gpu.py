@@ -22,7 +22,7 @@ def _models():
 
 
 def test_device_explore_matches_reference_outcomes():
-    with np.load(golden_files('evalset_')[0]) as f:
+    with np.load(golden_files('evalset_mazehard_first12')[0]) as f:
         r = {k: f[k] for k in f.files}
     n = r['rows'].shape[0]
     problems = [dict(map=r['maps'][i], init_state=r['init_states'][i], goal_state=r['goal_states'][i]) for i in range(n)]
@@ -42,7 +42,7 @@ def test_device_explore_matches_reference_outcomes():
 def test_device_explore_equals_host_counterpart_step_by_step():
     """Same problems through planner.explore (host frontier + host collision checker): identical explored
     order, identical explored_edges list (incl. the initial [0, 0]), identical path."""
-    with np.load(golden_files('evalset_')[0]) as f:
+    with np.load(golden_files('evalset_mazehard_first12')[0]) as f:
         r = {k: f[k] for k in f.files}
     idx = [0, 3, 5]
     m = _models()
@@ -89,7 +89,7 @@ def _smoother():
 def test_device_smoothing_matches_reference_outcomes():
     """Whole planner on the device (explore + 5 x (smoother forward, collision-checked steering)): per-problem
     collision-check counts of BOTH stages and the smoothed path cost against the reference planner's own run."""
-    with np.load(golden_files('evalset_')[0]) as f:
+    with np.load(golden_files('evalset_mazehard_first12')[0]) as f:
         r = {k: f[k] for k in f.files}
     n = r['rows'].shape[0]
     problems = [dict(map=r['maps'][i], init_state=r['init_states'][i], goal_state=r['goal_states'][i]) for i in range(n)]
@@ -112,7 +112,7 @@ def test_device_smoothing_equals_host_steering_bitwise():
     """Device steering against planner.model_smooth (host steering with the Maze2D checker, same GPU smoother
     network): identical waypoints bit for bit and identical collision-check counts, on real solved problems and
     on a batch with a two-waypoint path (nothing to steer)."""
-    with np.load(golden_files('evalset_')[0]) as f:
+    with np.load(golden_files('evalset_mazehard_first12')[0]) as f:
         r = {k: f[k] for k in f.files}
     idx = [0, 2, 4, 8, 9]
     m, ms = _models(), _smoother()

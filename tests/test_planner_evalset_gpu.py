@@ -19,7 +19,7 @@ DEV = 'cuda:0'
 @pytest.mark.parametrize('sparse,gpu_graph', [(False, False), (True, False), (True, True)],
                          ids=['dense_dropin', 'sparse_frontier', 'sparse_frontier_device_graph'])
 def test_eval_set_matches_reference(sparse, gpu_graph):
-    with np.load(golden_files('evalset_')[0]) as f:
+    with np.load(golden_files('evalset_mazehard_first12')[0]) as f:
         r = {k: f[k] for k in f.files}
     env = Maze2D(r['maps'], r['init_states'], r['goal_states'])
     m = gnnmp.EncoderProcessDecoder(2, 2, 32, 2)

@@ -237,7 +237,8 @@ def eval_set_case(n_problems=12):
         print('  problem %d: success=%d c_explore=%d c_smooth=%d explored=%d (%.1f s)' %
               (idx, r['success'], r['c_explore'], r['c_smooth'], len(r['explored']), _t.time() - t0))
     np.savez_compressed(os.path.join(OUT, 'evalset_mazehard_first%d.npz' % n_problems),
-                        maps=env.maps[:n_problems].copy(), init_states=env.init_states[:n_problems].copy(),
+                        maps=env.maps[:n_problems].copy().astype(np.float64 if n_problems <= 100 else np.uint8),
+                        init_states=env.init_states[:n_problems].copy(),
                         goal_states=env.goal_states[:n_problems].copy(), seed=1234, batch=500, t_max=500, k=30,
                         rows=np.array(rows, dtype=np.float64),
                         columns=np.array(['success', 'path_cost', 'smooth_cost', 'c_explore', 'c_smooth', 'path_len', 'explored']))
@@ -275,6 +276,6 @@ if __name__ == '__main__':
         planner_cases({'maze2': save_weights('weights_maze')})
     elif len(sys.argv) > 1 and sys.argv[1] == 'evalset':
         torch.set_num_threads(8)
-        eval_set_case()
+        eval_set_case(int(sys.argv[2]) if len(sys.argv) > 2 else 12)
     else:
         main()

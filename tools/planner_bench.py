@@ -34,7 +34,7 @@ def main():
     ap.add_argument('--batch', type=int, default=500)
     ap.add_argument('--k', type=int, default=30)
     a = ap.parse_args()
-    with np.load(golden_files('evalset_')[0]) as f:
+    with np.load(golden_files('evalset_mazehard_first12')[0]) as f:
         maps, init, goal = f['maps'], f['init_states'], f['goal_states']
     env = Maze2D(maps, init, goal)
     dev = 'cuda:0'

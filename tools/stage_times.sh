@@ -1,5 +1,6 @@
 #!/bin/bash
-# perf experiments on the GPU box: stage times of the headline workload and of the cfg-3 shape
+# per-stage times (HIP events inside bench.py) of the headline workload and of the cfg-3 shape, fp32 and bf16;
+# run on the GPU box:  gpurun -- 'bash tools/stage_times.sh'
 cd $GRAFT_REPO_ROOT
 show() { tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d['value'],1), d['config']['stage_ms_per_step'], d['config']['result_checksum'])"; }
 timeout 300 python bench.py --no-cpu-baseline --pcie-steps 0 --dense-steps 0 2>&1 | show
