@@ -165,7 +165,8 @@ def main():
                                     ('v', 'goal', 'obstacles', 'edge_index', 'node_ptr', 'edge_ptr', 'obs_ptr')),
                                   batch.max_obstacles)
             out_host.copy_(model.forward_batch(b2, args.loop), non_blocking=True)
-        step_e2e()
+        for _ in range(3):                               # first touches of the pinned buffers / allocator growth
+            step_e2e()
         torch.cuda.synchronize(dev)
         t1 = time.perf_counter()
         for _ in range(args.pcie_steps):
