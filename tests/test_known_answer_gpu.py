@@ -56,3 +56,22 @@ def test_published_run_1000_problems():
     # (b) the notebook
     assert n_success == PUBLISHED['success']
     assert abs(collision_explore - PUBLISHED['collision_explore']) <= 0.001 * PUBLISHED['collision_explore']
+
+
+def test_sharded_evaluation_equals_sequential():
+    """Two shards (rank 0 / rank 1 of 2, run one after the other here) of the first 64 problems: the union of the
+    per-problem rows equals the single-process run (the skipped sampling puts each shard at the right RNG position)."""
+    path = os.path.join(GOLDEN, 'evalset_mazehard_first1000.npz')
+    with np.load(path) as f:
+        r = {k: f[k] for k in f.files}
+    env = Maze2D(r['maps'], r['init_states'], r['goal_states'])
+    m = gnnmp.EncoderProcessDecoder(2, 2, 32, 2)
+    m.load_state_dict(load_weights('weights_maze'))
+    ms = gnnmp.ModelSmoother(workspace_size=2, config_size=2, embed_size=128, obs_size=6)
+    ms.load_state_dict(load_weights('smooth_2d_attv3'))
+    whole, parts = [], []
+    planner.eval_gnn_device(env, range(64), m, ms, device=DEV, rows_out=whole)
+    for rank in range(2):
+        planner.eval_gnn_device(env, range(64), m, ms, device=DEV, rows_out=parts, shard=(rank, 2))
+    assert len(parts) == 64
+    assert np.array_equal(np.array(whole), np.array(parts))

@@ -169,3 +169,24 @@ def test_attempt_stream_equals_one_by_one_sampling():
         assert env.collision_check_count == ref[i][2]
     st.close()
     assert np.array_equal(np.random.uniform(size=3), tail_ref)
+
+
+def test_skip_maze_sampling_reaches_the_sequential_stream_position():
+    """Sharded evaluation: skipping the sampling of problems [0, lo) leaves the global RNG where the sequential
+    planner loop would be when it starts problem lo."""
+    from gnnmp.maze2d import Maze2D
+    from gnnmp import planner
+    rng = np.random.RandomState(5)
+    maps = (rng.rand(6, 15, 15) < 0.3).astype(np.float64)
+    maps[:, 0, 0] = 0
+    z = np.zeros((6, 2))
+    env = Maze2D(maps, z, z)
+    np.random.seed(1234)
+    for i in range(4):                               # the one-by-one loop through problems 0..3
+        e = Maze2D(maps, z, z)
+        e.init_new_problem(i)
+        e.sample_n_points(30, need_negative=True)
+    expect = np.random.uniform(size=4)
+    np.random.seed(1234)
+    planner.skip_maze_sampling(env, range(4), batch=30)
+    assert np.array_equal(np.random.uniform(size=4), expect)
