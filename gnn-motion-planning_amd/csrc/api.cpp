@@ -601,10 +601,10 @@ bool carve(const gnnmp_explorer* h, const gnnmp_batch* b, Carve& c) {
     c.ff_beg = o;
     c.ntile_graph = take(sizeof(int) * (c.Npad / 32));
     c.etile_graph = take(sizeof(int) * (c.Epad / 32));
+    c.tile_meta = take(sizeof(int) * (c.Epad / 32));            // -1 = tile beyond the last graph
     c.csr = take(sizeof(int) * 4 * (size_t)c.Epad);
     c.ff_end = o;
     c.row_beg = take(sizeof(int) * c.Npad);
-    c.tile_meta = take(sizeof(int) * (c.Epad / 32));
     const size_t nrow = sizeof(float) * (size_t)c.Npad * D, erow = sizeof(float) * (size_t)c.Epad * D;
     c.XI = take(nrow); c.X = take(nrow); c.A = take(nrow); c.B = take(nrow); c.DN = take(nrow); c.H = take(nrow);
     c.agg = take(nrow);

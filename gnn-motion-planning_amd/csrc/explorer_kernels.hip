@@ -87,88 +87,102 @@ __device__ __forceinline__ int find_graph(const int* __restrict__ ptr, int G, in
     return lo;
 }
 
-// graph of caller column e: one binary search per workgroup (first column), then a short walk
-__device__ __forceinline__ int find_graph_wg(const int* __restrict__ ptr, int G, int e) {
-    __shared__ int s_g0;
-    if (threadIdx.x == 0) s_g0 = find_graph(ptr, G, blockIdx.x * blockDim.x);
-    __syncthreads();
-    int g = s_g0;
-    while (g + 1 < G && e >= ptr[g + 1]) ++g;
-    return g;
-}
+// =====================================================================================================
+// prep_graph: the whole CSR-by-destination build of ONE graph in one 1024-thread workgroup (graphs are independent
+// and their caller columns contiguous): in-degree histogram + arrival rank with LDS atomics, block scan, scatter of
+// the int4 records, pad records, tile -> graph maps and the per-tile segment metadata (owner of a slot = binary
+// search in the LDS copy of row_beg).  Replaces the device-wide count / scan / fill / tilemeta passes (2.9 M global
+// returning atomics at cfg 2).  Graphs beyond kPrepCap padded nodes keep their counters in global memory
+// (same code through flat pointers).
+// =====================================================================================================
+constexpr int kPrepCap = 8192;
 
-__global__ void prep_count_kernel(int G, int E, const long long* __restrict__ edge_index, const int* __restrict__ edge_ptr,
-                                  const int* __restrict__ node_ptr_pad, int* __restrict__ deg, int* __restrict__ rank) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    const int g = find_graph_wg(edge_ptr, G, e < E ? e : E - 1);
-    if (e >= E) return;
-    const int dst = node_ptr_pad[g] + (int)edge_index[(size_t)E + e];
-    rank[e] = atomicAdd(&deg[dst], 1);        // arrival order inside the destination's segment (any order is fine:
-}                                             // max-aggregation is order-free and per-edge results do not depend on position)
-
-// one workgroup per graph: exclusive scan of deg over the graph's padded node range
-__global__ void prep_scan_kernel(const int* __restrict__ node_ptr_pad, const int* __restrict__ edge_ptr_pad,
-                                 const int* __restrict__ deg, int* __restrict__ row_beg,
-                                 int* __restrict__ ntile_graph, int* __restrict__ etile_graph) {
-    __shared__ int s[256];
+__global__ __launch_bounds__(1024) void prep_graph_kernel(PrepParams q) {
+    extern __shared__ int prep_lds[];                  // cnt[kPrepCap], rb[kPrepCap], scan[1024]
     __shared__ int carry;
     const int g = blockIdx.x, tid = threadIdx.x;
-    const int n0 = node_ptr_pad[g], n1 = node_ptr_pad[g + 1];
-    const int e0 = edge_ptr_pad[g], e1 = edge_ptr_pad[g + 1];
+    const int n0 = q.node_ptr_pad[g], Np = q.node_ptr_pad[g + 1] - n0;
+    const int c0 = q.edge_ptr[g], Eg = q.edge_ptr[g + 1] - c0;            // caller columns of this graph
+    const int e0 = q.edge_ptr_pad[g], e1 = q.edge_ptr_pad[g + 1];
+    const bool in_lds = Np <= kPrepCap;
+    int* cnt = in_lds ? prep_lds : q.deg + n0;
+    int* rb = in_lds ? prep_lds + kPrepCap : q.row_beg + n0;
+    int* scan = prep_lds + 2 * kPrepCap;
+    const long long* srcs = q.edge_index + c0;
+    const long long* dsts = q.edge_index + (size_t)q.E + c0;
+    for (int i = tid; i < Np; i += 1024) cnt[i] = 0;
     if (tid == 0) carry = e0;
     __syncthreads();
-    for (int base = n0; base < n1; base += 256) {
+    // arrival order inside the destination's segment (any order is fine: max-aggregation is order-free);
+    // four independent columns per thread and trip so their loads are in flight together
+    for (int c = tid; c < Eg; c += 4096) {
+        int d[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) d[u] = (c + u * 1024 < Eg) ? (int)dsts[c + u * 1024] : -1;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (d[u] >= 0) q.cursor[c0 + c + u * 1024] = atomicAdd(&cnt[d[u]], 1);
+    }
+    __syncthreads();
+    for (int base = 0; base < Np; base += 1024) {      // exclusive scan -> absolute first slot of every node
         const int i = base + tid;
-        const int d = (i < n1) ? deg[i] : 0;
-        s[tid] = d;
+        const int d = (i < Np) ? cnt[i] : 0;
+        scan[tid] = d;
         __syncthreads();
-        for (int off = 1; off < 256; off <<= 1) {
+        for (int off = 1; off < 1024; off <<= 1) {
             int a = 0;
-            if (tid >= off) a = s[tid - off];
+            if (tid >= off) a = scan[tid - off];
             __syncthreads();
-            s[tid] += a;
+            scan[tid] += a;
             __syncthreads();
         }
-        if (i < n1) row_beg[i] = carry + s[tid] - d;
+        if (i < Np) {
+            const int r = carry + scan[tid] - d;
+            rb[i] = r;
+            if (in_lds) { q.row_beg[n0 + i] = r; q.deg[n0 + i] = d; }
+        }
         __syncthreads();
-        if (tid == 255) carry += s[255];
+        if (tid == 1023) carry += scan[1023];
         __syncthreads();
     }
-    for (int t = n0 / 32 + tid; t < n1 / 32; t += 256) ntile_graph[t] = g;
-    for (int t = e0 / 32 + tid; t < e1 / 32; t += 256) etile_graph[t] = g;
-}
-
-__global__ void prep_fill_kernel(int G, int E, const long long* __restrict__ edge_index, const int* __restrict__ edge_ptr,
-                                 const int* __restrict__ node_ptr_pad, const int* __restrict__ row_beg,
-                                 const int* __restrict__ rank, int4* __restrict__ csr) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    const int g = find_graph_wg(edge_ptr, G, e < E ? e : E - 1);
-    if (e >= E) return;
-    const int base = node_ptr_pad[g];
-    const int src = base + (int)edge_index[e];
-    const int dst = base + (int)edge_index[(size_t)E + e];
-    const int pos = row_beg[dst] + rank[e];
-    csr[pos] = make_int4(src, dst, e, 0);      // one 16-byte record per edge: {source, target, caller column}
-}
-
-// per 32-edge tile: bit0 = its first segment starts in an earlier tile, bit1 = its last segment
-// continues in a later tile, bit2 = tile holds at least one edge; -1 = unused tile.  Lets mp_edge walk
-// its segments without any dependent row_beg/deg loads.
-__global__ void prep_tilemeta_kernel(int n_tiles, const int4* __restrict__ csr, const int* __restrict__ row_beg,
-                                     const int* __restrict__ deg, const int* __restrict__ etile_graph,
-                                     int* __restrict__ tile_meta) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_tiles) return;
-    if (etile_graph[t] < 0) { tile_meta[t] = -1; return; }
-    const int start = t * 32;
-    const int d0 = csr[start].y;
-    if (d0 < 0) { tile_meta[t] = 0; return; }
-    int last = 31;
-    while (last > 0 && csr[start + last].y < 0) --last;
-    const int dl = csr[start + last].y;
-    const int first_open = row_beg[d0] < start;
-    const int last_open = row_beg[dl] + deg[dl] > start + 32;
-    tile_meta[t] = 4 | first_open | (last_open << 1);
+    for (int c = tid; c < Eg; c += 4096) {
+        int sv[4], tv[4], rk[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int cc = c + u * 1024;
+            const bool ok = cc < Eg;
+            sv[u] = ok ? (int)srcs[cc] : 0;
+            tv[u] = ok ? (int)dsts[cc] : -1;
+            rk[u] = ok ? q.cursor[c0 + cc] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (tv[u] >= 0)                                              // {source, target, caller column}
+                q.csr[rb[tv[u]] + rk[u]] = make_int4(n0 + sv[u], n0 + tv[u], c0 + c + u * 1024, 0);
+    }
+    for (int sl = e0 + Eg + tid; sl < e1; sl += 1024) q.csr[sl] = make_int4(-1, -1, -1, -1);
+    for (int t = n0 / 32 + tid; t < (n0 + Np) / 32; t += 1024) q.ntile_graph[t] = g;
+    for (int t = e0 / 32 + tid; t < e1 / 32; t += 1024) {
+        q.etile_graph[t] = g;
+        // bit0 = first segment starts in an earlier tile, bit1 = last segment continues in a later tile,
+        // bit2 = tile holds at least one edge (see mp_edge)
+        const int start = t * 32;
+        int meta = 0;
+        if (start < e0 + Eg) {
+            auto owner = [&](int slot) {               // largest node i with rb[i] <= slot
+                int lo = 0, hi = Np;
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    if (rb[mid] <= slot) lo = mid; else hi = mid;
+                }
+                return lo;
+            };
+            const int lastslot = min(start + 31, e0 + Eg - 1);
+            const int d0 = owner(start), dl = owner(lastslot);
+            meta = 4 | (rb[d0] < start ? 1 : 0) | (rb[dl] + cnt[dl] > start + 32 ? 2 : 0);
+        }
+        q.tile_meta[t] = meta;
+    }
 }
 
 // =====================================================================================================
@@ -934,37 +948,29 @@ __global__ void goal_tap_kernel(int G, const int* __restrict__ goal_node, const 
         if (_e != hipSuccess) return _e;      \
     } while (0)
 
+template <class K>
+static hipError_t set_lds(K kernel, size_t bytes) {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)bytes);
+}
+
 hipError_t launch_prep(const PrepParams& q, hipStream_t st) {
     hipLaunchKernelGGL(prep_ptrs_kernel, dim3(1), dim3(256), 0, st, q.G, q.node_ptr, q.edge_ptr, q.node_ptr_pad,
                        q.edge_ptr_pad, q.dense_ptr);
     LAUNCH_CHECK();
-    if (q.E > 0) {
-        hipLaunchKernelGGL(prep_count_kernel, dim3((q.E + 255) / 256), dim3(256), 0, st, q.G, q.E, q.edge_index,
-                           q.edge_ptr, q.node_ptr_pad, q.deg, q.cursor);
+    {
+        const size_t lds = (size_t)(2 * kPrepCap + 1024) * sizeof(int);
+        static const hipError_t attr = set_lds(prep_graph_kernel, (size_t)(2 * kPrepCap + 1024) * sizeof(int));
+        if (attr != hipSuccess) return attr;
+        hipLaunchKernelGGL(prep_graph_kernel, dim3(q.G), dim3(1024), lds, st, q);
         LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(prep_scan_kernel, dim3(q.G), dim3(256), 0, st, q.node_ptr_pad, q.edge_ptr_pad, q.deg, q.row_beg,
-                       q.ntile_graph, q.etile_graph);
-    LAUNCH_CHECK();
-    if (q.E > 0) {
-        hipLaunchKernelGGL(prep_fill_kernel, dim3((q.E + 255) / 256), dim3(256), 0, st, q.G, q.E, q.edge_index,
-                           q.edge_ptr, q.node_ptr_pad, q.row_beg, q.cursor, q.csr);
-        LAUNCH_CHECK();
-    }
-    hipLaunchKernelGGL(prep_tilemeta_kernel, dim3((q.n_etiles + 255) / 256), dim3(256), 0, st, q.n_etiles, q.csr,
-                       q.row_beg, q.deg, q.etile_graph, q.tile_meta);
-    LAUNCH_CHECK();
     hipLaunchKernelGGL(goal_kernel, dim3(q.G), dim3(256), 0, st, q.C, q.v, q.goal, q.node_ptr, q.node_ptr_pad,
                        q.goal_node);
     LAUNCH_CHECK();
     return hipSuccess;
 }
 
-template <class K>
-static hipError_t set_lds(K kernel, size_t bytes) {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)bytes);
-}
 
 template <int D, int P>
 static hipError_t launch_obs_t(const ObsParams& p, int G, hipStream_t st) {

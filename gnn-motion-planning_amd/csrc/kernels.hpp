@@ -16,7 +16,7 @@ struct PrepParams {
     int *ntile_graph, *etile_graph;              // per 32-row tile
     int4* csr;                                   // [Epad] {source, target, caller column, 0}; -1 = pad slot
     int* goal_node;                              // [G] padded node id
-    int* tile_meta;                              // per 32-edge tile, see prep_tilemeta_kernel
+    int* tile_meta;                              // per 32-edge tile, see prep_graph_kernel
     int n_etiles;
 };
 

@@ -89,3 +89,17 @@ def test_star_graph_hub_spans_many_tiles():
     g2['goal'] = g2['v'][9].clone()
     s2 = m2.edge_scores(g2['goal'].to(DEV), 3, g2['v'].to(DEV), g2['obstacles'].to(DEV), ei.to(DEV)).cpu()
     print(check(s2, w2, g2, 3))
+
+
+def test_graph_beyond_the_lds_share_of_the_csr_build():
+    """9 000 nodes: the per-graph CSR build keeps its counters in global memory instead of LDS (kPrepCap = 8192);
+    batched with a small graph that takes the LDS path."""
+    gen = torch.Generator().manual_seed(77)
+    w = load_weights('weights_maze')
+    m = gnnmp.EncoderProcessDecoder(2, 2, 32, 2)
+    m.load_state_dict(w)
+    graphs = [random_graph(gen, 9000, 30000, 20, hub=150), random_graph(gen, 50, 200, 7)]
+    b = gnnmp.GraphBatch.from_graphs(graphs, 2, DEV)
+    out = m.forward_batch(b, 2)
+    for g, part in zip(graphs, b.split_edges(out)):
+        print(check(part.cpu(), w, g, 2))
