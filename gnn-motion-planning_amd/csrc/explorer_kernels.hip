@@ -814,8 +814,9 @@ __global__ __launch_bounds__(256) void mp_node_kernel(MpNodeParams p) {
         const int tile = wk.cur * 4 + wave;
         if (tile >= p.n_tiles || p.ntile_graph[tile] < 0) continue;
         const int t = tile * 32 + j;
-        f32x16 x[NT], ag[NT];
+        f32x16 x[NT], ag[NT], y[NT];
         load_row<NT>(p.X + (size_t)t * D, x, h);
+        load_row<NT>(p.R + (size_t)t * D, y, h);           // all three rows of the tile are requested up front
         const int a0 = p.row_beg[t], dg = p.deg[t];
         if (dg == 0) {
 #pragma unroll
@@ -836,12 +837,11 @@ __global__ __launch_bounds__(256) void mp_node_kernel(MpNodeParams p) {
                 }
             }
         }
-        f32x16 H[NT], y[NT], z[NT];
+        f32x16 H[NT], z[NT];
         load_vec<NT>(wl + L::bl, H, lane);
         linear_acc_p<P, NT, NT>(wl + L::wlx, x, H, lane);
         linear_acc_p<P, NT, NT>(wl + L::wla, ag, H, lane);
         if (p.store_h) store_row<NT>(p.Hout + (size_t)t * D, H, h);
-        load_row<NT>(p.R + (size_t)t * D, y, h);
         linear_acc_p<P, NT, NT>(wl + L::m1, H, y, lane);
         store_row<NT>(p.Xout + (size_t)t * D, y, h);
 #pragma unroll
