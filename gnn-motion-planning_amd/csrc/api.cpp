@@ -171,14 +171,6 @@ void pack_a_small_bf16(const float* w, int out_f, int ld, int col0, int n_in, fl
                 }
 }
 
-// dst <- a (+/-) b over a [D x n] column block of row-major matrices with leading dimension ld
-std::vector<float> colblock(const float* w, int D, int ld, int col0, int n) {
-    std::vector<float> r((size_t)D * n);
-    for (int i = 0; i < D; ++i)
-        for (int k = 0; k < n; ++k) r[(size_t)i * n + k] = w[(size_t)i * ld + col0 + k];
-    return r;
-}
-
 std::vector<float> matvec(const float* w, int D, int ld, int col0, int n, const float* x) {
     std::vector<float> r(D);
     for (int i = 0; i < D; ++i) {

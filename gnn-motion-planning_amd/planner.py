@@ -11,7 +11,6 @@ models are called through the same keyword signatures the reference uses.  ``exp
 reference's observable behaviour including two quirks (SURVEY.md finding 0.6): the explored-edge mask is
 applied with LEGACY tuple-index semantics, and the pair list is reshaped (2, -1) rather than transposed.
 """
-import math
 import time
 from copy import deepcopy
 

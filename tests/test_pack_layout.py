@@ -1,7 +1,6 @@
 """CPU check of the MFMA operand packing (gnnmp_pack_* in include/gnnmp.h) against a numpy
 emulation of v_mfma_f32_32x32x2_f32's lane/register layout: a chain of packed layers evaluated
 exactly the way the kernels' linear_acc / linear_in do must equal plain X @ W^T."""
-import ctypes
 
 import numpy as np
 import pytest
