@@ -98,6 +98,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--pcie-steps', type=int, default=5, help='extra steps timed incl. H2D/D2H (0 = skip)')
     ap.add_argument('--dense-steps', type=int, default=5, help='extra steps timed with the dense N x N output (0 = skip)')
+    ap.add_argument('--bf16x3-steps', type=int, default=5,
+                    help='extra steps timed in the opt-in bf16x3 mode (fp32-class results from the bf16 matrix pipe, '
+                         'DESIGN.md 4.2b); reported next to, never instead of, `value`; only with --mlp-dtype fp32')
     ap.add_argument('--unique', type=int, default=0, help='distinct synthetic graphs per GPU (0 = all)')
     args = ap.parse_args()
 
@@ -185,6 +188,20 @@ def main():
         torch.cuda.synchronize(dev)
         dense_rate = G * args.dense_steps / (time.perf_counter() - t1)
 
+    # secondary: the same workload in the opt-in bf16x3 mode (held to the same parity bar, tests/test_explorer_bf16x3.py)
+    x3_rate = None
+    if args.bf16x3_steps > 0 and args.mlp_dtype == 'fp32':
+        model.mlp_dtype = 'bf16x3'
+        for _ in range(2):
+            model.forward_batch(batch, args.loop)
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for _ in range(args.bf16x3_steps):
+            model.forward_batch(batch, args.loop)
+        torch.cuda.synchronize(dev)
+        x3_rate = G * args.bf16x3_steps / (time.perf_counter() - t1)
+        model.mlp_dtype = args.mlp_dtype
+
     # final result gather (the only collective of the job): per-rank edge scores -> every rank
     checksum = float(scores.double().sum().item())
     if use_dist:
@@ -239,7 +256,8 @@ def main():
                                          'frac_hbm_peak': round(bytes_batch * args.steps / elapsed / 1e9 / PEAK_HBM_GBS, 6)},
                        'stage_ms_per_step': stages, 'result_checksum': checksum,
                        'pcie_inclusive_graphs_per_s_per_gpu': None if e2e is None else round(e2e, 1),
-                       'dense_output_graphs_per_s_per_gpu': None if dense_rate is None else round(dense_rate, 1)},
+                       'dense_output_graphs_per_s_per_gpu': None if dense_rate is None else round(dense_rate, 1),
+                       'bf16x3_mode_graphs_per_s_per_gpu': None if x3_rate is None else round(x3_rate, 1)},
             'roofline': {'kernel': 'pre_resident_kernel<%d,%s,EDGE> (edge encoders + 3 obstacle-attention blocks)' % (e['d'], args.mlp_dtype),
                          'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
                          'frac': round(achieved / peak, 4), 'traffic': traffic if args.mlp_dtype == 'fp32' else None,
