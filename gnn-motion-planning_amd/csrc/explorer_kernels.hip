@@ -96,6 +96,7 @@ __device__ __forceinline__ int find_graph(const int* __restrict__ ptr, int G, in
 // (same code through flat pointers).
 // =====================================================================================================
 constexpr int kPrepCap = 8192;
+constexpr int kPrepGraphMin = 64;      // batches of at least this many graphs take the per-graph kernel
 
 __global__ __launch_bounds__(1024) void prep_graph_kernel(PrepParams q) {
     extern __shared__ int prep_lds[];                  // cnt[kPrepCap], rb[kPrepCap], scan[1024]
@@ -183,6 +184,95 @@ __global__ __launch_bounds__(1024) void prep_graph_kernel(PrepParams q) {
         }
         q.tile_meta[t] = meta;
     }
+}
+
+// -----------------------------------------------------------------------------------------------------
+// Device-wide form of the same build (count -> scan -> fill -> tile metadata, one thread per edge), used for
+// small batches: a single graph with 56 k edges would keep one workgroup busy for ~90 us in prep_graph_kernel,
+// while these four passes spread it over the device in ~25 us.
+// -----------------------------------------------------------------------------------------------------
+// graph of caller column e: one binary search per workgroup (first column), then a short walk
+__device__ __forceinline__ int find_graph_wg(const int* __restrict__ ptr, int G, int e) {
+    __shared__ int s_g0;
+    if (threadIdx.x == 0) s_g0 = find_graph(ptr, G, blockIdx.x * blockDim.x);
+    __syncthreads();
+    int g = s_g0;
+    while (g + 1 < G && e >= ptr[g + 1]) ++g;
+    return g;
+}
+
+__global__ void prep_count_kernel(int G, int E, const long long* __restrict__ edge_index, const int* __restrict__ edge_ptr,
+                                  const int* __restrict__ node_ptr_pad, int* __restrict__ deg, int* __restrict__ rank) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const int g = find_graph_wg(edge_ptr, G, e < E ? e : E - 1);
+    if (e >= E) return;
+    const int dst = node_ptr_pad[g] + (int)edge_index[(size_t)E + e];
+    rank[e] = atomicAdd(&deg[dst], 1);        // arrival order inside the destination's segment (any order is fine:
+}                                             // max-aggregation is order-free and per-edge results do not depend on position)
+
+// one workgroup per graph: exclusive scan of deg over the graph's padded node range
+__global__ void prep_scan_kernel(const int* __restrict__ node_ptr_pad, const int* __restrict__ edge_ptr_pad,
+                                 const int* __restrict__ deg, int* __restrict__ row_beg,
+                                 int* __restrict__ ntile_graph, int* __restrict__ etile_graph) {
+    __shared__ int s[256];
+    __shared__ int carry;
+    const int g = blockIdx.x, tid = threadIdx.x;
+    const int n0 = node_ptr_pad[g], n1 = node_ptr_pad[g + 1];
+    const int e0 = edge_ptr_pad[g], e1 = edge_ptr_pad[g + 1];
+    if (tid == 0) carry = e0;
+    __syncthreads();
+    for (int base = n0; base < n1; base += 256) {
+        const int i = base + tid;
+        const int d = (i < n1) ? deg[i] : 0;
+        s[tid] = d;
+        __syncthreads();
+        for (int off = 1; off < 256; off <<= 1) {
+            int a = 0;
+            if (tid >= off) a = s[tid - off];
+            __syncthreads();
+            s[tid] += a;
+            __syncthreads();
+        }
+        if (i < n1) row_beg[i] = carry + s[tid] - d;
+        __syncthreads();
+        if (tid == 255) carry += s[255];
+        __syncthreads();
+    }
+    for (int t = n0 / 32 + tid; t < n1 / 32; t += 256) ntile_graph[t] = g;
+    for (int t = e0 / 32 + tid; t < e1 / 32; t += 256) etile_graph[t] = g;
+}
+
+__global__ void prep_fill_kernel(int G, int E, const long long* __restrict__ edge_index, const int* __restrict__ edge_ptr,
+                                 const int* __restrict__ node_ptr_pad, const int* __restrict__ row_beg,
+                                 const int* __restrict__ rank, int4* __restrict__ csr) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const int g = find_graph_wg(edge_ptr, G, e < E ? e : E - 1);
+    if (e >= E) return;
+    const int base = node_ptr_pad[g];
+    const int src = base + (int)edge_index[e];
+    const int dst = base + (int)edge_index[(size_t)E + e];
+    const int pos = row_beg[dst] + rank[e];
+    csr[pos] = make_int4(src, dst, e, 0);      // one 16-byte record per edge: {source, target, caller column}
+}
+
+// per 32-edge tile: bit0 = its first segment starts in an earlier tile, bit1 = its last segment
+// continues in a later tile, bit2 = tile holds at least one edge; -1 = unused tile.  Lets mp_edge walk
+// its segments without any dependent row_beg/deg loads.
+__global__ void prep_tilemeta_kernel(int n_tiles, const int4* __restrict__ csr, const int* __restrict__ row_beg,
+                                     const int* __restrict__ deg, const int* __restrict__ etile_graph,
+                                     int* __restrict__ tile_meta) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_tiles) return;
+    if (etile_graph[t] < 0) { tile_meta[t] = -1; return; }
+    const int start = t * 32;
+    const int d0 = csr[start].y;
+    if (d0 < 0) { tile_meta[t] = 0; return; }
+    int last = 31;
+    while (last > 0 && csr[start + last].y < 0) --last;
+    const int dl = csr[start + last].y;
+    const int first_open = row_beg[d0] < start;
+    const int last_open = row_beg[dl] + deg[dl] > start + 32;
+    tile_meta[t] = 4 | first_open | (last_open << 1);
 }
 
 // =====================================================================================================
@@ -958,11 +1048,28 @@ hipError_t launch_prep(const PrepParams& q, hipStream_t st) {
     hipLaunchKernelGGL(prep_ptrs_kernel, dim3(1), dim3(256), 0, st, q.G, q.node_ptr, q.edge_ptr, q.node_ptr_pad,
                        q.edge_ptr_pad, q.dense_ptr);
     LAUNCH_CHECK();
-    {
+    if (q.G >= kPrepGraphMin) {                        // one workgroup per graph
         const size_t lds = (size_t)(2 * kPrepCap + 1024) * sizeof(int);
         static const hipError_t attr = set_lds(prep_graph_kernel, (size_t)(2 * kPrepCap + 1024) * sizeof(int));
         if (attr != hipSuccess) return attr;
         hipLaunchKernelGGL(prep_graph_kernel, dim3(q.G), dim3(1024), lds, st, q);
+        LAUNCH_CHECK();
+    } else {                                           // few graphs: one thread per edge across the device
+        if (q.E > 0) {
+            hipLaunchKernelGGL(prep_count_kernel, dim3((q.E + 255) / 256), dim3(256), 0, st, q.G, q.E, q.edge_index,
+                               q.edge_ptr, q.node_ptr_pad, q.deg, q.cursor);
+            LAUNCH_CHECK();
+        }
+        hipLaunchKernelGGL(prep_scan_kernel, dim3(q.G), dim3(256), 0, st, q.node_ptr_pad, q.edge_ptr_pad, q.deg, q.row_beg,
+                           q.ntile_graph, q.etile_graph);
+        LAUNCH_CHECK();
+        if (q.E > 0) {
+            hipLaunchKernelGGL(prep_fill_kernel, dim3((q.E + 255) / 256), dim3(256), 0, st, q.G, q.E, q.edge_index,
+                               q.edge_ptr, q.node_ptr_pad, q.row_beg, q.cursor, q.csr);
+            LAUNCH_CHECK();
+        }
+        hipLaunchKernelGGL(prep_tilemeta_kernel, dim3((q.n_etiles + 255) / 256), dim3(256), 0, st, q.n_etiles, q.csr,
+                           q.row_beg, q.deg, q.etile_graph, q.tile_meta);
         LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(goal_kernel, dim3(q.G), dim3(256), 0, st, q.C, q.v, q.goal, q.node_ptr, q.node_ptr_pad,

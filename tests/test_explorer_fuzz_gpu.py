@@ -91,15 +91,41 @@ def test_star_graph_hub_spans_many_tiles():
     print(check(s2, w2, g2, 3))
 
 
+def test_per_graph_csr_build_ragged_batch():
+    """Batches of >= 64 graphs take the one-workgroup-per-graph CSR build (prep_graph_kernel; smaller batches the
+    device-wide passes): 80 random graphs incl. empty edge lists, single nodes and hubs, and bit-equality with the
+    same graphs scored one by one (device-wide path)."""
+    gen = torch.Generator().manual_seed(31)
+    w = load_weights('weights_maze')
+    m = gnnmp.EncoderProcessDecoder(2, 2, 32, 2)
+    m.load_state_dict(w)
+    graphs = []
+    for i in range(80):
+        n = int(torch.randint(1, 120, (1,), generator=gen))
+        e = 0 if i % 13 == 0 else int(torch.randint(1, 5 * n + 2, (1,), generator=gen))
+        graphs.append(random_graph(gen, n, e, int(torch.randint(0, 40, (1,), generator=gen)), hub=40 if i % 7 == 3 and e > 50 else None))
+    b = gnnmp.GraphBatch.from_graphs(graphs, 2, DEV)
+    parts = b.split_edges(m.forward_batch(b, 3))
+    for i, (g, part) in enumerate(zip(graphs, parts)):
+        if g['edge_index'].shape[1] == 0:
+            assert part.numel() == 0
+            continue
+        one = m.edge_scores(g['goal'].to(DEV), 3, g['v'].to(DEV), g['obstacles'].to(DEV), g['edge_index'].to(DEV))
+        assert torch.equal(part, one), i
+        if i % 8 == 0:
+            check(part.cpu(), w, g, 3)
+
+
 def test_graph_beyond_the_lds_share_of_the_csr_build():
-    """9 000 nodes: the per-graph CSR build keeps its counters in global memory instead of LDS (kPrepCap = 8192);
-    batched with a small graph that takes the LDS path."""
+    """9 000 nodes inside a 66-graph batch: the per-graph CSR build keeps this graph's counters in global memory
+    instead of LDS (kPrepCap = 8192), the 65 small graphs next to it take the LDS path."""
     gen = torch.Generator().manual_seed(77)
     w = load_weights('weights_maze')
     m = gnnmp.EncoderProcessDecoder(2, 2, 32, 2)
     m.load_state_dict(w)
-    graphs = [random_graph(gen, 9000, 30000, 20, hub=150), random_graph(gen, 50, 200, 7)]
+    graphs = [random_graph(gen, 30, 100, 7) for _ in range(30)] + [random_graph(gen, 9000, 30000, 20, hub=150)] + \
+        [random_graph(gen, 50, 200, 7) for _ in range(35)]
     b = gnnmp.GraphBatch.from_graphs(graphs, 2, DEV)
-    out = m.forward_batch(b, 2)
-    for g, part in zip(graphs, b.split_edges(out)):
-        print(check(part.cpu(), w, g, 2))
+    parts = b.split_edges(m.forward_batch(b, 2))
+    for i in (0, 30, 31, 65):
+        print(check(parts[i].cpu(), w, graphs[i], 2))
