@@ -1143,27 +1143,35 @@ hipError_t launch_pre_resident(int D, int P, bool edge, const PreParams& p, size
 // RESIDENT (occupancy query x CUs): the tile space is split evenly by XcdWalk, so a grid beyond residency only
 // adds a second, thinly populated round of workgroups (measured: mp_edge 0.72 -> 0.66 ms per step at d = 32,
 // 0.56 -> 0.52 at d = 64 / bf16).  Multiple of 8 for the XCD walk.
-static int resident_workgroups(const void* kernel, size_t lds_bytes) {
+struct Residency { int per_cu, cus; };
+static Residency resident_workgroups(const void* kernel, size_t lds_bytes) {
     static std::mutex mu;
-    static std::map<std::pair<const void*, size_t>, int> cache;
+    static std::map<std::pair<const void*, size_t>, Residency> cache;
     std::lock_guard<std::mutex> lock(mu);
     auto it = cache.find({kernel, lds_bytes});
     if (it != cache.end()) return it->second;
-    int per_cu = 0, dev = 0, cus = 256;
+    Residency r{0, 256};
+    int dev = 0;
     hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, lds_bytes) != hipSuccess || per_cu < 1) per_cu = 4;
-    if (getenv("GNNMP_DEBUG_GRID")) fprintf(stderr, "[gnnmp] resident workgroups per CU: %d (lds %zu)\n", per_cu, lds_bytes);
-    if (const char* ov = getenv("GNNMP_WGS_PER_CU")) per_cu = atoi(ov) > 0 ? atoi(ov) : per_cu;
-    return cache[{kernel, lds_bytes}] = cus * per_cu;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) r.cus = prop.multiProcessorCount;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&r.per_cu, kernel, 256, lds_bytes) != hipSuccess || r.per_cu < 1) r.per_cu = 4;
+    if (getenv("GNNMP_DEBUG_GRID")) fprintf(stderr, "[gnnmp] resident workgroups per CU: %d (lds %zu)\n", r.per_cu, lds_bytes);
+    return cache[{kernel, lds_bytes}] = r;
 }
 
+// max_per_cu: measured sweet spot of the kernel -- more resident waves than that only add contention in the memory
+// system (mp_edge at d = 32: 0.657 ms per step at 4 workgroups per CU, 0.669 at 5, 0.81 at 6-7 when the compiler is
+// forced to fit them; policy: 0.137 at 3, 0.152 at 6); GNNMP_WGS_PER_CU overrides it for experiments
 template <class K>
-static int grid_for(K kernel, size_t lds_bytes, int n_tiles) {
+static int grid_for(K kernel, size_t lds_bytes, int n_tiles, int max_per_cu) {
     int groups = ((n_tiles + 3) / 4 + 7) & ~7;
     if (groups < 8) groups = 8;
-    const int cap = resident_workgroups(reinterpret_cast<const void*>(kernel), lds_bytes) & ~7;
-    return groups < cap ? groups : cap;
+    const Residency r = resident_workgroups(reinterpret_cast<const void*>(kernel), lds_bytes);
+    int per_cu = r.per_cu < max_per_cu ? r.per_cu : max_per_cu;
+    static const int forced = getenv("GNNMP_WGS_PER_CU") ? atoi(getenv("GNNMP_WGS_PER_CU")) : 0;
+    if (forced > 0) per_cu = forced;
+    const int cap = (r.cus * per_cu) & ~7;
+    return groups < cap ? groups : (cap < 8 ? 8 : cap);
 }
 
 template <int D, int P>
@@ -1171,7 +1179,7 @@ static hipError_t launch_mp_edge_t(const MpEdgeParams& p, hipStream_t st) {
     const size_t lds = (size_t)(((MpEBlob<D, P>::size + 3) & ~3) + 4 * 32 * (D + 1)) * sizeof(float);
     hipError_t e = set_lds(mp_edge_kernel<D, P>, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((mp_edge_kernel<D, P>), dim3(grid_for(mp_edge_kernel<D, P>, lds, p.n_tiles)), dim3(256), lds, st, p);
+    hipLaunchKernelGGL((mp_edge_kernel<D, P>), dim3(grid_for(mp_edge_kernel<D, P>, lds, p.n_tiles, 4)), dim3(256), lds, st, p);
     LAUNCH_CHECK();
     return hipSuccess;
 }
@@ -1184,7 +1192,7 @@ static hipError_t launch_mp_node_t(const MpNodeParams& p, hipStream_t st) {
     const size_t lds = (size_t)MpNBlob<D, P>::size * sizeof(float);
     hipError_t e = set_lds(mp_node_kernel<D, P>, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((mp_node_kernel<D, P>), dim3(grid_for(mp_node_kernel<D, P>, lds, p.n_tiles)), dim3(256), lds, st, p);
+    hipLaunchKernelGGL((mp_node_kernel<D, P>), dim3(grid_for(mp_node_kernel<D, P>, lds, p.n_tiles, 8)), dim3(256), lds, st, p);
     LAUNCH_CHECK();
     return hipSuccess;
 }
@@ -1197,7 +1205,7 @@ static hipError_t launch_policy_t(const PolicyParams& p, hipStream_t st) {
     const size_t lds = (size_t)PolBlob<D, P>::size * sizeof(float);
     hipError_t e = set_lds(policy_kernel<D, P>, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((policy_kernel<D, P>), dim3(grid_for(policy_kernel<D, P>, lds, p.n_tiles)), dim3(256), lds, st, p);
+    hipLaunchKernelGGL((policy_kernel<D, P>), dim3(grid_for(policy_kernel<D, P>, lds, p.n_tiles, 3)), dim3(256), lds, st, p);
     LAUNCH_CHECK();
     return hipSuccess;
 }
