@@ -91,7 +91,11 @@ def greedy_expand_sparse(scores, edge_index, labels, v, env, state):
     instead of the dense N x N matrix): a max-heap over the live cells
     ``P[a, b]`` with ``a`` explored, keyed so that ties break exactly like the dense row-major argmax
     (position of ``a`` in the explored list, then column ``b``).  ``scores[e]`` is the score of column e
-    of ``edge_index`` = dense cell ``P[target, source]``."""
+    of ``edge_index`` = dense cell ``P[target, source]``.
+    One deliberate difference: the reference's loop condition is ``policy[explored, :].sum() != 0``
+    (eval_gnn.py:204), so it also stops when live cells remain but their float32 sum cancels to exactly 0;
+    this frontier (and the device one, maze_kernels.hip) stops only when no live cell remains.  For real
+    network scores the two differ with probability ~0 (never on the 1000 recorded problems)."""
     import heapq
     explored, explored_edges = state['explored'], state['explored_edges']
     src, dst = edge_index[0], edge_index[1]
@@ -339,6 +343,43 @@ def eval_gnn_device(env, indexes, model, model_s, seed=1234, batch=500, k=30, de
 # --------------------------------------------------------------------------------------------------
 # batched explore stage with everything but the sampling on the device (2-D mazes)
 # --------------------------------------------------------------------------------------------------
+def maze_explore_device(v, node_ptr, edge_ptr, n_free, ei, scores, maps, goal64):
+    """``gnnmp_maze_explore`` on device tensors: greedy best-edge expansion + grid collision checks of B problems
+    (``v`` [sum N, 2] float32, ``ei`` [2, sum E] int64 graph-local, ``scores`` [sum E], ``maps`` [B, w, w] float64,
+    ``goal64`` [B, 2] float64).  Returns host-side (success, n_explored, n_pairs, path_len, checks) lists and the
+    compacted ``explored`` / ``explored_edges`` (+ per-problem int offsets) / ``path`` arrays."""
+    import ctypes
+    from . import _lib
+    device = v.device
+    B, w = int(maps.shape[0]), int(maps.shape[1])
+    nf = torch.as_tensor(n_free, dtype=torch.int32).to(device)
+    total_n, total_e = int(v.shape[0]), int(ei.shape[1])
+    mb = _lib.MazeBatch(B, total_n, total_e, w, v.data_ptr(), node_ptr.data_ptr(), edge_ptr.data_ptr(), nf.data_ptr(),
+                        ei.data_ptr(), scores.data_ptr(), maps.data_ptr(), goal64.data_ptr())
+    need = ctypes.c_size_t()
+    _lib.check(_lib.lib().gnnmp_maze_explore_workspace_bytes(ctypes.byref(mb), ctypes.byref(need)), 'maze ws')
+    ws = torch.empty(need.value, dtype=torch.uint8, device=device)
+    i32 = lambda n: torch.zeros(n, dtype=torch.int32, device=device)      # noqa: E731
+    success, n_expl, expl, n_pairs, ee, plen, path = i32(B), i32(B), i32(total_n), i32(B), i32(2 * (2 * total_e + B)), \
+        i32(B), i32(total_n)
+    checks = torch.zeros(B, dtype=torch.int64, device=device)
+    with torch.cuda.device(device):
+        st = torch.cuda.current_stream().cuda_stream
+        _lib.check(_lib.lib().gnnmp_maze_explore(ctypes.byref(mb), success.data_ptr(), n_expl.data_ptr(), expl.data_ptr(),
+                                                 n_pairs.data_ptr(), ee.data_ptr(), plen.data_ptr(), path.data_ptr(),
+                                                 checks.data_ptr(), ws.data_ptr(), ws.numel(), st), 'gnnmp_maze_explore')
+    success, n_expl, n_pairs, plen, checks = (t.cpu().tolist() for t in (success, n_expl, n_pairs, plen, checks))
+    eptr = edge_ptr.cpu().tolist()
+    # the pair list has room for 2E + 1 pairs per problem but holds a few hundred: compact it on the device
+    ee_off = np.zeros(B + 1, dtype=np.int64)
+    ee_off[1:] = np.cumsum([2 * n for n in n_pairs])
+    take = np.concatenate([np.arange(2 * (2 * eptr[b] + b), 2 * (2 * eptr[b] + b) + 2 * n_pairs[b], dtype=np.int64)
+                           for b in range(B)])
+    ee = ee[torch.from_numpy(take).to(device)].cpu().numpy()
+    return success, n_expl, n_pairs, plen, checks, expl.cpu().numpy(), ee, ee_off, path.cpu().numpy()
+
+
+
 @torch.no_grad()
 def explore_maze_batch(problems, model, device, batch=500, k=30, loop=5, model_s=None, smooth_iters=5, timings=None):
     """Many 2-D maze problems at once: sampling on the host (the reference's numpy RNG
@@ -398,31 +439,9 @@ def explore_maze_batch(problems, model, device, batch=500, k=30, loop=5, model_s
     w = int(np.asarray(problems[0]['map']).shape[0])
     maps = torch.tensor(np.asarray([np.asarray(pr['map'], dtype=np.float64) for pr in problems])).to(device)
     goal64 = torch.tensor(np.asarray([e.goal_state for e in envs], dtype=np.float64)).to(device)
-    nf = torch.tensor(n_free, dtype=torch.int32, device=device)
-    total_n, total_e = int(v.shape[0]), int(ei.shape[1])
-    mb = _lib.MazeBatch(B, total_n, total_e, w, v.data_ptr(), node_ptr.data_ptr(), edge_ptr.data_ptr(), nf.data_ptr(),
-                        ei.data_ptr(), scores.data_ptr(), maps.data_ptr(), goal64.data_ptr())
-    need = ctypes.c_size_t()
-    _lib.check(_lib.lib().gnnmp_maze_explore_workspace_bytes(ctypes.byref(mb), ctypes.byref(need)), 'maze ws')
-    ws = torch.empty(need.value, dtype=torch.uint8, device=device)
-    i32 = lambda n: torch.zeros(n, dtype=torch.int32, device=device)      # noqa: E731
-    success, n_expl, expl, n_pairs, ee, plen, path = i32(B), i32(B), i32(total_n), i32(B), i32(2 * (2 * total_e + B)), \
-        i32(B), i32(total_n)
-    checks = torch.zeros(B, dtype=torch.int64, device=device)
-    with torch.cuda.device(device):
-        st = torch.cuda.current_stream().cuda_stream
-        _lib.check(_lib.lib().gnnmp_maze_explore(ctypes.byref(mb), success.data_ptr(), n_expl.data_ptr(), expl.data_ptr(),
-                                                 n_pairs.data_ptr(), ee.data_ptr(), plen.data_ptr(), path.data_ptr(),
-                                                 checks.data_ptr(), ws.data_ptr(), ws.numel(), st), 'gnnmp_maze_explore')
-    success, n_expl, n_pairs, plen, checks = (t.cpu().tolist() for t in (success, n_expl, n_pairs, plen, checks))
-    nptr, eptr = ptr.tolist(), edge_ptr.cpu().tolist()
-    # the pair list has room for 2E + 1 pairs per problem but holds a few hundred: compact it on the device
-    ee_off = np.zeros(B + 1, dtype=np.int64)
-    ee_off[1:] = np.cumsum([2 * n for n in n_pairs])
-    take = np.concatenate([np.arange(2 * (2 * eptr[b] + b), 2 * (2 * eptr[b] + b) + 2 * n_pairs[b], dtype=np.int64)
-                           for b in range(B)])
-    ee = ee[torch.from_numpy(take).to(device)].cpu().numpy()
-    expl, path = expl.cpu().numpy(), path.cpu().numpy()
+    success, n_expl, n_pairs, plen, checks, expl, ee, ee_off, path = maze_explore_device(
+        v, node_ptr, edge_ptr, n_free, ei, scores, maps, goal64)
+    nptr = ptr.tolist()
     tm = mark('greedy_explore', tm)
     smoothed = {}
     if model_s is not None and any(success):

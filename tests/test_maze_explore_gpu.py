@@ -135,3 +135,52 @@ def test_device_smoothing_equals_host_steering_bitwise():
         assert all(np.array_equal(a, b) for a, b in zip(host, d['smooth_path'])), \
             np.abs(np.array(host) - np.array(d['smooth_path'])).max()
         assert c_host == d['c_smooth']
+
+
+@pytest.mark.parametrize('seed', range(6))
+def test_device_frontier_tie_breaking_on_quantised_scores(seed):
+    """gnnmp_maze_explore fed with synthetic scores that take only a few distinct values (ties in every row, exact
+    zeros, a few collided nodes): the cached-row-maximum frontier must pick cells in exactly the order of the host
+    frontier (row-major first maximum over explored rows) -- same explored order, pair list, path and check counts."""
+    from gnnmp import graph_build
+    rng = np.random.RandomState(100 + seed)
+    B = 5
+    maps = (rng.rand(B, 15, 15) < 0.25).astype(np.float64)
+    envs, vs, n_free, eis, scs = [], [], [], [], []
+    np.random.seed(seed)
+    for b in range(B):
+        free_cells = np.argwhere(maps[b] == 0)
+        cell2state = lambda c: (c + 0.5) / 15 * 2 - 1          # noqa: E731
+        init, goal = cell2state(free_cells[rng.randint(len(free_cells))]), cell2state(free_cells[rng.randint(len(free_cells))])
+        env = Maze2D(maps[b][None], init[None], goal[None])
+        env.init_new_problem(0)
+        free, coll = env.sample_n_points(int(rng.randint(30, 90)), need_negative=True)
+        coll = coll[:len(free)]
+        free = [env.init_state, env.goal_state] + list(free)
+        data = planner.create_data(free, coll, env.goal_state, int(rng.randint(4, 12)))
+        ei = data['edge_index'].numpy()
+        sc = rng.choice(np.array([-2.1, -1.3, 0.0, 0.5, 0.5, 1.7], dtype=np.float32), size=ei.shape[1])
+        envs.append(env); vs.append(data['v']); n_free.append(len(free)); eis.append(data['edge_index']); scs.append(sc)
+    ptr = torch.zeros(B + 1, dtype=torch.int64)
+    ptr[1:] = torch.tensor([x.shape[0] for x in vs]).cumsum(0)
+    eptr = torch.zeros(B + 1, dtype=torch.int64)
+    eptr[1:] = torch.tensor([x.shape[1] for x in eis]).cumsum(0)
+    goal64 = torch.tensor(np.asarray([e.goal_state for e in envs], dtype=np.float64)).to(DEV)
+    out = planner.maze_explore_device(torch.cat(vs).to(DEV), ptr.to(torch.int32).to(DEV), eptr.to(torch.int32).to(DEV), n_free,
+                                      torch.cat(eis, dim=1).to(DEV), torch.from_numpy(np.concatenate(scs)).to(DEV),
+                                      torch.tensor(maps).to(DEV), goal64)
+    success, n_expl, n_pairs, plen, checks, expl, ee, ee_off, path = out
+    nptr = ptr.tolist()
+    for b in range(B):
+        env = envs[b]
+        c0 = env.collision_check_count
+        labels = np.zeros((vs[b].shape[0], 2), dtype=np.int64)
+        labels[n_free[b]:, 1] = 1
+        state = {'explored': [0], 'explored_edges': [[0, 0]], 'costs': {0: 0.}, 'prev': {0: 0}}
+        ref = planner.greedy_expand_sparse(scs[b], eis[b].numpy(), labels, vs[b].numpy(), env, state)
+        assert expl[nptr[b]:nptr[b] + n_expl[b]].tolist() == state['explored'], b
+        assert ee[ee_off[b]:ee_off[b + 1]].reshape(-1, 2).tolist() == state['explored_edges'], b
+        assert bool(success[b]) == (ref is not None)
+        if ref is not None:
+            assert path[nptr[b]:nptr[b] + plen[b]].tolist() == ref
+        assert checks[b] == env.collision_check_count - c0

@@ -190,3 +190,68 @@ def test_skip_maze_sampling_reaches_the_sequential_stream_position():
     np.random.seed(1234)
     planner.skip_maze_sampling(env, range(4), batch=30)
     assert np.array_equal(np.random.uniform(size=4), expect)
+
+
+class _StubEnv:
+    """Deterministic toy environment for frontier tests: an edge is free unless its (unordered) pair hashes into
+    the blocked set; the goal region is one node."""
+
+    def __init__(self, v, blocked, goal_node):
+        self.v, self.blocked, self.goal_node = v, blocked, goal_node
+        self.collision_check_count = 0
+
+    def _key(self, x):
+        return int(np.argmin(np.abs(self.v - x).sum(axis=1)))
+
+    def _edge_fp(self, a, b):
+        self.collision_check_count += 1
+        i, j = self._key(a), self._key(b)
+        return (min(i, j), max(i, j)) not in self.blocked
+
+    def in_goal_region(self, x):
+        return self._key(x) == self.goal_node
+
+
+@pytest.mark.parametrize('seed', range(25))
+def test_sparse_frontier_equals_dense_on_random_ties(seed):
+    """Heap-based sparse frontier vs the reference's dense masked argmax on random graphs whose scores take only a
+    few distinct values (ties everywhere), contain exact zeros, collided nodes, blocked edges and a non-trivial
+    starting state (several explored nodes, an explored_edges history that goes through the legacy-index quirk)."""
+    from gnnmp import planner
+    rng = np.random.RandomState(seed)
+    n = int(rng.randint(6, 40))
+    v = rng.rand(n, 2).astype(np.float32)
+    dense_mask = rng.rand(n, n) < 0.3
+    tgt, src = np.nonzero(dense_mask)
+    ei = np.stack((src, tgt))                                       # column e: edge src -> tgt = cell P[tgt, src]
+    # values whose float32 sums do not cancel to exactly 0: the dense loop of the reference ALSO stops when the sum
+    # of the live frontier cells is exactly zero (eval_gnn.py:204), which the sparse frontier does not imitate
+    scores = rng.choice(np.array([-2.1, -1.3, 0.0, 0.5, 0.5, 1.7], dtype=np.float32), size=ei.shape[1])
+    labels = np.zeros((n, 2), dtype=np.int64)
+    labels[rng.rand(n) < 0.15, 1] = 1
+    labels[0, 1] = 0
+    blocked = set()
+    for _ in range(int(rng.randint(0, n))):
+        i, j = sorted(rng.randint(0, n, 2).tolist())
+        blocked.add((i, j))
+    goal = int(rng.randint(1, n))
+    start_explored = [0] + [int(x) for x in rng.permutation(np.arange(1, n))[:int(rng.randint(0, 3))]]
+    hist = [[0, 0]]
+    for _ in range(int(rng.randint(0, 3))):
+        a, b = rng.randint(0, n, 2).tolist()
+        hist.extend([[a, b], [b, a]])
+
+    def fresh():
+        return {'explored': list(start_explored), 'explored_edges': [list(x) for x in hist],
+                'costs': {k: 0. for k in start_explored}, 'prev': {k: 0 for k in start_explored}}
+    P = np.zeros((n, n), dtype=np.float32)
+    P[ei[1], ei[0]] = scores
+    sd, ss = fresh(), fresh()
+    env_d, env_s = _StubEnv(v, blocked, goal), _StubEnv(v, blocked, goal)
+    Pm = planner._mask_policy(P.copy(), labels, sd['explored'], sd['explored_edges'])
+    path_d = planner.greedy_expand(Pm, v, env_d, sd)
+    path_s = planner.greedy_expand_sparse(scores, ei, labels, v, env_s, ss)
+    assert path_d == path_s
+    assert sd['explored'] == ss['explored']
+    assert sd['explored_edges'] == ss['explored_edges']
+    assert env_d.collision_check_count == env_s.collision_check_count
