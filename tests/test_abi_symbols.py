@@ -34,3 +34,34 @@ def test_status_strings_and_manifest():
     assert sum(n for _, n in man) == 280320
     # unsupported embed size is refused, not silently accepted
     assert L.gnnmp_explorer_manifest(ctypes.byref(_lib.ExplorerDims(2, 48, 2)), -1, None, 0, None) == -2
+
+
+def test_ctypes_structs_mirror_the_header():
+    """Field names and order of every struct in include/gnnmp.h against the ctypes mirrors in gnnmp/_lib.py
+    (a silent drift here corrupts every call)."""
+    import ctypes
+    import re
+    from gnnmp import _lib
+    text = open(os.path.join(REPO, 'include', 'gnnmp.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    structs = {}
+    for body, name in re.findall(r'typedef struct\s*\{(.*?)\}\s*(\w+);', text, flags=re.S):
+        fields = []
+        for decl in body.split(';'):
+            decl = decl.strip()
+            if not decl:
+                continue
+            # "const int32_t *node_ptr, *edge_ptr, *n_free" -> names after stripping the type and stars
+            names = re.findall(r'[\*\s,](\w+)\s*(?=,|$)', ' ' + decl)
+            first = decl.split(',')[0].split()[-1].lstrip('*')
+            rest = [x.strip().lstrip('*') for x in decl.split(',')[1:]]
+            fields.extend([first] + rest)
+            assert names
+        structs[name] = fields
+    mirrors = {'gnnmp_explorer_dims': _lib.ExplorerDims, 'gnnmp_batch': _lib.Batch, 'gnnmp_smoother_dims': _lib.SmootherDims,
+               'gnnmp_smooth_batch': _lib.SmoothBatch, 'gnnmp_graph_batch': _lib.GraphBuildBatch,
+               'gnnmp_maze_batch': _lib.MazeBatch}
+    assert set(mirrors) <= set(structs), sorted(structs)
+    for cname, cls in mirrors.items():
+        assert [f[0] for f in cls._fields_] == structs[cname], cname
+    assert ctypes.sizeof(_lib.ExplorerDims) == 16 and ctypes.sizeof(_lib.SmootherDims) == 16
