@@ -29,8 +29,21 @@ constexpr int kTile = 32;             // rows per wave, features per tile
 constexpr int kATile = 1024;          // floats in one 32x32 A tile
 
 
-__device__ __forceinline__ float xhalf(float x) {       // value held by the partner lane (l ^ 32)
-    return __shfl_xor(x, 32, 64);
+// A row lives in lanes l and l ^ 32.  v_permlane32_swap (gfx950) exchanges the upper half of one register with the
+// lower half of another on the VALU -- no LDS crossbar trip and no lgkmcnt wait like ds_bpermute: with both operands
+// = x it leaves the half-0 lane's value of the row in every lane of one result and the half-1 lane's in the other.
+struct RowPair { float lo, hi; };
+__device__ __forceinline__ RowPair xpair(float x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return RowPair{__uint_as_float(r[0]), __uint_as_float(r[1])};
+}
+__device__ __forceinline__ float xsum(float x) {        // x(l) + x(l ^ 32), the same bits in both lanes
+    const RowPair p = xpair(x);
+    return p.lo + p.hi;
+}
+__device__ __forceinline__ float xmax(float x) {
+    const RowPair p = xpair(x);
+    return fmaxf(p.lo, p.hi);
 }
 
 __device__ __forceinline__ f32x16 splat16(float x) {
@@ -296,7 +309,7 @@ __device__ __forceinline__ void layer_norm_(f32x16 (&x)[NT], const float* gamma,
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) s += x[t][r];
-    s += xhalf(s);
+    s = xsum(s);
     const float mean = s * inv_d;
     float v = 0.f;
 #pragma unroll
@@ -307,7 +320,7 @@ __device__ __forceinline__ void layer_norm_(f32x16 (&x)[NT], const float* gamma,
             x[t][r] = c;
             v = fmaf(c, c, v);
         }
-    v += xhalf(v);
+    v = xsum(v);
     const float rstd = 1.0f / sqrtf(v * inv_d + eps);
     f32x16 g[NT], b[NT];
     load_vec<NT>(gamma, g, lane);

@@ -467,7 +467,7 @@ __device__ __forceinline__ void attention_block(const float* wl, const float* wg
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) l0 = fmaf(Q[t][r], Km[t][r], l0);
-        l0 += xhalf(l0);
+        l0 = xsum(l0);
         // softmax(x / sqrt(d)) evaluated as exp2((x - max) * log2(e) / sqrt(d))
         mx = l0;
         psum = (h == 0) ? 1.0f : 0.0f;     // the self term exp(0) is counted once per row
@@ -501,7 +501,7 @@ __device__ __forceinline__ void attention_block(const float* wl, const float* wg
             float tmax = s[0];
 #pragma unroll
             for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, s[r]);
-            tmax = fmaxf(tmax, xhalf(tmax));
+            tmax = xmax(tmax);
             const float nmx = fmaxf(mx, tmax);
             const float off = -nmx * cs;
             float ps = 0.f;
@@ -524,7 +524,7 @@ __device__ __forceinline__ void attention_block(const float* wl, const float* wg
             mx = nmx;
         }
     }
-    const float inv = 1.0f / (psum + xhalf(psum));
+    const float inv = 1.0f / xsum(psum);
 #pragma unroll
     for (int t = 0; t < NT; ++t) m[t] = acc[t] * inv + m[t];         // value mix + residual
     layer_norm_<NT>(m, wg + L::ln1g, wg + L::ln1b, 1e-6f, lane);        // vectors: global (L1/L2 hits)
@@ -994,7 +994,7 @@ __global__ __launch_bounds__(256) void policy_kernel(PolicyParams p) {
         for (int tt = 0; tt < NT; ++tt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) sc = fmaf(w3[tt][r], y[tt][r], sc);
-        sc += xhalf(sc);
+        sc = xsum(sc);
         if (h == 0 && s >= 0) {
             p.scores[rec.z] = sc;
             if (p.dense) {
