@@ -24,6 +24,7 @@ namespace gnnmp {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kTile = 32;             // rows per wave, features per tile
 constexpr int kATile = 1024;          // floats in one 32x32 A tile
@@ -300,35 +301,38 @@ __device__ __forceinline__ void relu_(f32x16 (&x)[NT]) {
         for (int r = 0; r < 16; ++r) x[t][r] = fmaxf(x[t][r], 0.0f);
 }
 
-// LayerNorm over the D = 32*NT features of each row (biased variance, eps inside the sqrt).
+// sum of the 16 registers as a pairwise tree of whole-vector adds (v_pk_add_f32: two lanes' worth per instruction,
+// 8 + 1 instructions instead of a 16-deep serial chain)
+__device__ __forceinline__ float tree_sum(const f32x16& a) {
+    const f32x8 a8 = a.lo + a.hi;
+    const f32x4 a4 = a8.lo + a8.hi;
+    const f32x2 a2 = a4.lo + a4.hi;
+    return a2.x + a2.y;
+}
+
+// LayerNorm over the D = 32*NT features of each row (biased variance, eps inside the sqrt).  Written with
+// whole-vector arithmetic so that the adds / multiplies / fmas issue as packed fp32 pairs: VALU instructions cost
+// MFMA issue time in the kernels that use this.
 template <int NT>
 __device__ __forceinline__ void layer_norm_(f32x16 (&x)[NT], const float* gamma, const float* beta, float eps, int lane) {
     constexpr float inv_d = 1.0f / (32 * NT);
-    float s = 0.f;
+    f32x16 acc = x[0];
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int t = 1; t < NT; ++t) acc += x[t];
+    const float mean = xsum(tree_sum(acc)) * inv_d;
+    f32x16 sq = splat16(0.f);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s += x[t][r];
-    s = xsum(s);
-    const float mean = s * inv_d;
-    float v = 0.f;
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float c = x[t][r] - mean;
-            x[t][r] = c;
-            v = fmaf(c, c, v);
-        }
-    v = xsum(v);
+    for (int t = 0; t < NT; ++t) {
+        x[t] -= mean;
+        sq += x[t] * x[t];
+    }
+    const float v = xsum(tree_sum(sq));
     const float rstd = 1.0f / sqrtf(v * inv_d + eps);
     f32x16 g[NT], b[NT];
     load_vec<NT>(gamma, g, lane);
     load_vec<NT>(beta, b, lane);
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) x[t][r] = fmaf(x[t][r] * rstd, g[t][r], b[t][r]);
+    for (int t = 0; t < NT; ++t) x[t] = (x[t] * rstd) * g[t] + b[t];
 }
 
 // ---- row-major [rows, D] <-> register order.  Lane (j,h) touches 16-byte pieces

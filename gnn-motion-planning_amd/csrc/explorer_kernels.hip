@@ -504,12 +504,10 @@ __device__ __forceinline__ void attention_block(const float* wl, const float* wg
             tmax = xmax(tmax);
             const float nmx = fmaxf(mx, tmax);
             const float off = -nmx * cs;
-            float ps = 0.f;
+            s = s * cs + off;                               // packed fmas
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], cs, off));
-                ps += s[r];
-            }
+            for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(s[r]);
+            const float ps = tree_sum(s);
             const int nq = min(4, (O - ot * 32 + 7) >> 3);
             const BOp<P> pop(s);
             if (__builtin_amdgcn_ballot_w64(nmx != mx) != 0) {      // some row's maximum moved: rescale (alpha = 1 elsewhere)
