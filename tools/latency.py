@@ -50,14 +50,17 @@ def single(env, n, k):
 
 
 def batched(env, n, k, G, uniq=16):
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()          # the previous configuration's workspace (GBs) must not be reclaimed inside the timing
     m, e = model_for(env)
     base = [synth_graph(env, n, k, seed=1234 + i) for i in range(uniq)]
     b = gnnmp.GraphBatch.from_graphs([base[i % uniq] for i in range(G)], e['S'], dev)
     m.profile(dev, True)
-    t = timeit(lambda: m.forward_batch(b, 5), n=10, warm=3)
+    t = timeit(lambda: m.forward_batch(b, 5), n=10, warm=5)
     prof = m.profile_read(dev)
     print('%-7s N=%-5d k1=%-3d batch %-4d: %.3f ms/step = %.1f graphs/s   stages(ms/step): %s' %
-          (env, n, k, G, t * 1e3, G / t, {kk: round(v[0] / 13, 3) for kk, v in prof.items()}))
+          (env, n, k, G, t * 1e3, G / t, {kk: round(v[0] / 15, 3) for kk, v in prof.items()}))
 
 
 if __name__ == '__main__':
