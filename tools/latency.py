@@ -63,6 +63,29 @@ def batched(env, n, k, G, uniq=16):
           (env, n, k, G, t * 1e3, G / t, {kk: round(v[0] / 15, 3) for kk, v in prof.items()}))
 
 
+def smoother(name, C, P=20, F=500, Co=500, B=256, scale=1.0):
+    """SURVEY.md 8(d) smoother addendum: ms per call (the reference calls it with loop = 1 five times per problem,
+    smoother.py:243) and the batched rate."""
+    import gc
+    from gnnmp.planner import chain_edge_index
+    from gnnmp.smoother import SmoothBatch
+    gc.collect()
+    torch.cuda.empty_cache()
+    gen = torch.Generator().manual_seed(3)
+    for dtype in ('fp32', 'bf16'):
+        ms = gnnmp.ModelSmoother(workspace_size=3, config_size=C, embed_size=128, obs_size=6, scale=scale)
+        ms.load_state_dict(load_weights(name))
+        ms.mlp_dtype = dtype
+        mk = lambda n: (torch.rand(n, C, generator=gen) * 2 - 1)          # noqa: E731
+        one = SmoothBatch([mk(P)], [mk(F)], [mk(Co)], [chain_edge_index(P)], dev)
+        many = SmoothBatch([mk(P) for _ in range(B)], [mk(F) for _ in range(B)], [mk(Co) for _ in range(B)],
+                           [chain_edge_index(P)] * B, dev)
+        t1 = timeit(lambda: ms.forward_batch(one, 1))
+        tb = timeit(lambda: ms.forward_batch(many, 1), n=10)
+        print('%-18s C=%-2d %s  P=%d F=%d Co=%d: single call %.3f ms | batch of %d: %.3f ms = %.0f calls/s' %
+              (name, C, dtype, P, F, Co, t1 * 1e3, B, tb * 1e3, B / tb))
+
+
 if __name__ == '__main__':
     single('maze2', 200, 6)        # BASELINE configs[0]
     single('maze2', 1000, 8)
@@ -73,3 +96,6 @@ if __name__ == '__main__':
     batched('kuka14', 5000, 16, 32, uniq=4)     # configs[4] shape (fp32 here)
     batched('ur5', 1000, 8, 256)
     batched('snake7', 1000, 8, 256)
+    smoother('smooth_2d_attv3', 2)
+    smoother('smooth_7d_attv3', 7)
+    smoother('smooth_14d_attv3', 14)     # configs[4]: "+ smoother GNN"
