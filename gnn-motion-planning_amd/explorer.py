@@ -173,10 +173,22 @@ class EncoderProcessDecoder(nn.Module):
 
     # ------------------------------------------------------------------ batched entry points
     @torch.no_grad()
-    def forward_batch(self, batch, loop, dense=False):
+    def workspace_bytes(self, batch):
+        """Bytes of workspace one forward over ``batch`` needs (for callers that keep their own buffers)."""
+        dev = batch.v.device
+        need = ctypes.c_size_t()
+        cb = self._cbatch(batch)
+        _lib.check(_lib.lib().gnnmp_explorer_workspace_bytes(self._native(dev), ctypes.byref(cb), ctypes.byref(need)),
+                   'gnnmp_explorer_workspace_bytes')
+        return int(need.value)
+
+    def forward_batch(self, batch, loop, dense=False, ws=None, out=None):
         """Score every edge of a :class:`GraphBatch`.  Returns ``scores [sumE]`` in the batch's
         column order, or ``(scores, dense_blocks)`` with the concatenated zero-filled
-        ``P_g[target, source]`` matrices (model.py:148-149) when ``dense``."""
+        ``P_g[target, source]`` matrices (model.py:148-149) when ``dense``.
+        ``ws`` (uint8, 256-byte aligned, >= ``workspace_bytes``) and ``out`` (float32 [>= sumE]) let a caller that
+        runs several batches concurrently on different streams give each its own buffers; everything is enqueued
+        on the current stream."""
         dev = batch.v.device
         if dev.type != 'cuda':
             raise RuntimeError('gnnmp runs on the GPU only (got %s tensors); there is no CPU fallback' % dev)
@@ -185,8 +197,9 @@ class EncoderProcessDecoder(nn.Module):
                              '(model.py:139-145)')
         h = self._native(dev)
         cb = self._cbatch(batch)
-        ws = self._workspace(h, cb, dev)
-        scores = torch.empty(batch.total_edges, dtype=torch.float32, device=dev)
+        if ws is None:
+            ws = self._workspace(h, cb, dev)
+        scores = torch.empty(batch.total_edges, dtype=torch.float32, device=dev) if out is None else out[:batch.total_edges]
         dn = None
         if dense:
             n = (batch.node_ptr[1:] - batch.node_ptr[:-1]).to(torch.int64)
