@@ -283,6 +283,16 @@ def eval_gnn(env, indexes, model, model_s, seed=1234, smooth=True, batch=500, t_
             total_time_explore)
 
 
+def _collect(res, wall, t_explore, sol, paths, smooth_paths, rows_out):
+    for r in res:
+        paths.append(r['path'] if r['success'] else [])
+        smooth_paths.append(r['smooth_path'] if r['success'] else [])
+        sol.append((r['success'], path_cost(paths[-1]), path_cost(smooth_paths[-1]), r['c_explore'], r['c_smooth'],
+                    wall, t_explore))
+        if rows_out is not None:
+            rows_out.append(sol[-1][:5] + (len(paths[-1]), len(r['explored'])))
+
+
 def skip_maze_sampling(env, indexes, batch=500):
     """Advance the global numpy RNG exactly as the planner's sampling of the problems ``indexes`` would (nothing
     else in the default single-forward planner draws random numbers): lets rank r of a sharded evaluation start its
@@ -316,21 +326,32 @@ def eval_gnn_device(env, indexes, model, model_s, seed=1234, batch=500, k=30, de
         skip_maze_sampling(env, indexes[:lo], batch)
         indexes = indexes[lo:hi]
     sol, paths, smooth_paths = [], [], []
-    for c0 in range(0, len(indexes), chunk):
-        idx = indexes[c0:c0 + chunk]
-        problems = [dict(map=env.maps[i], init_state=env.init_states[i], goal_state=env.goal_states[i]) for i in idx]
-        tm = {}
-        t0 = time.perf_counter()
-        res = explore_maze_batch(problems, model, device, batch=batch, k=k, loop=loop, model_s=model_s, timings=tm)
-        wall = (time.perf_counter() - t0) / len(idx)
-        t_explore = wall - tm.get('smoothing', 0.) / len(idx)
-        for r in res:
-            paths.append(r['path'] if r['success'] else [])
-            smooth_paths.append(r['smooth_path'] if r['success'] else [])
-            sol.append((r['success'], path_cost(paths[-1]), path_cost(smooth_paths[-1]), r['c_explore'], r['c_smooth'],
-                        wall, t_explore))
-            if rows_out is not None:
-                rows_out.append(sol[-1][:5] + (len(paths[-1]), len(r['explored'])))
+    from concurrent.futures import ThreadPoolExecutor
+
+    def prepare(c0):
+        pr = [dict(map=env.maps[i], init_state=env.init_states[i], goal_state=env.goal_states[i])
+              for i in indexes[c0:c0 + chunk]]
+        return pr, sample_maze_problems(pr, batch, k)
+    # the samples of chunk i+1 are drawn on a host thread while the device works on chunk i; the draws stay in
+    # problem order (one sampler at a time, started only after the previous one has finished)
+    t_begin = time.perf_counter()
+    t_smooth = 0.
+    with ThreadPoolExecutor(max_workers=1) as pool:
+        starts = list(range(0, len(indexes), chunk))
+        nxt = pool.submit(prepare, starts[0]) if starts else None
+        for ci, c0 in enumerate(starts):
+            problems, pre = nxt.result()
+            if ci + 1 < len(starts):
+                nxt = pool.submit(prepare, starts[ci + 1])
+            tm = {}
+            res = explore_maze_batch(problems, model, device, batch=batch, k=k, loop=loop, model_s=model_s, timings=tm,
+                                     presampled=pre)
+            t_smooth += tm.get('smoothing', 0.)
+            _collect(res, 0., 0., sol, paths, smooth_paths, rows_out)
+    # wall clock of the whole evaluation (sampling of chunk i+1 overlaps the device pass of chunk i), spread evenly
+    wall = (time.perf_counter() - t_begin) / max(len(sol), 1)
+    t_explore = wall - t_smooth / max(len(sol), 1)
+    sol = [x[:5] + (wall, t_explore) for x in sol]
     n_success = sum(s[0] for s in sol)
     collision_explore = float(np.mean([s[3] for s in sol]))
     collision = float(np.mean([s[3] + s[4] for s in sol]))
@@ -343,6 +364,31 @@ def eval_gnn_device(env, indexes, model, model_s, seed=1234, batch=500, k=30, de
 # --------------------------------------------------------------------------------------------------
 # batched explore stage with everything but the sampling on the device (2-D mazes)
 # --------------------------------------------------------------------------------------------------
+def sample_maze_problems(problems, batch, k):
+    """Host part of :func:`explore_maze_batch`: the reference's rejection sampling for every problem in order
+    (``explore``: eval_gnn.py:180-184), consuming the global numpy RNG exactly like the one-by-one loop.  Returns
+    (envs, node rows per problem [free incl. init / goal; collided], n_free, k1)."""
+    from .graph_build import k1_of
+    from .maze2d import AttemptStream, Maze2D
+    envs, vs, n_free, k1s = [], [], [], []
+    stream = AttemptStream()
+    for pr in problems:
+        env = Maze2D(np.asarray(pr['map'])[None], np.asarray(pr['init_state'])[None], np.asarray(pr['goal_state'])[None])
+        env.init_new_problem(0)
+        free, coll = env.sample_n_points_stream(stream, batch)                # same stream as sample_n_points
+        coll = coll[:len(free)]                                               # eval_gnn.py:182 (before init / goal join)
+        nf = len(free) + 2
+        vrows = np.concatenate((np.asarray(env.init_state, dtype=np.float64).reshape(1, 2),
+                                np.asarray(env.goal_state, dtype=np.float64).reshape(1, 2), free, coll)).astype(np.float32)
+        envs.append(env)
+        vs.append(torch.from_numpy(vrows))
+        n_free.append(nf)
+        k1s.append(k1_of(k, nf))
+    stream.close()                                                            # global RNG: as if sampled one by one
+    return envs, vs, n_free, k1s
+
+
+
 def maze_explore_device(v, node_ptr, edge_ptr, n_free, ei, scores, maps, goal64):
     """``gnnmp_maze_explore`` on device tensors: greedy best-edge expansion + grid collision checks of B problems
     (``v`` [sum N, 2] float32, ``ei`` [2, sum E] int64 graph-local, ``scores`` [sum E], ``maps`` [B, w, w] float64,
@@ -381,7 +427,8 @@ def maze_explore_device(v, node_ptr, edge_ptr, n_free, ei, scores, maps, goal64)
 
 
 @torch.no_grad()
-def explore_maze_batch(problems, model, device, batch=500, k=30, loop=5, model_s=None, smooth_iters=5, timings=None):
+def explore_maze_batch(problems, model, device, batch=500, k=30, loop=5, model_s=None, smooth_iters=5, timings=None,
+                       presampled=None):
     """Many 2-D maze problems at once: sampling on the host (the reference's numpy RNG
     stream, one problem after the other), then -- in ONE pass on the device -- kNN graphs
     (graph_kernels.hip), explorer forward (batched), greedy expansion + collision checks
@@ -390,9 +437,9 @@ def explore_maze_batch(problems, model, device, batch=500, k=30, loop=5, model_s
     the device)).  ``problems``: list of dicts(map [w, w], init_state, goal_state).
     Covers the reference's default single-forward case (batch == t_max); returns one
     result dict per problem with the fields of ``explore`` (``smooth_path`` / ``c_smooth`` with ``model_s``).
-    ``timings``: optional dict that receives wall-clock seconds per stage (adds device syncs)."""
-    import ctypes
-
+    ``timings``: optional dict that receives wall-clock seconds per stage (adds device syncs).
+    ``presampled``: the result of :func:`sample_maze_problems` for these problems (lets a caller sample the next
+    chunk on the host while the device works on this one)."""
     def mark(name, t_prev):
         if timings is None:
             return t_prev
@@ -401,25 +448,9 @@ def explore_maze_batch(problems, model, device, batch=500, k=30, loop=5, model_s
         timings[name] = timings.get(name, 0.) + now - t_prev
         return now
     tm = time.perf_counter()
-    from . import _lib
     from .batch import GraphBatch
-    from .graph_build import build_edges_gpu, k1_of
-    from .maze2d import AttemptStream, Maze2D
-    envs, vs, n_free, k1s = [], [], [], []
-    stream = AttemptStream()
-    for pr in problems:
-        env = Maze2D(np.asarray(pr['map'])[None], np.asarray(pr['init_state'])[None], np.asarray(pr['goal_state'])[None])
-        env.init_new_problem(0)
-        free, coll = env.sample_n_points_stream(stream, batch)                # same stream as sample_n_points
-        coll = coll[:len(free)]                                               # eval_gnn.py:182 (before init / goal join)
-        nf = len(free) + 2
-        vrows = np.concatenate((np.asarray(env.init_state, dtype=np.float64).reshape(1, 2),
-                                np.asarray(env.goal_state, dtype=np.float64).reshape(1, 2), free, coll)).astype(np.float32)
-        envs.append(env)
-        vs.append(torch.from_numpy(vrows))
-        n_free.append(nf)
-        k1s.append(k1_of(k, nf))
-    stream.close()                                                            # global RNG: as if sampled one by one
+    from .graph_build import build_edges_gpu
+    envs, vs, n_free, k1s = presampled if presampled is not None else sample_maze_problems(problems, batch, k)
     tm = mark('host_sampling', tm)
     B = len(problems)
     ptr = torch.zeros(B + 1, dtype=torch.int64)
