@@ -129,3 +129,39 @@ def test_graph_beyond_the_lds_share_of_the_csr_build():
     parts = b.split_edges(m.forward_batch(b, 2))
     for i in (0, 30, 31, 65):
         print(check(parts[i].cpu(), w, graphs[i], 2))
+
+
+@pytest.mark.parametrize('seed', range(4))
+@pytest.mark.parametrize('mode', ['kuka7_fp32', 'maze_bf16x3', 'kuka7_bf16'])
+def test_random_graphs_other_kernels(mode, seed):
+    """The same structure fuzz through the d = 64 kernels (kuka7 checkpoint: general pre_kernel, two feature tiles),
+    the bf16x3 kernels (held to the fp32 bar) and the bf16 kernels (against the exact-fp32 GPU result, bf16 bar)."""
+    gen = torch.Generator().manual_seed(4000 + seed)
+    ck, C, d, S, ws = ('weights_maze', 2, 32, 2, 2) if mode.startswith('maze') else ('weights_kuka', 7, 64, 6, 3)
+    w = load_weights(ck)
+    m = gnnmp.EncoderProcessDecoder(ws, C, d, S)
+    m.load_state_dict(w)
+    graphs = []
+    for i in range(int(torch.randint(2, 5, (1,), generator=gen))):
+        n = int(torch.randint(2, 220, (1,), generator=gen))
+        e = int(torch.randint(1, 5 * n + 2, (1,), generator=gen))
+        g = random_graph(gen, n, e, 0, hub=70 if i == 1 and e > 80 else None)
+        g['v'] = torch.rand(n, C, generator=gen) * 2 - 1
+        g['goal'] = g['v'][0].clone()
+        g['obstacles'] = torch.rand(int(torch.randint(0, 9, (1,), generator=gen)), S, generator=gen) - 0.5
+        graphs.append(g)
+    loop = int(torch.randint(1, 5, (1,), generator=gen))
+    b = gnnmp.GraphBatch.from_graphs(graphs, S, DEV)
+    exact = [x.cpu() for x in b.split_edges(m.forward_batch(b, loop))]
+    if mode.endswith('fp32'):
+        for g, part in zip(graphs, exact):
+            check(part, w, g, loop)
+        return
+    m.mlp_dtype = 'bf16x3' if mode.endswith('bf16x3') else 'bf16'
+    other = [x.cpu() for x in b.split_edges(m.forward_batch(b, loop))]
+    for g, part, ref in zip(graphs, other, exact):
+        if mode.endswith('bf16x3'):
+            check(part, w, g, loop)
+        else:
+            err = (part - ref).abs()
+            assert err.mean().item() <= 0.03 and err.max().item() <= 0.25, (err.mean().item(), err.max().item())
