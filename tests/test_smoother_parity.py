@@ -93,3 +93,33 @@ def test_batch_equals_single_bitwise():
         ref = ref_cpu.smoother_forward(w, path, free, coll, ei, loop=1)
         assert torch.allclose(single.cpu(), ref, rtol=1e-5, atol=1e-5)
         off += path.shape[0]
+
+
+@pytest.mark.parametrize('seed', range(8))
+def test_random_problems(seed):
+    """Structure fuzz: random waypoint counts (incl. paths longer than one 32-row tile), sample counts from fewer than
+    k = 10 up to the 1000-sample cap of the planner, random extra caller edges (into path nodes and into samples,
+    duplicates, self loops), every checkpoint's dimension, scale and loop count, ragged batches."""
+    gen = torch.Generator().manual_seed(900 + seed)
+    name = list(CONF)[seed % len(CONF)]
+    C, scale = CONF[name]
+    m = make(name)
+    w = load_weights(name)
+    loop = int(torch.randint(1, 4, (1,), generator=gen))
+    probs = []
+    for _ in range(int(torch.randint(1, 5, (1,), generator=gen))):
+        P = int(torch.randint(2, 70, (1,), generator=gen))
+        F = int(torch.randint(1, 520, (1,), generator=gen))
+        Co = int(torch.randint(1, 520, (1,), generator=gen))
+        M = P + F + Co
+        extra = torch.randint(0, M, (2, int(torch.randint(0, 40, (1,), generator=gen))), generator=gen)
+        mk = lambda n: (torch.rand(n, C, generator=gen) * 2 - 1) * scale       # noqa: E731
+        probs.append((mk(P), mk(F), mk(Co), torch.cat((chain_edges(P), extra), dim=1)))
+    sb = gnnmp.SmoothBatch([p[0] for p in probs], [p[1] for p in probs], [p[2] for p in probs], [p[3] for p in probs], DEV)
+    out = m.forward_batch(sb, loop).cpu()
+    off = 0
+    for path, free, coll, ei in probs:
+        ref = ref_cpu.smoother_forward(w, path, free, coll, ei, loop=loop, scale=scale)
+        got = out[off:off + path.shape[0]]
+        assert torch.allclose(got, ref, rtol=1e-5, atol=1e-5 * scale), (name, (got - ref).abs().max())
+        off += path.shape[0]
