@@ -192,7 +192,10 @@ typedef struct {
 
 int gnnmp_smoother_workspace_bytes(const gnnmp_smoother* h, const gnnmp_smooth_batch* shape, size_t* bytes);
 
-/* out_path [total_path, C]: the new waypoints (end points copied through, model_smoother.py:139). */
+/* out_path [total_path, C]: the new waypoints (end points copied through, model_smoother.py:139).
+ * Per-problem limits of the kernels (GNNMP_ERR_DIMS beyond them, nothing is silently truncated): at most 2048 samples
+ * (free + collided; the reference's planner passes at most 500 + 500, smoother.py:57-58) and at most 7500 candidate
+ * edges (caller edges + 10 kNN edges per waypoint). */
 int gnnmp_smoother_forward(const gnnmp_smoother* h, const gnnmp_smooth_batch* batch, int loop,
                            float* out_path, void* workspace, size_t workspace_bytes, void* hip_stream);
 

@@ -123,3 +123,12 @@ def test_random_problems(seed):
         got = out[off:off + path.shape[0]]
         assert torch.allclose(got, ref, rtol=1e-5, atol=1e-5 * scale), (name, (got - ref).abs().max())
         off += path.shape[0]
+
+
+def test_limits_fail_loudly():
+    """More samples than the kNN kernel holds per lane (2048) is an error, never a silent truncation."""
+    m = make('smooth_2d_attv3')
+    gen = torch.Generator().manual_seed(1)
+    path, free, coll = (torch.rand(n, 2, generator=gen).to(DEV) for n in (6, 1500, 700))
+    with pytest.raises(RuntimeError, match='gnnmp_smoother_forward'):
+        m(path=path, free=free, collided=coll, edge_index=chain_edges(6).to(DEV), loop=1)
