@@ -1048,7 +1048,7 @@ hipError_t launch_prep(const PrepParams& q, hipStream_t st) {
     LAUNCH_CHECK();
     if (q.G >= kPrepGraphMin) {                        // one workgroup per graph
         const size_t lds = (size_t)(2 * kPrepCap + 1024) * sizeof(int);
-        static const hipError_t attr = set_lds(prep_graph_kernel, (size_t)(2 * kPrepCap + 1024) * sizeof(int));
+        const hipError_t attr = set_lds(prep_graph_kernel, lds);      // per launch: the attribute is per device
         if (attr != hipSuccess) return attr;
         hipLaunchKernelGGL(prep_graph_kernel, dim3(q.G), dim3(1024), lds, st, q);
         LAUNCH_CHECK();
