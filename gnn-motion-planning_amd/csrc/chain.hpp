@@ -30,22 +30,12 @@ constexpr int kTile = 32;             // rows per wave, features per tile
 constexpr int kATile = 1024;          // floats in one 32x32 A tile
 
 
-// A row lives in lanes l and l ^ 32.  v_permlane32_swap (gfx950) exchanges the upper half of one register with the
-// lower half of another on the VALU -- no LDS crossbar trip and no lgkmcnt wait like ds_bpermute: with both operands
-// = x it leaves the half-0 lane's value of the row in every lane of one result and the half-1 lane's in the other.
-struct RowPair { float lo, hi; };
-__device__ __forceinline__ RowPair xpair(float x) {
-    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-    return RowPair{__uint_as_float(r[0]), __uint_as_float(r[1])};
-}
-__device__ __forceinline__ float xsum(float x) {        // x(l) + x(l ^ 32), the same bits in both lanes
-    const RowPair p = xpair(x);
-    return p.lo + p.hi;
-}
-__device__ __forceinline__ float xmax(float x) {
-    const RowPair p = xpair(x);
-    return fmaxf(p.lo, p.hi);
-}
+// A row lives in lanes l and l ^ 32: x(l) (+ | max) x(l ^ 32), the same bits in both lanes.  The exchange goes through
+// the LDS crossbar (ds_bpermute).  gfx950's v_permlane32_swap does the same on the VALU; measured on the two pre
+// kernels it is a wash for the edge kernel (2.223 -> 2.219 ms) and a loss for the register-tight node kernel
+// (0.233 -> 0.250 ms), so the VALU -- which shares its issue time with the fp32 MFMAs -- is left alone here.
+__device__ __forceinline__ float xsum(float x) { return x + __shfl_xor(x, 32, 64); }
+__device__ __forceinline__ float xmax(float x) { return fmaxf(x, __shfl_xor(x, 32, 64)); }
 
 __device__ __forceinline__ f32x16 splat16(float x) {
     f32x16 v;
