@@ -184,3 +184,36 @@ def test_device_frontier_tie_breaking_on_quantised_scores(seed):
         if ref is not None:
             assert path[nptr[b]:nptr[b] + plen[b]].tolist() == ref
         assert checks[b] == env.collision_check_count - c0
+
+
+def test_unsolvable_problem_matches_host_planner():
+    """Goal cell walled in: the device planner must exhaust the frontier exactly like the host loop (same explored
+    order, pair list and check count), report failure, and skip smoothing for that problem while its solvable batch
+    neighbour is smoothed."""
+    with np.load(golden_files('evalset_mazehard_first12')[0]) as f:
+        r = {k: f[k] for k in f.files}
+    m, ms = _models(), _smoother()
+    walled = np.zeros((15, 15))
+    walled[9:12, 9:12] = 1
+    walled[10, 10] = 0                                                   # free cell enclosed by obstacles
+    cell = lambda i, j: (np.array([i, j]) + 0.5) / 15 * 2 - 1            # noqa: E731
+    problems = [dict(map=walled, init_state=cell(2, 2), goal_state=cell(10, 10)),
+                dict(map=r['maps'][1], init_state=r['init_states'][1], goal_state=r['goal_states'][1])]
+    np.random.seed(3)
+    res = planner.explore_maze_batch(problems, m, DEV, batch=200, k=15, model_s=ms)
+    assert not res[0]['success'] and len(res[0]['path']) == 0 and len(res[0]['smooth_path']) == 0 and res[0]['c_smooth'] == 0
+    assert res[1]['success'] and len(res[1]['smooth_path']) == len(res[1]['path'])
+    # host frontier on the same samples and the same scores
+    d = res[0]
+    env = Maze2D(walled[None], cell(2, 2)[None], cell(10, 10)[None])
+    env.init_new_problem(0)
+    v, nf = d['v'].numpy(), d['n_free']
+    data = planner.create_data([x for x in v[:nf]], [x for x in v[nf:]], env.goal_state, 15)
+    od = planner.obs_data(env, [x for x in v[:nf]], [x for x in v[nf:]], DEV)
+    sc = m.edge_scores(goal=data['goal'].to(DEV), v=data['v'].to(DEV), edge_index=data['edge_index'].to(DEV), loop=5,
+                       obstacles=od['obstacles']).cpu().numpy()
+    state = {'explored': [0], 'explored_edges': [[0, 0]], 'costs': {0: 0.}, 'prev': {0: 0}}
+    assert planner.greedy_expand_sparse(sc, data['edge_index'].numpy(), data['labels'].numpy(), data['v'].numpy(), env, state) is None
+    assert d['explored'].tolist() == state['explored']
+    assert d['explored_edges'].tolist() == state['explored_edges']
+    assert d['c_explore'] - d['env'].collision_check_count == env.collision_check_count
