@@ -117,6 +117,11 @@ class EncoderProcessDecoder(nn.Module):
         except Exception:
             pass
 
+    def __getstate__(self):                 # copy.deepcopy / pickle: the native handle and buffers stay with the original
+        st = self.__dict__.copy()
+        st.update(_handle=None, _handle_key=None, _ws=None, _wt=None, _manifest=None)
+        return st
+
     def _dims(self):
         modes = {'fp32': 0, 'bf16': 1, 'bf16x3': 2}
         if self.mlp_dtype not in modes:

@@ -113,6 +113,11 @@ class ModelSmoother(nn.Module):
         except Exception:
             pass
 
+    def __getstate__(self):                 # copy.deepcopy / pickle: the native handle and buffers stay with the original
+        st = self.__dict__.copy()
+        st.update(_handle=None, _handle_key=None, _ws=None, _wt=None, _manifest=None)
+        return st
+
     def _apply(self, fn, *a, **k):
         self._drop_handle()
         return super()._apply(fn, *a, **k)

@@ -216,3 +216,18 @@ def test_weights_follow_in_place_updates():
         m.policy[4].weight.mul_(2.0)
     s1 = m.edge_scores(d['goal'], 1, d['v'], d['obstacles'], d['edge_index'])
     assert torch.allclose(s1, 2 * s0, rtol=1e-6, atol=1e-6)
+
+
+def test_deepcopy_after_forward():
+    """copy.deepcopy of a model that already owns a native handle: the copy builds its own handle (no shared pointer,
+    no double free) and scores identically."""
+    import copy
+    g = to_dev(synth_graph('maze2', 80, 5, seed=3))
+    m = make_model('maze2')
+    a = m.edge_scores(g['goal'], 3, g['v'], g['obstacles'], g['edge_index'])
+    m2 = copy.deepcopy(m)
+    assert m2._handle is None
+    b = m2.edge_scores(g['goal'], 3, g['v'], g['obstacles'], g['edge_index'])
+    assert torch.equal(a, b)
+    del m
+    assert torch.equal(b, m2.edge_scores(g['goal'], 3, g['v'], g['obstacles'], g['edge_index']))
