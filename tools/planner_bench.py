@@ -47,7 +47,8 @@ def main():
                  for i in range(a.problems)]
         np.random.seed(1234)
         sm = ms if a.device_smooth else None
-        planner.explore_maze_batch(probs[:4], m, dev, batch=a.batch, k=a.k, model_s=sm)          # warm-up
+        np.random.seed(1234)
+        planner.explore_maze_batch(probs, m, dev, batch=a.batch, k=a.k, model_s=sm)              # warm-up at full size (allocator)
         np.random.seed(1234)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
