@@ -217,3 +217,36 @@ def test_unsolvable_problem_matches_host_planner():
     assert d['explored'].tolist() == state['explored']
     assert d['explored_edges'].tolist() == state['explored_edges']
     assert d['c_explore'] - d['env'].collision_check_count == env.collision_check_count
+
+
+@pytest.mark.parametrize('batch,k,density,seed', [(150, 12, 0.2, 0), (260, 18, 0.4, 1)])
+def test_device_planner_equals_host_planner_on_random_maps(batch, k, density, seed):
+    """Random occupancy maps (not from the reference's data set; the dense ones contain unsolvable problems), other
+    batch / k settings: every problem through the device planner and through planner.explore (host frontier, host
+    collision checks, host steering) -- same success flag, collision-check counts of both stages, explored order
+    and bit-identical smoothed path.  (A 200-problem version of this loop was run once per shape with 0 mismatches.)"""
+    rng = np.random.RandomState(2024 + seed)
+    B = 14
+    maps = (rng.rand(B, 15, 15) < density).astype(np.float64)
+    cell = lambda x: (x + 0.5) / 15 * 2 - 1                               # noqa: E731
+    inits, goals = [], []
+    for b in range(B):
+        free_cells = np.argwhere(maps[b] == 0)
+        inits.append(cell(free_cells[rng.randint(len(free_cells))]))
+        goals.append(cell(free_cells[rng.randint(len(free_cells))]))
+    inits, goals = np.array(inits), np.array(goals)
+    m, ms = _models(), _smoother()
+    problems = [dict(map=maps[b], init_state=inits[b], goal_state=goals[b]) for b in range(B)]
+    np.random.seed(100 + seed)
+    res = planner.explore_maze_batch(problems, m, DEV, batch=batch, k=k, model_s=ms)
+    np.random.seed(100 + seed)
+    env = Maze2D(maps, inits, goals)
+    for b in range(B):
+        env.init_new_problem(b)
+        r = planner.explore(env, m, ms, True, batch=batch, t_max=batch, k=k, device=DEV, sparse=True)
+        d = res[b]
+        assert bool(r['success']) == d['success'], b
+        assert r['c_explore'] == d['c_explore'] and r['explored'] == d['explored'].tolist(), b
+        if r['success']:
+            assert r['c_smooth'] == d['c_smooth'], b
+            assert np.array_equal(np.array(r['smooth_path']), np.array(d['smooth_path'])), b
