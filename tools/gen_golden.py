@@ -210,7 +210,7 @@ def planner_cases(sds):
     planner_case(eg, env, 7, sds['maze2'], sd_s, batch=40, t_max=200, k=8, seed=77)
 
 
-def eval_set_case(n_problems=12):
+def eval_set_case(n_problems=12, batch=500, k=30, seed=1234, rows_only=False):
     """The reference's eval_gnn defaults (batch=500, t_max=500, k=30 -> N ~ 1002, k1 = 41, E ~ 56 k, smoothing on)
     on the first problems of mazes_hard.npz, seed 1234 -- the setting of the notebook's published run
     (main.ipynb:57-61).  Records the problem definitions (data) and the per-problem outcomes."""
@@ -225,21 +225,25 @@ def eval_set_case(n_problems=12):
     ms = ref_smoother.ModelSmoother(workspace_size=2, config_size=2, embed_size=128, obs_size=6)
     ms.load_state_dict(sd_s, strict=True)
     m.eval(); ms.eval()
-    set_random_seed(1234)
+    set_random_seed(seed)
     rows, explored_n = [], []
     import time as _t
     t0 = _t.time()
     for idx in range(n_problems):
         env.init_new_problem(idx)
-        r = eg.explore(env, m, ms, True, batch=500, t_max=500, k=30)
+        r = eg.explore(env, m, ms, True, batch=batch, t_max=batch, k=k)
         rows.append([int(r['success']), eg.path_cost(r['path']), eg.path_cost(r['smooth_path']), r['c_explore'],
                      r['c_smooth'], len(r['path']), len(r['explored'])])
         print('  problem %d: success=%d c_explore=%d c_smooth=%d explored=%d (%.1f s)' %
               (idx, r['success'], r['c_explore'], r['c_smooth'], len(r['explored']), _t.time() - t0))
+    if rows_only:                       # same problems as evalset_mazehard_first1000.npz, another planner setting
+        np.savez_compressed(os.path.join(OUT, 'evalrows_mazehard_first%d_b%d_k%d_s%d.npz' % (n_problems, batch, k, seed)),
+                            seed=seed, batch=batch, t_max=batch, k=k, rows=np.array(rows, dtype=np.float64))
+        return
     np.savez_compressed(os.path.join(OUT, 'evalset_mazehard_first%d.npz' % n_problems),
                         maps=env.maps[:n_problems].copy().astype(np.float64 if n_problems <= 100 else np.uint8),
                         init_states=env.init_states[:n_problems].copy(),
-                        goal_states=env.goal_states[:n_problems].copy(), seed=1234, batch=500, t_max=500, k=30,
+                        goal_states=env.goal_states[:n_problems].copy(), seed=seed, batch=batch, t_max=batch, k=k,
                         rows=np.array(rows, dtype=np.float64),
                         columns=np.array(['success', 'path_cost', 'smooth_cost', 'c_explore', 'c_smooth', 'path_len', 'explored']))
 
@@ -276,6 +280,9 @@ if __name__ == '__main__':
         planner_cases({'maze2': save_weights('weights_maze')})
     elif len(sys.argv) > 1 and sys.argv[1] == 'evalset':
         torch.set_num_threads(8)
-        eval_set_case(int(sys.argv[2]) if len(sys.argv) > 2 else 12)
+        if len(sys.argv) > 5:               # evalset N batch k seed -> rows only (problems are in the first-1000 fixture)
+            eval_set_case(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), rows_only=True)
+        else:
+            eval_set_case(int(sys.argv[2]) if len(sys.argv) > 2 else 12)
     else:
         main()
