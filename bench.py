@@ -51,10 +51,20 @@ def algorithmic_bytes(N, E, O, C, S):
     return 4 * N * C + 4 * C + 4 * O * S + 8 * E + 4 * E
 
 
+def kernel_source_hash():
+    """sha256 over the sources of the dominant kernel (what profiles/edge_pre_traffic.json was measured on)."""
+    import hashlib
+    hsh = hashlib.sha256()
+    for f in ('chain.hpp', 'layout.hpp', 'kernels.hpp', 'explorer_kernels.hip'):
+        with open(os.path.join(REPO, 'gnn-motion-planning_amd', 'csrc', f), 'rb') as fh:
+            hsh.update(fh.read())
+    return hsh.hexdigest()
+
+
 def cpu_baseline(env, n_nodes, k1, budget_s, seed0):
     """The oracle (a port of the reference's CPU path, materialising attention form) timed on this
     host: single-graph calls in a loop exactly like eval_gnn.py:113-116,194."""
-    from conftest import load_weights
+    from gnnmp.weights import load_weights
     from gnnmp.synth import ENVS, synth_graph
     from oracle import ref_cpu
     w = load_weights(ENVS[env]['ckpt'])
@@ -108,8 +118,11 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('launch with torch.distributed.run --nproc-per-node %d for --gpus %d' % (args.gpus, args.gpus))
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d -- launch one rank per GPU: python -m torch.distributed.run '
+                         '--nnodes=1 --nproc-per-node %d --master-addr 127.0.0.1 --master-port P bench.py --gpus %d ...'
+                         % (args.gpus, world, args.gpus, args.gpus))
+    if local >= torch.cuda.device_count():
+        raise SystemExit('bench.py: LOCAL_RANK %d but only %d GPU(s) visible' % (local, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     # GNNMP_BENCH_FORCE_DIST=1 exercises the RCCL code path (init, barrier, all_reduce, all_gather) with one rank
@@ -118,7 +131,7 @@ def main():
         dist.init_process_group('nccl', device_id=dev)
 
     import gnnmp
-    from conftest import load_weights
+    from gnnmp.weights import load_weights
     from gnnmp.synth import ENVS, synth_batch_gpu
     e = ENVS[args.env]
     G = args.graphs
@@ -240,11 +253,16 @@ def main():
         ep_avg_ms = ep_ms / max(ep_n, 1)
         achieved = ep_flops / (ep_avg_ms * 1e-3) / 1e12 if ep_avg_ms > 0 else 0.0
         peak = PEAK_BF16_TFLOPS if args.mlp_dtype == 'bf16' else PEAK_FP32_TFLOPS
+        # HBM bytes of the dominant kernel come from separate rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE cannot be
+        # read inside this process); the summary tool stamps the file with a hash of the kernel sources it measured,
+        # and the number is reported only while that hash still matches the sources of the library in use
         traffic = None
         tpath = os.path.join(REPO, 'profiles', 'edge_pre_traffic.json')
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get('hbm_bytes_per_launch')
+                tj = json.load(open(tpath))
+                if tj.get('kernel_source_sha256') == kernel_source_hash():
+                    traffic = tj.get('hbm_bytes_per_launch')
             except Exception:
                 traffic = None
         cfg_name = 'BASELINE configs[1]' if (args.env, args.nodes, args.k1, G, args.mlp_dtype) == ('maze2', 1000, 8, 256, 'fp32') \

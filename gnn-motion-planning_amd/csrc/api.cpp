@@ -485,6 +485,9 @@ extern "C" int gnnmp_explorer_create(gnnmp_explorer** out, const gnnmp_explorer_
         else if (P == 1) pack_explorer<64, 1>(B, *dims, h, packed);
         else pack_explorer<64, 0>(B, *dims, h, packed);
     }
+    // the handle lives on `device`; the caller's current device is restored before returning
+    int prev_dev = -1;
+    (void)hipGetDevice(&prev_dev);
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) {
         int ncu = 0;
@@ -496,6 +499,7 @@ extern "C" int gnnmp_explorer_create(gnnmp_explorer** out, const gnnmp_explorer_
     }
     if (e == hipSuccess) e = hipMalloc((void**)&h->w_dev, packed.size() * sizeof(float));
     if (e == hipSuccess) e = hipMemcpy(h->w_dev, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (prev_dev >= 0 && prev_dev != device) (void)hipSetDevice(prev_dev);
     if (e != hipSuccess) {
         if (h->w_dev) (void)hipFree(h->w_dev);
         delete h->prof;
@@ -924,9 +928,12 @@ extern "C" int gnnmp_smoother_create(gnnmp_smoother** out, const gnnmp_smoother_
         ptiles(ws.data(), 32, D, P.data() + L.ws);
         gnnmp_pack_vec(bs.data(), 32, P.data() + L.bs);
     }
+    int prev_dev = -1;
+    (void)hipGetDevice(&prev_dev);
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) e = hipMalloc((void**)&h->w_dev, P.size() * sizeof(float));
     if (e == hipSuccess) e = hipMemcpy(h->w_dev, P.data(), P.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (prev_dev >= 0 && prev_dev != device) (void)hipSetDevice(prev_dev);
     if (e != hipSuccess) {
         if (h->w_dev) (void)hipFree(h->w_dev);
         delete h;

@@ -132,22 +132,46 @@ class EncoderProcessDecoder(nn.Module):
         self._drop_handle()
         return super()._apply(fn, *a, **k)
 
-    def _native(self, device):
-        """Opaque library handle holding the packed weights on ``device`` (rebuilt when the
-        parameters were reloaded, moved or modified in place)."""
+    def _live_weights(self):
+        """The state_dict tensors forward() reads, looked up on the live modules every call (so a replaced
+        Parameter object is seen); the (module, slot) paths are resolved once."""
         if self._manifest is None:
             self._manifest = _lib.manifest('explorer', self._dims())
-            sd = self.state_dict(keep_vars=True)
-            self._wt = [sd[n] for n, _ in self._manifest]
-        key = (str(device), self.mlp_dtype, tuple(t._version for t in self._wt))
+            paths = []
+            for n, _ in self._manifest:
+                mod, _, leaf = n.rpartition('.')
+                m = self.get_submodule(mod) if mod else self
+                paths.append((m, leaf))
+            self._wt = paths
+        out = []
+        for m, leaf in self._wt:
+            t = m._parameters.get(leaf)
+            out.append(t if t is not None else m._buffers[leaf])
+        return out
+
+    def refresh_weights(self):
+        """Drop the packed device copy of the weights; the next forward re-packs from the current parameters.
+        Needed only after writes the cache key cannot see (``p.data.copy_(...)`` and other ``.data`` writes do not
+        bump ``_version``); ``load_state_dict``, ``.to()``, in-place autograd-visible ops and replacing a Parameter
+        are detected automatically."""
+        self._drop_handle()
+
+    @staticmethod
+    def _device_index(device):
+        dev = torch.device(device)
+        return dev.index if dev.index is not None else torch.cuda.current_device()
+
+    def _native(self, device):
+        """Opaque library handle holding the packed weights on ``device`` (rebuilt when the
+        parameters were reloaded, moved, replaced or modified in place)."""
+        wt = self._live_weights()
+        idx = self._device_index(device)
+        key = (idx, self.mlp_dtype, tuple((id(t), t._version) for t in wt))
         if self._handle is not None and key == self._handle_key:
             return self._handle
         self._drop_handle()
-        sd = self.state_dict(keep_vars=True)
-        self._wt = [sd[n] for n, _ in self._manifest]
-        key = (str(device), self.mlp_dtype, tuple(t._version for t in self._wt))
         parts = []
-        for (n, numel), t in zip(self._manifest, self._wt):
+        for (n, numel), t in zip(self._manifest, wt):
             t = t.detach().to('cpu', torch.float32).contiguous().reshape(-1)
             if t.numel() != numel:
                 raise RuntimeError('parameter %s has %d elements, library expects %d' % (n, t.numel(), numel))
@@ -155,9 +179,9 @@ class EncoderProcessDecoder(nn.Module):
         blob = torch.cat(parts).contiguous()
         h = ctypes.c_void_p()
         dims = self._dims()
-        _lib.check(_lib.lib().gnnmp_explorer_create(ctypes.byref(h), ctypes.byref(dims), blob.data_ptr(),
-                                                    blob.numel(), torch.device(device).index or 0),
-                   'gnnmp_explorer_create')
+        with torch.cuda.device(idx):            # the library also restores the caller's current device itself
+            _lib.check(_lib.lib().gnnmp_explorer_create(ctypes.byref(h), ctypes.byref(dims), blob.data_ptr(),
+                                                        blob.numel(), idx), 'gnnmp_explorer_create')
         self._handle, self._handle_key = h, key
         return h
 

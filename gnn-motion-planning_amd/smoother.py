@@ -127,20 +127,27 @@ class ModelSmoother(nn.Module):
             raise ValueError("mlp_dtype must be 'fp32' or 'bf16'")
         return _lib.SmootherDims(self.config_size, self.embed_size, float(self.scale), 1 if self.mlp_dtype == 'bf16' else 0)
 
+    def refresh_weights(self):
+        """Drop the packed device copy of the weights (see EncoderProcessDecoder.refresh_weights)."""
+        self._drop_handle()
+
     def _native(self, device):
         if self._manifest is None:
             self._manifest = _lib.manifest('smoother', self._dims())
         sd = self.state_dict(keep_vars=True)
         wt = [sd[n] for n, _ in self._manifest]
-        key = (str(device), float(self.scale), self.mlp_dtype, tuple(t._version for t in wt))
+        dev = torch.device(device)
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        key = (idx, float(self.scale), self.mlp_dtype, tuple((id(t), t._version) for t in wt))
         if self._handle is not None and key == self._handle_key:
             return self._handle
         self._drop_handle()
         blob = torch.cat([t.detach().to('cpu', torch.float32).reshape(-1) for t in wt]).contiguous()
         h = ctypes.c_void_p()
         dims = self._dims()
-        _lib.check(_lib.lib().gnnmp_smoother_create(ctypes.byref(h), ctypes.byref(dims), blob.data_ptr(), blob.numel(),
-                                                    torch.device(device).index or 0), 'gnnmp_smoother_create')
+        with torch.cuda.device(idx):
+            _lib.check(_lib.lib().gnnmp_smoother_create(ctypes.byref(h), ctypes.byref(dims), blob.data_ptr(), blob.numel(),
+                                                        idx), 'gnnmp_smoother_create')
         self._handle, self._handle_key = h, key
         return h
 

@@ -84,7 +84,9 @@ int gnnmp_explorer_manifest(const gnnmp_explorer_dims* dims, int index,
                             char* name, size_t name_cap, int64_t* numel);
 
 /* weights_host: HOST pointer to the concatenated manifest tensors; n_floats must equal the
- * manifest total.  device: HIP device ordinal the handle lives on. */
+ * manifest total.  device: HIP device ordinal the handle lives on (the packed weights are allocated
+ * there; forward must be given streams, inputs and workspace of the SAME device).  The calling
+ * thread's current HIP device is saved and restored: creating a handle never changes it. */
 int gnnmp_explorer_create(gnnmp_explorer** out, const gnnmp_explorer_dims* dims,
                           const float* weights_host, size_t n_floats, int device);
 int gnnmp_explorer_destroy(gnnmp_explorer* h);
@@ -166,6 +168,7 @@ typedef struct {
 
 int gnnmp_smoother_manifest(const gnnmp_smoother_dims* dims, int index,
                             char* name, size_t name_cap, int64_t* numel);
+/* device semantics as for gnnmp_explorer_create (current device saved and restored) */
 int gnnmp_smoother_create(gnnmp_smoother** out, const gnnmp_smoother_dims* dims,
                           const float* weights_host, size_t n_floats, int device);
 int gnnmp_smoother_destroy(gnnmp_smoother* h);

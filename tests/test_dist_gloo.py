@@ -38,7 +38,7 @@ def _worker(rank, world, port, n_problems, q):
     parts = gather_variable(local)
     rows = torch.tensor([[float(i), float(i * i)] for i in range(lo, hi)], dtype=torch.float64).reshape(-1, 2)
     allrows = gather_problem_results(rows)
-    q.put((rank, lo, hi, [p.clone() for p in parts], allrows.clone()))
+    q.put((rank, lo, hi, [p.numpy().copy() for p in parts], allrows.numpy().copy()))      # numpy: no fd passing of tensors
     dist.barrier()
     dist.destroy_process_group()
 
@@ -57,6 +57,8 @@ def test_two_rank_gather_equals_single_process():
         assert p.exitcode == 0
     whole = _fake_scores(0, n)
     for rank, lo, hi, parts, allrows in got:
+        parts = [torch.from_numpy(p) for p in parts]
+        allrows = torch.from_numpy(allrows)
         assert torch.equal(torch.cat(parts), whole)                 # same bytes as the unsharded run
         assert torch.equal(parts[rank], _fake_scores(lo, hi))       # a shard run alone gives its slice
         assert torch.equal(allrows[:, 0], torch.arange(n, dtype=torch.float64))

@@ -11,7 +11,7 @@ sys.path.insert(0, REPO)
 sys.path.insert(0, os.path.join(REPO, 'tests'))
 import torch  # noqa: E402
 import gnnmp  # noqa: F401,E402
-from conftest import load_weights  # noqa: E402
+from gnnmp.weights import load_weights  # noqa: E402
 from gnnmp.synth import ENVS, synth_graph  # noqa: E402
 from oracle import ref_cpu  # noqa: E402
 

@@ -19,7 +19,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 import gnnmp  # noqa: E402
-from conftest import load_weights  # noqa: E402
+from gnnmp.weights import load_weights  # noqa: E402
 from gnnmp import planner  # noqa: E402
 from gnnmp.dist import gather_problem_results  # noqa: E402
 from gnnmp.maze2d import Maze2D  # noqa: E402

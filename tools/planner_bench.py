@@ -17,7 +17,8 @@ sys.path.insert(0, os.path.join(REPO, 'tests'))
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import gnnmp  # noqa: E402
-from conftest import golden_files, load_weights  # noqa: E402
+from conftest import golden_files  # noqa: E402
+from gnnmp.weights import load_weights  # noqa: E402
 from gnnmp import planner  # noqa: E402
 from gnnmp.maze2d import Maze2D  # noqa: E402
 
