@@ -65,6 +65,48 @@ def test_two_rank_gather_equals_single_process():
         assert torch.equal(allrows[:, 1], torch.arange(n, dtype=torch.float64) ** 2)
 
 
+def _rows_worker(rank, world, port, fixture, q):
+    import numpy as np
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    with np.load(fixture) as f:
+        rows = f['rows']
+    lo, hi = shard_range(rows.shape[0], rank, world)          # what eval_gnn_device(shard=(rank, world)) evaluates
+    allrows = gather_problem_results(torch.from_numpy(rows[lo:hi].copy()))
+    q.put((rank, allrows.numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_gather_recorded_device_planner_rows():
+    """Real per-problem rows (success, path cost, smoothed cost, c_explore, c_smooth, path length, explored:
+    eval_gnn.py:120-122) recorded from planner.eval_gnn_device on an MI355X (tools/record_device_rows.py); rank r owns
+    the contiguous block eval_gnn_device(shard=(r, 2)) evaluates (the GPU test tests/test_dist_gpu.py runs exactly that
+    with two processes and compares with this fixture); the gather restores the sequential order and the aggregates
+    of eval_gnn.py:128-145."""
+    import numpy as np
+    fixture = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'evalrows_device_first64.npz')
+    with np.load(fixture) as f:
+        want = f['rows']
+    assert want.shape == (64, 7)
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rows_worker, args=(r, world, port, fixture, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, allrows in got:
+        assert np.array_equal(allrows, want)
+        assert int(allrows[:, 0].sum()) == int(want[:, 0].sum())
+        assert float(np.mean(allrows[:, 3] + allrows[:, 4])) == float(np.mean(want[:, 3] + want[:, 4]))
+
+
 def test_shard_ranges_cover_and_balance():
     for n in (0, 1, 7, 256, 1000):
         for world in (1, 2, 3, 8):

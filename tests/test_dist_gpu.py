@@ -1,0 +1,102 @@
+"""Multi-process paths on the GPU box (one MI355X): (1) bench.py's RCCL code path -- init_process_group('nccl'),
+barrier, all_reduce, all_gather -- under torch.distributed.run with one rank, against the plain single-process line;
+(2) two host processes sharing the GPU, each evaluating ITS shard of planning problems with the device planner
+(planner.eval_gnn_device(shard=(rank, 2))) and gathering the per-problem rows (eval_gnn.py:120-122) with
+gnnmp.dist.gather_problem_results over gloo (two ranks cannot share one GPU under RCCL) -- against the
+single-process rows and the committed fixture."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, REPO
+
+pytestmark = pytest.mark.gpu
+BENCH_ARGS = ['--steps', '3', '--warmup', '1', '--graphs', '32', '--no-cpu-baseline', '--pcie-steps', '0', '--dense-steps', '0',
+              '--bf16x3-steps', '0']
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _json_line(out):
+    lines = [ln for ln in out.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, out
+    return json.loads(lines[0])
+
+
+def test_bench_rccl_path_one_rank_equals_plain_run():
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    plain = subprocess.run([sys.executable, 'bench.py', '--gpus', '1'] + BENCH_ARGS, cwd=REPO, env=env, capture_output=True,
+                           text=True, timeout=600)
+    assert plain.returncode == 0, plain.stderr[-2000:]
+    a = _json_line(plain.stdout)
+    env2 = dict(env, GNNMP_BENCH_FORCE_DIST='1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), 'bench.py', '--gpus', '1'] + BENCH_ARGS
+    dist_run = subprocess.run(cmd, cwd=REPO, env=env2, capture_output=True, text=True, timeout=600)
+    assert dist_run.returncode == 0, dist_run.stderr[-2000:]
+    b = _json_line(dist_run.stdout)
+    assert b['n_gpus'] == 1 and a['n_gpus'] == 1
+    # the gathered (all_gather over RCCL) scores are the same bytes as the local ones
+    assert a['config']['result_checksum'] == b['config']['result_checksum']
+    assert b['value'] > 0.5 * a['value']
+
+
+def test_bench_refuses_world_size_mismatch():
+    r = subprocess.run([sys.executable, 'bench.py', '--gpus', '2', '--steps', '1'], cwd=REPO, capture_output=True, text=True,
+                       timeout=300, env={k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')})
+    assert r.returncode != 0 and 'WORLD_SIZE' in (r.stderr + r.stdout)
+
+
+_WORKER = r'''
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %(repo)r)
+import gnnmp
+from gnnmp import planner
+from gnnmp.dist import gather_problem_results
+from gnnmp.maze2d import Maze2D
+from gnnmp.weights import load_weights
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+dist.init_process_group('gloo')
+with np.load(%(fixture)r) as f:
+    r = {k: f[k] for k in f.files}
+env = Maze2D(r['maps'], r['init_states'], r['goal_states'])
+m = gnnmp.EncoderProcessDecoder(2, 2, 32, 2); m.load_state_dict(load_weights('weights_maze'))
+ms = gnnmp.ModelSmoother(workspace_size=2, config_size=2, embed_size=128, obs_size=6); ms.load_state_dict(load_weights('smooth_2d_attv3'))
+rows = []
+planner.eval_gnn_device(env, range(64), m, ms, seed=int(r['seed']), batch=int(r['batch']), k=int(r['k']), device='cuda:0',
+                        rows_out=rows, shard=(rank, world))
+allrows = gather_problem_results(torch.tensor(np.array(rows, dtype=np.float64).reshape(-1, 7)))
+if rank == 0:
+    np.save(%(out)r, allrows.numpy())
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_two_processes_shard_the_device_planner(tmp_path):
+    fixture = os.path.join(GOLDEN, 'evalset_mazehard_first1000.npz')
+    out = str(tmp_path / 'rows.npy')
+    script = tmp_path / 'worker.py'
+    script.write_text(_WORKER % dict(repo=REPO, fixture=fixture, out=out))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), str(script)]
+    r = subprocess.run(cmd, cwd=REPO, capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0'))
+    assert r.returncode == 0, r.stderr[-3000:]
+    got = np.load(out)
+    with np.load(os.path.join(GOLDEN, 'evalrows_device_first64.npz')) as f:
+        want = f['rows']
+    assert got.shape == want.shape == (64, 7)
+    assert np.array_equal(got, want)          # union over ranks == the recorded single-process device run, row by row
