@@ -53,14 +53,24 @@ def scatter_rows(msg, index, n_rows, reduce):
     return out.scatter_reduce(0, idx, msg, reduce=red, include_self=False)
 
 
-def knn(x, y, k):
+def knn(x, y, k, input_dtype=False):
     """torch_geometric.nn.pool.knn(x, y, k): for each row of y the k nearest rows of x.
 
     Returns int64 [2, len(y)*min(k, len(x))]; row 0 indexes y, row 1 indexes x
     (call sites model.py:132, model_smoother.py:125).  Distances in float64,
-    ``topk(largest=False)`` ordering.
+    ``topk(largest=False)`` ordering.  ``input_dtype``: squared distances accumulated coordinate by coordinate in
+    the dtype of the inputs instead (a float32 kNN library's arithmetic; torch_cluster's dtype is unpinned by the
+    reference), ties to the lower index -- pinned by tests/golden/smoother_*_knn32.npz.
     """
     k = min(k, x.shape[0])
+    if input_dtype:
+        d = torch.zeros(y.shape[0], x.shape[0], dtype=x.dtype)
+        for c in range(x.shape[1]):
+            df = x[:, c].view(1, -1) - y[:, c].view(-1, 1)
+            d = d + df * df
+        nb = torch.sort(d, dim=1, stable=True).indices[:, :k]
+        q = torch.arange(y.shape[0]).view(-1, 1).expand_as(nb)
+        return torch.stack((q.reshape(-1), nb.reshape(-1)), dim=0)
     d = torch.cdist(y.to(torch.float64), x.to(torch.float64))
     nb = d.topk(k, dim=1, largest=False).indices
     q = torch.arange(y.shape[0]).view(-1, 1).expand_as(nb)
@@ -207,7 +217,7 @@ def explorer_forward(w, v, goal, obstacles, edge_index, loop, use_obstacles=True
 # smoother
 # --------------------------------------------------------------------------------------
 @torch.no_grad()
-def smoother_forward(w, path, free, collided, edge_index, loop=1, scale=1.0, taps=None):
+def smoother_forward(w, path, free, collided, edge_index, loop=1, scale=1.0, taps=None, knn_input_dtype=False):
     """``ModelSmoother.forward`` (model_smoother.py:104-142); ``obstacles`` is accepted and
     ignored by the reference, so it is not a parameter here."""
     path = path / scale                                                       # :118
@@ -217,7 +227,7 @@ def smoother_forward(w, path, free, collided, edge_index, loop=1, scale=1.0, tap
     nodes = torch.cat((path, free, collided), dim=0)                          # :121
     n = nodes.shape[0]
     for _ in range(loop):                                                     # :123
-        ne = knn(nodes[P:], path, 10).flip(0)                                 # :125
+        ne = knn(nodes[P:], path, 10, knn_input_dtype).flip(0)                # :125
         ne[0, :] = ne[0, :] + P                                               # :126
         ei = coalesce(torch.cat((edge_index, ne), dim=-1), n)                 # :127-128
         info = nodes.new_zeros(n, 3)                                          # :130-133

@@ -8,10 +8,10 @@ import torch
 from conftest import load_weights
 import gnnmp
 from oracle import ref_cpu
+from parity_bar import assert_fp32_parity
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
-RTOL, ATOL = 1e-5, 2e-5
 
 
 def random_graph(gen, n, e, n_obs, hub=None):
@@ -32,18 +32,12 @@ def oracle(w, g, loop, dtype=torch.float32):
 
 
 def check(part, w, g, loop):
-    """Structure fuzz, so the bar is "fp32 rounding noise, nothing structural": allclose against the fp32 oracle
-    with the absolute term widened to the oracle's own fp32-vs-fp64 noise on this input, and against the fp64
-    oracle within 4x that noise (the max over a few hundred edges of two different fp32 summation orders is a
-    noisy statistic: 2.3x was observed; an indexing / segmentation bug shows up as 1e-2 or more on scores that
-    span [-30, 10])."""
+    """Structure fuzz: the per-input fp32 bar of tests/parity_bar.py with own_factor 2.5 (the max over a few hundred
+    edges of two different fp32 summation orders is a noisy statistic on tiny inputs: 2.3x was observed; an indexing /
+    segmentation bug shows up as 1e-2 or more on scores that span [-30, 10])."""
     ref32, ref64 = oracle(w, g, loop), oracle(w, g, loop, torch.float64)
-    own = (ref32.double() - ref64).abs().max().item()
-    err32 = (part - ref32).abs().max().item()
-    err64 = (part.double() - ref64).abs().max().item()
-    assert torch.allclose(part, ref32, rtol=RTOL, atol=max(ATOL, 2.0 * own)), (err32, own)
-    assert err64 <= max(4.0 * own, 4e-5), (err64, own)
-    return err32, err64, own
+    r = assert_fp32_parity(part, ref32, ref64, 'fuzz', own_factor=2.5)
+    return r['err32'], r['err64'], r['own']
 
 
 @pytest.mark.parametrize('seed', range(12))

@@ -2,12 +2,10 @@
  (a) the golden vectors recorded from the unmodified reference, fp32 and fp64, and
  (b) the CPU oracle on seeded inputs, including the edge cases the domain has.
 
-Tolerance (north_star: "within 1e-5 fp32"; SURVEY.md finding 0.7): edge scores span about
-[-32, +12] and the reference's own fp32 run differs from the same module in fp64 by up to
-2.4e-5 (tests/golden: explorer_maze2_N1000), i.e. a bare absolute 1e-5 is below the fp32 noise floor
-of the reference itself.  The bar used here:
-    |gpu - ref_fp32| <= ATOL + RTOL * |ref_fp32|   with RTOL = 1e-5, ATOL = 2e-5, and independently
-    max|gpu - ref_fp64| <= max(2 * max|ref_fp32 - ref_fp64|, 2e-5)   (no worse than the reference's own fp32)."""
+Tolerance (north_star: "within 1e-5 fp32"; SURVEY.md finding 0.7): the per-fixture bar of tests/parity_bar.py --
+    atol = max(1e-5, 1.25 * own),  own = max|ref_fp32 - ref_fp64| of the reference itself on that fixture,
+    |gpu - ref_fp32| <= atol + 1e-5 |ref|   and   |gpu - ref_fp64| <= atol + 1e-5 |ref|   elementwise.
+profiles/r02_parity.txt lists every fixture's three maxima and which ones meet the bare 1e-5."""
 import os
 
 import numpy as np
@@ -18,10 +16,10 @@ from conftest import env_of, golden_files, load_weights
 import gnnmp
 from gnnmp.synth import ENVS, synth_graph
 from oracle import ref_cpu
+from parity_bar import assert_fp32_parity, explorer_oracle_pair
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
-RTOL, ATOL = 1e-5, 2e-5      # allclose(rtol, atol) against the fp32 reference
 
 
 def make_model(env, use_obstacles=True):
@@ -55,8 +53,7 @@ def test_golden_scores(path):
     own = (ref32.double() - ref64).abs().max().item()
     print('\n%s: max|gpu-ref32|=%.2e  max|gpu-ref64|=%.2e  (reference fp32-vs-fp64: %.2e)' %
           (os.path.basename(path), err32, err64, own))
-    assert torch.allclose(s, ref32, rtol=RTOL, atol=ATOL), err32
-    assert err64 <= max(2.0 * own, 2e-5), (err64, own)
+    assert_fp32_parity(s, ref32, ref64, os.path.basename(path))
     # the planner consumes orderings: per-target argmax over incoming edges must agree wherever the
     # reference's top-2 margin is above the noise floor
     ei = torch.from_numpy(r['edge_index'])
@@ -112,9 +109,8 @@ def test_dense_is_reference_layout():
     mask = torch.ones_like(P, dtype=torch.bool)
     mask[ei[1], ei[0]] = False
     assert float(P[mask].abs().max()) == 0.0                    # zero-filled elsewhere (model.py:148)
-    ref = ref_cpu.explorer_forward(load_weights('weights_maze'), g['v'], g['goal'], g['obstacles'], g['edge_index'], 3,
-                                   dense=True)
-    assert torch.allclose(P.cpu(), ref, rtol=RTOL, atol=ATOL)
+    ref32, ref64 = explorer_oracle_pair(load_weights('weights_maze'), g, 3, dense=True)
+    assert_fp32_parity(P.cpu().reshape(-1), ref32.reshape(-1), ref64.reshape(-1), 'dense')
 
 
 @pytest.mark.parametrize('env,n,k', [('maze2', 300, 6), ('kuka7', 150, 5), ('ur5', 97, 4), ('kuka14', 130, 9)])
@@ -123,8 +119,8 @@ def test_oracle_seeded(env, n, k):
     m = make_model(env)
     d = to_dev(g)
     s = m.edge_scores(d['goal'], 5, d['v'], d['obstacles'], d['edge_index']).cpu()
-    ref = ref_cpu.explorer_forward(load_weights(ENVS[env]['ckpt']), g['v'], g['goal'], g['obstacles'], g['edge_index'], 5)
-    assert torch.allclose(s, ref, rtol=RTOL, atol=ATOL), (s - ref).abs().max()
+    ref32, ref64 = explorer_oracle_pair(load_weights(ENVS[env]['ckpt']), g, 5)
+    assert_fp32_parity(s, ref32, ref64, env)
 
 
 def test_batch_equals_per_graph_bitwise():
@@ -138,8 +134,8 @@ def test_batch_equals_per_graph_bitwise():
         d = to_dev(g)
         s1 = m.edge_scores(d['goal'], 4, d['v'], d['obstacles'], d['edge_index'])
         assert torch.equal(s1, p)          # problems are independent: batching must not change a bit
-        ref = ref_cpu.explorer_forward(load_weights('weights_maze'), g['v'], g['goal'], g['obstacles'], g['edge_index'], 4)
-        assert torch.allclose(p.cpu(), ref, rtol=RTOL, atol=ATOL)
+        ref32, ref64 = explorer_oracle_pair(load_weights('weights_maze'), g, 4)
+        assert_fp32_parity(p.cpu(), ref32, ref64, 'batched graph')
 
 
 def test_edge_order_and_duplicates():
@@ -171,8 +167,8 @@ def test_degenerate_graphs(case):
     w = load_weights('weights_maze')
     m = make_model('maze2')
     s = m.edge_scores(v[1].to(DEV), 5, v.to(DEV), obstacles.to(DEV), ei.to(DEV)).cpu()
-    ref = ref_cpu.explorer_forward(w, v, v[1].clone(), obstacles, ei, 5)
-    assert torch.allclose(s, ref, rtol=RTOL, atol=ATOL), (s - ref).abs().max()
+    ref32, ref64 = explorer_oracle_pair(w, dict(v=v, goal=v[1].clone(), obstacles=obstacles, edge_index=ei), 5)
+    assert_fp32_parity(s, ref32, ref64, 'structure case', own_factor=2.5)
 
 
 @pytest.mark.parametrize('n_obs', [0, 1, 31, 32, 33, 128, 129, 300])
@@ -186,8 +182,8 @@ def test_obstacle_counts(n_obs):
     w = load_weights('weights_maze')
     m = make_model('maze2')
     s = m.edge_scores(v[1].to(DEV), 5, v.to(DEV), obstacles.to(DEV), ei.to(DEV)).cpu()
-    ref = ref_cpu.explorer_forward(w, v, v[1].clone(), obstacles, ei, 5)
-    assert torch.allclose(s, ref, rtol=RTOL, atol=ATOL), (s - ref).abs().max()
+    ref32, ref64 = explorer_oracle_pair(w, dict(v=v, goal=v[1].clone(), obstacles=obstacles, edge_index=ei), 5)
+    assert_fp32_parity(s, ref32, ref64, 'structure case', own_factor=2.5)
 
 
 def test_use_obstacles_toggle_and_loop_validation():
@@ -199,8 +195,8 @@ def test_use_obstacles_toggle_and_loop_validation():
     s_off = m.edge_scores(d['goal'], 2, d['v'], d['obstacles'], d['edge_index']).cpu()
     w = load_weights('weights_maze')
     for s, flag in ((s_on, True), (s_off, False)):
-        ref = ref_cpu.explorer_forward(w, g['v'], g['goal'], g['obstacles'], g['edge_index'], 2, use_obstacles=flag)
-        assert torch.allclose(s, ref, rtol=RTOL, atol=ATOL)
+        ref32, ref64 = explorer_oracle_pair(w, g, 2, use_obstacles=flag)
+        assert_fp32_parity(s, ref32, ref64, 'use_obstacles=%s' % flag)
     with pytest.raises(ValueError):
         m.edge_scores(d['goal'], 0, d['v'], d['obstacles'], d['edge_index'])
     with pytest.raises(RuntimeError):

@@ -10,6 +10,7 @@ from conftest import load_weights
 import gnnmp
 from gnnmp.synth import ENVS, synth_batch_gpu, synth_graph
 from oracle import ref_cpu
+from parity_bar import assert_fp32_parity, explorer_oracle_pair
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
@@ -39,12 +40,8 @@ def test_cfg2_full_batch_properties():
         w64 = {k: (t.double() if t.is_floating_point() else t) for k, t in w.items()}
         ref64 = ref_cpu.explorer_forward(w64, host['v'].double(), host['goal'].double(), host['obstacles'].double(),
                                          host['edge_index'], 5)
-        own = (ref.double() - ref64).abs().max().item()
-        err64 = (parts[i].cpu().double() - ref64).abs().max().item()
-        err32 = (parts[i].cpu() - ref).abs().max().item()
-        print('graph %d: |gpu-ref64| %.2e  |gpu-ref32| %.2e  oracle fp32-vs-fp64 %.2e' % (i, err64, err32, own))
-        assert err64 <= max(2.0 * own, 2e-5), (err64, own)
-        assert torch.allclose(parts[i].cpu(), ref, rtol=1e-5, atol=max(2e-5, 2.0 * own)), (err32, own)
+        c = assert_fp32_parity(parts[i].cpu(), ref, ref64, 'graph %d' % i)
+        print('graph %d: |gpu-ref64| %.2e  |gpu-ref32| %.2e  oracle fp32-vs-fp64 %.2e  bar %.2e' % (i, c['err64'], c['err32'], c['own'], c['atol']))
     sub = gnnmp.GraphBatch.from_graphs(graphs[:8], 2, DEV)
     sc, dense = m.forward_batch(sub, 5, dense=True)
     off = 0
@@ -72,6 +69,6 @@ def test_mixed_environment_set():
     scores = run_mixed(problems, models, loop=4)
     assert len(scores) == len(problems)
     for p, s in zip(problems, scores):
-        ref = ref_cpu.explorer_forward(load_weights(ENVS[p['env']]['ckpt']), p['v'].cpu(), p['goal'].cpu(),
-                                       p['obstacles'].cpu(), p['edge_index'].cpu(), 4)
-        assert torch.allclose(s.cpu(), ref, rtol=1e-5, atol=2e-5), p['env']
+        g = {k: p[k].cpu() for k in ('v', 'goal', 'obstacles', 'edge_index')}
+        ref32, ref64 = explorer_oracle_pair(load_weights(ENVS[p['env']]['ckpt']), g, 4)
+        assert_fp32_parity(s.cpu(), ref32, ref64, p['env'])

@@ -90,8 +90,9 @@ def test_feeds_the_explorer():
     m = gnnmp.EncoderProcessDecoder(2, 2, 32, 2)
     m.load_state_dict(load_weights('weights_maze'))
     s = m.edge_scores(g['goal'].to(DEV), 5, g['v'].to(DEV), g['obstacles'].to(DEV), ei).cpu()
-    ref = ref_cpu.explorer_forward(load_weights('weights_maze'), g['v'], g['goal'], g['obstacles'], g['edge_index'], 5)
-    assert torch.allclose(s, ref, rtol=1e-5, atol=2e-5)
+    from parity_bar import assert_fp32_parity, explorer_oracle_pair
+    ref32, ref64 = explorer_oracle_pair(load_weights('weights_maze'), g, 5)
+    assert_fp32_parity(s, ref32, ref64, 'device-built graph')
 
 
 def test_hub_bucket_beyond_lds_share_and_large_graphs():

@@ -78,6 +78,16 @@ def test_smoother_oracle_matches_reference(path):
               collided=torch.from_numpy(r['collided']), edge_index=torch.from_numpy(r['edge_index']),
               loop=int(r['loop']), scale=float(r['scale']))
     keep = kw['path'].clone()
+    if 'out_fp32_knn64' in r:
+        # the float32-kNN fixture (tools/gen_golden.py smoother_knn32_case): the oracle with input-dtype distances
+        # reproduces the run recorded under the float32 stand-in, the float64-distance oracle the other run, and the
+        # two differ by far more than the parity bar -- i.e. the fixture does discriminate the kNN dtype
+        out32 = ref_cpu.smoother_forward(w, knn_input_dtype=True, **kw)
+        out64k = ref_cpu.smoother_forward(w, **kw)
+        assert torch.allclose(out32, torch.from_numpy(r['out_fp32']), rtol=1e-5, atol=1e-5)
+        assert torch.allclose(out64k, torch.from_numpy(r['out_fp32_knn64']), rtol=1e-5, atol=1e-5)
+        assert (out32 - out64k).abs().max() > 1e-4
+        return
     out = ref_cpu.smoother_forward(w, **kw)
     assert torch.equal(keep, kw['path'])            # caller's path untouched
     assert torch.allclose(out, torch.from_numpy(r['out_fp32']), rtol=1e-5, atol=1e-5)

@@ -41,9 +41,17 @@ def test_golden(path):
             obstacles=torch.zeros(1, 6, device=DEV), edge_index=torch.from_numpy(r['edge_index']).to(DEV),
             loop=int(r['loop'])).cpu()
     assert torch.equal(keep, p_in)                    # caller's path untouched
-    ref32, ref64 = torch.from_numpy(r['out_fp32']), torch.from_numpy(r['out_fp64'])
-    e32, e64 = (out - ref32).abs().max().item(), (out.double() - ref64).abs().max().item()
-    print('\n%s: max|gpu-ref32|=%.2e max|gpu-ref64|=%.2e' % (os.path.basename(path), e32, e64))
+    ref32 = torch.from_numpy(r['out_fp32'])
+    e32 = (out - ref32).abs().max().item()
+    if 'out_fp64' in r:
+        e64 = (out.double() - torch.from_numpy(r['out_fp64'])).abs().max().item()
+        print('\n%s: max|gpu-ref32|=%.2e max|gpu-ref64|=%.2e' % (os.path.basename(path), e32, e64))
+    else:
+        # float32-kNN fixture (model_smoother.py:125 runs torch_cluster in the input dtype): the kernel's float32
+        # distances + lower-index tie rule pick the neighbours of the float32 run, not those of the float64 run
+        other = (out - torch.from_numpy(r['out_fp32_knn64'])).abs().max().item()
+        print('\n%s: max|gpu-ref32(float32 kNN)|=%.2e, vs the float64-kNN run %.2e' % (os.path.basename(path), e32, other))
+        assert other > 1e-4
     assert torch.allclose(out, ref32, rtol=1e-5, atol=1e-5), e32
     # end points are passed through (x / scale * scale), interior moved
     assert torch.equal(out[0], ref32[0]) and torch.equal(out[-1], ref32[-1])

@@ -143,6 +143,71 @@ def smoother_case(name, C, scale, P=12, F=60, Co=60, loop=1, seed=4321):
            (outs['fp32'] - path).abs().max().item()))
 
 
+def smoother_knn32_case(name='smooth_7d_attv3', C=7, P=12, F=60, Co=60, seed=99):
+    """A smoother fixture that tells float32 kNN distances from float64 ones (model_smoother.py:125; torch_cluster
+    works in the input dtype, our default stand-in in float64).  For three path rows the sample that is their 11th
+    nearest is overwritten with a copy of the 10th nearest moved by one float32 ulp along the coordinate in which it
+    is closest to the path row: float64 distances still order the pair (the original stays the 10th), in float32 the
+    two squared distances are bit-equal under plain and fused accumulation alike (asserted), so the lower index
+    wins -- and the copy is given the lower index.  Recorded with GNNMP_STANDIN_KNN=input; fp32 output only (the same
+    module in fp64 picks other neighbours)."""
+    sd = save_weights(name)
+    gen = torch.Generator().manual_seed(seed)
+    path = (torch.rand(P, C, generator=gen, dtype=torch.float64) * 2 - 1).float()
+    free = (torch.rand(F, C, generator=gen, dtype=torch.float64) * 2 - 1).float()
+    coll = (torch.rand(Co, C, generator=gen, dtype=torch.float64) * 2 - 1).float()
+    samples = torch.cat((free, coll)).clone()
+    flipped = 0
+    for row in (2, 5, 9):
+        q = path[row]
+        order = torch.cdist(q.double().view(1, -1), samples.double()).view(-1).argsort()
+        a, b = int(order[9]), int(order[10])                    # 10th and 11th nearest
+        lo, hi = min(a, b), max(a, b)
+        orig = samples[a].clone()
+        c = int((orig - q).abs().argmin())
+        moved = orig.clone()
+        # one ulp AWAY from the query along coordinate c
+        moved[c] = torch.nextafter(orig[c], orig[c] + (1.0 if orig[c] >= q[c] else -1.0))
+        samples[hi], samples[lo] = orig, moved                  # the moved copy gets the lower index
+        d64 = ((samples[[lo, hi]].double() - q.double()) ** 2).sum(1)
+        assert d64[0] > d64[1], 'float64 must prefer the original'
+        def f32_plain(s_):
+            acc = torch.zeros((), dtype=torch.float32)
+            for cc in range(C):
+                df = s_[cc] - q[cc]
+                acc = acc + df * df
+            return acc
+        def f32_fma(s_):
+            acc = np.float32(0)
+            for cc in range(C):
+                df = np.float32(s_[cc].item()) - np.float32(q[cc].item())
+                acc = np.float32(np.float64(df) * np.float64(df) + np.float64(acc))     # exact product + one rounding = fmaf
+            return acc
+        if f32_plain(samples[lo]) == f32_plain(samples[hi]) and f32_fma(samples[lo]) == f32_fma(samples[hi]):
+            flipped += 1
+    assert flipped >= 2, 'the crafted pairs must tie in float32 (%d of 3 do)' % flipped
+    free2, coll2 = samples[:F].contiguous(), samples[F:].contiguous()
+    a_ = torch.arange(1, P)
+    b_ = torch.arange(0, P - 1)
+    ei = torch.cat((torch.stack((a_, b_)), torch.stack((b_, a_)), torch.stack((torch.arange(P),) * 2)), dim=1)
+    outs = {}
+    for mode in ('input', 'float64'):
+        os.environ['GNNMP_STANDIN_KNN'] = mode
+        m = ref_smoother.ModelSmoother(workspace_size=3, config_size=C, embed_size=128, obs_size=6, scale=1.0)
+        m.load_state_dict(sd, strict=True)
+        m.eval()
+        with torch.no_grad():
+            outs[mode] = m(path=path.clone(), free=free2, collided=coll2, obstacles=torch.zeros(1, 6), edge_index=ei, loop=1)
+    os.environ.pop('GNNMP_STANDIN_KNN')
+    diff = (outs['input'] - outs['float64']).abs().max().item()
+    assert diff > 1e-4, 'the fixture must discriminate the two kNN dtypes (max|diff| %.2e)' % diff
+    fn = 'smoother_%s_P%d_L1_knn32.npz' % (name, P)
+    np.savez_compressed(os.path.join(OUT, fn), path=path.numpy(), free=free2.numpy(), collided=coll2.numpy(),
+                        edge_index=ei.numpy(), loop=1, scale=1.0, out_fp32=outs['input'].numpy(),
+                        out_fp32_knn64=outs['float64'].numpy())
+    print('%-44s float32-kNN vs float64-kNN output: max|diff| %.3e (%d of 3 crafted pairs tie in float32)' % (fn, diff, flipped))
+
+
 def load_patched_eval_gnn():
     """The reference's eval_gnn module with the ONE in-memory token patch SURVEY.md finding 0.6
     describes (torch >= 2 no longer treats a 2 x M ndarray index as a tuple); file on disk untouched."""
@@ -271,6 +336,7 @@ def main():
         smoother_case(name, C, scale)
     smoother_case('smooth_2d_attv3', 2, 1.0, P=30, F=500, Co=500, loop=1)
     smoother_case('smooth_14d_attv3', 14, 1.0, P=7, F=40, Co=3, loop=3)
+    smoother_knn32_case()
     planner_cases(sds)
     eval_set_case()
 
@@ -279,6 +345,8 @@ if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'planner':
         torch.set_num_threads(8)
         planner_cases({'maze2': save_weights('weights_maze')})
+    elif len(sys.argv) > 1 and sys.argv[1] == 'knn32':
+        smoother_knn32_case()
     elif len(sys.argv) > 1 and sys.argv[1] == 'evalset':
         torch.set_num_threads(8)
         if len(sys.argv) > 5:               # evalset N batch k seed -> rows only (problems are in the first-1000 fixture)
