@@ -38,7 +38,7 @@ class SmoothBatch(ctypes.Structure):
                 ('coll_ptr', ctypes.c_void_p), ('edge_ptr', ctypes.c_void_p)]
 
 
-STAGES = ('prep', 'obs', 'node_pre', 'edge_pre', 'mp_edge', 'mp_node', 'policy')
+STAGES = ('prep', 'obs', 'node_pre', 'edge_pre', 'mp', 'policy')
 
 class GraphBuildBatch(ctypes.Structure):
     _fields_ = [('n_graphs', ctypes.c_int32), ('total_nodes', ctypes.c_int32), ('k1_max', ctypes.c_int32),

@@ -232,7 +232,7 @@ extern "C" const char* gnnmp_status_string(int s) {
     return "unknown status";
 }
 extern "C" const char* gnnmp_last_hip_error(void) { return g_hip_error.c_str(); }
-extern "C" int gnnmp_abi_version(void) { return 1; }
+extern "C" int gnnmp_abi_version(void) { return 2; }    // 2: stage list of gnnmp_explorer_profile_read (fused message passing)
 
 // ---------------------------------------------------------------------------------------------
 // explorer handle
@@ -562,9 +562,9 @@ struct Carve {
     // offsets in bytes
     size_t node_ptr_pad, edge_ptr_pad, goal_node, dense_ptr;
     size_t zero_beg, deg, cursor, zero_end;
-    size_t ff_beg, ntile_graph, etile_graph, csr, ff_end, tile_meta;
+    size_t ff_beg, ntile_graph, etile_graph, csr, ff_end, tile_meta, rec32;
     size_t row_beg;
-    size_t XI, X, A, B, DN, H, agg, Ke, PE, part_first, part_last, kv_e, kv_n;
+    size_t XI, X, A, A2, B, DN, H, Ke, PE, kv_e, kv_n;
     size_t total;
 };
 
@@ -600,13 +600,12 @@ bool carve(const gnnmp_explorer* h, const gnnmp_batch* b, Carve& c) {
     c.tile_meta = take(sizeof(int) * (c.Epad / 32));            // -1 = tile beyond the last graph
     c.csr = take(sizeof(int) * 4 * (size_t)c.Epad);
     c.ff_end = o;
+    c.rec32 = take(sizeof(int) * (size_t)c.Epad);
     c.row_beg = take(sizeof(int) * c.Npad);
     const size_t nrow = sizeof(float) * (size_t)c.Npad * D, erow = sizeof(float) * (size_t)c.Epad * D;
-    c.XI = take(nrow); c.X = take(nrow); c.A = take(nrow); c.B = take(nrow); c.DN = take(nrow); c.H = take(nrow);
-    c.agg = take(nrow);
+    c.XI = take(nrow); c.X = take(nrow); c.A = take(nrow); c.A2 = take(nrow); c.B = take(nrow); c.DN = take(nrow);
+    c.H = take(nrow);
     c.Ke = take(erow); c.PE = take(erow);
-    c.part_first = take(sizeof(float) * (size_t)(c.Epad / 32) * D);
-    c.part_last = take(sizeof(float) * (size_t)(c.Epad / 32) * D);
     c.kv_e = take(sizeof(float) * (size_t)c.G * 3 * c.kv_stride);
     c.kv_n = take(sizeof(float) * (size_t)c.G * 3 * c.kv_stride);
     c.total = o;
@@ -715,6 +714,7 @@ extern "C" int gnnmp_explorer_forward(const gnnmp_explorer* h, const gnnmp_batch
         p.node_ptr = b->node_ptr; p.node_ptr_pad = q.node_ptr_pad;
         p.tile_graph = edge ? q.etile_graph : q.ntile_graph;
         p.csr = q.csr;
+        p.rec32 = at<int>(ws, c.rec32);
         p.obs_ptr = b->obs_ptr; p.goal_node = q.goal_node;
         p.enc = W + (edge ? h->off.enc_e : h->off.enc_n);
         p.encb = edge ? h->enc_e : h->enc_n;
@@ -744,36 +744,30 @@ extern "C" int gnnmp_explorer_forward(const gnnmp_explorer* h, const gnnmp_batch
         HIP_TRY(launch_pre(D, P, edge != 0, pl.waves, p, (edge ? c.Epad : c.Npad) / 32, pl.lds_bytes, st));
     }
 
+    // message passing: one fused launch per iteration (edge phase + node phase per 32-node tile); the gathered A rows
+    // ping-pong between two buffers because other tiles still read this iteration's A while a tile writes the next one
+    float* Abuf[2] = {at<float>(ws, c.A), at<float>(ws, c.A2)};
+    int cur = 0;
     for (int it = 0; it < loop; ++it) {
         const bool last = (it == loop - 1);
-        if (b->total_edges > 0) {
-            MpEdgeParams e;
-            e.csr = q.csr; e.tile_meta = q.tile_meta;
-            e.A = at<float>(ws, c.A); e.B = at<float>(ws, c.B); e.Ke = at<float>(ws, c.Ke);
-            e.w = W + h->off.mpe;
-            e.agg = at<float>(ws, c.agg); e.part_first = at<float>(ws, c.part_first);
-            e.part_last = at<float>(ws, c.part_last);
-            e.n_tiles = c.Epad / 32;
-            StageScope sc(prof, GNNMP_STAGE_MP_EDGE, st);
-            HIP_TRY(launch_mp_edge(D, P, e, st));
-        }
-        MpNodeParams n;
-        n.row_beg = q.row_beg; n.deg = q.deg; n.ntile_graph = q.ntile_graph;
-        n.X = at<float>(ws, c.X); n.R = at<float>(ws, last ? c.DN : c.XI);
-        n.agg = at<float>(ws, c.agg); n.part_first = at<float>(ws, c.part_first); n.part_last = at<float>(ws, c.part_last);
-        n.w = W + (last ? h->off.mpn_last : h->off.mpn);
-        n.Hout = at<float>(ws, c.H); n.Xout = at<float>(ws, c.X); n.Aout = at<float>(ws, c.A); n.Bout = at<float>(ws, c.B);
-        n.n_tiles = c.Npad / 32;
-        n.store_h = last ? 1 : 0;
-        StageScope sc(prof, GNNMP_STAGE_MP_NODE, st);
-        HIP_TRY(launch_mp_node(D, P, n, st));
+        MpFusedParams f;
+        f.rec32 = at<int>(ws, c.rec32); f.row_beg = q.row_beg; f.deg = q.deg; f.ntile_graph = q.ntile_graph; f.node_ptr_pad = q.node_ptr_pad;
+        f.A = Abuf[cur]; f.B = at<float>(ws, c.B); f.Ke = at<float>(ws, c.Ke);
+        f.X = at<float>(ws, c.X); f.R = at<float>(ws, last ? c.DN : c.XI);
+        f.we = W + h->off.mpe; f.wn = W + (last ? h->off.mpn_last : h->off.mpn);
+        f.Hout = at<float>(ws, c.H); f.Xout = at<float>(ws, c.X); f.Aout = Abuf[cur ^ 1]; f.Bout = at<float>(ws, c.B);
+        f.n_tiles = c.Npad / 32;
+        f.store_h = last ? 1 : 0;
+        StageScope sc(prof, GNNMP_STAGE_MP, st);
+        HIP_TRY(launch_mp_fused(D, P, f, st));
+        cur ^= 1;
     }
 
     if (b->total_edges > 0) {
         PolicyParams p;
         p.csr = q.csr; p.etile_graph = q.etile_graph;
         p.node_ptr = b->node_ptr; p.node_ptr_pad = q.node_ptr_pad; p.dense_ptr = q.dense_ptr;
-        p.PS = at<float>(ws, c.A); p.PT = at<float>(ws, c.B); p.PE = at<float>(ws, c.PE);
+        p.PS = Abuf[cur]; p.PT = at<float>(ws, c.B); p.PE = at<float>(ws, c.PE);
         p.w = W + h->off.pol;
         p.scores = edge_scores; p.dense = dense;
         p.n_tiles = c.Epad / 32;

@@ -100,7 +100,13 @@ template <> struct BOp<2> {
     }
 };
 
-template <int P>
+// SWAP = false: D = W . X^T (A operand = weight tile, B operand = activations): the lane keeps a ROW (edge / node) and
+//                16 output features -- the chain layout.
+// SWAP = true:  D = X . W^T (A operand = activations, B operand = the same packed weight tile): the lane keeps an output
+//                FEATURE (lane & 31) and 16 ROWS phi(r, h) -- the layout for reductions over rows (max aggregation).
+//                Products are commutative and the k order is the same, so every D element is bit-identical to the
+//                unswapped form's.
+template <int P, bool SWAP = false>
 __device__ __forceinline__ void mfma_tile_p(const float* a, const BOp<P>& x, f32x16& acc, int lane) {
     if constexpr (P == 0) {
         // all four 16-byte operand reads of the tile are issued before the first MFMA, so only the first
@@ -111,13 +117,20 @@ __device__ __forceinline__ void mfma_tile_p(const float* a, const BOp<P>& x, f32
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[q][c], x.v[q * 4 + c], acc, 0, 0, 0);
+            for (int c = 0; c < 4; ++c) {
+                if constexpr (SWAP) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x.v[q * 4 + c], w[q][c], acc, 0, 0, 0);
+                else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[q][c], x.v[q * 4 + c], acc, 0, 0, 0);
+            }
     } else if constexpr (P == 1) {
         const bf16x8 w0 = *reinterpret_cast<const bf16x8*>(a + lane * 4);
         const bf16x8 w1 = *reinterpret_cast<const bf16x8*>(a + (64 + lane) * 4);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, x.lo, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, x.hi, acc, 0, 0, 0);
+        if constexpr (SWAP) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x.lo, w0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x.hi, w1, acc, 0, 0, 0);
+        } else {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, x.lo, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, x.hi, acc, 0, 0, 0);
+        }
     } else {
         // weight piece pw of K half m sits at a + ((pw*2 + m)*64 + lane)*4; pairs (weight piece, x piece), smallest first
         bf16x8 w[3][2];
@@ -128,8 +141,13 @@ __device__ __forceinline__ void mfma_tile_p(const float* a, const BOp<P>& x, f32
         constexpr int PW[6] = {2, 0, 1, 1, 0, 0}, PX[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
         for (int t = 0; t < 6; ++t) {
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[PW[t]][0], x.lo[PX[t]], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[PW[t]][1], x.hi[PX[t]], acc, 0, 0, 0);
+            if constexpr (SWAP) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x.lo[PX[t]], w[PW[t]][0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x.hi[PX[t]], w[PW[t]][1], acc, 0, 0, 0);
+            } else {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[PW[t]][0], x.lo[PX[t]], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[PW[t]][1], x.hi[PX[t]], acc, 0, 0, 0);
+            }
         }
     }
 }

@@ -8,9 +8,9 @@
 //   pre_kernel    per node / per edge: encoders + 3 obstacle cross-attention blocks, all in
 //                 registers, + the loop-invariant halves of the first message / encoder /
 //                 decoder / policy layers                                   (model.py:119-130)
-//   mp_edge       message second layer + segmented max over incoming edges  (model.py:33,38-41)
-//   mp_node       lin_1, encoder, and the next iteration's node-level first-layer terms
-//                                                                            (model.py:36,141,143)
+//   mp_fused      one loop iteration per launch: message second layer + max over incoming edges (LDS float
+//                 atomics), lin_1, encoder and the next iteration's node-level first-layer terms
+//                                                                            (model.py:33,36,38-41,141,143)
 //   policy        per-edge 3-layer head, scattered to caller order / dense  (model.py:145-149)
 //
 // The algebra follows SURVEY.md Appendix E: first layers acting on concatenations are split into
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(1024) void prep_graph_kernel(PrepParams q) {
     for (int t = e0 / 32 + tid; t < e1 / 32; t += 1024) {
         q.etile_graph[t] = g;
         // bit0 = first segment starts in an earlier tile, bit1 = last segment continues in a later tile,
-        // bit2 = tile holds at least one edge (see mp_edge)
+        // bit2 = tile holds at least one edge (the edge pre kernel skips tiles of pure padding)
         const int start = t * 32;
         int meta = 0;
         if (start < e0 + Eg) {
@@ -256,7 +256,7 @@ __global__ void prep_fill_kernel(int G, int E, const long long* __restrict__ edg
 }
 
 // per 32-edge tile: bit0 = its first segment starts in an earlier tile, bit1 = its last segment
-// continues in a later tile, bit2 = tile holds at least one edge; -1 = unused tile.  Lets mp_edge walk
+// continues in a later tile, bit2 = tile holds at least one edge; -1 = unused tile.  Lets the edge kernels skip
 // its segments without any dependent row_beg/deg loads.
 __global__ void prep_tilemeta_kernel(int n_tiles, const int4* __restrict__ csr, const int* __restrict__ row_beg,
                                      const int* __restrict__ deg, const int* __restrict__ etile_graph,
@@ -559,6 +559,9 @@ __global__ __launch_bounds__(WAVES * 64) void pre_kernel(PreParams p) {
     if constexpr (EDGE) {
         const int4 rec = p.csr[row];
         const int s = rec.x, t = rec.y;
+        // the message-passing kernels read 4 bytes per edge: source id within the graph | (target's row in its 32-node
+        // tile) << 27 (written here, coalesced, by the compute-bound kernel that reads the 16-byte records anyway)
+        if (h == 0 && s >= 0) p.rec32[row] = (s - nbase_pad) | (((t - nbase_pad) & 31) << 27);
         const float* vs = p.v + (size_t)(nbase + (s >= 0 ? s - nbase_pad : 0)) * C;
         const float* vt = p.v + (size_t)(nbase + (t >= 0 ? t - nbase_pad : 0)) * C;
         auto getin = [&](int k) {                           // [v_src, v_dst], branch-free
@@ -698,6 +701,7 @@ __global__ __launch_bounds__(WAVES * 64) void pre_resident_kernel(PreParams p) {
             if constexpr (EDGE) {
                 const int4 rec = p.csr[row];
                 const int s = rec.x, t = rec.y;
+                if (h == 0 && s >= 0) p.rec32[row] = (s - nbase_pad) | (((t - nbase_pad) & 31) << 27);    // see pre_kernel
                 const float* vs = p.v + (size_t)(nbase + (s >= 0 ? s - nbase_pad : 0)) * C;
                 const float* vt = p.v + (size_t)(nbase + (t >= 0 ? t - nbase_pad : 0)) * C;
                 // [v_src, v_dst]; branch-free: one clamped load + select (a divergent lambda would cost far more
@@ -793,153 +797,171 @@ struct XcdWalk {
     __device__ __forceinline__ void next() { cur += step; }
 };
 
+
 // =====================================================================================================
-// mp_edge: per 32-edge CSR tile: hidden = relu(A[src] + B[dst] + K_e); M = W2 hidden + b2;
-// segmented max over runs of equal destination.  Complete segments go to agg[dst]; segments cut by
-// the tile boundary go to part_first / part_last and are merged by mp_node.
+// mp_fused: one message-passing iteration (model.py:139-143 for one loop index) in ONE launch.  A job = one 32-node
+// tile (padded node space) handled by one wave:
+//   edge phase   the tile's incoming edges are one contiguous CSR range [row_beg[first], row_beg[last] + deg[last]);
+//                per 32-edge chunk: hidden = relu(A[src] + B[dst] + K_e), M = W2 hidden + b2 with the MFMA operands
+//                SWAPPED (chain.hpp): the accumulator comes out as [lane = feature][16 registers = edges], i.e. the
+//                reduction over edges runs over registers and the 32 lanes of a half wave are 32 consecutive
+//                features.  Max aggregation = one LDS float atomic (ds_max_f32) per (edge, feature) into the wave's
+//                private [32 nodes][D] tile: order-free, exact, conflict-free (lanes hit consecutive banks), no
+//                transpose, no segment walk, no partial maxima across tile boundaries, no agg round trip to HBM.
+//   node phase   agg tile (0 for nodes without incoming edges: torch_scatter) -> H = Wlx X + Wla agg + bl,
+//                Y = R + M1 H, A' = M2 Y, B' = M3 Y  (the former mp_node; weights read as MFMA operands from L1/L2).
+// A' goes to the OTHER A buffer: other jobs still gather this iteration's A rows.
 // =====================================================================================================
-template <int D, int P>
-__global__ __launch_bounds__(256) void mp_edge_kernel(MpEdgeParams p) {
-    constexpr int NT = D / 32;
-    constexpr int LD = D + 1;
-    using L = MpEBlob<D, P>;
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* wl = lds;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
-    float* scr = lds + ((L::size + 3) & ~3) + wave * (32 * LD);
-    stage(wl, p.w, L::size);
-    __syncthreads();
-    // software pipeline: the next tile's edge records and metadata are requested before this tile's
-    // arithmetic starts, so the gathers below never wait behind a dependent index load
-    XcdWalk wk((p.n_tiles + 3) / 4);
-    int4 rec_n = make_int4(-1, -1, -1, 0);
-    int meta_n = -1;
-    auto fetch = [&](int grp) {
-        const int tl = grp * 4 + wave;
-        meta_n = -1;
-        if (tl < p.n_tiles) {
-            meta_n = p.tile_meta[tl];
-            rec_n = p.csr[tl * 32 + j];
-        }
-    };
-    if (wk.valid()) fetch(wk.cur);
-    while (wk.valid()) {
-        const int tile = wk.cur * 4 + wave;
-        const int4 rec = rec_n;
-        const int meta = __builtin_amdgcn_readfirstlane(meta_n);
-        wk.next();
-        if (wk.valid()) fetch(wk.cur);
-        if (meta < 4) continue;                            // unused or empty tile (wave-uniform)
-        const int s = rec.x, t = rec.y;
-        f32x16 hid[NT], a[NT], b[NT];
-        load_tile_nt_p<P, NT>(p.Ke + (size_t)tile * NT * kETile, hid, lane);
-        load_row_p<P, NT>(p.A, (size_t)(s >= 0 ? s : 0), a, h);
-        load_row_p<P, NT>(p.B, (size_t)(t >= 0 ? t : 0), b, h);
+template <int P, int NT>
+__device__ __forceinline__ void load_edge_slot(const float* base_f32_units, int slot, int h, f32x16 (&x)[NT]) {
+    // per-edge tiles are stored tile-native ([slot / 32][NT][...][64 lanes][...], chain.hpp store_tile_p); a chunk need
+    // not start on a tile boundary, so every lane addresses its own slot
+    const size_t tile = (size_t)(slot >> 5);
+    const int ln = (slot & 31) + 32 * h;
+    if constexpr (P != 1) {
+        const float* b = base_f32_units + tile * NT * 1024 + ln * 4;
 #pragma unroll
-        for (int tt = 0; tt < NT; ++tt) hid[tt] += a[tt] + b[tt];
-        relu_<NT>(hid);
-        f32x16 M[NT];
-        load_vec<NT>(wl + L::b2, M, lane);
-        linear_acc_p<P, NT, NT>(wl + L::w2, hid, M, lane);
-        // transpose through this wave's LDS scratch: scr[edge j][feature]
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int tt = 0; tt < NT; ++tt)
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 a = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(b + (t * 4 + q) * 256));
 #pragma unroll
-            for (int r = 0; r < 16; ++r) scr[j * LD + tt * 32 + phi(r, h)] = M[tt][r];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // segment ends as a wave-uniform bit mask (valid edges are a prefix of the tile, pads carry -1):
-        // the walk below is 32 x (LDS read, max, one scalar bit test) plus one flush per segment
-        const int td = t;                                  // lanes j and j+32 hold the same value
-        const int td_next = __shfl_down(td, 1, 64);
-        const unsigned endmask = (unsigned)__ballot(td >= 0 && (j == 31 || td_next != td));
-        const int last_jj = 31 - __builtin_clz(endmask);  // meta >= 4: at least one valid edge
-#pragma unroll
-        for (int fc = 0; fc < (D + 63) / 64; ++fc) {
-            const int f = fc * 64 + lane;
-            const bool fok = f < D;
-            float run = -INFINITY;
-            bool first = true;
-#pragma unroll
-            for (int jj = 0; jj < 32; ++jj) {
-                if (fok) run = fmaxf(run, scr[jj * LD + f]);
-                if ((endmask >> jj) & 1u) {
-                    const int dj = __builtin_amdgcn_readlane(td, jj);
-                    const bool last = jj == last_jj;
-                    const bool closed = !((first && (meta & 1)) || (last && (meta & 2)));
-                    if (fok) {
-                        if (closed) p.agg[(size_t)dj * D + f] = run;
-                        else {
-                            if (first) p.part_first[(size_t)tile * D + f] = run;
-                            if (last) p.part_last[(size_t)tile * D + f] = run;
-                        }
-                    }
-                    first = false;
-                    run = -INFINITY;
-                }
+                for (int c = 0; c < 4; ++c) x[t][q * 4 + c] = a[c];
             }
+    } else {
+        const __bf16* b = reinterpret_cast<const __bf16*>(base_f32_units) + tile * NT * 1024 + ln * 8;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const bf16x8 lo = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(b + (t * 2 + 0) * 512));
+            const bf16x8 hi = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(b + (t * 2 + 1) * 512));
+            const f32x8 a = __builtin_convertvector(lo, f32x8), c = __builtin_convertvector(hi, f32x8);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) { x[t][r] = a[r]; x[t][8 + r] = c[r]; }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
     }
 }
 
-// =====================================================================================================
-// mp_node: per 32-node tile: agg (merge partial maxima; 0 for empty), H = Wlx X + Wla agg + bl,
-// Y = R + M1 H, A' = M2 Y, B' = M3 Y.
-// =====================================================================================================
+typedef __attribute__((address_space(3))) float lds_float;
+
 template <int D, int P>
-__global__ __launch_bounds__(256) void mp_node_kernel(MpNodeParams p) {
+__global__ __launch_bounds__(256) void mp_fused_kernel(MpFusedParams p) {
     constexpr int NT = D / 32;
-    using L = MpNBlob<D, P>;
+    constexpr int LD = D + 4;                    // agg tile row stride (floats): conflict-free 16-byte row reads
+    constexpr int TF = Prec<P>::TF;
+    using LE = MpEBlob<D, P>;
+    using LN = MpNBlob<D, P>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* wl = lds;
+    float* wl = lds;                                             // MpEBlob
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
-    stage(wl, p.w, L::size);
+    float* agg = lds + ((LE::size + 3) & ~3) + wave * (33 * LD + 32);      // [33][LD]: row 32 swallows pad edges
+    int* dl = reinterpret_cast<int*>(agg + 33 * LD);            // [32] row offsets (floats) of this chunk's targets
+    stage(wl, p.we, LE::size);
     __syncthreads();
+    // b2 of the lane's feature(s): packed vectors are in register order, vec[(t*2 + h')*16 + r'] = b[32 t + phi(r', h')]
+    float bias[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) bias[t] = wl[LE::b2 + (t * 2 + ((j >> 2) & 1)) * 16 + (j & 3) + 4 * (j >> 3)];
+    const float* wn = p.wn;                                      // MpNBlob in global memory
     for (XcdWalk wk((p.n_tiles + 3) / 4); wk.valid(); wk.next()) {
+        // static strided split: at any moment the resident workgroups of an XCD work on ADJACENT tiles, so the K_e stream
+        // is one dense front in HBM and neighbouring tiles share gathered A rows.  Measured alternatives (256 x 1000-node
+        // graphs, 0.98 ms for 5 iterations): tiles pulled one by one from a per-XCD counter 1.11 ms, one contiguous run of
+        // tiles per workgroup 1.16 ms, 16 instead of 12 waves per CU 1.23 ms -- the kernel is bound by HBM traffic
+        // (~750 MB per launch at 3.7 TB/s), not by latency or occupancy
         const int tile = wk.cur * 4 + wave;
         if (tile >= p.n_tiles || p.ntile_graph[tile] < 0) continue;
-        const int t = tile * 32 + j;
-        f32x16 x[NT], ag[NT], y[NT];
-        load_row<NT>(p.X + (size_t)t * D, x, h);
-        load_row<NT>(p.R + (size_t)t * D, y, h);           // all three rows of the tile are requested up front
-        const int a0 = p.row_beg[t], dg = p.deg[t];
+        const int t0 = tile * 32;
+        const int node = t0 + j;
+        const int rb = p.row_beg[node], dg = p.deg[node];
+        const int beg = __builtin_amdgcn_readfirstlane(rb);
+        const int end = __builtin_amdgcn_readlane(rb + dg, 31);
+        {   // agg tile <- -inf
+            const f32x4 ninf = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+            for (int q = 0; q < D / 8; ++q) *reinterpret_cast<f32x4*>(agg + j * LD + h * (D / 2) + q * 4) = ninf;
+        }
+        // software pipeline: the next chunk's packed record (source id local to the graph | target's row in this tile
+        // << 27) and its K_e rows -- the HBM stream of this kernel -- are requested before this chunk's arithmetic
+        const int n0 = p.node_ptr_pad[p.ntile_graph[tile]];
+        int rec_n = 0;
+        f32x16 ke_n[NT];
+        if (beg + j < end) rec_n = p.rec32[beg + j];
+        load_edge_slot<P, NT>(p.Ke, beg + j < end ? beg + j : beg, h, ke_n);
+        for (int c0 = beg; c0 < ((p.dbg & 8) ? beg : end); c0 += 32) {
+            const int slot = c0 + j;
+            const bool valid = slot < end;
+            const int rec = rec_n;
+            f32x16 hid[NT], a[NT], b[NT];
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt) hid[tt] = ke_n[tt];
+            const int s = n0 + (rec & 0x7ffffff), t = t0 + ((rec >> 27) & 31);
+            load_row_p<P, NT>(p.A, (size_t)((valid && !(p.dbg & 4)) ? s : t0), a, h);
+            load_row_p<P, NT>(p.B, (size_t)((valid && !(p.dbg & 4)) ? t : t0), b, h);
+            if (c0 + 32 < end) {                                          // wave-uniform
+                const int sn = c0 + 32 + j;
+                if (sn < end) rec_n = p.rec32[sn];
+                load_edge_slot<P, NT>(p.Ke, sn < end ? sn : beg, h, ke_n);
+            }
+            if (h == 0) dl[j] = (valid ? t - t0 : 32) * LD;
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt) hid[tt] += a[tt] + b[tt];
+            relu_<NT>(hid);
+            BOp<P> hop[NT];
+            make_ops<P, NT>(hid, hop);
+            f32x16 M[NT];
+#pragma unroll
+            for (int ot = 0; ot < NT; ++ot) M[ot] = splat16(bias[ot]);
+#pragma unroll
+            for (int it = 0; it < NT; ++it)
+#pragma unroll
+                for (int ot = 0; ot < NT; ++ot)
+                    mfma_tile_p<P, true>(wl + LE::w2 + (ot * NT + it) * TF, hop[it], M[ot], lane);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // register r of this lane is edge phi(r, h) = 8 (r >> 2) + 4 h + (r & 3) of the chunk
+            int off[16];
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int4 o = *reinterpret_cast<const int4*>(dl + 8 * g4 + 4 * h);
+                off[g4 * 4 + 0] = o.x; off[g4 * 4 + 1] = o.y; off[g4 * 4 + 2] = o.z; off[g4 * 4 + 3] = o.w;
+            }
+#pragma unroll
+            for (int ot = 0; ot < NT; ++ot)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (!(p.dbg & 1)) __builtin_amdgcn_ds_fmaxf((lds_float*)(agg + off[r] + ot * 32 + j), M[ot][r], 0, 0, false);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        if (p.dbg & 2) continue;
+        // ---- node phase
+        f32x16 x[NT], y[NT], ag[NT];
+        load_row<NT>(p.X + (size_t)node * D, x, h);
+        load_row<NT>(p.R + (size_t)node * D, y, h);
+        load_row<NT>(agg + j * LD, ag, h);
         if (dg == 0) {
 #pragma unroll
-            for (int tt = 0; tt < NT; ++tt) ag[tt] = splat16(0.f);      // torch_scatter: empty -> 0
-        } else {
-            const int k0 = a0 >> 5, k1 = (a0 + dg - 1) >> 5;
-            if (k0 == k1) {
-                load_row<NT>(p.agg + (size_t)t * D, ag, h);
-            } else {
-                load_row<NT>(p.part_last + (size_t)k0 * D, ag, h);
-                for (int k = k0 + 1; k <= k1; ++k) {
-                    f32x16 o[NT];
-                    load_row<NT>(p.part_first + (size_t)k * D, o, h);
-#pragma unroll
-                    for (int tt = 0; tt < NT; ++tt)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) ag[tt][r] = fmaxf(ag[tt][r], o[tt][r]);
-                }
-            }
+            for (int tt = 0; tt < NT; ++tt) ag[tt] = splat16(0.f);          // torch_scatter: no incoming edge -> 0
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");              // tile is re-initialised by the next job
+        __builtin_amdgcn_wave_barrier();
         f32x16 H[NT], z[NT];
-        load_vec<NT>(wl + L::bl, H, lane);
-        linear_acc_p<P, NT, NT>(wl + L::wlx, x, H, lane);
-        linear_acc_p<P, NT, NT>(wl + L::wla, ag, H, lane);
-        if (p.store_h) store_row<NT>(p.Hout + (size_t)t * D, H, h);
-        linear_acc_p<P, NT, NT>(wl + L::m1, H, y, lane);
-        store_row<NT>(p.Xout + (size_t)t * D, y, h);
+        load_vec<NT>(wn + LN::bl, H, lane);
+        linear_acc_p<P, NT, NT>(wn + LN::wlx, x, H, lane);
+        linear_acc_p<P, NT, NT>(wn + LN::wla, ag, H, lane);
+        if (p.store_h) store_row<NT>(p.Hout + (size_t)node * D, H, h);
+        linear_acc_p<P, NT, NT>(wn + LN::m1, H, y, lane);
+        store_row<NT>(p.Xout + (size_t)node * D, y, h);
 #pragma unroll
         for (int tt = 0; tt < NT; ++tt) z[tt] = splat16(0.f);
-        linear_acc_p<P, NT, NT>(wl + L::m2, y, z, lane);
-        store_row_p<P, NT>(p.Aout, (size_t)t, z, h);
+        linear_acc_p<P, NT, NT>(wn + LN::m2, y, z, lane);
+        store_row_p<P, NT>(p.Aout, (size_t)node, z, h);
 #pragma unroll
         for (int tt = 0; tt < NT; ++tt) z[tt] = splat16(0.f);
-        linear_acc_p<P, NT, NT>(wl + L::m3, y, z, lane);
-        store_row_p<P, NT>(p.Bout, (size_t)t, z, h);
+        linear_acc_p<P, NT, NT>(wn + LN::m3, y, z, lane);
+        store_row_p<P, NT>(p.Bout, (size_t)node, z, h);
     }
 }
 
@@ -1139,7 +1161,7 @@ hipError_t launch_pre_resident(int D, int P, bool edge, const PreParams& p, size
 
 // Grid of the grid-stride kernels: one workgroup per 4 tiles, but never more workgroups than the device keeps
 // RESIDENT (occupancy query x CUs): the tile space is split evenly by XcdWalk, so a grid beyond residency only
-// adds a second, thinly populated round of workgroups (measured: mp_edge 0.72 -> 0.66 ms per step at d = 32,
+// adds a second, thinly populated round of workgroups (measured on round 1's message kernel: 0.72 -> 0.66 ms per step at d = 32,
 // 0.56 -> 0.52 at d = 64 / bf16).  Multiple of 8 for the XCD walk.
 struct Residency { int per_cu, cus; };
 static Residency resident_workgroups(const void* kernel, size_t lds_bytes) {
@@ -1158,7 +1180,7 @@ static Residency resident_workgroups(const void* kernel, size_t lds_bytes) {
 }
 
 // max_per_cu: measured sweet spot of the kernel -- more resident waves than that only add contention in the memory
-// system (mp_edge at d = 32: 0.657 ms per step at 4 workgroups per CU, 0.669 at 5, 0.81 at 6-7 when the compiler is
+// system (round 1's message kernel at d = 32: 0.657 ms per step at 4 workgroups per CU, 0.669 at 5, 0.81 at 6-7 when the compiler is
 // forced to fit them; policy: 0.137 at 3, 0.152 at 6); GNNMP_WGS_PER_CU overrides it for experiments
 template <class K>
 static int grid_for(K kernel, size_t lds_bytes, int n_tiles, int max_per_cu) {
@@ -1173,29 +1195,19 @@ static int grid_for(K kernel, size_t lds_bytes, int n_tiles, int max_per_cu) {
 }
 
 template <int D, int P>
-static hipError_t launch_mp_edge_t(const MpEdgeParams& p, hipStream_t st) {
-    const size_t lds = (size_t)(((MpEBlob<D, P>::size + 3) & ~3) + 4 * 32 * (D + 1)) * sizeof(float);
-    hipError_t e = set_lds(mp_edge_kernel<D, P>, lds);
+static hipError_t launch_mp_fused_t(const MpFusedParams& p, hipStream_t st) {
+    const size_t lds = (size_t)(((MpEBlob<D, P>::size + 3) & ~3) + 4 * (33 * (D + 4) + 32)) * sizeof(float);
+    hipError_t e = set_lds(mp_fused_kernel<D, P>, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((mp_edge_kernel<D, P>), dim3(grid_for(mp_edge_kernel<D, P>, lds, p.n_tiles, 4)), dim3(256), lds, st, p);
+    hipLaunchKernelGGL((mp_fused_kernel<D, P>), dim3(grid_for(mp_fused_kernel<D, P>, lds, p.n_tiles, 4)), dim3(256), lds, st, p);
     LAUNCH_CHECK();
     return hipSuccess;
 }
-hipError_t launch_mp_edge(int D, int P, const MpEdgeParams& p, hipStream_t st) {
-    GNNMP_DISPATCH_DP(D, P, (launch_mp_edge_t<DD, PP>(p, st)));
-}
-
-template <int D, int P>
-static hipError_t launch_mp_node_t(const MpNodeParams& p, hipStream_t st) {
-    const size_t lds = (size_t)MpNBlob<D, P>::size * sizeof(float);
-    hipError_t e = set_lds(mp_node_kernel<D, P>, lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((mp_node_kernel<D, P>), dim3(grid_for(mp_node_kernel<D, P>, lds, p.n_tiles, 8)), dim3(256), lds, st, p);
-    LAUNCH_CHECK();
-    return hipSuccess;
-}
-hipError_t launch_mp_node(int D, int P, const MpNodeParams& p, hipStream_t st) {
-    GNNMP_DISPATCH_DP(D, P, (launch_mp_node_t<DD, PP>(p, st)));
+hipError_t launch_mp_fused(int D, int P, const MpFusedParams& p_in, hipStream_t st) {
+    MpFusedParams p = p_in;
+    static const int dbg = getenv("GNNMP_MP_DBG") ? atoi(getenv("GNNMP_MP_DBG")) : 0;
+    p.dbg = dbg;
+    GNNMP_DISPATCH_DP(D, P, (launch_mp_fused_t<DD, PP>(p, st)));
 }
 
 template <int D, int P>

@@ -37,6 +37,7 @@ struct PreParams {
     const int *node_ptr, *node_ptr_pad;
     const int* tile_graph;
     const int4* csr;
+    int* rec32;              // out (EDGE): packed per-edge record of the message-passing kernels
     const int* obs_ptr;
     const int* goal_node;
     const float* enc;
@@ -56,20 +57,15 @@ struct PreParams {
     float *o0, *o1, *o2, *o3, *o4;
 };
 
-struct MpEdgeParams {
-    const int4* csr;
-    const int* tile_meta;
-    const float *A, *B, *Ke, *w;
-    float *agg, *part_first, *part_last;
-    int n_tiles;
-};
-
-struct MpNodeParams {
-    const int *row_beg, *deg, *ntile_graph;
-    const float *X, *R, *agg, *part_first, *part_last, *w;
+struct MpFusedParams {
+    const int* rec32;
+    const int *row_beg, *deg, *ntile_graph, *node_ptr_pad;
+    const float *A, *B, *Ke, *X, *R;
+    const float *we, *wn;        // MpEBlob (staged into LDS), MpNBlob (read from global)
     float *Hout, *Xout, *Aout, *Bout;
-    int n_tiles;
-    int store_h;             // write h_i (only the last iteration's is ever consumed: debug tap)
+    int n_tiles;                 // 32-node tiles of the padded node space
+    int store_h;
+    int dbg;
 };
 
 struct PolicyParams {
@@ -146,8 +142,7 @@ hipError_t launch_prep(const PrepParams& q, hipStream_t st);
 hipError_t launch_obs(int D, int P, const ObsParams& p, int G, hipStream_t st);
 hipError_t launch_pre(int D, int P, bool edge, int waves, const PreParams& p, int n_tiles32, size_t lds_bytes, hipStream_t st);
 hipError_t launch_pre_resident(int D, int P, bool edge, const PreParams& p, size_t lds_bytes, int n_cu, hipStream_t st);
-hipError_t launch_mp_edge(int D, int P, const MpEdgeParams& p, hipStream_t st);
-hipError_t launch_mp_node(int D, int P, const MpNodeParams& p, hipStream_t st);
+hipError_t launch_mp_fused(int D, int P, const MpFusedParams& p, hipStream_t st);
 hipError_t launch_policy(int D, int P, const PolicyParams& p, hipStream_t st);
 hipError_t launch_unpad_rows(int G, int total_nodes, int D, const int* node_ptr, const int* node_ptr_pad,
                              const float* src, float* dst, hipStream_t st);

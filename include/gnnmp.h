@@ -138,10 +138,10 @@ enum {
     GNNMP_STAGE_OBS = 1,       /* obstacle codes and K/V operands                               */
     GNNMP_STAGE_NODE_PRE = 2,  /* node encoders + 3 attention blocks + loop invariants          */
     GNNMP_STAGE_EDGE_PRE = 3,  /* edge encoders + 3 attention blocks + loop invariants (dominant) */
-    GNNMP_STAGE_MP_EDGE = 4,   /* message MLP + segmented max, one launch per loop iteration    */
-    GNNMP_STAGE_MP_NODE = 5,   /* node update, one launch per loop iteration                    */
-    GNNMP_STAGE_POLICY = 6,    /* per-edge policy head                                          */
-    GNNMP_N_STAGES = 7
+    GNNMP_STAGE_MP = 4,        /* message passing: message MLP + max aggregation + node update, ONE fused launch
+                                  per loop iteration                                            */
+    GNNMP_STAGE_POLICY = 5,    /* per-edge policy head                                          */
+    GNNMP_N_STAGES = 6
 };
 int gnnmp_explorer_profile(gnnmp_explorer* h, int enable);
 int gnnmp_explorer_profile_read(gnnmp_explorer* h, double* ms_sum /* [GNNMP_N_STAGES] */,
