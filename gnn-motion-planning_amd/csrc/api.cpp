@@ -736,7 +736,7 @@ extern "C" int gnnmp_explorer_forward(const gnnmp_explorer* h, const gnnmp_batch
         p.ptr_pad_total = edge ? q.edge_ptr_pad : q.node_ptr_pad;
         p.tile_meta = q.tile_meta;
         p.G = c.G;
-        const size_t res_bytes = ((size_t)3 * att_staged(D, P) + (size_t)3 * c.kv_stride) * sizeof(float) + 64;
+        const size_t res_bytes = ((size_t)3 * (att_staged(D, P) + 6 * vec_floats(D)) + (size_t)3 * c.kv_stride) * sizeof(float) + 64;
         if (((D == 32 && P == 0) || P == 1) && use_obs && res_bytes <= 163840 && h->resident) {
             HIP_TRY(launch_pre_resident(D, P, edge != 0, p, res_bytes, h->n_cu, st));
             continue;

@@ -665,10 +665,11 @@ __global__ __launch_bounds__(WAVES * 64) void pre_kernel(PreParams p) {
 template <int D, int P, bool EDGE, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void pre_resident_kernel(PreParams p) {
     constexpr int NT = D / 32;
+    constexpr bool kRecomputeAux = EDGE && D == 64;
     using AB = AttBlob<D, P>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* wl = lds;                                           // [3][AB::staged]
-    float* kvl = lds + 3 * AB::staged;                         // [3][kv_stride]
+    float* wl = lds;                                           // [3][AB::size]: matrices AND the six vectors of a block
+    float* kvl = lds + 3 * AB::size;                           // [3][kv_stride]
     int* ctr = reinterpret_cast<int*>(kvl + 3 * (size_t)p.kv_stride);
     const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
     const int C = p.C;
@@ -679,7 +680,7 @@ __global__ __launch_bounds__(WAVES * 64) void pre_resident_kernel(PreParams p) {
     int t0 = wg * share;
     const int t1 = min(total, t0 + share);
     if (t0 >= t1) return;
-    for (int b = 0; b < 3; ++b) stage(wl + b * AB::staged, p.att + (size_t)b * AB::size, AB::staged);
+    stage(wl, p.att, 3 * AB::size);
     const EncBlob E = p.encb;
     while (t0 < t1) {
         const int g = p.tile_graph[t0];
@@ -697,6 +698,11 @@ __global__ __launch_bounds__(WAVES * 64) void pre_resident_kernel(PreParams p) {
             if (tile >= seg_end) break;
             if (EDGE && p.tile_meta[tile] < 4) continue;       // tile of pure padding
             const int row = tile * 32 + j;
+            // encoder / epilogue weights are MFMA operands read from global memory; laundering the pointers per tile
+            // keeps the compiler from hoisting those loop-invariant loads out of the tile loop into dozens of registers
+            const float* enc_w = p.enc;
+            const float* out_w = p.out;
+            if constexpr (D > 32) asm volatile("" : "+s"(enc_w), "+s"(out_w));    // d = 32: registers to spare, hoisting pays
             f32x16 m[NT], aux[NT];
             if constexpr (EDGE) {
                 const int4 rec = p.csr[row];
@@ -712,8 +718,11 @@ __global__ __launch_bounds__(WAVES * 64) void pre_resident_kernel(PreParams p) {
                     const float x = base[ok ? k : C];
                     return ok ? x : 0.f;
                 };
-                mlp2_in<NT, P>(p.enc + E.as0, E.ks0, p.enc + E.b0, p.enc + E.a0, p.enc + E.c0, getin, aux, lane);
-                mlp2_in<NT, P>(p.enc + E.as1, E.ks1, p.enc + E.b1, p.enc + E.a1, p.enc + E.c1, getin, m, lane);
+                // d = 64: edge_code (10 MFMAs from the raw coordinates) is recomputed right before its only use in the
+                // epilogue instead of living in 32 registers through the three attention blocks
+                if constexpr (!kRecomputeAux)
+                    mlp2_in<NT, P>(enc_w + E.as0, E.ks0, enc_w + E.b0, enc_w + E.a0, enc_w + E.c0, getin, aux, lane);
+                mlp2_in<NT, P>(enc_w + E.as1, E.ks1, enc_w + E.b1, enc_w + E.a1, enc_w + E.c1, getin, m, lane);
             } else {
                 const int local = row - nbase_pad;
                 const int ng = p.node_ptr[g + 1] - nbase;
@@ -729,49 +738,62 @@ __global__ __launch_bounds__(WAVES * 64) void pre_resident_kernel(PreParams p) {
                     return ok ? val : 0.f;
                 };
                 auto getin_nf = [&](int k) { const bool ok = k < C; const float x = vr[ok ? k : 0]; return ok ? x : 0.f; };
-                mlp2_in<NT, P>(p.enc + E.as0, E.ks0, p.enc + E.b0, p.enc + E.a0, p.enc + E.c0, getin_nc, aux, lane);
-                mlp2_in<NT, P>(p.enc + E.as1, E.ks1, p.enc + E.b1, p.enc + E.a1, p.enc + E.c1, getin_nf, m, lane);
+                mlp2_in<NT, P>(enc_w + E.as0, E.ks0, enc_w + E.b0, enc_w + E.a0, enc_w + E.c0, getin_nc, aux, lane);
+                mlp2_in<NT, P>(enc_w + E.as1, E.ks1, enc_w + E.b1, enc_w + E.a1, enc_w + E.c1, getin_nf, m, lane);
             }
             for (int b = 0; b < 3; ++b)
-                attention_block<D, P>(wl + b * AB::staged, p.att + (size_t)b * AB::size, kvl + (size_t)b * p.kv_stride, nullptr,
+                attention_block<D, P>(wl + b * AB::size, wl + b * AB::size, kvl + (size_t)b * p.kv_stride, nullptr,
                                    O, p.ot_max, p.ot_max, m, lane);
             if constexpr (EDGE) {
                 using L = OutEBlob<D, P>;
                 f32x16 y[NT];
                 BOp<P> mop[NT];
                 make_ops<P, NT>(m, mop);
-                load_vec<NT>(p.out + L::b1, y, lane);
-                linear_acc_ops<P, NT, NT>(p.out + L::w1d, mop, y, lane);
-                linear_acc_p<P, NT, NT>(p.out + L::w1e, aux, y, lane);
+                load_vec<NT>(out_w + L::b1, y, lane);
+                linear_acc_ops<P, NT, NT>(out_w + L::w1d, mop, y, lane);
+                if constexpr (kRecomputeAux) {
+                    const int4 rec = p.csr[row];
+                    const int s = rec.x, t = rec.y;
+                    const float* vs = p.v + (size_t)(nbase + (s >= 0 ? s - nbase_pad : 0)) * C;
+                    const float* vt = p.v + (size_t)(nbase + (t >= 0 ? t - nbase_pad : 0)) * C;
+                    auto getin = [&](int k) {
+                        const bool ok = k < 2 * C;
+                        const float* base = (k < C) ? vs : vt - C;
+                        const float x = base[ok ? k : C];
+                        return ok ? x : 0.f;
+                    };
+                    mlp2_in<NT, P>(enc_w + E.as0, E.ks0, enc_w + E.b0, enc_w + E.a0, enc_w + E.c0, getin, aux, lane);
+                }
+                linear_acc_p<P, NT, NT>(out_w + L::w1e, aux, y, lane);
                 store_tile_p<P, NT>(p.o0 + (size_t)tile * NT * kETile, y, lane);
-                load_vec<NT>(p.out + L::bp0, y, lane);
-                linear_acc_ops<P, NT, NT>(p.out + L::wpc, mop, y, lane);
+                load_vec<NT>(out_w + L::bp0, y, lane);
+                linear_acc_ops<P, NT, NT>(out_w + L::wpc, mop, y, lane);
                 store_tile_p<P, NT>(p.o1 + (size_t)tile * NT * kETile, y, lane);
             } else {
                 using L = OutNBlob<D, P>;
                 const bool isgoal = (row == p.goal_node[g]);
                 f32x16 xi[NT], tmp[NT], y[NT];
-                load_vec<NT>(p.out + L::be, xi, lane);
-                linear_acc_p<P, NT, NT>(p.out + L::we_nc, aux, xi, lane);
-                linear_acc_p<P, NT, NT>(p.out + L::we_nf, m, xi, lane);
-                load_vec<NT>(p.out + L::weg, tmp, lane);
+                load_vec<NT>(out_w + L::be, xi, lane);
+                linear_acc_p<P, NT, NT>(out_w + L::we_nc, aux, xi, lane);
+                linear_acc_p<P, NT, NT>(out_w + L::we_nf, m, xi, lane);
+                load_vec<NT>(out_w + L::weg, tmp, lane);
 #pragma unroll
                 for (int t = 0; t < NT; ++t) xi[t] += isgoal ? tmp[t] : splat16(0.f);
                 store_row<NT>(p.o0 + (size_t)row * D, xi, h);
-                load_vec<NT>(p.out + L::wehg, tmp, lane);
+                load_vec<NT>(out_w + L::wehg, tmp, lane);
 #pragma unroll
                 for (int t = 0; t < NT; ++t) xi[t] += isgoal ? tmp[t] : splat16(0.f);
                 store_row<NT>(p.o1 + (size_t)row * D, xi, h);
 #pragma unroll
                 for (int t = 0; t < NT; ++t) y[t] = splat16(0.f);
-                linear_acc_p<P, NT, NT>(p.out + L::wsrc, xi, y, lane);
+                linear_acc_p<P, NT, NT>(out_w + L::wsrc, xi, y, lane);
                 store_row_p<P, NT>(p.o2, (size_t)row, y, h);
 #pragma unroll
                 for (int t = 0; t < NT; ++t) y[t] = splat16(0.f);
-                linear_acc_p<P, NT, NT>(p.out + L::wdst, xi, y, lane);
+                linear_acc_p<P, NT, NT>(out_w + L::wdst, xi, y, lane);
                 store_row_p<P, NT>(p.o3, (size_t)row, y, h);
-                load_vec<NT>(p.out + L::bd, y, lane);
-                linear_acc_p<P, NT, NT>(p.out + L::wd_nc, aux, y, lane);
+                load_vec<NT>(out_w + L::bd, y, lane);
+                linear_acc_p<P, NT, NT>(out_w + L::wd_nc, aux, y, lane);
                 store_row<NT>(p.o4 + (size_t)row * D, y, h);
             }
         }
@@ -812,62 +834,156 @@ struct XcdWalk {
 //                Y = R + M1 H, A' = M2 Y, B' = M3 Y  (the former mp_node; weights read as MFMA operands from L1/L2).
 // A' goes to the OTHER A buffer: other jobs still gather this iteration's A rows.
 // =====================================================================================================
+// one 32-feature tile `t` of edge slot `slot` (per-edge tiles are stored tile-native, [slot / 32][NT][...][64 lanes][...],
+// chain.hpp store_tile_p; a chunk need not start on a tile boundary, so every lane addresses its own slot)
 template <int P, int NT>
-__device__ __forceinline__ void load_edge_slot(const float* base_f32_units, int slot, int h, f32x16 (&x)[NT]) {
-    // per-edge tiles are stored tile-native ([slot / 32][NT][...][64 lanes][...], chain.hpp store_tile_p); a chunk need
-    // not start on a tile boundary, so every lane addresses its own slot
+__device__ __forceinline__ void load_edge_slot_tile(const float* base_f32_units, int slot, int h, int t, f32x16& x) {
     const size_t tile = (size_t)(slot >> 5);
     const int ln = (slot & 31) + 32 * h;
     if constexpr (P != 1) {
         const float* b = base_f32_units + tile * NT * 1024 + ln * 4;
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 a = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(b + (t * 4 + q) * 256));
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 a = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(b + (t * 4 + q) * 256));
-#pragma unroll
-                for (int c = 0; c < 4; ++c) x[t][q * 4 + c] = a[c];
-            }
+            for (int c = 0; c < 4; ++c) x[q * 4 + c] = a[c];
+        }
     } else {
         const __bf16* b = reinterpret_cast<const __bf16*>(base_f32_units) + tile * NT * 1024 + ln * 8;
+        const bf16x8 lo = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(b + (t * 2 + 0) * 512));
+        const bf16x8 hi = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(b + (t * 2 + 1) * 512));
+        const f32x8 a = __builtin_convertvector(lo, f32x8), c = __builtin_convertvector(hi, f32x8);
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const bf16x8 lo = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(b + (t * 2 + 0) * 512));
-            const bf16x8 hi = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(b + (t * 2 + 1) * 512));
-            const f32x8 a = __builtin_convertvector(lo, f32x8), c = __builtin_convertvector(hi, f32x8);
+        for (int r = 0; r < 8; ++r) { x[r] = a[r]; x[8 + r] = c[r]; }
+    }
+}
+
+// one 32-feature tile `t` of row `row` of a [rows, D] array stored in the precision-dependent format of load_row_p
+template <int P, int NT>
+__device__ __forceinline__ void load_row_tile(const float* array_f32_units, size_t row, int h, int t, f32x16& x) {
+    if constexpr (P != 1) {
+        const float* base = array_f32_units + row * (NT * 32) + t * 32;
 #pragma unroll
-            for (int r = 0; r < 8; ++r) { x[t][r] = a[r]; x[t][8 + r] = c[r]; }
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(base + q * 8 + h * 4);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) x[q * 4 + c] = a[c];
+        }
+    } else {
+        const __bf16* base = reinterpret_cast<const __bf16*>(array_f32_units) + row * (NT * 32) + t * 32;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 a = __builtin_convertvector(*reinterpret_cast<const bf16x4*>(base + q * 8 + h * 4), f32x4);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) x[q * 4 + c] = a[c];
         }
     }
 }
 
 typedef __attribute__((address_space(3))) float lds_float;
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Row gathers through LDS.  A wave-wide global load in the chain layout (lane = row, 16 bytes per lane per instruction)
+// costs ONE L1 access PER LANE: neighbouring lanes hold different rows, nothing coalesces, and the message-passing
+// kernels were bound by exactly that (rocprofv3: ~1 TCP access per cycle and CU, 563 accesses per 32-edge chunk at
+// d = 32 fp32, 955 at d = 64 bf16; TA busy 52-59 %).  Here 32 rows are fetched with the LDS-DMA path
+// (global_load_lds_dwordx4): lane l asks for piece (l % PP) of row (l / PP) of its instruction, so the four lanes of
+// a quad read 64 contiguous bytes = one access, 4 x fewer than before, and no VGPR is tied up while the rows are in
+// flight.  The DMA writes LDS linearly (wave-uniform base + lane * 16), so the bank-conflict swizzle is applied to the
+// SOURCE piece index and again, as the same involution, when the chain layout reads the rows back (16-byte / 8-byte
+// LDS reads).
+// ---------------------------------------------------------------------------------------------------------------------
 template <int D, int P>
-__global__ __launch_bounds__(256) void mp_fused_kernel(MpFusedParams p) {
+struct RowGeom {
+    static constexpr int RB = D * (P == 1 ? 2 : 4);         // bytes per row (64, 128 or 256)
+    static constexpr int PP = RB / 16;                       // 16-byte pieces per row
+    static constexpr int RPI = 64 / PP;                      // rows per DMA instruction
+    static constexpr int NI = 32 / RPI;                      // DMA instructions per 32 rows
+    static constexpr int SH = RB == 64 ? 2 : (RB == 128 ? 1 : 0);     // rows 2^SH apart share their banks (256-byte period)
+    static constexpr int STAGE_FLOATS = 32 * RB / 4;
+    __device__ static __forceinline__ int swz(int row) { return (row >> SH) & (PP - 1); }
+};
+
+// stage <- 32 rows; `row_id(sr)` = array row of stage row sr as seen by THIS lane (the caller shuffles if needed)
+template <int D, int P, class RowId>
+__device__ __forceinline__ void dma_rows(const float* array_f32_units, RowId row_id, float* stage, int lane) {
+    using G = RowGeom<D, P>;
+    const char* base = reinterpret_cast<const char*>(array_f32_units);
+#pragma unroll
+    for (int i = 0; i < G::NI; ++i) {
+        const int sr = G::RPI * i + lane / G::PP;
+        const int pc = (lane % G::PP) ^ G::swz(sr);
+        const char* g = base + (size_t)row_id(sr) * G::RB + pc * 16;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                         (__attribute__((address_space(3))) void*)(stage + i * 256), 16, 0, 0);
+    }
+}
+
+// 32-feature tile `t` of stage row `sr` in the chain layout (lane half h)
+template <int D, int P>
+__device__ __forceinline__ void read_stage_tile(const float* stage, int sr, int h, int t, f32x16& x) {
+    using G = RowGeom<D, P>;
+    const char* row = reinterpret_cast<const char*>(stage) + sr * G::RB;
+    const int sw = G::swz(sr);
+    if constexpr (P != 1) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(row + (((t * 8 + q * 2 + h) ^ sw) * 16));
+#pragma unroll
+            for (int c = 0; c < 4; ++c) x[q * 4 + c] = a[c];
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 a = __builtin_convertvector(*reinterpret_cast<const bf16x4*>(row + (((t * 4 + q) ^ sw) * 16) + h * 8), f32x4);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) x[q * 4 + c] = a[c];
+        }
+    }
+}
+
+// y[ot] += sum_it W[ot][it] . x[it] with the inputs produced one 32-feature tile at a time by `get(it, tile)`: only one
+// input tile is live, which is what lets the d = 64 instantiation keep its register count down
+template <int P, int NT, bool SWAP, class Get>
+__device__ __forceinline__ void linear_acc_stream(const float* A, Get get, f32x16 (&y)[NT], int lane) {
+#pragma unroll
+    for (int it = 0; it < NT; ++it) {
+        f32x16 x;
+        get(it, x);
+        const BOp<P> xb(x);
+#pragma unroll
+        for (int ot = 0; ot < NT; ++ot) mfma_tile_p<P, SWAP>(A + (ot * NT + it) * Prec<P>::TF, xb, y[ot], lane);
+    }
+}
+
+// LDS floats one wave of mp_fused owns: max-aggregation tile [32][D], 32 row offsets, two 32-row gather stages
+template <int D, int P>
+__host__ __device__ constexpr int mp_wave_floats() { return 32 * D + 32 + 2 * (32 * D * (P == 1 ? 2 : 4) / 4); }
+
+template <int D, int P>
+__global__ __launch_bounds__(256, (P == 2 || D > 32) ? 2 : 3) void mp_fused_kernel(MpFusedParams p) {
     constexpr int NT = D / 32;
-    constexpr int LD = D + 4;                    // agg tile row stride (floats): conflict-free 16-byte row reads
-    constexpr int TF = Prec<P>::TF;
     using LE = MpEBlob<D, P>;
     using LN = MpNBlob<D, P>;
+    using G = RowGeom<D, P>;
+    using GX = RowGeom<D, 0>;                                    // X / R rows are always fp32
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* wl = lds;                                             // MpEBlob
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
-    float* agg = lds + ((LE::size + 3) & ~3) + wave * (33 * LD + 32);      // [33][LD]: row 32 swallows pad edges
-    int* dl = reinterpret_cast<int*>(agg + 33 * LD);            // [32] row offsets (floats) of this chunk's targets
+    float* agg = lds + ((LE::size + 3) & ~3) + wave * mp_wave_floats<D, P>();        // [32][D]
+    int* dl = reinterpret_cast<int*>(agg + 32 * D);              // [32] agg row offsets (floats) of this chunk's targets
+    float* astage = agg + 32 * D + 32;                           // gathered A rows of the current chunk
+    float* btile = astage + G::STAGE_FLOATS;                     // B rows of this job's 32 nodes
     stage(wl, p.we, LE::size);
     __syncthreads();
     // b2 of the lane's feature(s): packed vectors are in register order, vec[(t*2 + h')*16 + r'] = b[32 t + phi(r', h')]
     float bias[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) bias[t] = wl[LE::b2 + (t * 2 + ((j >> 2) & 1)) * 16 + (j & 3) + 4 * (j >> 3)];
-    const float* wn = p.wn;                                      // MpNBlob in global memory
     for (XcdWalk wk((p.n_tiles + 3) / 4); wk.valid(); wk.next()) {
         // static strided split: at any moment the resident workgroups of an XCD work on ADJACENT tiles, so the K_e stream
-        // is one dense front in HBM and neighbouring tiles share gathered A rows.  Measured alternatives (256 x 1000-node
-        // graphs, 0.98 ms for 5 iterations): tiles pulled one by one from a per-XCD counter 1.11 ms, one contiguous run of
-        // tiles per workgroup 1.16 ms, 16 instead of 12 waves per CU 1.23 ms -- the kernel is bound by HBM traffic
-        // (~750 MB per launch at 3.7 TB/s), not by latency or occupancy
+        // is one dense front in HBM and neighbouring tiles share gathered A rows (tiles pulled one by one from a per-XCD
+        // counter, or one contiguous run of tiles per workgroup, both measured 13-18 % slower)
         const int tile = wk.cur * 4 + wave;
         if (tile >= p.n_tiles || p.ntile_graph[tile] < 0) continue;
         const int t0 = tile * 32;
@@ -875,47 +991,67 @@ __global__ __launch_bounds__(256) void mp_fused_kernel(MpFusedParams p) {
         const int rb = p.row_beg[node], dg = p.deg[node];
         const int beg = __builtin_amdgcn_readfirstlane(rb);
         const int end = __builtin_amdgcn_readlane(rb + dg, 31);
+        const int n0 = p.node_ptr_pad[p.ntile_graph[tile]];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the previous job's LDS reads are done
+        dma_rows<D, P>(p.B, [&](int sr) { return t0 + sr; }, btile, lane);
         {   // agg tile <- -inf
             const f32x4 ninf = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
-            for (int q = 0; q < D / 8; ++q) *reinterpret_cast<f32x4*>(agg + j * LD + h * (D / 2) + q * 4) = ninf;
+            for (int q = 0; q < D / 8; ++q) *reinterpret_cast<f32x4*>(agg + j * D + h * (D / 2) + q * 4) = ninf;
         }
-        // software pipeline: the next chunk's packed record (source id local to the graph | target's row in this tile
-        // << 27) and its K_e rows -- the HBM stream of this kernel -- are requested before this chunk's arithmetic
-        const int n0 = p.node_ptr_pad[p.ntile_graph[tile]];
-        int rec_n = 0;
-        f32x16 ke_n[NT];
-        if (beg + j < end) rec_n = p.rec32[beg + j];
-        load_edge_slot<P, NT>(p.Ke, beg + j < end ? beg + j : beg, h, ke_n);
-        for (int c0 = beg; c0 < ((p.dbg & 8) ? beg : end); c0 += 32) {
+        // software pipeline over 32-edge chunks: while chunk c is multiplied and aggregated, the A rows of chunk c + 1 are
+        // in flight to the LDS stage (DMA, no registers), its first K_e tile to registers, and the packed record
+        // (source id local to the graph | target's row in this tile << 27) of chunk c + 2 is requested
+        auto src_row = [&](int rec, bool valid) { return valid ? n0 + (rec & 0x7ffffff) : t0; };
+        int rec_c = 0, rec_n = 0;
+        if (beg + j < end) rec_c = p.rec32[beg + j];
+        if (beg + 32 + j < end) rec_n = p.rec32[beg + 32 + j];
+        f32x16 ke_n;
+        if (beg < end) {
+            const int mine = src_row(rec_c, beg + j < end);
+            dma_rows<D, P>(p.A, [&](int sr) { return __builtin_amdgcn_ds_bpermute(sr * 4, mine); }, astage, lane);
+            load_edge_slot_tile<P, NT>(p.Ke, beg + j < end ? beg + j : beg, h, 0, ke_n);
+        }
+        for (int c0 = beg; c0 < end; c0 += 32) {
             const int slot = c0 + j;
             const bool valid = slot < end;
-            const int rec = rec_n;
-            f32x16 hid[NT], a[NT], b[NT];
-#pragma unroll
-            for (int tt = 0; tt < NT; ++tt) hid[tt] = ke_n[tt];
-            const int s = n0 + (rec & 0x7ffffff), t = t0 + ((rec >> 27) & 31);
-            load_row_p<P, NT>(p.A, (size_t)((valid && !(p.dbg & 4)) ? s : t0), a, h);
-            load_row_p<P, NT>(p.B, (size_t)((valid && !(p.dbg & 4)) ? t : t0), b, h);
-            if (c0 + 32 < end) {                                          // wave-uniform
-                const int sn = c0 + 32 + j;
-                if (sn < end) rec_n = p.rec32[sn];
-                load_edge_slot<P, NT>(p.Ke, sn < end ? sn : beg, h, ke_n);
-            }
-            if (h == 0) dl[j] = (valid ? t - t0 : 32) * LD;
-#pragma unroll
-            for (int tt = 0; tt < NT; ++tt) hid[tt] += a[tt] + b[tt];
-            relu_<NT>(hid);
-            BOp<P> hop[NT];
-            make_ops<P, NT>(hid, hop);
+            const int rec = rec_c;
+            const int dloc = valid ? ((rec >> 27) & 31) : 0;
+            const int eslot = valid ? slot : beg;
+            const f32x16 ke0 = ke_n;
+            if (h == 0) dl[j] = dloc * D;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this chunk's A rows (and the job's B rows) have landed
             f32x16 M[NT];
 #pragma unroll
             for (int ot = 0; ot < NT; ++ot) M[ot] = splat16(bias[ot]);
+            // hidden = relu(A[src] + B[dst] + K_e), one 32-feature tile at a time, straight into the swapped MFMA
+            linear_acc_stream<P, NT, true>(wl + LE::w2, [&](int it, f32x16& x) {
+                f32x16 a, b;
+                if (it == 0) x = ke0; else load_edge_slot_tile<P, NT>(p.Ke, eslot, h, it, x);
+                read_stage_tile<D, P>(astage, j, h, it, a);
+                read_stage_tile<D, P>(btile, dloc, h, it, b);
+                if (it == NT - 1) {
+                    // the stage has been read: request the next chunk's rows, K_e and the record after that
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    rec_c = rec_n;
+                    if (c0 + 32 < end) {                                       // wave-uniform
+                        const int mine = src_row(rec_c, c0 + 32 + j < end);
+                        dma_rows<D, P>(p.A, [&](int sr) { return __builtin_amdgcn_ds_bpermute(sr * 4, mine); }, astage, lane);
+                        load_edge_slot_tile<P, NT>(p.Ke, c0 + 32 + j < end ? c0 + 32 + j : beg, h, 0, ke_n);
+                        if (c0 + 64 + j < end) rec_n = p.rec32[c0 + 64 + j];
+                    }
+                }
+                x += a + b;
 #pragma unroll
-            for (int it = 0; it < NT; ++it)
+                for (int r = 0; r < 16; ++r) x[r] = fmaxf(x[r], 0.0f);
+            }, M, lane);
+            if (end - c0 < 32) {                                 // wave-uniform: the last, partial chunk -- pad edges aggregate -inf
+                const int nv = end - c0;
 #pragma unroll
                 for (int ot = 0; ot < NT; ++ot)
-                    mfma_tile_p<P, true>(wl + LE::w2 + (ot * NT + it) * TF, hop[it], M[ot], lane);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) M[ot][r] = phi(r, h) < nv ? M[ot][r] : -INFINITY;
+            }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -930,38 +1066,64 @@ __global__ __launch_bounds__(256) void mp_fused_kernel(MpFusedParams p) {
             for (int ot = 0; ot < NT; ++ot)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    if (!(p.dbg & 1)) __builtin_amdgcn_ds_fmaxf((lds_float*)(agg + off[r] + ot * 32 + j), M[ot][r], 0, 0, false);
+                    __builtin_amdgcn_ds_fmaxf((lds_float*)(agg + off[r] + ot * 32 + j), M[ot][r], 0, 0, false);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
-        if (p.dbg & 2) continue;
-        // ---- node phase
-        f32x16 x[NT], y[NT], ag[NT];
-        load_row<NT>(p.X + (size_t)node * D, x, h);
-        load_row<NT>(p.R + (size_t)node * D, y, h);
-        load_row<NT>(agg + j * LD, ag, h);
-        if (dg == 0) {
-#pragma unroll
-            for (int tt = 0; tt < NT; ++tt) ag[tt] = splat16(0.f);          // torch_scatter: no incoming edge -> 0
+        // ---- node phase.  X and R rows of the tile (contiguous, fp32) come through the two stages as well; the weights
+        // (MpNBlob) are read from global memory as MFMA operands (at d = 64 the pointer is laundered per job so that the
+        // compiler does not hoist those loop-invariant loads out of the job loop into ~70 registers)
+        const float* wn = p.wn;
+        asm volatile("" : "+s"(wn));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (P != 1) {                                  // fp32 rows fill a whole stage each
+            dma_rows<D, 0>(p.X, [&](int sr) { return t0 + sr; }, astage, lane);
+            dma_rows<D, 0>(p.R, [&](int sr) { return t0 + sr; }, btile, lane);
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");              // tile is re-initialised by the next job
-        __builtin_amdgcn_wave_barrier();
-        f32x16 H[NT], z[NT];
+        f32x16 H[NT];
         load_vec<NT>(wn + LN::bl, H, lane);
-        linear_acc_p<P, NT, NT>(wn + LN::wlx, x, H, lane);
-        linear_acc_p<P, NT, NT>(wn + LN::wla, ag, H, lane);
+        if constexpr (P != 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        linear_acc_stream<P, NT, false>(wn + LN::wlx, [&](int it, f32x16& x) {
+            if constexpr (P != 1) read_stage_tile<D, 0>(astage, j, h, it, x);
+            else load_row_tile<0, NT>(p.X, (size_t)node, h, it, x);
+        }, H, lane);
+        linear_acc_stream<P, NT, false>(wn + LN::wla, [&](int it, f32x16& x) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(agg + j * D + it * 32 + q * 8 + h * 4);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) x[q * 4 + c] = dg == 0 ? 0.f : a[c];      // torch_scatter: no incoming edge -> 0
+            }
+        }, H, lane);
         if (p.store_h) store_row<NT>(p.Hout + (size_t)node * D, H, h);
-        linear_acc_p<P, NT, NT>(wn + LN::m1, H, y, lane);
-        store_row<NT>(p.Xout + (size_t)node * D, y, h);
+        BOp<P> yop[NT];
+        {
+            f32x16 y[NT];
+            if constexpr (P != 1) {
 #pragma unroll
-        for (int tt = 0; tt < NT; ++tt) z[tt] = splat16(0.f);
-        linear_acc_p<P, NT, NT>(wn + LN::m2, y, z, lane);
-        store_row_p<P, NT>(p.Aout, (size_t)node, z, h);
+                for (int tt = 0; tt < NT; ++tt) read_stage_tile<D, 0>(btile, j, h, tt, y[tt]);
+            } else {
+                load_row<NT>(p.R + (size_t)node * D, y, h);
+            }
+            linear_acc_p<P, NT, NT>(wn + LN::m1, H, y, lane);
+            store_row<NT>(p.Xout + (size_t)node * D, y, h);
+            make_ops<P, NT>(y, yop);
+        }
+        {
+            f32x16 z[NT];
 #pragma unroll
-        for (int tt = 0; tt < NT; ++tt) z[tt] = splat16(0.f);
-        linear_acc_p<P, NT, NT>(wn + LN::m3, y, z, lane);
-        store_row_p<P, NT>(p.Bout, (size_t)node, z, h);
+            for (int tt = 0; tt < NT; ++tt) z[tt] = splat16(0.f);
+            linear_acc_ops<P, NT, NT>(wn + LN::m2, yop, z, lane);
+            store_row_p<P, NT>(p.Aout, (size_t)node, z, h);
+        }
+        {
+            f32x16 z[NT];
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt) z[tt] = splat16(0.f);
+            linear_acc_ops<P, NT, NT>(wn + LN::m3, yop, z, lane);
+            store_row_p<P, NT>(p.Bout, (size_t)node, z, h);
+        }
     }
 }
 
@@ -1155,7 +1317,7 @@ static hipError_t launch_pre_resident_t(const PreParams& p, size_t lds_bytes, in
 hipError_t launch_pre_resident(int D, int P, bool edge, const PreParams& p, size_t lds_bytes, int n_cu, hipStream_t st) {
     if (D == 32 && P == 0) return edge ? launch_pre_resident_t<32, 0, true, 12>(p, lds_bytes, n_cu, st) : launch_pre_resident_t<32, 0, false, 12>(p, lds_bytes, n_cu, st);
     if (D == 32 && P == 1) return edge ? launch_pre_resident_t<32, 1, true, 12>(p, lds_bytes, n_cu, st) : launch_pre_resident_t<32, 1, false, 12>(p, lds_bytes, n_cu, st);
-    if (D == 64 && P == 1) return edge ? launch_pre_resident_t<64, 1, true, 8>(p, lds_bytes, n_cu, st) : launch_pre_resident_t<64, 1, false, 8>(p, lds_bytes, n_cu, st);
+    if (D == 64 && P == 1) return edge ? launch_pre_resident_t<64, 1, true, 12>(p, lds_bytes, n_cu, st) : launch_pre_resident_t<64, 1, false, 8>(p, lds_bytes, n_cu, st);
     return hipErrorInvalidValue;
 }
 
@@ -1196,10 +1358,10 @@ static int grid_for(K kernel, size_t lds_bytes, int n_tiles, int max_per_cu) {
 
 template <int D, int P>
 static hipError_t launch_mp_fused_t(const MpFusedParams& p, hipStream_t st) {
-    const size_t lds = (size_t)(((MpEBlob<D, P>::size + 3) & ~3) + 4 * (33 * (D + 4) + 32)) * sizeof(float);
+    const size_t lds = (size_t)(((MpEBlob<D, P>::size + 3) & ~3) + 4 * mp_wave_floats<D, P>()) * sizeof(float);
     hipError_t e = set_lds(mp_fused_kernel<D, P>, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((mp_fused_kernel<D, P>), dim3(grid_for(mp_fused_kernel<D, P>, lds, p.n_tiles, 4)), dim3(256), lds, st, p);
+    hipLaunchKernelGGL((mp_fused_kernel<D, P>), dim3(grid_for(mp_fused_kernel<D, P>, lds, p.n_tiles, 2)), dim3(256), lds, st, p);
     LAUNCH_CHECK();
     return hipSuccess;
 }
