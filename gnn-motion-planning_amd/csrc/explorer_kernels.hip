@@ -95,6 +95,7 @@ __device__ __forceinline__ int find_graph(const int* __restrict__ ptr, int G, in
 // returning atomics at cfg 2).  Graphs beyond kPrepCap padded nodes keep their counters in global memory
 // (same code through flat pointers).
 // =====================================================================================================
+constexpr int kCoopMaxTiles = 1024;     // up to this many 32-node tiles, mp_fused runs one tile per workgroup of 8 waves
 constexpr int kPrepCap = 8192;
 constexpr int kPrepGraphMin = 64;      // batches of at least this many graphs take the per-graph kernel
 
@@ -956,36 +957,48 @@ __device__ __forceinline__ void linear_acc_stream(const float* A, Get get, f32x1
     }
 }
 
-// LDS floats one wave of mp_fused owns: max-aggregation tile [32][D], 32 row offsets, two 32-row gather stages
-template <int D, int P>
-__host__ __device__ constexpr int mp_wave_floats() { return 32 * D + 32 + 2 * (32 * D * (P == 1 ? 2 : 4) / 4); }
+// LDS floats of mp_fused besides the staged MpEBlob.  COOP = 1: every wave owns a max-aggregation tile [32][D], 32 row
+// offsets and two 32-row gather stages; COOP > 1: the workgroup's COOP waves share the aggregation tile and the B-row
+// stage, every wave keeps its own row offsets and A-row stage
+template <int D, int P, int COOP>
+__host__ __device__ constexpr int mp_lds_floats() {
+    constexpr int stage_f = 32 * D * (P == 1 ? 2 : 4) / 4;
+    return COOP == 1 ? 4 * (32 * D + 32 + 2 * stage_f) : (32 * D + stage_f + COOP * (32 + stage_f));
+}
 
-template <int D, int P>
-__global__ __launch_bounds__(256, (P == 2 || D > 32) ? 2 : 3) void mp_fused_kernel(MpFusedParams p) {
+// COOP = 1 (large batches): one 32-node tile per WAVE, four independent waves per workgroup.
+// COOP > 1 (few tiles -- single graphs, small batches): one tile per WORKGROUP of COOP waves; the tile's 32-edge chunks
+// go round-robin to the waves, which all aggregate into the shared LDS tile (float atomics: order-free, exact), and
+// wave 0 runs the node phase.  A single 1000-node graph has 32 tiles of ~12 chunks: 25 us per launch with one wave
+// per tile, ~9 us with eight.
+template <int D, int P, int COOP>
+__global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((P == 2 || D > 32) ? 2 : 3) : 1) void mp_fused_kernel(MpFusedParams p) {
     constexpr int NT = D / 32;
+    constexpr bool kCoop = COOP > 1;
     using LE = MpEBlob<D, P>;
     using LN = MpNBlob<D, P>;
     using G = RowGeom<D, P>;
-    using GX = RowGeom<D, 0>;                                    // X / R rows are always fp32
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* wl = lds;                                             // MpEBlob
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
-    float* agg = lds + ((LE::size + 3) & ~3) + wave * mp_wave_floats<D, P>();        // [32][D]
-    int* dl = reinterpret_cast<int*>(agg + 32 * D);              // [32] agg row offsets (floats) of this chunk's targets
-    float* astage = agg + 32 * D + 32;                           // gathered A rows of the current chunk
-    float* btile = astage + G::STAGE_FLOATS;                     // B rows of this job's 32 nodes
+    float* base = lds + ((LE::size + 3) & ~3);
+    float* agg = kCoop ? base : base + wave * (32 * D + 32 + 2 * G::STAGE_FLOATS);                   // [32][D]
+    float* btile = kCoop ? base + 32 * D : agg + 32 * D + 32 + G::STAGE_FLOATS;                      // B rows of the tile
+    float* mine = kCoop ? base + 32 * D + G::STAGE_FLOATS + wave * (32 + G::STAGE_FLOATS) : agg + 32 * D;
+    int* dl = reinterpret_cast<int*>(mine);                      // [32] agg row offsets (floats) of this chunk's targets
+    float* astage = mine + 32;                                   // gathered A rows of the current chunk
     stage(wl, p.we, LE::size);
     __syncthreads();
     // b2 of the lane's feature(s): packed vectors are in register order, vec[(t*2 + h')*16 + r'] = b[32 t + phi(r', h')]
     float bias[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) bias[t] = wl[LE::b2 + (t * 2 + ((j >> 2) & 1)) * 16 + (j & 3) + 4 * (j >> 3)];
-    for (XcdWalk wk((p.n_tiles + 3) / 4); wk.valid(); wk.next()) {
+    for (XcdWalk wk(kCoop ? p.n_tiles : (p.n_tiles + 3) / 4); wk.valid(); wk.next()) {
         // static strided split: at any moment the resident workgroups of an XCD work on ADJACENT tiles, so the K_e stream
         // is one dense front in HBM and neighbouring tiles share gathered A rows (tiles pulled one by one from a per-XCD
         // counter, or one contiguous run of tiles per workgroup, both measured 13-18 % slower)
-        const int tile = wk.cur * 4 + wave;
-        if (tile >= p.n_tiles || p.ntile_graph[tile] < 0) continue;
+        const int tile = kCoop ? wk.cur : wk.cur * 4 + wave;
+        if (tile >= p.n_tiles || p.ntile_graph[tile] < 0) continue;           // workgroup-uniform when kCoop
         const int t0 = tile * 32;
         const int node = t0 + j;
         const int rb = p.row_beg[node], dg = p.deg[node];
@@ -993,26 +1006,33 @@ __global__ __launch_bounds__(256, (P == 2 || D > 32) ? 2 : 3) void mp_fused_kern
         const int end = __builtin_amdgcn_readlane(rb + dg, 31);
         const int n0 = p.node_ptr_pad[p.ntile_graph[tile]];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the previous job's LDS reads are done
-        dma_rows<D, P>(p.B, [&](int sr) { return t0 + sr; }, btile, lane);
-        {   // agg tile <- -inf
-            const f32x4 ninf = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        if constexpr (kCoop) __syncthreads();                    // ... by every wave of the workgroup
+        if (!kCoop || wave == 0) {
+            dma_rows<D, P>(p.B, [&](int sr) { return t0 + sr; }, btile, lane);
+            const f32x4 ninf = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};      // agg tile <- -inf
 #pragma unroll
             for (int q = 0; q < D / 8; ++q) *reinterpret_cast<f32x4*>(agg + j * D + h * (D / 2) + q * 4) = ninf;
         }
-        // software pipeline over 32-edge chunks: while chunk c is multiplied and aggregated, the A rows of chunk c + 1 are
-        // in flight to the LDS stage (DMA, no registers), its first K_e tile to registers, and the packed record
-        // (source id local to the graph | target's row in this tile << 27) of chunk c + 2 is requested
+        if constexpr (kCoop) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        // software pipeline over 32-edge chunks: while chunk c is multiplied and aggregated, the A rows of this wave's
+        // next chunk are in flight to the LDS stage (DMA, no registers), its first K_e tile to registers, and the packed
+        // record (source id local to the graph | target's row in this tile << 27) of the one after is requested
+        constexpr int STEP = 32 * COOP;
+        const int first = beg + (kCoop ? 32 * wave : 0);
         auto src_row = [&](int rec, bool valid) { return valid ? n0 + (rec & 0x7ffffff) : t0; };
         int rec_c = 0, rec_n = 0;
-        if (beg + j < end) rec_c = p.rec32[beg + j];
-        if (beg + 32 + j < end) rec_n = p.rec32[beg + 32 + j];
+        if (first + j < end) rec_c = p.rec32[first + j];
+        if (first + STEP + j < end) rec_n = p.rec32[first + STEP + j];
         f32x16 ke_n;
-        if (beg < end) {
-            const int mine = src_row(rec_c, beg + j < end);
-            dma_rows<D, P>(p.A, [&](int sr) { return __builtin_amdgcn_ds_bpermute(sr * 4, mine); }, astage, lane);
-            load_edge_slot_tile<P, NT>(p.Ke, beg + j < end ? beg + j : beg, h, 0, ke_n);
+        if (first < end) {
+            const int mine_row = src_row(rec_c, first + j < end);
+            dma_rows<D, P>(p.A, [&](int sr) { return __builtin_amdgcn_ds_bpermute(sr * 4, mine_row); }, astage, lane);
+            load_edge_slot_tile<P, NT>(p.Ke, first + j < end ? first + j : beg, h, 0, ke_n);
         }
-        for (int c0 = beg; c0 < end; c0 += 32) {
+        for (int c0 = first; c0 < end; c0 += STEP) {
             const int slot = c0 + j;
             const bool valid = slot < end;
             const int rec = rec_c;
@@ -1034,11 +1054,11 @@ __global__ __launch_bounds__(256, (P == 2 || D > 32) ? 2 : 3) void mp_fused_kern
                     // the stage has been read: request the next chunk's rows, K_e and the record after that
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     rec_c = rec_n;
-                    if (c0 + 32 < end) {                                       // wave-uniform
-                        const int mine = src_row(rec_c, c0 + 32 + j < end);
-                        dma_rows<D, P>(p.A, [&](int sr) { return __builtin_amdgcn_ds_bpermute(sr * 4, mine); }, astage, lane);
-                        load_edge_slot_tile<P, NT>(p.Ke, c0 + 32 + j < end ? c0 + 32 + j : beg, h, 0, ke_n);
-                        if (c0 + 64 + j < end) rec_n = p.rec32[c0 + 64 + j];
+                    if (c0 + STEP < end) {                                     // wave-uniform
+                        const int mine_row = src_row(rec_c, c0 + STEP + j < end);
+                        dma_rows<D, P>(p.A, [&](int sr) { return __builtin_amdgcn_ds_bpermute(sr * 4, mine_row); }, astage, lane);
+                        load_edge_slot_tile<P, NT>(p.Ke, c0 + STEP + j < end ? c0 + STEP + j : beg, h, 0, ke_n);
+                        if (c0 + 2 * STEP + j < end) rec_n = p.rec32[c0 + 2 * STEP + j];
                     }
                 }
                 x += a + b;
@@ -1070,6 +1090,11 @@ __global__ __launch_bounds__(256, (P == 2 || D > 32) ? 2 : 3) void mp_fused_kern
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        if constexpr (kCoop) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's aggregation atomics have been performed
+            __syncthreads();
+            if (wave != 0) continue;                             // wave 0 runs the node phase; the others wait at the next tile
         }
         // ---- node phase.  X and R rows of the tile (contiguous, fp32) come through the two stages as well; the weights
         // (MpNBlob) are read from global memory as MFMA operands (at d = 64 the pointer is laundered per job so that the
@@ -1356,20 +1381,32 @@ static int grid_for(K kernel, size_t lds_bytes, int n_tiles, int max_per_cu) {
     return groups < cap ? groups : (cap < 8 ? 8 : cap);
 }
 
-template <int D, int P>
+template <int D, int P, int COOP>
 static hipError_t launch_mp_fused_t(const MpFusedParams& p, hipStream_t st) {
-    const size_t lds = (size_t)(((MpEBlob<D, P>::size + 3) & ~3) + 4 * mp_wave_floats<D, P>()) * sizeof(float);
-    hipError_t e = set_lds(mp_fused_kernel<D, P>, lds);
+    const size_t lds = (size_t)(((MpEBlob<D, P>::size + 3) & ~3) + mp_lds_floats<D, P, COOP>()) * sizeof(float);
+    hipError_t e = set_lds(mp_fused_kernel<D, P, COOP>, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((mp_fused_kernel<D, P>), dim3(grid_for(mp_fused_kernel<D, P>, lds, p.n_tiles, 2)), dim3(256), lds, st, p);
+    if (COOP == 1) {
+        hipLaunchKernelGGL((mp_fused_kernel<D, P, COOP>), dim3(grid_for(mp_fused_kernel<D, P, COOP>, lds, p.n_tiles, 2)), dim3(256), lds, st, p);
+    } else {
+        const int grid = ((p.n_tiles + 7) & ~7) < 8 ? 8 : ((p.n_tiles + 7) & ~7);          // one workgroup per tile
+        hipLaunchKernelGGL((mp_fused_kernel<D, P, COOP>), dim3(grid), dim3(COOP * 64), lds, st, p);
+    }
     LAUNCH_CHECK();
     return hipSuccess;
+}
+// few tiles (single graphs, small batches): eight waves share a tile
+template <int D, int P>
+static hipError_t launch_mp_fused_dp(const MpFusedParams& p, hipStream_t st) {
+    static const int forced = getenv("GNNMP_MP_COOP") ? atoi(getenv("GNNMP_MP_COOP")) : -1;
+    const bool coop = forced >= 0 ? forced != 0 : p.n_tiles <= kCoopMaxTiles;
+    return coop ? launch_mp_fused_t<D, P, 8>(p, st) : launch_mp_fused_t<D, P, 1>(p, st);
 }
 hipError_t launch_mp_fused(int D, int P, const MpFusedParams& p_in, hipStream_t st) {
     MpFusedParams p = p_in;
     static const int dbg = getenv("GNNMP_MP_DBG") ? atoi(getenv("GNNMP_MP_DBG")) : 0;
     p.dbg = dbg;
-    GNNMP_DISPATCH_DP(D, P, (launch_mp_fused_t<DD, PP>(p, st)));
+    GNNMP_DISPATCH_DP(D, P, (launch_mp_fused_dp<DD, PP>(p, st)));
 }
 
 template <int D, int P>
