@@ -53,6 +53,11 @@ class MazeBatch(ctypes.Structure):
                 ('scores', ctypes.c_void_p), ('maps', ctypes.c_void_p), ('goal_states', ctypes.c_void_p)]
 
 
+class MazeResume(ctypes.Structure):
+    _fields_ = [('n_explored', ctypes.c_void_p), ('explored', ctypes.c_void_p), ('prev', ctypes.c_void_p),
+                ('n_pairs', ctypes.c_void_p), ('pairs', ctypes.c_void_p), ('pair_ptr', ctypes.c_void_p)]
+
+
 _lib = None
 
 
@@ -83,6 +88,8 @@ def lib():
     L.gnnmp_graph_build.argtypes = [ctypes.POINTER(GraphBuildBatch), vp, ctypes.c_int64, vp, vp, sz, vp]
     L.gnnmp_maze_explore_workspace_bytes.argtypes = [ctypes.POINTER(MazeBatch), ctypes.POINTER(sz)]
     L.gnnmp_maze_explore.argtypes = [ctypes.POINTER(MazeBatch), vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
+    L.gnnmp_maze_explore_ex.argtypes = [ctypes.POINTER(MazeBatch), ctypes.c_int32, ctypes.POINTER(MazeResume), vp, vp, vp, vp, vp,
+                                        vp, vp, vp, vp, vp, sz, vp]
     L.gnnmp_maze_steer.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, vp, vp, vp, vp, vp, vp, vp, vp]
     L.gnnmp_pack_a_tiles.restype = ctypes.c_int64
     L.gnnmp_pack_a_tiles.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp]

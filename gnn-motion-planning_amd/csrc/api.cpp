@@ -1119,13 +1119,18 @@ extern "C" int gnnmp_maze_explore_workspace_bytes(const gnnmp_maze_batch* b, siz
     return GNNMP_OK;
 }
 
-extern "C" int gnnmp_maze_explore(const gnnmp_maze_batch* b, int32_t* success, int32_t* n_explored, int32_t* explored,
-                                  int32_t* n_pairs, int32_t* explored_edges, int32_t* path_len, int32_t* path,
-                                  int64_t* checks, void* ws, size_t ws_bytes, void* hip_stream) {
+extern "C" int gnnmp_maze_explore_ex(const gnnmp_maze_batch* b, int32_t dim, const gnnmp_maze_resume* resume,
+                                     int32_t* success, int32_t* n_explored, int32_t* explored, int32_t* n_pairs,
+                                     int32_t* explored_edges, int32_t* path_len, int32_t* path, int64_t* checks,
+                                     int32_t* prev_out, void* ws, size_t ws_bytes, void* hip_stream) {
     if (!b || !success || !n_explored || !explored || !n_pairs || !explored_edges || !path_len || !path || !checks || !ws)
         return GNNMP_ERR_NULL;
     if (!b->v || !b->node_ptr || !b->edge_ptr || !b->n_free || !b->maps || !b->goal_states) return GNNMP_ERR_NULL;
     if (b->total_edges > 0 && (!b->edge_index || !b->scores)) return GNNMP_ERR_NULL;
+    if (dim != 2 && dim != 3) return GNNMP_ERR_DIMS;
+    const bool res = resume && resume->n_explored;
+    if (res && (!resume->explored || !resume->prev || !resume->n_pairs || !resume->pairs || !resume->pair_ptr))
+        return GNNMP_ERR_NULL;
     MzCarve c;
     if (!mz_carve(b, c)) return GNNMP_ERR_ARG;
     if (ws_bytes < c.total || (reinterpret_cast<uintptr_t>(ws) & 255)) return GNNMP_ERR_WORKSPACE;
@@ -1140,8 +1145,20 @@ extern "C" int gnnmp_maze_explore(const gnnmp_maze_batch* b, int32_t* success, i
     p.success = success; p.n_explored = n_explored; p.explored = explored; p.n_pairs = n_pairs;
     p.explored_edges = explored_edges; p.path_len = path_len; p.path = path;
     p.checks = reinterpret_cast<long long*>(checks);
+    p.dim = dim;
+    p.n_explored0 = res ? resume->n_explored : nullptr; p.explored0 = res ? resume->explored : nullptr;
+    p.prev0 = res ? resume->prev : nullptr; p.n_pairs0 = res ? resume->n_pairs : nullptr;
+    p.pairs0 = res ? resume->pairs : nullptr; p.pair_ptr0 = res ? resume->pair_ptr : nullptr;
+    p.prev_out = prev_out;
     HIP_TRY(launch_maze_explore(p, static_cast<hipStream_t>(hip_stream)));
     return GNNMP_OK;
+}
+
+extern "C" int gnnmp_maze_explore(const gnnmp_maze_batch* b, int32_t* success, int32_t* n_explored, int32_t* explored,
+                                  int32_t* n_pairs, int32_t* explored_edges, int32_t* path_len, int32_t* path,
+                                  int64_t* checks, void* ws, size_t ws_bytes, void* hip_stream) {
+    return gnnmp_maze_explore_ex(b, 2, nullptr, success, n_explored, explored, n_pairs, explored_edges, path_len, path, checks,
+                                 nullptr, ws, ws_bytes, hip_stream);
 }
 
 extern "C" int gnnmp_maze_steer(int32_t n_problems, int32_t total_path, int32_t width, const double* maps,

@@ -124,6 +124,10 @@ struct MazeParams {
     unsigned char* alive;
     int *success, *n_explored, *explored, *n_pairs, *explored_edges, *path_len, *path;
     long long* checks;
+    int dim;                              // 2 (point robot, v [.,2]) or 3 (stick robot, v [.,3])
+    // resume (all nullptr = fresh trees): tree and pair list of the earlier rounds
+    const int *n_explored0, *explored0, *prev0, *n_pairs0, *pairs0, *pair_ptr0;
+    int* prev_out;                        // optional [sumN]: parent of every explored node
 };
 hipError_t launch_maze_explore(const MazeParams& p, hipStream_t st);
 

@@ -12,8 +12,9 @@
 //     contraction: every operation rounded on its own (contraction off)), count one check per in-bounds configuration query, short-circuit left
 //     to right, bisect while the end cells are > 1 grid step apart and the L1 distance exceeds RRT_EPS;
 //   * goal test in float64 against the float64 goal state, then one more query.
-// Scope: one explorer forward per problem with a fresh tree (the reference's defaults batch = t_max = 500 give
-// exactly that); resample rounds stay on the host path (planner.explore).
+// A launch is one round (one explorer forward per problem): with a fresh tree (the reference's defaults
+// batch = t_max = 500 give exactly one round) or with the tree of earlier rounds carried over
+// (resample rounds, eval_gnn.py:235-247).  2-D point robot (maze2) and 3-DoF stick robot (maze3).
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include "kernels.hpp"
@@ -99,9 +100,87 @@ __device__ bool maze_edge_fp(MazeCtx& m, float ax, float ay, float bx, float by)
     return maze_segment_fp(m, ax, ay, bx, by);
 }
 
+// ---- 3-DoF maze (MazeEnv(dim=3)): a stick of length 0.2 at (x, y), orientation coordinate z in [-0.4, 0.4]
+// (environment/maze_env.py:254-302,330-347).  The reference's numpy dtype flow is part of the behaviour: node rows are
+// float32, the stick ends come out float64 (float32 coordinate / float64 limit), so the 2-D point / segment queries of
+// the ends run in float64, while the interpolation along an edge runs in float32.
+__device__ __forceinline__ int maze_cell64(double x, int w) {
+    int c = (int)((x + 1.0) * (double)w / 2.0);
+    return c > w - 1 ? w - 1 : c;
+}
+__device__ __forceinline__ bool maze_valid64(double x, double y) { return x >= -1.0 && x <= 1.0 && y >= -1.0 && y <= 1.0; }
+__device__ __forceinline__ bool maze_point_fp64(MazeCtx& m, double x, double y) {
+    if (!maze_valid64(x, y)) return false;
+    m.checks += 1;
+    const int idx = maze_cell64(x, m.w) * m.w + maze_cell64(y, m.w);
+    return m.occ ? m.occ[idx] == 0 : m.map[idx] == 0.0;
+}
+__device__ bool maze_segment_fp64(MazeCtx& m, double ax, double ay, double bx, double by) {
+    double sx0[48], sy0[48], sx1[48], sy1[48];
+    int sp = 1;
+    sx0[0] = ax; sy0[0] = ay; sx1[0] = bx; sy1[0] = by;
+    while (sp > 0) {
+        --sp;
+        const double lx = sx0[sp], ly = sy0[sp], rx = sx1[sp], ry = sy1[sp];
+        const int dc = abs(maze_cell64(lx, m.w) - maze_cell64(rx, m.w)) + abs(maze_cell64(ly, m.w) - maze_cell64(ry, m.w));
+        const double l1 = fabs(lx - rx) + fabs(ly - ry);
+        if (dc > 1 && l1 > 0.05) {
+            const double mx = (lx + rx) / 2.0, my = (ly + ry) / 2.0;
+            if (!maze_point_fp64(m, mx, my)) return false;
+            if (sp + 2 > 48) return false;
+            sx0[sp] = mx; sy0[sp] = my; sx1[sp] = rx; sy1[sp] = ry; ++sp;
+            sx0[sp] = lx; sy0[sp] = ly; sx1[sp] = mx; sy1[sp] = my; ++sp;
+        }
+    }
+    return true;
+}
+__device__ __forceinline__ bool maze_valid3(float x, float y, float z) {
+    return maze_valid(x, y) && (double)z >= -0.4 && (double)z <= 0.4;
+}
+// stick ends: theta = z / LIMITS[2] * pi (float64), end = center -+ (STICK_LENGTH / 2) * (cos, sin)
+__device__ __forceinline__ void stick_ends(float x, float y, float z, double& ax, double& ay, double& bx, double& by) {
+    const double theta = (double)z / 0.4 * 3.141592653589793;
+    const double ox = 0.1 * cos(theta), oy = 0.1 * sin(theta);
+    ax = (double)x - ox; ay = (double)y - oy;
+    bx = (double)x + ox; by = (double)y + oy;
+}
+__device__ bool stick_state_fp(MazeCtx& m, float x, float y, float z) {        // _stick_in_free_space
+    if (!maze_valid3(x, y, z)) return false;
+    double ax, ay, bx, by;
+    stick_ends(x, y, z, ax, ay, bx, by);
+    if (!maze_point_fp64(m, ax, ay) || !maze_point_fp64(m, bx, by)) return false;
+    return maze_segment_fp64(m, ax, ay, bx, by);
+}
+__device__ bool stick_edge_fp(MazeCtx& m, const float* s, const float* t) {      // _edge_fp, state.size == 3
+    if (!maze_valid3(s[0], s[1], s[2]) || !maze_valid3(t[0], t[1], t[2])) return false;
+    if (!stick_state_fp(m, s[0], s[1], s[2]) || !stick_state_fp(m, t[0], t[1], t[2])) return false;
+    const float d0 = f_sub(t[0], s[0]), d1 = f_sub(t[1], s[1]);
+    float d2 = f_sub(t[2], s[2]);
+    if (fabs((double)d2) > 0.4) d2 = (float)(d2 > 0.f ? (double)d2 - 0.8 : (double)d2 + 0.8);
+    // distance(): |diff| in float32, third coordinate wrapped through float64, sqrt of the float32 sum of squares
+    const float a0 = fabsf(f_sub(t[0], s[0])), a1 = fabsf(f_sub(t[1], s[1]));
+    const float a2r = fabsf(f_sub(t[2], s[2]));
+    const double w2 = fabs((double)a2r - 0.8);
+    const float a2 = (float)((double)a2r < w2 ? (double)a2r : w2);
+    const float dist = f_sqrt(f_add(f_add(f_mul(a0, a0), f_mul(a1, a1)), f_mul(a2, a2)));
+    const int K = (int)f_div(dist, 0.015f);
+    for (int k = 1; k < K; ++k) {
+        const float r = (float)((double)k * 1.0 / (double)K);
+        const float cx = f_add(s[0], f_mul(r, d0)), cy = f_add(s[1], f_mul(r, d1)), cz = f_add(s[2], f_mul(r, d2));
+        double ax, ay, bx, by;
+        stick_ends(cx, cy, cz, ax, ay, bx, by);
+        // the 2-D _edge_fp of the two ends
+        if (!maze_valid64(ax, ay) || !maze_valid64(bx, by)) return false;
+        if (!maze_point_fp64(m, ax, ay) || !maze_point_fp64(m, bx, by)) return false;
+        if (!maze_segment_fp64(m, ax, ay, bx, by)) return false;
+    }
+    return true;
+}
+
 }  // namespace
 
-// one wave per problem
+// one wave per problem.  DIM = 2: point robot; DIM = 3: stick robot (maze3)
+template <int DIM>
 __global__ __launch_bounds__(64) void maze_explore_kernel(MazeParams p) {
     const int b = blockIdx.x, lane = threadIdx.x;
     const int n0 = p.node_ptr[b], N = p.node_ptr[b + 1] - n0;
@@ -110,7 +189,7 @@ __global__ __launch_bounds__(64) void maze_explore_kernel(MazeParams p) {
     const long long* src = p.edge_index + e0;
     const long long* dst = p.edge_index + (size_t)p.total_edges + e0;
     const float* sc = p.scores + e0;
-    const float* v = p.v + (size_t)n0 * 2;
+    const float* v = p.v + (size_t)n0 * DIM;
     int* in_ptr = p.in_ptr + n0 + b;              // [N + 1] per problem
     int* cnt = p.cnt + n0;
     int* in_eid = p.in_eid + e0;
@@ -160,9 +239,30 @@ __global__ __launch_bounds__(64) void maze_explore_kernel(MazeParams p) {
     __shared__ unsigned char occ_lds[kMazeLdsCells];
     MazeCtx m;
     maze_ctx_init(m, p.maps + (size_t)b * p.w * p.w, p.w, occ_lds, lane);
-    const double gx = p.goal_states[2 * b], gy = p.goal_states[2 * b + 1];
+    const double* goal = p.goal_states + (size_t)DIM * b;
     int n_expl = 1, n_pairs = 1, success = 0, path_len = 0;
-    if (lane == 0) { explored[0] = 0; pos[0] = 0; prev[0] = 0; ee[0] = 0; ee[1] = 0; }
+    if (p.n_explored0 == nullptr) {                                        // fresh tree (eval_gnn.py:183-186)
+        if (lane == 0) { explored[0] = 0; pos[0] = 0; prev[0] = 0; ee[0] = 0; ee[1] = 0; }
+    } else {
+        // tree carried over from earlier rounds (eval_gnn.py:235-247): explored nodes keep their indices (new free
+        // samples are appended behind the old ones).  The masks are rebuilt on the fresh scores as the reference does:
+        // columns of explored nodes (through pos[]), and the legacy-index line eval_gnn.py:202, which pairs the FLATTENED
+        // pair list's first half with its second half (cell (flat[i], flat[M + i])), not the recorded (a, b) pairs
+        n_expl = p.n_explored0[b];
+        n_pairs = 0;                                                       // only this round's pairs are written out
+        for (int i = lane; i < n_expl; i += 64) {
+            const int a = p.explored0[n0 + i];
+            explored[i] = a; pos[a] = i; prev[a] = p.prev0[n0 + a];
+        }
+        const int M = p.n_pairs0[b];
+        const int* flat = p.pairs0 + 2 * (size_t)p.pair_ptr0[b];
+        for (int i = lane; i < M; i += 64) {
+            const int r = flat[i], c = flat[M + i];
+            if (r >= N) continue;
+            for (int q = in_ptr[r]; q < in_ptr[r + 1]; ++q)
+                if ((int)src[in_eid[q]] == c) alive[in_eid[q]] = 0;
+        }
+    }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
 
@@ -196,7 +296,7 @@ __global__ __launch_bounds__(64) void maze_explore_kernel(MazeParams p) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
     };
-    rescan(0);
+    for (int i = 0; i < n_expl; ++i) rescan(i);
     sync();
 
     while (true) {
@@ -218,16 +318,26 @@ __global__ __launch_bounds__(64) void maze_explore_kernel(MazeParams p) {
         }
         if (be < 0) break;                                                 // nothing left on the frontier
         const int a = explored[bp], nb = bb;
-        int free_edge = 0, goal = 0;
+        int free_edge = 0, goal_hit = 0;
         if (lane == 0) {
             ee[2 * n_pairs] = a; ee[2 * n_pairs + 1] = nb;
             ee[2 * n_pairs + 2] = nb; ee[2 * n_pairs + 3] = a;
-            free_edge = maze_edge_fp(m, v[2 * a], v[2 * a + 1], v[2 * nb], v[2 * nb + 1]) ? 1 : 0;
+            if constexpr (DIM == 2) free_edge = maze_edge_fp(m, v[2 * a], v[2 * a + 1], v[2 * nb], v[2 * nb + 1]) ? 1 : 0;
+            else free_edge = stick_edge_fp(m, v + 3 * a, v + 3 * nb) ? 1 : 0;
             if (free_edge) {
                 explored[n_expl] = nb; pos[nb] = n_expl; prev[nb] = a;
-                const double dx = fabs(gx - (double)v[2 * nb]), dy = fabs(gy - (double)v[2 * nb + 1]);
-                const double d = sqrt(dx * dx + dy * dy);                  // no contraction: see the pragma above
-                if (d < 0.05) goal = maze_state_fp(m, v[2 * nb], v[2 * nb + 1]) ? 1 : 0;
+                if constexpr (DIM == 2) {
+                    const double dx = fabs(goal[0] - (double)v[2 * nb]), dy = fabs(goal[1] - (double)v[2 * nb + 1]);
+                    const double d = sqrt(dx * dx + dy * dy);              // no contraction: see the pragma above
+                    if (d < 0.05) goal_hit = maze_state_fp(m, v[2 * nb], v[2 * nb + 1]) ? 1 : 0;
+                } else {                                                   // distance() wraps the orientation coordinate
+                    const double dx = fabs(goal[0] - (double)v[3 * nb]), dy = fabs(goal[1] - (double)v[3 * nb + 1]);
+                    double dz = fabs(goal[2] - (double)v[3 * nb + 2]);
+                    const double wz = fabs(dz - 0.8);
+                    dz = dz < wz ? dz : wz;
+                    const double d = sqrt((dx * dx + dy * dy) + dz * dz);
+                    if (d < 0.05) goal_hit = stick_state_fp(m, v[3 * nb], v[3 * nb + 1], v[3 * nb + 2]) ? 1 : 0;
+                }
             } else {
                 alive[be] = 0;                                             // cell (a, nb)
                 for (int q = in_ptr[nb]; q < in_ptr[nb + 1]; ++q)          // cell (nb, a): edge a -> nb
@@ -236,11 +346,11 @@ __global__ __launch_bounds__(64) void maze_explore_kernel(MazeParams p) {
         }
         n_pairs += 2;
         free_edge = __shfl(free_edge, 0, 64);
-        goal = __shfl(goal, 0, 64);
+        goal_hit = __shfl(goal_hit, 0, 64);
         sync();
         if (free_edge) {
             ++n_expl;
-            if (goal) { success = 1; break; }
+            if (goal_hit) { success = 1; break; }
             // column nb is gone: every row whose cached best sat in it looks again; the new row is scanned
             for (int base = 0; base < n_expl - 1; base += 64) {
                 const int i = base + lane;
@@ -264,6 +374,7 @@ __global__ __launch_bounds__(64) void maze_explore_kernel(MazeParams p) {
             for (int i = 0; i < len / 2; ++i) { const int t = path[i]; path[i] = path[len - 1 - i]; path[len - 1 - i] = t; }
             path_len = len;
         }
+        if (p.prev_out) for (int i = 0; i < n_expl; ++i) p.prev_out[n0 + explored[i]] = prev[explored[i]];
         p.success[b] = success;
         p.n_explored[b] = n_expl;
         p.n_pairs[b] = n_pairs;
@@ -345,7 +456,8 @@ hipError_t launch_maze_steer(const MazeSteerParams& p, hipStream_t st) {
 
 hipError_t launch_maze_explore(const MazeParams& p, hipStream_t st) {
     if (p.B <= 0) return hipSuccess;
-    hipLaunchKernelGGL(maze_explore_kernel, dim3(p.B), dim3(64), 0, st, p);
+    if (p.dim == 3) hipLaunchKernelGGL(maze_explore_kernel<3>, dim3(p.B), dim3(64), 0, st, p);
+    else hipLaunchKernelGGL(maze_explore_kernel<2>, dim3(p.B), dim3(64), 0, st, p);
     return hipGetLastError();
 }
 

@@ -199,3 +199,112 @@ class Maze2D:
         if not self._state_fp(a) or not self._state_fp(b):
             return False
         return self._segment_fp(a, b)
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# 3-DoF maze: a stick of length 0.2 at (x, y) with orientation coordinate z in [-0.4, 0.4] (theta = z / 0.4 * pi),
+# the reference's MazeEnv(dim=3) (environment/maze_env.py with environment/env_config.py:4-5) as far as the GNN planner
+# touches it.  Restated behaviour:
+#   * a configuration is free iff both stick ends are inside the bounds and in free cells and the 2-D bisection between
+#     them finds no occupied cell (maze_env.py:289-302); every in-bounds point query counts one collision check,
+#     evaluation is short-circuit (end a, end b, then midpoints, left half first);
+#   * an edge query = both configurations, then K - 1 = int(d / 0.015) - 1 interpolated configurations (orientation
+#     wrapped across +-0.4), each checked as the 2-D EDGE between its stick ends (maze_env.py:330-347);
+#   * distance / goal test wrap the third coordinate (maze_env.py:138-149,173-178);
+#   * numpy dtype promotion is part of the behaviour (NumPy >= 2, NEP 50): node rows arrive as float32, the stick ends are
+#     float64 (float32 coordinate / float64 limit), interpolation happens in float32.
+# --------------------------------------------------------------------------------------------------------------------
+STICK_LENGTH = 1.5 * 2 / 15                   # environment/env_config.py:4
+LIMITS3 = np.array([1., 1., 8. * RRT_EPS])   # environment/env_config.py:5
+
+
+class Maze3D(Maze2D):
+    def __init__(self, maps, init_states, goal_states):
+        super().__init__(maps, init_states, goal_states)
+        self.dim = 3
+        self.config_dim = 3
+        self.bound = (-1, -1, -0.4, 1, 1, 0.4)
+
+    def __str__(self):
+        return 'maze3'
+
+    def uniform_sample(self):
+        return np.random.uniform(-LIMITS3, LIMITS3, (1, 3)).reshape(-1)
+
+    # sampling: the one-by-one loop of Maze2D.sample_n_points applies (it calls self._state_fp)
+    def sample_n_points_arrays(self, n):
+        free, rej = self.sample_n_points(n, need_negative=True)
+        return np.array(free).reshape(-1, 3), np.array(rej).reshape(-1, 3)
+
+    def sample_n_points_stream(self, stream, n):
+        raise NotImplementedError('the look-ahead sampler is 2-D only; Maze3D samples one configuration at a time')
+
+    def distance(self, a, b):
+        d = np.abs(b - a)
+        if d.ndim == 1:
+            d = d.reshape(1, -1)
+        d[:, 2] = np.min((d[:, 2], np.abs(d[:, 2] - 2 * LIMITS3[2])), axis=0)
+        return np.sqrt(np.sum(d ** 2, axis=-1))
+
+    def interpolate(self, a, b, ratio):
+        diff = b - a
+        if np.abs(diff[2]) > LIMITS3[2]:
+            if diff[2] > 0:
+                diff[2] -= 2 * LIMITS3[2]
+            else:
+                diff[2] += 2 * LIMITS3[2]
+        new = a + diff * ratio
+        if np.abs(new[2]) > LIMITS3[2]:
+            if new[2] > 0:
+                new[2] -= 2 * LIMITS3[2]
+            else:
+                new[2] += 2 * LIMITS3[2]
+        return new
+
+    @staticmethod
+    def _ends(coord):
+        theta = coord[2] / LIMITS3[2] * np.pi
+        orient = np.array([np.cos(theta), np.sin(theta)])
+        center = np.array(coord[:2])
+        return center - STICK_LENGTH / 2. * orient, center + STICK_LENGTH / 2. * orient
+
+    def _valid(self, state):
+        return bool((state >= -LIMITS3[:state.size]).all() and (state <= LIMITS3[:state.size]).all())
+
+    def _point_fp(self, p):
+        if not self._valid(p):
+            return False
+        self.collision_check_count += 1
+        return bool(self.map[tuple(self._cell(p))] == 0)
+
+    def _state_fp(self, state):
+        if state.size == 2:
+            return self._point_fp(state)
+        if not self._valid(state):
+            return False
+        a, b = self._ends(state)
+        if not self._point_fp(a) or not self._point_fp(b):
+            return False
+        return self._segment_fp(a, b)
+
+    def _edge_fp(self, a, b):
+        if not self._valid(a) or not self._valid(b):
+            return False
+        if not self._state_fp(a) or not self._state_fp(b):
+            return False
+        if a.size == 2:
+            return self._segment_fp(a, b)
+        disp = b - a
+        if np.abs(disp[2]) > LIMITS3[2]:
+            if disp[2] > 0:
+                disp[2] -= 2 * LIMITS3[2]
+            else:
+                disp[2] += 2 * LIMITS3[2]
+        d = self.distance(a, b)
+        K = int((d / 0.015)[0])                  # float32 array / python float: float32 division
+        for k in range(1, K):
+            c = a + k * 1. / K * disp
+            ca, cb = self._ends(c)
+            if not self._edge_fp(ca, cb):
+                return False
+        return True

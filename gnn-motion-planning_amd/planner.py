@@ -389,15 +389,18 @@ def sample_maze_problems(problems, batch, k):
 
 
 
-def maze_explore_device(v, node_ptr, edge_ptr, n_free, ei, scores, maps, goal64):
-    """``gnnmp_maze_explore`` on device tensors: greedy best-edge expansion + grid collision checks of B problems
-    (``v`` [sum N, 2] float32, ``ei`` [2, sum E] int64 graph-local, ``scores`` [sum E], ``maps`` [B, w, w] float64,
-    ``goal64`` [B, 2] float64).  Returns host-side (success, n_explored, n_pairs, path_len, checks) lists and the
-    compacted ``explored`` / ``explored_edges`` (+ per-problem int offsets) / ``path`` arrays."""
+def maze_explore_device(v, node_ptr, edge_ptr, n_free, ei, scores, maps, goal64, resume=None, want_prev=False):
+    """``gnnmp_maze_explore_ex`` on device tensors: greedy best-edge expansion + grid collision checks of B problems
+    (``v`` [sum N, dim] float32 with dim 2 (point robot) or 3 (stick robot), ``ei`` [2, sum E] int64 graph-local,
+    ``scores`` [sum E], ``maps`` [B, w, w] float64, ``goal64`` [B, dim] float64).  ``resume``: per-problem list of dicts
+    (explored, prev {node: parent}, pairs [[a, b], ...]) of earlier rounds (eval_gnn.py:235-247) or None for fresh trees.
+    Returns host-side (success, n_explored, n_pairs, path_len, checks) lists and the compacted ``explored`` /
+    ``explored_edges`` (+ per-problem int offsets; in resume mode only the pairs added by this round) / ``path`` arrays,
+    plus the parent array [sum N] when ``want_prev``."""
     import ctypes
     from . import _lib
     device = v.device
-    B, w = int(maps.shape[0]), int(maps.shape[1])
+    B, w, dim = int(maps.shape[0]), int(maps.shape[1]), int(v.shape[1])
     nf = torch.as_tensor(n_free, dtype=torch.int32).to(device)
     total_n, total_e = int(v.shape[0]), int(ei.shape[1])
     mb = _lib.MazeBatch(B, total_n, total_e, w, v.data_ptr(), node_ptr.data_ptr(), edge_ptr.data_ptr(), nf.data_ptr(),
@@ -409,11 +412,30 @@ def maze_explore_device(v, node_ptr, edge_ptr, n_free, ei, scores, maps, goal64)
     success, n_expl, expl, n_pairs, ee, plen, path = i32(B), i32(B), i32(total_n), i32(B), i32(2 * (2 * total_e + B)), \
         i32(B), i32(total_n)
     checks = torch.zeros(B, dtype=torch.int64, device=device)
+    prev_out = i32(total_n) if want_prev else None
+    nptr_h = node_ptr.cpu().tolist()
+    rs, keep = None, None
+    if resume is not None:
+        ne0 = np.array([len(r['explored']) for r in resume], dtype=np.int32)
+        ex0 = np.zeros(total_n, dtype=np.int32)
+        pv0 = np.zeros(total_n, dtype=np.int32)
+        pptr = np.zeros(B + 1, dtype=np.int32)
+        for b, r in enumerate(resume):
+            ex0[nptr_h[b]:nptr_h[b] + len(r['explored'])] = r['explored']
+            for node, par in r['prev'].items():
+                pv0[nptr_h[b] + node] = par
+            pptr[b + 1] = pptr[b] + len(r['pairs'])
+        pairs = np.concatenate([np.asarray(r['pairs'], dtype=np.int32).reshape(-1) for r in resume])
+        np0 = np.array([len(r['pairs']) for r in resume], dtype=np.int32)
+        keep = [torch.from_numpy(a).to(device) for a in (ne0, ex0, pv0, np0, pairs, pptr)]
+        rs = _lib.MazeResume(*(t.data_ptr() for t in keep))
     with torch.cuda.device(device):
         st = torch.cuda.current_stream().cuda_stream
-        _lib.check(_lib.lib().gnnmp_maze_explore(ctypes.byref(mb), success.data_ptr(), n_expl.data_ptr(), expl.data_ptr(),
-                                                 n_pairs.data_ptr(), ee.data_ptr(), plen.data_ptr(), path.data_ptr(),
-                                                 checks.data_ptr(), ws.data_ptr(), ws.numel(), st), 'gnnmp_maze_explore')
+        _lib.check(_lib.lib().gnnmp_maze_explore_ex(ctypes.byref(mb), dim, ctypes.byref(rs) if rs is not None else None,
+                                                    success.data_ptr(), n_expl.data_ptr(), expl.data_ptr(), n_pairs.data_ptr(),
+                                                    ee.data_ptr(), plen.data_ptr(), path.data_ptr(), checks.data_ptr(),
+                                                    prev_out.data_ptr() if want_prev else None, ws.data_ptr(), ws.numel(), st),
+                   'gnnmp_maze_explore_ex')
     success, n_expl, n_pairs, plen, checks = (t.cpu().tolist() for t in (success, n_expl, n_pairs, plen, checks))
     eptr = edge_ptr.cpu().tolist()
     # the pair list has room for 2E + 1 pairs per problem but holds a few hundred: compact it on the device
@@ -421,8 +443,9 @@ def maze_explore_device(v, node_ptr, edge_ptr, n_free, ei, scores, maps, goal64)
     ee_off[1:] = np.cumsum([2 * n for n in n_pairs])
     take = np.concatenate([np.arange(2 * (2 * eptr[b] + b), 2 * (2 * eptr[b] + b) + 2 * n_pairs[b], dtype=np.int64)
                            for b in range(B)])
-    ee = ee[torch.from_numpy(take).to(device)].cpu().numpy()
-    return success, n_expl, n_pairs, plen, checks, expl.cpu().numpy(), ee, ee_off, path.cpu().numpy()
+    ee = ee[torch.from_numpy(take).to(device)].cpu().numpy() if take.size else np.zeros(0, dtype=np.int32)
+    out = (success, n_expl, n_pairs, plen, checks, expl.cpu().numpy(), ee, ee_off, path.cpu().numpy())
+    return out + (prev_out.cpu().numpy(),) if want_prev else out
 
 
 
@@ -534,3 +557,137 @@ def _smooth_maze_batch(model_s, sel, v, nptr, n_free, path, plen, maps, w, iters
         res[b] = (final[o:o + plen[b]], int(checks[i]))
         o += plen[b]
     return res
+
+
+# --------------------------------------------------------------------------------------------------
+# the general planner loop on the device: resample rounds (t_max > batch) and the 3-DoF maze
+# --------------------------------------------------------------------------------------------------
+def _device_round(states, model, device, k, loop, fresh):
+    """One explorer forward + one greedy expansion round for a list of per-problem states (see
+    :func:`eval_gnn_device_rounds`): graphs over the CURRENT sample sets, batched forward, device explore with the
+    trees of earlier rounds carried over unless ``fresh``.  Updates the states in place."""
+    from .batch import GraphBatch
+    from .graph_build import build_edges_gpu, k1_of
+    dim = states[0]['env'].config_dim
+    vs, n_free, k1s = [], [], []
+    for st in states:
+        st['v'] = np.concatenate((np.asarray(st['free'], dtype=np.float64).reshape(-1, dim),
+                                  np.asarray(st['coll'], dtype=np.float64).reshape(-1, dim))).astype(np.float32)
+        vs.append(torch.from_numpy(st['v']))
+        n_free.append(len(st['free']))
+        k1s.append(k1_of(k, len(st['free'])))
+    B = len(states)
+    ptr = torch.zeros(B + 1, dtype=torch.int64)
+    ptr[1:] = torch.tensor([x.shape[0] for x in vs]).cumsum(0)
+    node_ptr = ptr.to(torch.int32).to(device)
+    v = torch.cat(vs).to(device)
+    ei, edge_ptr = build_edges_gpu(v, node_ptr, n_free, k1s)
+    obs = [torch.tensor(np.asarray(st['env'].obstacles), dtype=torch.float32).reshape(-1, 2) for st in states]
+    optr = torch.zeros(B + 1, dtype=torch.int64)
+    optr[1:] = torch.tensor([o.shape[0] for o in obs]).cumsum(0)
+    goals = torch.tensor(np.asarray([st['env'].goal_state for st in states]), dtype=torch.float32).to(device)
+    gb = GraphBatch(v, goals, torch.cat(obs).to(device), ei, node_ptr, edge_ptr, optr.to(torch.int32).to(device),
+                    max(o.shape[0] for o in obs))
+    scores = model.forward_batch(gb, loop)
+    maps = torch.tensor(np.asarray([np.asarray(st['env'].map, dtype=np.float64) for st in states])).to(device)
+    goal64 = torch.tensor(np.asarray([st['env'].goal_state for st in states], dtype=np.float64)).to(device)
+    resume = None if fresh else [{'explored': st['explored'], 'prev': st['prev'], 'pairs': st['pairs']} for st in states]
+    success, n_expl, n_pairs, plen, checks, expl, ee, ee_off, path, prev = maze_explore_device(
+        v, node_ptr, edge_ptr, n_free, ei, scores, maps, goal64, resume=resume, want_prev=True)
+    nptr = ptr.tolist()
+    for b, st in enumerate(states):
+        st['explored'] = expl[nptr[b]:nptr[b] + n_expl[b]].tolist()
+        new_pairs = ee[ee_off[b]:ee_off[b + 1]].reshape(-1, 2).tolist()
+        st['pairs'] = new_pairs if fresh else st['pairs'] + new_pairs
+        st['prev'] = {a: int(prev[nptr[b] + a]) for a in st['explored']}
+        st['checks'] += int(checks[b])
+        st['success'] = bool(success[b])
+        st['path_nodes'] = path[nptr[b]:nptr[b] + plen[b]].tolist()
+        st['rounds'] += 1
+
+
+def eval_gnn_device_rounds(env, indexes, model, model_s=None, seed=1234, batch=500, t_max=500, k=30, device='cuda', loop=5,
+                           chunk=64, rows_out=None):
+    """:func:`eval_gnn` (eval_gnn.py:96-145) with the planner on the device for the GENERAL loop of ``explore``
+    (eval_gnn.py:191-247): when the frontier dies the problem gets ``batch`` more samples, the explorer runs again on
+    the larger graph and the search tree carries over -- up to ``t_max`` free samples -- for ``Maze2D`` and ``Maze3D``
+    environments (``model_s`` = None: the reference's smoother='none' branch, as maze3 has no shipped smoother).
+
+    The reference draws every sample from ONE global numpy stream, problem after problem, and a problem that needs a
+    second round draws it before the next problem's first.  Batched rounds keep that order by speculation: a chunk of
+    problems is sampled and explored as if nobody needed a second round; the first problem that does is rewound to
+    the stream position right after ITS first sampling, finished on its own (device rounds with the tree carried over),
+    and the problems behind it -- whose samples came from the wrong stream position -- are sampled and explored again
+    from the position the sequential loop would have reached.  Per-problem outcomes therefore equal the one-by-one loop's
+    (tests/test_planner_rounds_gpu.py against rows recorded from the unmodified reference)."""
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    dim = env.config_dim
+    results = {}
+
+    def sample(e, n):
+        if dim == 2:
+            f, c = e.sample_n_points_arrays(n)
+            return list(f), list(c)
+        return e.sample_n_points(n, need_negative=True)
+
+    def new_state(i):
+        e = type(env)(np.asarray(env.maps[i])[None], np.asarray(env.init_states[i])[None], np.asarray(env.goal_states[i])[None])
+        e.init_new_problem(0)
+        free, coll = sample(e, batch)
+        coll = coll[:len(free)]                                         # eval_gnn.py:180 (before init / goal join)
+        free = [np.asarray(e.init_state, dtype=np.float64), np.asarray(e.goal_state, dtype=np.float64)] + free
+        return {'i': i, 'env': e, 'free': free, 'coll': coll, 'explored': [0], 'prev': {0: 0}, 'pairs': [[0, 0]],
+                'checks': 0, 'success': False, 'rounds': 0, 'path_nodes': []}
+
+    def may_resample(st):
+        return (batch + len(st['free']) - 2) <= t_max                   # eval_gnn.py:239-240
+
+    todo = list(indexes)
+    while todo:
+        part = todo[:chunk]
+        states, rng_after = [], []
+        for i in part:
+            states.append(new_state(i))
+            rng_after.append(np.random.get_state())
+        _device_round(states, model, device, k, loop, fresh=True)
+        done = len(part)
+        for pos, st in enumerate(states):
+            if st['success'] or not may_resample(st):
+                results[st['i']] = st
+                continue
+            np.random.set_state(rng_after[pos])                          # where the sequential loop stands now
+            while not st['success'] and may_resample(st):
+                nf, nc = sample(st['env'], batch)
+                st['free'] = st['free'] + nf
+                st['coll'] = (st['coll'] + nc)[:len(st['free'])]        # eval_gnn.py:243-245
+                _device_round([st], model, device, k, loop, fresh=False)
+            results[st['i']] = st
+            done = pos + 1                                               # samples of the problems behind are stale
+            break
+        todo = todo[done:]
+    out = [results[i] for i in indexes]
+    smoothed = {}
+    if model_s is not None and dim == 2:
+        sel = [b for b, st in enumerate(out) if st['success']]
+        if sel:
+            vcat = torch.cat([torch.from_numpy(st['v']) for st in out]).to(device)
+            nptr = np.concatenate(([0], np.cumsum([st['v'].shape[0] for st in out]))).tolist()
+            path = np.zeros(nptr[-1], dtype=np.int32)
+            for b, st in enumerate(out):
+                path[nptr[b]:nptr[b] + len(st['path_nodes'])] = st['path_nodes']
+            maps = torch.tensor(np.asarray([np.asarray(st['env'].map, dtype=np.float64) for st in out])).to(device)
+            smoothed = _smooth_maze_batch(model_s, sel, vcat, nptr, [len(st['free']) for st in out], path,
+                                          [len(st['path_nodes']) for st in out], maps, int(maps.shape[1]), 5, device)
+    sol = []
+    for b, st in enumerate(out):
+        p = st['v'][st['path_nodes']] if st['success'] else np.zeros((0, dim), dtype=np.float32)
+        sp, cs = smoothed.get(b, (p, 0)) if st['success'] else (p, 0)
+        c_explore = st['env'].collision_check_count + st['checks']
+        sol.append((int(st['success']), path_cost(p), path_cost(sp), c_explore, cs, len(p), len(st['explored']), st['rounds']))
+        if rows_out is not None:
+            rows_out.append(sol[-1][:7])
+    n_success = sum(s[0] for s in sol)
+    return {'n_success': n_success, 'collision_explore': float(np.mean([s[3] for s in sol])),
+            'collision': float(np.mean([s[3] + s[4] for s in sol])),
+            'solution_cost': float(sum(s[2] for s in sol if s[0])) / max(n_success, 1), 'rounds': [s[7] for s in sol]}

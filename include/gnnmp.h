@@ -17,7 +17,7 @@
  *       create_data's edge construction                       eval_gnn.py:159-164
  *   gnnmp_maze_steer
  *       proposed_path_smootherv2 (steering of the smoothing stage)  smoother.py:194-216
- *   gnnmp_maze_explore_workspace_bytes / gnnmp_maze_explore
+ *   gnnmp_maze_explore_workspace_bytes / gnnmp_maze_explore / gnnmp_maze_explore_ex
  *       explore()'s greedy loop + MazeEnv._edge_fp            eval_gnn.py:198-233, environment/maze_env.py:270-326
  *
  * Conventions
@@ -255,6 +255,29 @@ int gnnmp_maze_explore_workspace_bytes(const gnnmp_maze_batch* shape, size_t* by
 int gnnmp_maze_explore(const gnnmp_maze_batch* batch, int32_t* success, int32_t* n_explored, int32_t* explored,
                        int32_t* n_pairs, int32_t* explored_edges, int32_t* path_len, int32_t* path, int64_t* checks,
                        void* workspace, size_t workspace_bytes, void* hip_stream);
+
+/* The general form: `dim` = 2 (point robot, as above) or 3 (the stick robot of MazeEnv(dim=3): v [.,3], goal_states
+ * [B,3], collision model maze_env.py:254-302,330-347), and optionally the search trees of EARLIER rounds, which is what
+ * the reference's resample loop carries across explorer forwards (eval_gnn.py:235-247; node ids of free samples are
+ * stable because new samples are appended behind the old ones).  resume == NULL or resume->n_explored == NULL: fresh
+ * trees.  Otherwise, per problem b: n_explored[b] >= 1 explored node ids at explored[node_ptr[b] ..] (order kept),
+ * prev[node_ptr[b] + node] = tree parent of every explored node, and the (a, b) pairs recorded so far
+ * (n_pairs[b] of them, starting with the initial [0, 0]) at pairs[2 * pair_ptr[b] ..]; they feed the reference's
+ * legacy-index mask (eval_gnn.py:202) on the new scores.  Outputs as for gnnmp_maze_explore, except that in resume mode
+ * explored_edges / n_pairs hold only the pairs added by THIS round (from index 0 of the problem's slot), and
+ * prev_out_or_null [total_nodes] receives the parents of all explored nodes (for the next round). */
+typedef struct {
+    const int32_t* n_explored;   /* [B] or NULL                                               */
+    const int32_t* explored;     /* [total_nodes]                                             */
+    const int32_t* prev;         /* [total_nodes]                                             */
+    const int32_t* n_pairs;      /* [B]                                                       */
+    const int32_t* pairs;        /* 2 ints per pair                                           */
+    const int32_t* pair_ptr;     /* [B+1] (in pairs)                                          */
+} gnnmp_maze_resume;
+int gnnmp_maze_explore_ex(const gnnmp_maze_batch* batch, int32_t dim, const gnnmp_maze_resume* resume_or_null,
+                          int32_t* success, int32_t* n_explored, int32_t* explored, int32_t* n_pairs,
+                          int32_t* explored_edges, int32_t* path_len, int32_t* path, int64_t* checks,
+                          int32_t* prev_out_or_null, void* workspace, size_t workspace_bytes, void* hip_stream);
 
 /* Collision-checked steering of the smoothing stage for 2-D mazes: proposed_path_smootherv2 (smoother.py:194-216)
  * with MazeEnv's checker (maze_env.py:270-326), batched.  Problem b owns waypoints [path_ptr[b], path_ptr[b+1])

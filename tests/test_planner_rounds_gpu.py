@@ -1,0 +1,90 @@
+"""The general planner loop on the device (planner.eval_gnn_device_rounds) against per-problem outcomes recorded from the
+UNMODIFIED reference in the authoring container (tools/gen_golden.py):
+
+ * resample rounds (eval_gnn.py:235-247): first 150 problems of mazes_hard.npz at batch = 100, t_max = 300, k = 12,
+   seed 5 -- 43 problems need a second or third explorer forward with the search tree carried over, 3 stay unsolved
+   (evalrows_mazehard_first150_b100_t300_k12_s5.npz);
+ * the 3-DoF maze (MazeEnv(dim=3), stick robot, weights_maze_3): first 40 problems of mazes_hard_3.npz at
+   batch = t_max = 200, k = 12, seed 9, smoother='none' (its smoother checkpoint is not shipped)
+   (evalset_maze3_first40_b200_k12_s9.npz: problem definitions + rows).
+
+Rows: success, path cost, smoothed cost, c_explore, c_smooth, path length, explored nodes.  The GPU scores differ from the
+reference's CPU scores by ~1e-5, so a near-tie between two frontier edges may resolve differently on a few problems:
+success flags must agree everywhere and the explore stage (checks, explored nodes, path length) on >= 95 %."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, load_weights
+import gnnmp
+from gnnmp import planner
+from gnnmp.maze2d import Maze2D, Maze3D
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _compare(rows, ref, what):
+    same = (rows[:, 0] == ref[:, 0]) & (rows[:, 3] == ref[:, 3]) & (rows[:, 6] == ref[:, 6]) & (rows[:, 5] == ref[:, 5])
+    print('\n%s: solved %d (reference %d) of %d; explore stage identical on %d; mean explore checks %.2f vs %.2f'
+          % (what, rows[:, 0].sum(), ref[:, 0].sum(), ref.shape[0], same.sum(), rows[:, 3].mean(), ref[:, 3].mean()))
+    return same
+
+
+def test_resample_rounds_150_problems():
+    with np.load(os.path.join(GOLDEN, 'evalset_mazehard_first1000.npz')) as f:
+        env = Maze2D(f['maps'], f['init_states'], f['goal_states'])
+    with np.load(os.path.join(GOLDEN, 'evalrows_mazehard_first150_b100_t300_k12_s5.npz')) as f:
+        ref, seed, batch, t_max, k = f['rows'], int(f['seed']), int(f['batch']), int(f['t_max']), int(f['k'])
+    assert t_max == 3 * batch
+    m = gnnmp.EncoderProcessDecoder(2, 2, 32, 2)
+    m.load_state_dict(load_weights('weights_maze'))
+    ms = gnnmp.ModelSmoother(workspace_size=2, config_size=2, embed_size=128, obs_size=6)
+    ms.load_state_dict(load_weights('smooth_2d_attv3'))
+    rows = []
+    out = planner.eval_gnn_device_rounds(env, range(ref.shape[0]), m, ms, seed=seed, batch=batch, t_max=t_max, k=k, device=DEV,
+                                         rows_out=rows, chunk=32)
+    rows = np.array(rows, dtype=np.float64)
+    multi = np.array(out['rounds']) > 1
+    print('problems with more than one explorer forward: %d (max %d rounds)' % (multi.sum(), max(out['rounds'])))
+    assert multi.sum() >= 30                                  # the resample path is what this test is about
+    same = _compare(rows, ref, 'resample rounds')
+    assert np.array_equal(rows[:, 0], ref[:, 0])
+    assert same.sum() >= 0.95 * ref.shape[0]
+    assert same[multi].sum() >= 0.9 * multi.sum()             # ... including the multi-round problems
+    sm_same = same & (rows[:, 4] == ref[:, 4])
+    assert sm_same.sum() >= 0.95 * same.sum()
+
+
+def test_maze3_40_problems():
+    with np.load(os.path.join(GOLDEN, 'evalset_maze3_first40_b200_k12_s9.npz')) as f:
+        env = Maze3D(f['maps'], f['init_states'], f['goal_states'])
+        ref, seed, batch, k = f['rows'], int(f['seed']), int(f['batch']), int(f['k'])
+    m = gnnmp.EncoderProcessDecoder(2, 3, 32, 2)
+    m.load_state_dict(load_weights('weights_maze_3'))
+    rows = []
+    planner.eval_gnn_device_rounds(env, range(ref.shape[0]), m, None, seed=seed, batch=batch, t_max=batch, k=k, device=DEV,
+                                   rows_out=rows)
+    rows = np.array(rows, dtype=np.float64)
+    same = _compare(rows, ref, 'maze3 (stick robot)')
+    assert np.array_equal(rows[:, 0], ref[:, 0])
+    assert same.sum() >= 0.95 * ref.shape[0]
+    ok = same & (ref[:, 0] > 0)
+    assert np.allclose(rows[ok, 1], ref[ok, 1], rtol=0, atol=1e-6)       # same nodes -> same path cost
+
+
+def test_maze3_host_planner_matches_device():
+    """The host counterpart (planner.explore with Maze3D: collision checks on the CPU) on the first problems."""
+    with np.load(os.path.join(GOLDEN, 'evalset_maze3_first40_b200_k12_s9.npz')) as f:
+        env = Maze3D(f['maps'], f['init_states'], f['goal_states'])
+        ref, seed, batch, k = f['rows'], int(f['seed']), int(f['batch']), int(f['k'])
+    m = gnnmp.EncoderProcessDecoder(2, 3, 32, 2)
+    m.load_state_dict(load_weights('weights_maze_3'))
+    np.random.seed(seed)
+    agree = 0
+    for i in range(8):
+        env.init_new_problem(i)
+        r = planner.explore(env, m, None, True, batch=batch, t_max=batch, k=k, smoother='none', device=DEV, sparse=True)
+        agree += int(r['success'] == bool(ref[i, 0]) and r['c_explore'] == int(ref[i, 3]) and len(r['explored']) == int(ref[i, 6]))
+    assert agree >= 7

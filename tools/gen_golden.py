@@ -276,17 +276,21 @@ def planner_cases(sds):
     planner_case(eg, env, 7, sds['maze2'], sd_s, batch=40, t_max=200, k=8, seed=77)
 
 
-def eval_set_case(n_problems=12, batch=500, k=30, seed=1234, rows_only=False):
+def eval_set_case(n_problems=12, batch=500, k=30, seed=1234, rows_only=False, t_max=None, dim=2, map_file='maze_files/mazes_hard.npz'):
     """The reference's eval_gnn defaults (batch=500, t_max=500, k=30 -> N ~ 1002, k1 = 41, E ~ 56 k, smoothing on)
     on the first problems of mazes_hard.npz, seed 1234 -- the setting of the notebook's published run
-    (main.ipynb:57-61).  Records the problem definitions (data) and the per-problem outcomes."""
+    (main.ipynb:57-61).  Records the problem definitions (data) and the per-problem outcomes.
+    ``t_max`` > ``batch``: the planner resamples and re-runs the explorer when the frontier dies (eval_gnn.py:235-247).
+    ``dim`` = 3: the stick robot (maze3, weights_maze_3); its smoother checkpoint is not shipped (str2name.py:25 asks for
+    a missing file), so those runs use explore(..., smoother='none') -- the explore stage is what is recorded."""
     from environment import MazeEnv
     from config import set_random_seed
     eg = load_patched_eval_gnn()
-    env = MazeEnv(dim=2, map_file='maze_files/mazes_hard.npz')
-    sd_e = torch.load(os.path.join(REF, 'data', 'weights', 'weights_maze.pt'), map_location='cpu')
+    t_max = batch if t_max is None else t_max
+    env = MazeEnv(dim=dim, map_file=map_file)
+    sd_e = torch.load(os.path.join(REF, 'data', 'weights', 'weights_maze.pt' if dim == 2 else 'weights_maze_3.pt'), map_location='cpu')
     sd_s = torch.load(os.path.join(REF, 'data', 'weights', 'smooth_2d_attv3.pt'), map_location='cpu')
-    m = ref_model.EncoderProcessDecoder(2, 2, 32, 2)
+    m = ref_model.EncoderProcessDecoder(2, dim, 32, 2)
     m.load_state_dict(sd_e, strict=True)
     ms = ref_smoother.ModelSmoother(workspace_size=2, config_size=2, embed_size=128, obs_size=6)
     ms.load_state_dict(sd_s, strict=True)
@@ -295,21 +299,24 @@ def eval_set_case(n_problems=12, batch=500, k=30, seed=1234, rows_only=False):
     rows, explored_n = [], []
     import time as _t
     t0 = _t.time()
+    kw = {} if dim == 2 else {'smoother': 'none'}
     for idx in range(n_problems):
         env.init_new_problem(idx)
-        r = eg.explore(env, m, ms, True, batch=batch, t_max=batch, k=k)
+        r = eg.explore(env, m, ms, True, batch=batch, t_max=t_max, k=k, **kw)
         rows.append([int(r['success']), eg.path_cost(r['path']), eg.path_cost(r['smooth_path']), r['c_explore'],
                      r['c_smooth'], len(r['path']), len(r['explored'])])
-        print('  problem %d: success=%d c_explore=%d c_smooth=%d explored=%d (%.1f s)' %
-              (idx, r['success'], r['c_explore'], r['c_smooth'], len(r['explored']), _t.time() - t0))
+        print('  problem %d: success=%d c_explore=%d c_smooth=%d explored=%d nodes=%d (%.1f s)' %
+              (idx, r['success'], r['c_explore'], r['c_smooth'], len(r['explored']), len(r['data'].v), _t.time() - t0))
     if rows_only:                       # same problems as evalset_mazehard_first1000.npz, another planner setting
-        np.savez_compressed(os.path.join(OUT, 'evalrows_mazehard_first%d_b%d_k%d_s%d.npz' % (n_problems, batch, k, seed)),
-                            seed=seed, batch=batch, t_max=batch, k=k, rows=np.array(rows, dtype=np.float64))
+        tag = '' if t_max == batch else '_t%d' % t_max
+        np.savez_compressed(os.path.join(OUT, 'evalrows_mazehard_first%d_b%d%s_k%d_s%d.npz' % (n_problems, batch, tag, k, seed)),
+                            seed=seed, batch=batch, t_max=t_max, k=k, rows=np.array(rows, dtype=np.float64))
         return
-    np.savez_compressed(os.path.join(OUT, 'evalset_mazehard_first%d.npz' % n_problems),
+    name = 'evalset_mazehard_first%d.npz' % n_problems if dim == 2 else 'evalset_maze3_first%d_b%d_k%d_s%d.npz' % (n_problems, batch, k, seed)
+    np.savez_compressed(os.path.join(OUT, name),
                         maps=env.maps[:n_problems].copy().astype(np.float64 if n_problems <= 100 else np.uint8),
                         init_states=env.init_states[:n_problems].copy(),
-                        goal_states=env.goal_states[:n_problems].copy(), seed=seed, batch=batch, t_max=batch, k=k,
+                        goal_states=env.goal_states[:n_problems].copy(), seed=seed, batch=batch, t_max=t_max, k=k,
                         rows=np.array(rows, dtype=np.float64),
                         columns=np.array(['success', 'path_cost', 'smooth_cost', 'c_explore', 'c_smooth', 'path_len', 'explored']))
 
@@ -345,12 +352,17 @@ if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'planner':
         torch.set_num_threads(8)
         planner_cases({'maze2': save_weights('weights_maze')})
+    elif len(sys.argv) > 1 and sys.argv[1] == 'maze3':      # maze3 N batch k seed [t_max]
+        torch.set_num_threads(8)
+        eval_set_case(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), dim=3,
+                      map_file='maze_files/mazes_hard_3.npz', t_max=int(sys.argv[6]) if len(sys.argv) > 6 else None)
     elif len(sys.argv) > 1 and sys.argv[1] == 'knn32':
         smoother_knn32_case()
     elif len(sys.argv) > 1 and sys.argv[1] == 'evalset':
         torch.set_num_threads(8)
-        if len(sys.argv) > 5:               # evalset N batch k seed -> rows only (problems are in the first-1000 fixture)
-            eval_set_case(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), rows_only=True)
+        if len(sys.argv) > 5:               # evalset N batch k seed [t_max] -> rows only (problems are in the first-1000 fixture)
+            eval_set_case(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), rows_only=True,
+                          t_max=int(sys.argv[6]) if len(sys.argv) > 6 else None)
         else:
             eval_set_case(int(sys.argv[2]) if len(sys.argv) > 2 else 12)
     else:
