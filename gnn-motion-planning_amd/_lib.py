@@ -82,6 +82,11 @@ def lib():
     L.gnnmp_explorer_workspace_bytes.argtypes = [vp, ctypes.POINTER(Batch), ctypes.POINTER(sz)]
     L.gnnmp_explorer_forward.argtypes = [vp, ctypes.POINTER(Batch), ctypes.c_int, ctypes.c_int, vp, vp, vp, sz, vp]
     L.gnnmp_explorer_debug_tap.argtypes = [vp, ctypes.POINTER(Batch), ctypes.c_int, vp, vp, sz, vp]
+    L.gnnmp_explorer_grad_floats.restype = ctypes.c_int64
+    L.gnnmp_explorer_grad_floats.argtypes = [vp]
+    L.gnnmp_explorer_train_workspace_bytes.argtypes = [vp, ctypes.POINTER(Batch), ctypes.c_int, ctypes.POINTER(sz)]
+    L.gnnmp_explorer_train_forward.argtypes = [vp, ctypes.POINTER(Batch), ctypes.c_int, ctypes.c_int, vp, vp, sz, vp]
+    L.gnnmp_explorer_train_backward.argtypes = [vp, ctypes.POINTER(Batch), ctypes.c_int, vp, vp, vp, sz, vp]
     L.gnnmp_explorer_profile.argtypes = [vp, ctypes.c_int]
     L.gnnmp_explorer_profile_read.argtypes = [vp, ctypes.POINTER(ctypes.c_double), c_int64_p]
     L.gnnmp_graph_workspace_bytes.argtypes = [ctypes.POINTER(GraphBuildBatch), ctypes.POINTER(sz)]

@@ -261,6 +261,10 @@ struct gnnmp_explorer {
     StageProf* prof;      // mutable side state (profiling is single-threaded by contract)
     int n_cu;             // compute units of the device (persistent-kernel grid)
     int resident;         // use pre_resident_kernel when it fits (GNNMP_RESIDENT=0 disables)
+    float* w_raw_dev;     // the caller's weight blob as given (manifest order, torch row-major): the training path's view
+    std::vector<Entry> man;
+    std::vector<int64_t> man_off;
+    int64_t n_raw;
 };
 
 namespace {
@@ -473,6 +477,8 @@ extern "C" int gnnmp_explorer_create(gnnmp_explorer** out, const gnnmp_explorer_
     h->dims = *dims;
     h->device = device;
     h->w_dev = nullptr;
+    h->w_raw_dev = nullptr;
+    h->man = B.man; h->man_off = B.off; h->n_raw = tot;
     h->prof = new StageProf();
     std::vector<float> packed;
     const int P = dims->mlp_dtype;
@@ -499,9 +505,12 @@ extern "C" int gnnmp_explorer_create(gnnmp_explorer** out, const gnnmp_explorer_
     }
     if (e == hipSuccess) e = hipMalloc((void**)&h->w_dev, packed.size() * sizeof(float));
     if (e == hipSuccess) e = hipMemcpy(h->w_dev, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc((void**)&h->w_raw_dev, (size_t)tot * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(h->w_raw_dev, weights_host, (size_t)tot * sizeof(float), hipMemcpyHostToDevice);
     if (prev_dev >= 0 && prev_dev != device) (void)hipSetDevice(prev_dev);
     if (e != hipSuccess) {
         if (h->w_dev) (void)hipFree(h->w_dev);
+        if (h->w_raw_dev) (void)hipFree(h->w_raw_dev);
         delete h->prof;
         delete h;
         return hip_fail(e);
@@ -513,6 +522,7 @@ extern "C" int gnnmp_explorer_create(gnnmp_explorer** out, const gnnmp_explorer_
 extern "C" int gnnmp_explorer_destroy(gnnmp_explorer* h) {
     if (!h) return GNNMP_ERR_NULL;
     if (h->w_dev) (void)hipFree(h->w_dev);
+    if (h->w_raw_dev) (void)hipFree(h->w_raw_dev);
     if (h->prof) {
         for (auto& r : h->prof->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
         for (auto e : h->prof->pool) (void)hipEventDestroy(e);
@@ -660,11 +670,23 @@ extern "C" int gnnmp_explorer_workspace_bytes(const gnnmp_explorer* h, const gnn
     return GNNMP_OK;
 }
 
+namespace {
+int forward_impl(const gnnmp_explorer* h, const gnnmp_batch* b, int loop, int use_obstacles, float* edge_scores, float* dense,
+                 void* ws, size_t ws_bytes, void* hip_stream, float* om_nodes, float* om_edges, bool pre_only);
+}
 extern "C" int gnnmp_explorer_forward(const gnnmp_explorer* h, const gnnmp_batch* b, int loop, int use_obstacles,
                                       float* edge_scores, float* dense, void* ws, size_t ws_bytes, void* hip_stream) {
+    return forward_impl(h, b, loop, use_obstacles, edge_scores, dense, ws, ws_bytes, hip_stream, nullptr, nullptr, false);
+}
+
+namespace {
+// om_nodes / om_edges: optional [Npad, d] / [Epad, d] outputs of the attention stacks (training path); pre_only: stop
+// after the pre kernels (CSR, goal node, NF / EF are what the training path needs)
+int forward_impl(const gnnmp_explorer* h, const gnnmp_batch* b, int loop, int use_obstacles, float* edge_scores, float* dense,
+                 void* ws, size_t ws_bytes, void* hip_stream, float* om_nodes, float* om_edges, bool pre_only) {
     if (!h || !b || !ws) return GNNMP_ERR_NULL;
     if (!b->v || !b->goal || !b->node_ptr || !b->edge_ptr || !b->obs_ptr) return GNNMP_ERR_NULL;
-    if (b->total_edges > 0 && (!b->edge_index || !edge_scores)) return GNNMP_ERR_NULL;
+    if (b->total_edges > 0 && (!b->edge_index || (!edge_scores && !pre_only))) return GNNMP_ERR_NULL;
     if (use_obstacles && b->total_obstacles > 0 && !b->obstacles) return GNNMP_ERR_NULL;
     if (loop < 1) return GNNMP_ERR_ARG;                    // model.py:139-145: decode unbound for loop = 0
     Carve c;
@@ -725,6 +747,7 @@ extern "C" int gnnmp_explorer_forward(const gnnmp_explorer* h, const gnnmp_batch
         p.kv_stride = c.kv_stride; p.ot_max = c.ot_max;
         const PrePlan pl = plan_pre(D, P, c.ot_max, p.encb.size, p.out_size, use_obs);
         p.ot_chunk = pl.ot_chunk; p.wregion = pl.wregion; p.use_obstacles = use_obs ? 1 : 0;
+        p.om = edge ? om_edges : om_nodes;
         if (edge) { p.o0 = at<float>(ws, c.Ke); p.o1 = at<float>(ws, c.PE); p.o2 = p.o3 = p.o4 = nullptr; }
         else {
             p.o0 = at<float>(ws, c.XI); p.o1 = at<float>(ws, c.X); p.o2 = at<float>(ws, c.A);
@@ -743,6 +766,8 @@ extern "C" int gnnmp_explorer_forward(const gnnmp_explorer* h, const gnnmp_batch
         }
         HIP_TRY(launch_pre(D, P, edge != 0, pl.waves, p, (edge ? c.Epad : c.Npad) / 32, pl.lds_bytes, st));
     }
+
+    if (pre_only) return GNNMP_OK;
 
     // message passing: one fused launch per iteration (edge phase + node phase per 32-node tile); the gathered A rows
     // ping-pong between two buffers because other tiles still read this iteration's A while a tile writes the next one
@@ -776,6 +801,7 @@ extern "C" int gnnmp_explorer_forward(const gnnmp_explorer* h, const gnnmp_batch
     }
     return GNNMP_OK;
 }
+}  // namespace
 
 extern "C" int gnnmp_explorer_debug_tap(const gnnmp_explorer* h, const gnnmp_batch* b, int which, float* dst, void* ws,
                                         size_t ws_bytes, void* hip_stream) {
@@ -1173,5 +1199,212 @@ extern "C" int gnnmp_maze_steer(int32_t n_problems, int32_t total_path, int32_t 
     p.old_path = old_path; p.new_path = new_path; p.out_path = out_path; p.tmp = tmp;
     p.checks = reinterpret_cast<long long*>(checks);
     HIP_TRY(launch_maze_steer(p, static_cast<hipStream_t>(hip_stream)));
+    return GNNMP_OK;
+}
+
+// =============================================================================================
+// training path of the explorer (train_explorer.py:156-186)
+// =============================================================================================
+namespace {
+
+struct TrainCarve {
+    size_t inf_bytes;                  // the inference workspace comes first (CSR, goal node, padded pointers stay valid)
+    // offsets in floats from the start of the train region
+    size_t NF, EF, NCin, NCh, NC, ECin, ECh, EC, H0, it0, it_stride, Xin, X, Zh, A, arg, H, DinCat, Dn, Pin, P1, P2, sc;
+    size_t T5a, T5b, Te1, Te2, T3, dX, dH, dA, dNC, dH0, dXin, dEC, cat2, dcat2, dDn;
+    size_t total_floats;
+};
+
+bool train_carve(const gnnmp_explorer* h, const gnnmp_batch* b, int loop, const Carve& c, TrainCarve& t) {
+    const size_t Np = c.Npad, Ep = c.Epad, d = h->dims.embed_size, C = h->dims.config_size;
+    size_t o = 0;
+    auto take = [&](size_t n) { const size_t r = o; o += (n + 63) & ~(size_t)63; return r; };
+    t.inf_bytes = (c.total + 255) & ~(size_t)255;
+    t.NF = take(Np * d); t.EF = take(Ep * d);
+    t.NCin = take(Np * 4 * C); t.NCh = take(Np * d); t.NC = take(Np * d);
+    t.ECin = take(Ep * 2 * C); t.ECh = take(Ep * d); t.EC = take(Ep * d);
+    t.H0 = take(Np * d);
+    t.it0 = o;
+    t.Xin = take(Np * 4 * d) - t.it0; t.X = take(Np * d) - t.it0; t.Zh = take(Ep * d) - t.it0; t.A = take(Np * d) - t.it0;
+    t.arg = take(Np * d) - t.it0; t.H = take(Np * d) - t.it0;
+    t.it_stride = o - t.it0;
+    o = t.it0 + t.it_stride * (size_t)loop;
+    t.DinCat = take(Np * 2 * d); t.Dn = take(Np * d);
+    t.Pin = take(Ep * 3 * d); t.P1 = take(Ep * d); t.P2 = take(Ep * d); t.sc = take(Ep);
+    t.T5a = take(Ep * 5 * d); t.T5b = take(Ep * 5 * d); t.Te1 = take(Ep * d); t.Te2 = take(Ep * d); t.T3 = take(Ep * 3 * d);
+    t.dX = take(Np * d); t.dH = take(Np * d); t.dA = take(Np * d); t.dNC = take(Np * d); t.dH0 = take(Np * d);
+    t.dXin = take(Np * 4 * d); t.dEC = take(Ep * d); t.cat2 = take(Np * 2 * d); t.dcat2 = take(Np * 2 * d); t.dDn = take(Np * d);
+    t.total_floats = o;
+    (void)b;
+    return true;
+}
+
+struct WRef { const float* w; const float* b; float* gw; float* gb; int out, in; };
+
+// weight / bias of a Linear named `name` inside the raw blob, and the same slots inside the gradient blob
+WRef wref(const gnnmp_explorer* h, float* grad, const std::string& name, bool bias = true) {
+    WRef r{nullptr, nullptr, nullptr, nullptr, 0, 0};
+    for (size_t i = 0; i < h->man.size(); ++i) {
+        if (h->man[i].name == name + ".weight") {
+            r.w = h->w_raw_dev + h->man_off[i]; r.gw = grad ? grad + h->man_off[i] : nullptr;
+            r.out = h->man[i].rows; r.in = h->man[i].cols;
+        }
+        if (bias && h->man[i].name == name + ".bias") { r.b = h->w_raw_dev + h->man_off[i]; r.gb = grad ? grad + h->man_off[i] : nullptr; }
+    }
+    return r;
+}
+
+TrainGeom train_geom(const gnnmp_explorer* h, const gnnmp_batch* b, const Carve& c, void* ws) {
+    TrainGeom q;
+    q.G = c.G; q.C = h->dims.config_size; q.Npad = c.Npad; q.Epad = c.Epad;
+    q.v = b->v; q.goal = b->goal; q.node_ptr = b->node_ptr;
+    q.node_ptr_pad = at<int>(ws, c.node_ptr_pad); q.ntile_graph = at<int>(ws, c.ntile_graph);
+    q.goal_node = at<int>(ws, c.goal_node); q.row_beg = at<int>(ws, c.row_beg); q.deg = at<int>(ws, c.deg);
+    q.csr = at<int4>(ws, c.csr);
+    return q;
+}
+
+}  // namespace
+
+extern "C" int64_t gnnmp_explorer_grad_floats(const gnnmp_explorer* h) { return h ? h->n_raw : GNNMP_ERR_NULL; }
+
+extern "C" int gnnmp_explorer_train_workspace_bytes(const gnnmp_explorer* h, const gnnmp_batch* shape, int loop, size_t* bytes) {
+    if (!h || !shape || !bytes) return GNNMP_ERR_NULL;
+    if (loop < 1) return GNNMP_ERR_ARG;
+    if (h->dims.mlp_dtype != GNNMP_F32) return GNNMP_ERR_DIMS;          // training runs in fp32
+    Carve c;
+    if (!carve(h, shape, c)) return GNNMP_ERR_ARG;
+    TrainCarve t;
+    train_carve(h, shape, loop, c, t);
+    *bytes = t.inf_bytes + t.total_floats * sizeof(float);
+    return GNNMP_OK;
+}
+
+extern "C" int gnnmp_explorer_train_forward(const gnnmp_explorer* h, const gnnmp_batch* b, int loop, int use_obstacles,
+                                            float* edge_scores, void* ws, size_t ws_bytes, void* hip_stream) {
+    if (!h || !b || !ws || (b->total_edges > 0 && !edge_scores)) return GNNMP_ERR_NULL;
+    if (loop < 1) return GNNMP_ERR_ARG;
+    if (h->dims.mlp_dtype != GNNMP_F32) return GNNMP_ERR_DIMS;
+    Carve c;
+    if (!carve(h, b, c)) return GNNMP_ERR_ARG;
+    TrainCarve t;
+    train_carve(h, b, loop, c, t);
+    if (ws_bytes < t.inf_bytes + t.total_floats * sizeof(float) || (reinterpret_cast<uintptr_t>(ws) & 255)) return GNNMP_ERR_WORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    float* T = reinterpret_cast<float*>(static_cast<char*>(ws) + t.inf_bytes);
+    const int d = h->dims.embed_size, C = h->dims.config_size, Np = c.Npad, Ep = c.Epad;
+    // frozen inputs (model.py:141,142,146 detach them): node_free_code / edge_free_code after the attention stacks
+    const int rc = forward_impl(h, b, loop, use_obstacles, nullptr, nullptr, ws, t.inf_bytes, hip_stream, T + t.NF, T + t.EF, true);
+    if (rc != GNNMP_OK) return rc;
+    const TrainGeom q = train_geom(h, b, c, ws);
+    const WRef nc0 = wref(h, nullptr, "node_code.0"), nc2 = wref(h, nullptr, "node_code.2"), ec0 = wref(h, nullptr, "edge_code.0"),
+               ec2 = wref(h, nullptr, "edge_code.2"), enc = wref(h, nullptr, "encoder"), l00 = wref(h, nullptr, "process.lin_0.0"),
+               l02 = wref(h, nullptr, "process.lin_0.2"), l1 = wref(h, nullptr, "process.lin_1"), dec = wref(h, nullptr, "decoder"),
+               p0 = wref(h, nullptr, "policy.0"), p2 = wref(h, nullptr, "policy.2"), p4 = wref(h, nullptr, "policy.4", false);
+    const float* ge = nullptr;
+    for (size_t i = 0; i < h->man.size(); ++i) if (h->man[i].name == "goal_encoder") ge = h->w_raw_dev + h->man_off[i];
+    HIP_TRY(t_node_in(q, T + t.NCin, st));
+    HIP_TRY(t_linear(Np, 4 * C, d, T + t.NCin, nc0.w, nc0.b, T + t.NCh, true, st));
+    HIP_TRY(t_linear(Np, d, d, T + t.NCh, nc2.w, nc2.b, T + t.NC, false, st));
+    HIP_TRY(t_edge_in(q, T + t.ECin, st));
+    HIP_TRY(t_linear(Ep, 2 * C, d, T + t.ECin, ec0.w, ec0.b, T + t.ECh, true, st));
+    HIP_TRY(t_linear(Ep, d, d, T + t.ECh, ec2.w, ec2.b, T + t.EC, false, st));
+    HIP_TRY(t_h0(q, d, ge, T + t.H0, st));
+    const float* Hprev = T + t.H0;
+    for (int it = 0; it < loop; ++it) {
+        float* I = T + t.it0 + t.it_stride * (size_t)it;
+        HIP_TRY(t_concat(Np, d, 4, T + t.NC, T + t.NF, T + t.H0, Hprev, I + t.Xin, st));                 // model.py:141
+        HIP_TRY(t_linear(Np, 4 * d, d, I + t.Xin, enc.w, enc.b, I + t.X, false, st));
+        HIP_TRY(t_msg_in(q, d, I + t.X, T + t.EF, T + t.EC, T + t.T5a, st));                             // model.py:38-39
+        HIP_TRY(t_linear(Ep, 5 * d, d, T + t.T5a, l00.w, l00.b, I + t.Zh, true, st));
+        HIP_TRY(t_linear(Ep, d, d, I + t.Zh, l02.w, l02.b, T + t.Te1, false, st));
+        HIP_TRY(t_segment_max(q, d, T + t.Te1, I + t.A, reinterpret_cast<int*>(I + t.arg), st));         // model.py:33
+        HIP_TRY(t_concat(Np, d, 2, I + t.X, I + t.A, nullptr, nullptr, T + t.cat2, st));
+        HIP_TRY(t_linear(Np, 2 * d, d, T + t.cat2, l1.w, l1.b, I + t.H, false, st));                     // model.py:36
+        Hprev = I + t.H;
+    }
+    HIP_TRY(t_concat(Np, d, 2, T + t.NC, Hprev, nullptr, nullptr, T + t.DinCat, st));                    // model.py:143
+    HIP_TRY(t_linear(Np, 2 * d, d, T + t.DinCat, dec.w, dec.b, T + t.Dn, false, st));
+    HIP_TRY(t_pol_in(q, d, T + t.Dn, T + t.EF, T + t.Pin, st));                                          // model.py:145
+    HIP_TRY(t_linear(Ep, 3 * d, d, T + t.Pin, p0.w, p0.b, T + t.P1, true, st));
+    HIP_TRY(t_linear(Ep, d, d, T + t.P1, p2.w, p2.b, T + t.P2, true, st));
+    HIP_TRY(t_linear(Ep, d, 1, T + t.P2, p4.w, nullptr, T + t.sc, false, st));
+    if (b->total_edges > 0) HIP_TRY(t_scores_out(q, T + t.sc, edge_scores, st));
+    return GNNMP_OK;
+}
+
+extern "C" int gnnmp_explorer_train_backward(const gnnmp_explorer* h, const gnnmp_batch* b, int loop, const float* d_edge_scores,
+                                             float* grad, void* ws, size_t ws_bytes, void* hip_stream) {
+    if (!h || !b || !ws || !grad || (b->total_edges > 0 && !d_edge_scores)) return GNNMP_ERR_NULL;
+    if (loop < 1) return GNNMP_ERR_ARG;
+    Carve c;
+    if (!carve(h, b, c)) return GNNMP_ERR_ARG;
+    TrainCarve t;
+    train_carve(h, b, loop, c, t);
+    if (ws_bytes < t.inf_bytes + t.total_floats * sizeof(float)) return GNNMP_ERR_WORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    float* T = reinterpret_cast<float*>(static_cast<char*>(ws) + t.inf_bytes);
+    const int d = h->dims.embed_size, C = h->dims.config_size, Np = c.Npad, Ep = c.Epad;
+    const TrainGeom q = train_geom(h, b, c, ws);
+    HIP_TRY(hipMemsetAsync(grad, 0, (size_t)h->n_raw * sizeof(float), st));
+    const WRef nc0 = wref(h, grad, "node_code.0"), nc2 = wref(h, grad, "node_code.2"), ec0 = wref(h, grad, "edge_code.0"),
+               ec2 = wref(h, grad, "edge_code.2"), enc = wref(h, grad, "encoder"), l00 = wref(h, grad, "process.lin_0.0"),
+               l02 = wref(h, grad, "process.lin_0.2"), l1 = wref(h, grad, "process.lin_1"), dec = wref(h, grad, "decoder"),
+               p0 = wref(h, grad, "policy.0"), p2 = wref(h, grad, "policy.2"), p4 = wref(h, grad, "policy.4", false);
+    float* g_ge = nullptr;
+    for (size_t i = 0; i < h->man.size(); ++i) if (h->man[i].name == "goal_encoder") g_ge = grad + h->man_off[i];
+    // ---- policy head (model.py:145-146)
+    HIP_TRY(t_scores_in(q, d_edge_scores, T + t.Te1, st));                          // [Ep, 1]
+    HIP_TRY(t_linear_dw(Ep, d, 1, T + t.Te1, T + t.P2, p4.gw, nullptr, st));
+    HIP_TRY(t_linear_dx(Ep, d, 1, T + t.Te1, p4.w, T + t.Te2, false, st));          // dP2
+    HIP_TRY(t_relu_bwd((size_t)Ep * d, T + t.P2, T + t.Te2, st));
+    HIP_TRY(t_linear_dw(Ep, d, d, T + t.Te2, T + t.P1, p2.gw, p2.gb, st));
+    HIP_TRY(t_linear_dx(Ep, d, d, T + t.Te2, p2.w, T + t.Te1, false, st));          // dP1
+    HIP_TRY(t_relu_bwd((size_t)Ep * d, T + t.P1, T + t.Te1, st));
+    HIP_TRY(t_linear_dw(Ep, 3 * d, d, T + t.Te1, T + t.Pin, p0.gw, p0.gb, st));
+    HIP_TRY(t_linear_dx(Ep, 3 * d, d, T + t.Te1, p0.w, T + t.T3, false, st));       // dPin
+    HIP_TRY(t_fill((size_t)Np * d, T + t.dDn, 0.f, st));
+    HIP_TRY(t_pol_in_bwd(q, d, T + t.T3, T + t.dDn, st));
+    // ---- decoder (model.py:143)
+    HIP_TRY(t_linear_dw(Np, 2 * d, d, T + t.dDn, T + t.DinCat, dec.gw, dec.gb, st));
+    HIP_TRY(t_linear_dx(Np, 2 * d, d, T + t.dDn, dec.w, T + t.dcat2, false, st));
+    HIP_TRY(t_split(Np, d, 2, 0, T + t.dcat2, T + t.dNC, false, st));
+    HIP_TRY(t_split(Np, d, 2, 1, T + t.dcat2, T + t.dH, false, st));
+    HIP_TRY(t_fill((size_t)Np * d, T + t.dH0, 0.f, st));
+    HIP_TRY(t_fill((size_t)Ep * d, T + t.dEC, 0.f, st));
+    // ---- the loop, backwards (model.py:139-142)
+    for (int it = loop - 1; it >= 0; --it) {
+        float* I = T + t.it0 + t.it_stride * (size_t)it;
+        HIP_TRY(t_concat(Np, d, 2, I + t.X, I + t.A, nullptr, nullptr, T + t.cat2, st));
+        HIP_TRY(t_linear_dw(Np, 2 * d, d, T + t.dH, T + t.cat2, l1.gw, l1.gb, st));
+        HIP_TRY(t_linear_dx(Np, 2 * d, d, T + t.dH, l1.w, T + t.dcat2, false, st));
+        HIP_TRY(t_split(Np, d, 2, 0, T + t.dcat2, T + t.dX, false, st));
+        HIP_TRY(t_split(Np, d, 2, 1, T + t.dcat2, T + t.dA, false, st));
+        HIP_TRY(t_fill((size_t)Ep * d, T + t.Te1, 0.f, st));                        // dM
+        HIP_TRY(t_segment_max_bwd(Np, d, T + t.dA, reinterpret_cast<const int*>(I + t.arg), T + t.Te1, st));
+        HIP_TRY(t_linear_dw(Ep, d, d, T + t.Te1, I + t.Zh, l02.gw, l02.gb, st));
+        HIP_TRY(t_linear_dx(Ep, d, d, T + t.Te1, l02.w, T + t.Te2, false, st));      // dZh
+        HIP_TRY(t_relu_bwd((size_t)Ep * d, I + t.Zh, T + t.Te2, st));
+        HIP_TRY(t_msg_in(q, d, I + t.X, T + t.EF, T + t.EC, T + t.T5a, st));         // Zin recomputed
+        HIP_TRY(t_linear_dw(Ep, 5 * d, d, T + t.Te2, T + t.T5a, l00.gw, l00.gb, st));
+        HIP_TRY(t_linear_dx(Ep, 5 * d, d, T + t.Te2, l00.w, T + t.T5b, false, st));   // dZin
+        HIP_TRY(t_msg_in_bwd(q, d, T + t.T5b, T + t.dX, T + t.dEC, st));
+        HIP_TRY(t_linear_dw(Np, 4 * d, d, T + t.dX, I + t.Xin, enc.gw, enc.gb, st));
+        HIP_TRY(t_linear_dx(Np, 4 * d, d, T + t.dX, enc.w, T + t.dXin, false, st));
+        HIP_TRY(t_split(Np, d, 4, 0, T + t.dXin, T + t.dNC, true, st));              // node_code
+        HIP_TRY(t_split(Np, d, 4, 2, T + t.dXin, T + t.dH0, true, st));              // h_0   (part 1 = node_free_code: detached)
+        if (it > 0) HIP_TRY(t_split(Np, d, 4, 3, T + t.dXin, T + t.dH, false, st));  // h_{i-1}
+        else HIP_TRY(t_split(Np, d, 4, 3, T + t.dXin, T + t.dH0, true, st));         // h_i of the first iteration IS h_0
+    }
+    HIP_TRY(t_h0_bwd(q, d, T + t.dH0, g_ge, st));
+    // ---- edge_code, node_code encoders (model.py:119-120)
+    HIP_TRY(t_linear_dw(Ep, d, d, T + t.dEC, T + t.ECh, ec2.gw, ec2.gb, st));
+    HIP_TRY(t_linear_dx(Ep, d, d, T + t.dEC, ec2.w, T + t.Te1, false, st));
+    HIP_TRY(t_relu_bwd((size_t)Ep * d, T + t.ECh, T + t.Te1, st));
+    HIP_TRY(t_linear_dw(Ep, 2 * C, d, T + t.Te1, T + t.ECin, ec0.gw, ec0.gb, st));
+    HIP_TRY(t_linear_dw(Np, d, d, T + t.dNC, T + t.NCh, nc2.gw, nc2.gb, st));
+    HIP_TRY(t_linear_dx(Np, d, d, T + t.dNC, nc2.w, T + t.dX, false, st));
+    HIP_TRY(t_relu_bwd((size_t)Np * d, T + t.NCh, T + t.dX, st));
+    HIP_TRY(t_linear_dw(Np, 4 * C, d, T + t.dX, T + t.NCin, nc0.gw, nc0.gb, st));
     return GNNMP_OK;
 }

@@ -609,6 +609,7 @@ __global__ __launch_bounds__(WAVES * 64) void pre_kernel(PreParams p) {
         }
     }
 
+    if (p.om) store_row<NT>(p.om + (size_t)row * D, m, h);       // training path: frozen node_/edge_free_code
     __syncthreads();
     stage(wl, p.out, p.out_size);
     __syncthreads();
@@ -745,6 +746,7 @@ __global__ __launch_bounds__(WAVES * 64) void pre_resident_kernel(PreParams p) {
             for (int b = 0; b < 3; ++b)
                 attention_block<D, P>(wl + b * AB::size, wl + b * AB::size, kvl + (size_t)b * p.kv_stride, nullptr,
                                    O, p.ot_max, p.ot_max, m, lane);
+            if (p.om) store_row<NT>(p.om + (size_t)row * D, m, h);       // training path: frozen node_/edge_free_code
             if constexpr (EDGE) {
                 using L = OutEBlob<D, P>;
                 f32x16 y[NT];

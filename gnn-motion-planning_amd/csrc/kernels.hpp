@@ -55,6 +55,8 @@ struct PreParams {
     int G;
     int use_obstacles;
     float *o0, *o1, *o2, *o3, *o4;
+    float* om;               // optional: the attention output itself (node_free_code / edge_free_code after the 3 blocks),
+                             // row-major [rows of this launch's padded index space, d]: frozen input of the training path
 };
 
 struct MpFusedParams {
@@ -141,6 +143,34 @@ struct MazeSteerParams {
     long long* checks;                    // [B], incremented
 };
 hipError_t launch_maze_steer(const MazeSteerParams& p, hipStream_t st);
+
+// ---- training path (train_kernels.hip)
+struct TrainGeom {
+    int G, C, Npad, Epad;
+    const float *v, *goal;
+    const int *node_ptr, *node_ptr_pad, *ntile_graph, *goal_node, *row_beg, *deg;
+    const int4* csr;
+};
+hipError_t t_linear(int R, int K, int O, const float* X, const float* W, const float* b, float* Y, bool relu, hipStream_t st);
+hipError_t t_linear_dx(int R, int K, int O, const float* dY, const float* W, float* dX, bool accumulate, hipStream_t st);
+hipError_t t_linear_dw(int R, int K, int O, const float* dY, const float* X, float* dW, float* db, hipStream_t st);
+hipError_t t_relu_bwd(size_t n, const float* y, float* dy, hipStream_t st);
+hipError_t t_fill(size_t n, float* x, float val, hipStream_t st);
+hipError_t t_node_in(const TrainGeom& q, float* out, hipStream_t st);
+hipError_t t_edge_in(const TrainGeom& q, float* out, hipStream_t st);
+hipError_t t_h0(const TrainGeom& q, int D, const float* goal_encoder, float* H0, hipStream_t st);
+hipError_t t_h0_bwd(const TrainGeom& q, int D, const float* dH0, float* d_goal_encoder, hipStream_t st);
+hipError_t t_concat(int R, int D, int parts, const float* a0, const float* a1, const float* a2, const float* a3, float* out,
+                    hipStream_t st);
+hipError_t t_split(int R, int D, int parts, int part, const float* d_in, float* dst, bool accumulate, hipStream_t st);
+hipError_t t_msg_in(const TrainGeom& q, int D, const float* X, const float* EF, const float* EC, float* out, hipStream_t st);
+hipError_t t_msg_in_bwd(const TrainGeom& q, int D, const float* dZ, float* dX, float* dEC, hipStream_t st);
+hipError_t t_pol_in(const TrainGeom& q, int D, const float* Dn, const float* EF, float* out, hipStream_t st);
+hipError_t t_pol_in_bwd(const TrainGeom& q, int D, const float* dP, float* dDn, hipStream_t st);
+hipError_t t_segment_max(const TrainGeom& q, int D, const float* M, float* A, int* arg, hipStream_t st);
+hipError_t t_segment_max_bwd(int Npad, int D, const float* dA, const int* arg, float* dM, hipStream_t st);
+hipError_t t_scores_out(const TrainGeom& q, const float* slot_scores, float* out, hipStream_t st);
+hipError_t t_scores_in(const TrainGeom& q, const float* d_out, float* d_slot, hipStream_t st);
 
 hipError_t launch_prep(const PrepParams& q, hipStream_t st);
 hipError_t launch_obs(int D, int P, const ObsParams& p, int G, hipStream_t st);

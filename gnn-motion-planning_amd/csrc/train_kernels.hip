@@ -1,0 +1,358 @@
+// train_kernels.hip -- training-mode forward (activations kept) and backward of the explorer's TRAINABLE path
+// (train_explorer.py:156-186).
+//
+// What trains under the reference's loss: model.py:141,142,146 detach node_free_code / edge_free_code before every
+// use, so the policy loss reaches node_code, edge_code, goal_encoder, encoder, process.lin_0 / lin_1, decoder and
+// policy, and NOTHING of the obstacle-attention stack (node/edge_free_code, obs_*_code, *_attentions).  The frozen
+// inputs NF [N, d] and EF [E, d] therefore come from the inference kernels (pre_kernel / pre_resident_kernel store them
+// on request); this file restates the rest in the reference's own formulation (materialised concatenations), one
+// plain kernel per operator, in the padded CSR index space of explorer_kernels.hip:
+//
+//   rows_linear      Y = act(X W^T + b)                       W row-major [O, K] exactly as in the state_dict
+//   rows_linear_dx   dX (+)= dY W
+//   rows_linear_dw   dW += dY^T X, db += sum_rows dY          (per-block partial sums, float atomics across blocks)
+//   segment_max      A[n] = max over the node's CSR segment, with the arg-max slot per (node, feature); 0 if empty
+//   gather / scatter kernels for the concatenations [v, g, (v-g)^2, v-g], [v_s, v_t], [NC, NF, H0, H],
+//                    [X_s - X_t, X_s, X_t, EF, EC], [NC, H], [D_s, D_s - D_t, EF] and their adjoints
+//
+// These are correctness-first kernels (a training step is one graph, ~10 k edges, d = 32: every launch is microseconds);
+// the MFMA chains of the inference path are not reused because their packed, pre-combined weights (W_a + W_b, ...) are
+// the wrong parameterisation for gradients.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include "kernels.hpp"
+
+namespace gnnmp {
+
+#define TRAIN_LAUNCH_CHECK()                 \
+    do {                                     \
+        hipError_t _e = hipGetLastError();   \
+        if (_e != hipSuccess) return _e;     \
+    } while (0)
+
+// Y[r, o] = act(sum_k X[r, k] W[o, k] + b[o]);  rows with valid[r] == 0 (padding slots) produce 0
+__global__ void rows_linear_kernel(int R, int K, int O, const float* __restrict__ X, const float* __restrict__ W,
+                                   const float* __restrict__ b, float* __restrict__ Y, int relu) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)R * O) return;
+    const int r = (int)(i / O), o = (int)(i % O);
+    const float* x = X + (size_t)r * K;
+    const float* w = W + (size_t)o * K;
+    float acc = b ? b[o] : 0.f;
+    for (int k = 0; k < K; ++k) acc = fmaf(x[k], w[k], acc);
+    Y[i] = (relu && acc < 0.f) ? 0.f : acc;
+}
+
+// dX[r, k] (+)= sum_o dY[r, o] W[o, k]
+__global__ void rows_linear_dx_kernel(int R, int K, int O, const float* __restrict__ dY, const float* __restrict__ W,
+                                      float* __restrict__ dX, int accumulate) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)R * K) return;
+    const int r = (int)(i / K), k = (int)(i % K);
+    const float* dy = dY + (size_t)r * O;
+    float acc = 0.f;
+    for (int o = 0; o < O; ++o) acc = fmaf(dy[o], W[(size_t)o * K + k], acc);
+    dX[i] = accumulate ? dX[i] + acc : acc;
+}
+
+// dW[o, k] += sum_r dY[r, o] X[r, k];  db[o] += sum_r dY[r, o].  One block per chunk of rows.
+constexpr int kDwRows = 128;
+__global__ __launch_bounds__(256) void rows_linear_dw_kernel(int R, int K, int O, const float* __restrict__ dY,
+                                                             const float* __restrict__ X, float* __restrict__ dW,
+                                                             float* __restrict__ db) {
+    const int r0 = blockIdx.x * kDwRows, r1 = min(R, r0 + kDwRows);
+    for (int i = threadIdx.x; i < O * K; i += 256) {
+        const int o = i / K, k = i % K;
+        float acc = 0.f;
+        for (int r = r0; r < r1; ++r) acc = fmaf(dY[(size_t)r * O + o], X[(size_t)r * K + k], acc);
+        atomicAdd(&dW[i], acc);
+    }
+    if (db)
+        for (int o = threadIdx.x; o < O; o += 256) {
+            float acc = 0.f;
+            for (int r = r0; r < r1; ++r) acc += dY[(size_t)r * O + o];
+            atomicAdd(&db[o], acc);
+        }
+}
+
+__global__ void relu_bwd_kernel(size_t n, const float* __restrict__ y, float* __restrict__ dy) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && !(y[i] > 0.f)) dy[i] = 0.f;
+}
+
+__global__ void fill_kernel(size_t n, float* __restrict__ x, float val) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] = val;
+}
+
+// ---- node-level inputs.  padded node row n of graph g: caller row node_ptr[g] + (n - node_ptr_pad[g]) if inside
+__device__ __forceinline__ int caller_row(const TrainGeom& q, int n, int& g) {
+    g = q.ntile_graph[n >> 5];
+    if (g < 0) return -1;
+    const int local = n - q.node_ptr_pad[g];
+    return local < q.node_ptr[g + 1] - q.node_ptr[g] ? q.node_ptr[g] + local : -1;
+}
+
+// NCin[n] = [v, g, (v-g)^2, v-g]  (model.py:119), zeros for padding rows
+__global__ void node_in_kernel(TrainGeom q, float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int C = q.C;
+    if (i >= (size_t)q.Npad * 4 * C) return;
+    const int n = (int)(i / (4 * C)), k = (int)(i % (4 * C));
+    int g;
+    const int row = caller_row(q, n, g);
+    float val = 0.f;
+    if (row >= 0) {
+        const int part = k / C, c = k % C;
+        const float x = q.v[(size_t)row * C + c], gg = q.goal[(size_t)g * C + c];
+        const float dlt = x - gg;
+        val = part == 0 ? x : (part == 1 ? gg : (part == 2 ? dlt * dlt : dlt));
+    }
+    out[i] = val;
+}
+
+// ECin[e] = [v_src, v_dst]  (model.py:120), zeros for padding slots
+__global__ void edge_in_kernel(TrainGeom q, float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int C = q.C;
+    if (i >= (size_t)q.Epad * 2 * C) return;
+    const int e = (int)(i / (2 * C)), k = (int)(i % (2 * C));
+    const int4 rec = q.csr[e];
+    float val = 0.f;
+    if (rec.x >= 0) {
+        int g;
+        const int row = caller_row(q, k < C ? rec.x : rec.y, g);
+        val = q.v[(size_t)row * C + (k % C)];
+    }
+    out[i] = val;
+}
+
+// H0[n] = goal_encoder on the goal node, else 0  (model.py:133-134)
+__global__ void h0_kernel(TrainGeom q, int D, const float* __restrict__ goal_encoder, float* __restrict__ H0) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)q.Npad * D) return;
+    const int n = (int)(i / D), f = (int)(i % D);
+    const int g = q.ntile_graph[n >> 5];
+    H0[i] = (g >= 0 && q.goal_node[g] == n) ? goal_encoder[f] : 0.f;
+}
+__global__ void h0_bwd_kernel(TrainGeom q, int D, const float* __restrict__ dH0, float* __restrict__ d_goal_encoder) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= q.G * D) return;
+    const int g = i / D, f = i % D;
+    if (q.goal_node[g] >= 0) atomicAdd(&d_goal_encoder[f], dH0[(size_t)q.goal_node[g] * D + f]);
+}
+
+// out[n] = [a0[n], a1[n], a2[n], a3[n]] (row-major concat of up to four [Npad, D] arrays; nullptr parts are skipped)
+__global__ void concat_rows_kernel(int R, int D, int parts, const float* a0, const float* a1, const float* a2, const float* a3,
+                                   float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)R * parts * D) return;
+    const int r = (int)(i / (parts * D)), k = (int)(i % (parts * D));
+    const float* src = k / D == 0 ? a0 : (k / D == 1 ? a1 : (k / D == 2 ? a2 : a3));
+    out[i] = src[(size_t)r * D + k % D];
+}
+// dst[r] (+)= d_in[r, part*D : (part+1)*D]
+__global__ void split_rows_kernel(int R, int D, int parts, int part, const float* __restrict__ d_in, float* __restrict__ dst,
+                                  int accumulate) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)R * D) return;
+    const int r = (int)(i / D), f = (int)(i % D);
+    const float val = d_in[(size_t)r * parts * D + part * D + f];
+    dst[i] = accumulate ? dst[i] + val : val;
+}
+
+// Zin[e] = [X_s - X_t, X_s, X_t, EF_e, EC_e]  (model.py:38-39,142); zeros for padding slots
+__global__ void msg_in_kernel(TrainGeom q, int D, const float* __restrict__ X, const float* __restrict__ EF,
+                              const float* __restrict__ EC, float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)q.Epad * 5 * D) return;
+    const int e = (int)(i / (5 * D)), k = (int)(i % (5 * D));
+    const int4 rec = q.csr[e];
+    float val = 0.f;
+    if (rec.x >= 0) {
+        const int part = k / D, f = k % D;
+        const float xs = X[(size_t)rec.x * D + f], xt = X[(size_t)rec.y * D + f];
+        val = part == 0 ? xs - xt : (part == 1 ? xs : (part == 2 ? xt : (part == 3 ? EF[(size_t)e * D + f] : EC[(size_t)e * D + f])));
+    }
+    out[i] = val;
+}
+// adjoint: dX[s] += dZ[:, 0:D] + dZ[:, D:2D];  dX[t] += -dZ[:, 0:D] + dZ[:, 2D:3D];  dEC[e] += dZ[:, 4D:5D]  (EF detached)
+__global__ void msg_in_bwd_kernel(TrainGeom q, int D, const float* __restrict__ dZ, float* __restrict__ dX, float* __restrict__ dEC) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)q.Epad * D) return;
+    const int e = (int)(i / D), f = (int)(i % D);
+    const int4 rec = q.csr[e];
+    if (rec.x < 0) return;
+    const float* z = dZ + (size_t)e * 5 * D;
+    atomicAdd(&dX[(size_t)rec.x * D + f], z[f] + z[D + f]);
+    atomicAdd(&dX[(size_t)rec.y * D + f], z[2 * D + f] - z[f]);
+    dEC[i] += z[4 * D + f];
+}
+
+// Pin[e] = [D_s, D_s - D_t, EF_e]  (model.py:145)
+__global__ void pol_in_kernel(TrainGeom q, int D, const float* __restrict__ Dn, const float* __restrict__ EF, float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)q.Epad * 3 * D) return;
+    const int e = (int)(i / (3 * D)), k = (int)(i % (3 * D));
+    const int4 rec = q.csr[e];
+    float val = 0.f;
+    if (rec.x >= 0) {
+        const int part = k / D, f = k % D;
+        const float ds = Dn[(size_t)rec.x * D + f], dt = Dn[(size_t)rec.y * D + f];
+        val = part == 0 ? ds : (part == 1 ? ds - dt : EF[(size_t)e * D + f]);
+    }
+    out[i] = val;
+}
+__global__ void pol_in_bwd_kernel(TrainGeom q, int D, const float* __restrict__ dP, float* __restrict__ dDn) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)q.Epad * D) return;
+    const int e = (int)(i / D), f = (int)(i % D);
+    const int4 rec = q.csr[e];
+    if (rec.x < 0) return;
+    const float* z = dP + (size_t)e * 3 * D;
+    atomicAdd(&dDn[(size_t)rec.x * D + f], z[f] + z[D + f]);
+    atomicAdd(&dDn[(size_t)rec.y * D + f], -z[D + f]);
+}
+
+// A[n, f] = max over the node's CSR segment of M[slot, f]; arg = that slot (first maximum); 0 / -1 without incoming edges
+__global__ void segment_max_kernel(TrainGeom q, int D, const float* __restrict__ M, float* __restrict__ A, int* __restrict__ arg) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)q.Npad * D) return;
+    const int n = (int)(i / D), f = (int)(i % D);
+    const int b = q.row_beg[n], dg = q.deg[n];
+    float best = 0.f;
+    int bi = -1;
+    for (int s = b; s < b + dg; ++s) {
+        const float val = M[(size_t)s * D + f];
+        if (bi < 0 || val > best) { best = val; bi = s; }
+    }
+    A[i] = best;
+    arg[i] = bi;
+}
+// dM[arg[n, f], f] = dA[n, f] (dM zero-filled by the caller; every (slot, f) belongs to one node)
+__global__ void segment_max_bwd_kernel(int Npad, int D, const float* __restrict__ dA, const int* __restrict__ arg, float* __restrict__ dM) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)Npad * D) return;
+    const int s = arg[i];
+    if (s >= 0) dM[(size_t)s * D + i % D] = dA[i];
+}
+
+// scores in caller column order <-> CSR slot order
+__global__ void scores_out_kernel(TrainGeom q, const float* __restrict__ slot_scores, float* __restrict__ out) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= q.Epad) return;
+    const int4 rec = q.csr[e];
+    if (rec.x >= 0) out[rec.z] = slot_scores[e];
+}
+__global__ void scores_in_kernel(TrainGeom q, const float* __restrict__ d_out, float* __restrict__ d_slot) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= q.Epad) return;
+    const int4 rec = q.csr[e];
+    d_slot[e] = rec.x >= 0 ? d_out[rec.z] : 0.f;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+static inline unsigned blocks(size_t n) { return (unsigned)((n + 255) / 256); }
+
+hipError_t t_linear(int R, int K, int O, const float* X, const float* W, const float* b, float* Y, bool relu, hipStream_t st) {
+    if (R <= 0) return hipSuccess;
+    hipLaunchKernelGGL(rows_linear_kernel, dim3(blocks((size_t)R * O)), dim3(256), 0, st, R, K, O, X, W, b, Y, relu ? 1 : 0);
+    TRAIN_LAUNCH_CHECK();
+    return hipSuccess;
+}
+hipError_t t_linear_dx(int R, int K, int O, const float* dY, const float* W, float* dX, bool accumulate, hipStream_t st) {
+    if (R <= 0) return hipSuccess;
+    hipLaunchKernelGGL(rows_linear_dx_kernel, dim3(blocks((size_t)R * K)), dim3(256), 0, st, R, K, O, dY, W, dX, accumulate ? 1 : 0);
+    TRAIN_LAUNCH_CHECK();
+    return hipSuccess;
+}
+hipError_t t_linear_dw(int R, int K, int O, const float* dY, const float* X, float* dW, float* db, hipStream_t st) {
+    if (R <= 0) return hipSuccess;
+    hipLaunchKernelGGL(rows_linear_dw_kernel, dim3((R + kDwRows - 1) / kDwRows), dim3(256), 0, st, R, K, O, dY, X, dW, db);
+    TRAIN_LAUNCH_CHECK();
+    return hipSuccess;
+}
+hipError_t t_relu_bwd(size_t n, const float* y, float* dy, hipStream_t st) {
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3(blocks(n)), dim3(256), 0, st, n, y, dy);
+    TRAIN_LAUNCH_CHECK();
+    return hipSuccess;
+}
+hipError_t t_fill(size_t n, float* x, float val, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(fill_kernel, dim3(blocks(n)), dim3(256), 0, st, n, x, val);
+    TRAIN_LAUNCH_CHECK();
+    return hipSuccess;
+}
+hipError_t t_node_in(const TrainGeom& q, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(node_in_kernel, dim3(blocks((size_t)q.Npad * 4 * q.C)), dim3(256), 0, st, q, out);
+    TRAIN_LAUNCH_CHECK();
+    return hipSuccess;
+}
+hipError_t t_edge_in(const TrainGeom& q, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(edge_in_kernel, dim3(blocks((size_t)q.Epad * 2 * q.C)), dim3(256), 0, st, q, out);
+    TRAIN_LAUNCH_CHECK();
+    return hipSuccess;
+}
+hipError_t t_h0(const TrainGeom& q, int D, const float* ge, float* H0, hipStream_t st) {
+    hipLaunchKernelGGL(h0_kernel, dim3(blocks((size_t)q.Npad * D)), dim3(256), 0, st, q, D, ge, H0);
+    TRAIN_LAUNCH_CHECK();
+    return hipSuccess;
+}
+hipError_t t_h0_bwd(const TrainGeom& q, int D, const float* dH0, float* dge, hipStream_t st) {
+    hipLaunchKernelGGL(h0_bwd_kernel, dim3(blocks((size_t)q.G * D)), dim3(256), 0, st, q, D, dH0, dge);
+    TRAIN_LAUNCH_CHECK();
+    return hipSuccess;
+}
+hipError_t t_concat(int R, int D, int parts, const float* a0, const float* a1, const float* a2, const float* a3, float* out,
+                    hipStream_t st) {
+    hipLaunchKernelGGL(concat_rows_kernel, dim3(blocks((size_t)R * parts * D)), dim3(256), 0, st, R, D, parts, a0, a1, a2, a3, out);
+    TRAIN_LAUNCH_CHECK();
+    return hipSuccess;
+}
+hipError_t t_split(int R, int D, int parts, int part, const float* d_in, float* dst, bool accumulate, hipStream_t st) {
+    hipLaunchKernelGGL(split_rows_kernel, dim3(blocks((size_t)R * D)), dim3(256), 0, st, R, D, parts, part, d_in, dst, accumulate ? 1 : 0);
+    TRAIN_LAUNCH_CHECK();
+    return hipSuccess;
+}
+hipError_t t_msg_in(const TrainGeom& q, int D, const float* X, const float* EF, const float* EC, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(msg_in_kernel, dim3(blocks((size_t)q.Epad * 5 * D)), dim3(256), 0, st, q, D, X, EF, EC, out);
+    TRAIN_LAUNCH_CHECK();
+    return hipSuccess;
+}
+hipError_t t_msg_in_bwd(const TrainGeom& q, int D, const float* dZ, float* dX, float* dEC, hipStream_t st) {
+    hipLaunchKernelGGL(msg_in_bwd_kernel, dim3(blocks((size_t)q.Epad * D)), dim3(256), 0, st, q, D, dZ, dX, dEC);
+    TRAIN_LAUNCH_CHECK();
+    return hipSuccess;
+}
+hipError_t t_pol_in(const TrainGeom& q, int D, const float* Dn, const float* EF, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(pol_in_kernel, dim3(blocks((size_t)q.Epad * 3 * D)), dim3(256), 0, st, q, D, Dn, EF, out);
+    TRAIN_LAUNCH_CHECK();
+    return hipSuccess;
+}
+hipError_t t_pol_in_bwd(const TrainGeom& q, int D, const float* dP, float* dDn, hipStream_t st) {
+    hipLaunchKernelGGL(pol_in_bwd_kernel, dim3(blocks((size_t)q.Epad * D)), dim3(256), 0, st, q, D, dP, dDn);
+    TRAIN_LAUNCH_CHECK();
+    return hipSuccess;
+}
+hipError_t t_segment_max(const TrainGeom& q, int D, const float* M, float* A, int* arg, hipStream_t st) {
+    hipLaunchKernelGGL(segment_max_kernel, dim3(blocks((size_t)q.Npad * D)), dim3(256), 0, st, q, D, M, A, arg);
+    TRAIN_LAUNCH_CHECK();
+    return hipSuccess;
+}
+hipError_t t_segment_max_bwd(int Npad, int D, const float* dA, const int* arg, float* dM, hipStream_t st) {
+    hipLaunchKernelGGL(segment_max_bwd_kernel, dim3(blocks((size_t)Npad * D)), dim3(256), 0, st, Npad, D, dA, arg, dM);
+    TRAIN_LAUNCH_CHECK();
+    return hipSuccess;
+}
+hipError_t t_scores_out(const TrainGeom& q, const float* slot_scores, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(scores_out_kernel, dim3(blocks((size_t)q.Epad)), dim3(256), 0, st, q, slot_scores, out);
+    TRAIN_LAUNCH_CHECK();
+    return hipSuccess;
+}
+hipError_t t_scores_in(const TrainGeom& q, const float* d_out, float* d_slot, hipStream_t st) {
+    hipLaunchKernelGGL(scores_in_kernel, dim3(blocks((size_t)q.Epad)), dim3(256), 0, st, q, d_out, d_slot);
+    TRAIN_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+}  // namespace gnnmp

@@ -48,6 +48,54 @@ class _MPNN(nn.Module):                           # model.py:22-28
         self.bn = nn.BatchNorm1d(d)
 
 
+class _TrainScores(torch.autograd.Function):
+    """Per-edge scores with gradients for the parameters the reference's policy loss trains (train_explorer.py:156-186;
+    node_free_code / edge_free_code are detached at model.py:141,142,146, so the obstacle-attention stack gets none).
+    Forward and backward run in libgnnmp.so (gnnmp_explorer_train_forward / _backward)."""
+
+    @staticmethod
+    def forward(ctx, model, batch, loop, *params):
+        dev = batch.v.device
+        h = model._native(dev)
+        cb = model._cbatch(batch)
+        need = ctypes.c_size_t()
+        _lib.check(_lib.lib().gnnmp_explorer_train_workspace_bytes(h, ctypes.byref(cb), int(loop), ctypes.byref(need)),
+                   'gnnmp_explorer_train_workspace_bytes')
+        ws = torch.empty(need.value, dtype=torch.uint8, device=dev)
+        scores = torch.empty(batch.total_edges, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            st = torch.cuda.current_stream().cuda_stream
+            _lib.check(_lib.lib().gnnmp_explorer_train_forward(h, ctypes.byref(cb), int(loop), 1 if model.use_obstacles else 0,
+                                                               scores.data_ptr(), ws.data_ptr(), ws.numel(), st),
+                       'gnnmp_explorer_train_forward')
+        ctx.model, ctx.batch, ctx.loop, ctx.ws, ctx.handle = model, batch, int(loop), ws, h
+        return scores
+
+    @staticmethod
+    def backward(ctx, d_scores):
+        model, batch, dev = ctx.model, ctx.batch, ctx.batch.v.device
+        cb = model._cbatch(batch)
+        n = int(_lib.lib().gnnmp_explorer_grad_floats(ctx.handle))
+        grad = torch.empty(n, dtype=torch.float32, device=dev)
+        d_scores = d_scores.contiguous().float()
+        with torch.cuda.device(dev):
+            st = torch.cuda.current_stream().cuda_stream
+            _lib.check(_lib.lib().gnnmp_explorer_train_backward(ctx.handle, ctypes.byref(cb), ctx.loop, d_scores.data_ptr(),
+                                                                grad.data_ptr(), ctx.ws.data_ptr(), ctx.ws.numel(), st),
+                       'gnnmp_explorer_train_backward')
+        out, off = [], 0
+        for (name, numel), t in zip(model._manifest, model._live_weights()):
+            # parameters may live on the host (the reference keeps them wherever .to() put them): gradients follow them
+            g = grad[off:off + numel].view_as(t).to(t.device) if name.split('.')[0] in TRAINABLE else None
+            out.append(g)
+            off += numel
+        return (None, None, None) + tuple(out)
+
+
+# top-level modules that receive a gradient from the policy loss (everything else forward() reads is behind a detach)
+TRAINABLE = ('node_code', 'edge_code', 'goal_encoder', 'encoder', 'process', 'decoder', 'policy')
+
+
 class EncoderProcessDecoder(nn.Module):
     """``EncoderProcessDecoder(workspace_size, config_size, embed_size, obs_size, use_obstacles=True)``
     (model.py:49).  ``use_obstacles`` is read at call time (model.py:125; toggled by eval_gnn.py:88)."""
@@ -293,6 +341,28 @@ class EncoderProcessDecoder(nn.Module):
             _lib.check(_lib.lib().gnnmp_explorer_debug_tap(h, ctypes.byref(cb), which, out.data_ptr(),
                                                            self._ws.data_ptr(), self._ws.numel(), st), 'debug_tap')
         return out if which == 3 else out.view(batch.total_nodes, self.embed_size)
+
+    # ------------------------------------------------------------------ training path
+    def train_scores(self, batch, loop):
+        """Per-edge scores [sumE] of a :class:`GraphBatch` WITH autograd: ``loss(scores).backward()`` fills ``.grad`` of
+        node_code, edge_code, goal_encoder, encoder, process, decoder and policy -- the parameters the reference's policy
+        loss reaches (train_explorer.py:156-186); the obstacle-attention stack is behind the reference's ``detach()``
+        calls (model.py:141,142,146) and gets none.  fp32 only."""
+        if self.mlp_dtype != 'fp32':
+            raise RuntimeError('training runs in fp32 (mlp_dtype = %r)' % self.mlp_dtype)
+        if batch.v.device.type != 'cuda':
+            raise RuntimeError('gnnmp runs on the GPU only (got %s tensors); there is no CPU fallback' % batch.v.device)
+        self._native(batch.v.device)                      # builds the manifest / packed + raw weights on the device
+        return _TrainScores.apply(self, batch, loop, *self._live_weights())
+
+    def forward_train(self, goal, loop, v, obstacles, free=None, collided=None, edge_index=None, k=10, **kwargs):
+        """The reference call with gradients (train_explorer.py:156-160): dense ``policy_output[N, N]``; the scatter
+        of the per-edge scores into the matrix (model.py:148-149) is done by torch so that indexing / log_softmax on
+        the result back-propagate into :meth:`train_scores`."""
+        b = self._single(goal, v, obstacles, edge_index)
+        scores = self.train_scores(b, loop)
+        P = scores.new_zeros(v.shape[0], v.shape[0])
+        return P.index_put((edge_index[1], edge_index[0]), scores)
 
     def _single(self, goal, v, obstacles, edge_index):
         dev = v.device

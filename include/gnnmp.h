@@ -155,6 +155,26 @@ int gnnmp_explorer_debug_tap(const gnnmp_explorer* h, const gnnmp_batch* batch, 
                              void* workspace, size_t workspace_bytes, void* hip_stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Training path of the explorer   (train_explorer.py:156-186: loss.backward() through model.py:115-150)
+ * ------------------------------------------------------------------------------------------
+ * The reference detaches node_free_code / edge_free_code before every use (model.py:141,142,146), so its policy loss
+ * trains node_code, edge_code, goal_encoder, encoder, process.lin_0 / lin_1, decoder and policy and leaves the
+ * obstacle-attention stack untouched.  train_forward computes the same scores as forward (the frozen attention outputs
+ * come from the inference kernels, the trainable part is re-evaluated in the reference's formulation with activations
+ * kept in `workspace`); train_backward turns d loss / d edge_scores into d loss / d parameters.
+ * grad: DEVICE buffer of gnnmp_explorer_grad_floats(h) floats in MANIFEST order (the layout of the weight blob given to
+ * gnnmp_explorer_create); entries of frozen tensors are zero.  The handle must be GNNMP_F32.  The same workspace
+ * (>= gnnmp_explorer_train_workspace_bytes, 256-byte aligned) must be passed to forward and backward, untouched in
+ * between; both enqueue on hip_stream and never synchronise.  Weight-gradient sums use float atomics: bit patterns may
+ * differ from run to run in the last digits. */
+int64_t gnnmp_explorer_grad_floats(const gnnmp_explorer* h);
+int gnnmp_explorer_train_workspace_bytes(const gnnmp_explorer* h, const gnnmp_batch* shape, int loop, size_t* bytes);
+int gnnmp_explorer_train_forward(const gnnmp_explorer* h, const gnnmp_batch* batch, int loop, int use_obstacles,
+                                 float* edge_scores, void* workspace, size_t workspace_bytes, void* hip_stream);
+int gnnmp_explorer_train_backward(const gnnmp_explorer* h, const gnnmp_batch* batch, int loop, const float* d_edge_scores,
+                                  float* grad, void* workspace, size_t workspace_bytes, void* hip_stream);
+
+/* ------------------------------------------------------------------------------------------
  * Smoother   (ModelSmoother, model_smoother.py:46-142)
  * ---------------------------------------------------------------------------------------- */
 typedef struct gnnmp_smoother gnnmp_smoother;   /* opaque */

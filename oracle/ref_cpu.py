@@ -155,14 +155,25 @@ def _block(w, pre, m, o, materialize=False):
 # --------------------------------------------------------------------------------------
 # explorer
 # --------------------------------------------------------------------------------------
-@torch.no_grad()
 def explorer_forward(w, v, goal, obstacles, edge_index, loop, use_obstacles=True,
-                     obs_size=None, taps=None, dense=False, materialize=False):
+                     obs_size=None, taps=None, dense=False, materialize=False, detach=False):
+    """Inference restatement (eval_gnn.py:168 runs it under no_grad); with ``detach`` the autograd graph is kept and cut
+    where the reference cuts it -- see :func:`_explorer_forward`."""
+    if detach:
+        return _explorer_forward(w, v, goal, obstacles, edge_index, loop, use_obstacles, obs_size, taps, dense, materialize, True)
+    with torch.no_grad():
+        return _explorer_forward(w, v, goal, obstacles, edge_index, loop, use_obstacles, obs_size, taps, dense, materialize, False)
+
+
+def _explorer_forward(w, v, goal, obstacles, edge_index, loop, use_obstacles=True,
+                      obs_size=None, taps=None, dense=False, materialize=False, detach=False):
     """``EncoderProcessDecoder.forward`` (model.py:115-150).
 
     Returns per-edge scores [E] in the order of ``edge_index`` columns, or the dense
     ``P[target, source]`` matrix (model.py:148-149) when ``dense``.
     ``taps``: optional dict that receives intermediates for kernel-level diffing.
+    ``detach``: cut the autograd graph where the reference does (model.py:141,142,146: node_free_code and
+    edge_free_code are detached before every use) -- the gradient oracle of the training path.
     """
     C = v.shape[1]
     d = w['encoder.bias'].shape[0]
@@ -183,6 +194,8 @@ def explorer_forward(w, v, goal, obstacles, edge_index, loop, use_obstacles=True
         for b in range(3):                                                    # :128-130
             nf, on = _block(w, 'node_attentions.%d' % b, nf, on, materialize)
             ef, oe = _block(w, 'edge_attentions.%d' % b, ef, oe, materialize)
+    if detach:
+        nf, ef = nf.detach(), ef.detach()
     gi = knn(v, g, 1)[1]                                                      # :132
     h0 = node_code.new_zeros(n, d)                                            # :133
     h0[gi, :] = h0[gi, :] + w['goal_encoder']                                 # :134

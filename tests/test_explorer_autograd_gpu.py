@@ -1,0 +1,108 @@
+"""Training path of the explorer: gradients of the HIP backward against torch.autograd
+through the CPU oracle with the reference's detach points (model.py:141,142,146), fp64-anchored:
+
+    |g_gpu - g_oracle64| <= 1e-4 * max|g_oracle64| + 1e-6    per parameter tensor   (fp32 sums of ~10^3-10^4 terms with
+                                                              float atomics; the fp32 oracle itself is at 1e-6..1e-5)
+
+on the 64-node goldens of every checkpoint family, for a random linear loss and for the reference's loss form
+(-log_softmax over a frontier row set, train_explorer.py:174); frozen parameters get no gradient; the forward of the
+training path equals the inference forward."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import env_of, golden_files, load_weights
+import gnnmp
+from gnnmp.explorer import TRAINABLE
+from gnnmp.synth import ENVS
+from oracle import ref_cpu
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _oracle_grads(w, r, loop, loss_fn, dtype):
+    wd = {k: (t.to(dtype).clone().requires_grad_(True) if t.is_floating_point() else t) for k, t in w.items()}
+    s = ref_cpu.explorer_forward(wd, torch.from_numpy(r['v']).to(dtype), torch.from_numpy(r['goal']).to(dtype),
+                                 torch.from_numpy(r['obstacles']).to(dtype), torch.from_numpy(r['edge_index']), loop,
+                                 use_obstacles=bool(r['use_obstacles']), detach=True)
+    loss_fn(s).backward()
+    return s.detach(), {k: t.grad for k, t in wd.items() if torch.is_tensor(t) and t.is_floating_point()}
+
+
+@pytest.mark.parametrize('path', [p for p in golden_files('explorer_') if 'N64' in p], ids=os.path.basename)
+def test_gradients_match_oracle(path):
+    with np.load(path) as f:
+        r = {k: f[k] for k in f.files}
+    env = env_of(path)
+    e = ENVS[env]
+    w = load_weights(e['ckpt'])
+    L = int(r['loop'])
+    m = gnnmp.EncoderProcessDecoder(e['workspace'], e['C'], e['d'], e['S'], use_obstacles=bool(r['use_obstacles']))
+    m.load_state_dict(w, strict=True)
+    m.train()
+    g = dict(goal=torch.from_numpy(r['goal']).to(DEV), v=torch.from_numpy(r['v']).to(DEV),
+             obstacles=torch.from_numpy(r['obstacles']).to(DEV), edge_index=torch.from_numpy(r['edge_index']).to(DEV))
+    b = m._single(g['goal'], g['v'], g['obstacles'], g['edge_index'])
+    E = r['edge_index'].shape[1]
+    gen = torch.Generator().manual_seed(E)
+    coef = torch.randn(E, generator=gen, dtype=torch.float64)
+    ei = torch.from_numpy(r['edge_index'])
+    rows = ei[1] < 8                                                      # "frontier": edges into the first eight nodes
+    pick = int(rows.nonzero()[3])
+
+    def loss_lin(s):
+        return (s * coef.to(s.dtype).to(s.device)).sum()
+
+    def loss_ce(s):                                                       # train_explorer.py:174
+        return -s[rows.to(s.device)].log_softmax(dim=0)[int(rows[:pick].sum())]
+
+    for name, loss_fn in (('linear', loss_lin), ('cross-entropy', loss_ce)):
+        m.zero_grad()
+        s = m.train_scores(b, L)
+        s_inf = m.forward_batch(b, L)
+        assert torch.allclose(s.detach(), s_inf, rtol=1e-5, atol=2e-5)      # same function as the inference path
+        loss_fn(s).backward()
+        _, g64 = _oracle_grads(w, r, L, loss_fn, torch.float64)
+        worst = 0.0
+        for pname, p in m.named_parameters():
+            top = pname.split('.')[0]
+            ref = g64.get(pname)
+            if top not in TRAINABLE or ref is None or pname not in dict(m._manifest):
+                if top not in TRAINABLE:
+                    assert p.grad is None or float(p.grad.abs().max()) == 0.0, pname     # behind the reference's detach
+                continue
+            assert p.grad is not None, pname
+            scale = float(ref.abs().max())
+            err = float((p.grad.cpu().double() - ref).abs().max())
+            worst = max(worst, err / (scale + 1e-30))
+            assert err <= 1e-4 * scale + 1e-6, (name, pname, err, scale)
+        print('\n%s, %s loss: worst relative gradient error %.2e' % (os.path.basename(path), name, worst))
+
+
+def test_dense_training_call_and_optimizer_step():
+    """The reference's training call shape (dense policy matrix, indexing + log_softmax, optimizer step,
+    train_explorer.py:156-186): the loss goes down on a fixed problem, frozen parameters do not move."""
+    from gnnmp.synth import synth_graph
+    g = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in synth_graph('maze2', 120, 5, seed=12).items()}
+    m = gnnmp.EncoderProcessDecoder(2, 2, 32, 2)
+    m.load_state_dict(load_weights('weights_maze'))
+    m.to(DEV)
+    m.train()
+    frozen_before = m.edge_attentions[0].attention.key.weight.detach().clone()
+    opt = torch.optim.Adam([p for n, p in m.named_parameters() if n.split('.')[0] in TRAINABLE], lr=1e-3)
+    frontier = torch.tensor([0, 3, 7], device=DEV)
+    losses = []
+    for _ in range(6):
+        opt.zero_grad()
+        P = m.forward_train(goal=g['goal'], loop=3, v=g['v'], obstacles=g['obstacles'], edge_index=g['edge_index'])
+        cand = P[frontier].reshape(-1)
+        loss = -cand.log_softmax(dim=0)[5]
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    print('\nlosses', ['%.4f' % x for x in losses])
+    assert losses[-1] < losses[0]
+    assert torch.equal(frozen_before, m.edge_attentions[0].attention.key.weight.detach())
