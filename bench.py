@@ -84,12 +84,74 @@ def cpu_baseline(env, n_nodes, k1, budget_s, seed0):
             if el > budget_s / 2 or n >= 64:
                 break
         results.append((n / el, threads, n, el))
+    # the other BASELINE config shapes, single-graph calls like the reference makes them:
+    # cfg 1 (maze2 200-node k=6: the reference's own CPU-runnable case), cfg 3 (kuka7 2000-node k=10), cfg 5 (kuka14
+    # 5000-node k=16); a few calls each at the better thread count
+    torch.set_num_threads(max(results)[1])
+    others = {}
+    for name, (oenv, on, ok, calls) in {'cfg1_maze2_N200_k6': ('maze2', 200, 6, 8), 'cfg3_kuka7_N2000_k10': ('kuka7', 2000, 10, 2),
+                                        'cfg5_kuka14_N5000_k16': ('kuka14', 5000, 16, 1)}.items():
+        ow = load_weights(ENVS[oenv]['ckpt'])
+        og = synth_graph(oenv, on, ok, seed=seed0)
+        orun = lambda: ref_cpu.explorer_forward(ow, og['v'], og['goal'], og['obstacles'], og['edge_index'], 5, materialize=True)  # noqa: E731
+        orun()
+        t0 = time.perf_counter()
+        for _ in range(calls):
+            orun()
+        others[name] = round(calls / (time.perf_counter() - t0), 3)
     torch.set_num_threads(all_threads)
     best = max(results)
     return {'value': best[0], 'unit': 'graphs/s', 'cores': best[1], 'kind': 'port',
             'sample': 'single-graph oracle forwards (%s N=%d k1=%d loop=5, attention materialised as model.py:178-179): '
                       % (env, n_nodes, k1) + '; '.join('%d calls in %.1f s on %d torch threads = %.2f graphs/s' %
-                                                        (r[2], r[3], r[1], r[0]) for r in results) + '; best reported'}
+                                                        (r[2], r[3], r[1], r[0]) for r in results) + '; best reported',
+            'other_configs_graphs_per_s': others}
+
+
+def planner_leg(n_host, n_device, dev):
+    """north_star: "collision checks and the sequential planner control flow stay on the host CPU and are timed in the
+    same run (core count stated)".  Reference split first -- GNN forwards on the GPU, sampling + greedy loop + every
+    collision check + steering on ONE host core (planner.explore, the eval_gnn.py:168-276 counterpart) -- then the same
+    problems with the planner itself on the device (planner.explore_maze_batch).  2-D maze problems of the reference's
+    published run (mazes_hard.npz, batch = t_max = 500, k = 30, smoothing on)."""
+    import numpy as np
+    import gnnmp
+    from gnnmp import planner
+    from gnnmp.maze2d import Maze2D
+    from gnnmp.weights import load_weights
+    with np.load(os.path.join(REPO, 'tests', 'golden', 'evalset_mazehard_first1000.npz')) as f:
+        env = Maze2D(f['maps'], f['init_states'], f['goal_states'])
+    m = gnnmp.EncoderProcessDecoder(2, 2, 32, 2)
+    m.load_state_dict(load_weights('weights_maze'))
+    ms = gnnmp.ModelSmoother(workspace_size=2, config_size=2, embed_size=128, obs_size=6)
+    ms.load_state_dict(load_weights('smooth_2d_attv3'))
+    np.random.seed(1234)
+    env.init_new_problem(0)
+    planner.explore(env, m, ms, True, batch=500, t_max=500, k=30, device=dev)                    # warm-up
+    fwd = tot = 0.0
+    checks = 0
+    t0 = time.perf_counter()
+    for i in range(n_host):
+        env.init_new_problem(i)
+        r = planner.explore(env, m, ms, True, batch=500, t_max=500, k=30, device=dev)
+        fwd += r['forward']; tot += r['total']; checks += r['c_explore'] + r['c_smooth']
+    wall_host = time.perf_counter() - t0
+    np.random.seed(1234)
+    planner.eval_gnn_device(env, range(min(n_device, 64)), m, ms, device=dev)                     # warm-up
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    out = planner.eval_gnn_device(env, range(n_device), m, ms, device=dev)
+    torch.cuda.synchronize(dev)
+    wall_dev = time.perf_counter() - t0
+    return {'problems': 'mazes_hard.npz (2-D maze), batch = t_max = 500, k = 30, smoothing on',
+            'host_loop': {'problems': n_host, 'problems_per_s': round(n_host / wall_host, 2), 'host_cores': 1,
+                          'gnn_forward_ms_per_problem': round(1e3 * fwd / n_host, 2),
+                          'host_ms_per_problem': round(1e3 * (tot - fwd) / n_host, 2),
+                          'collision_checks_per_problem': round(checks / n_host, 1),
+                          'what': 'dense drop-in forward on the GPU; sampling, greedy loop, collision checks, steering on one host core'},
+            'device_planner': {'problems': n_device, 'problems_per_s': round(n_device / wall_dev, 1), 'host_cores': 1,
+                               'success': int(out[0]), 'collision_checks_per_problem': round(out[1], 2),
+                               'what': 'sampling on one host core; graphs, forwards, greedy loop, collision checks, steering on the GPU'}}
 
 
 def main():
@@ -112,6 +174,8 @@ def main():
                     help='extra steps timed in the opt-in bf16x3 mode (fp32-class results from the bf16 matrix pipe, '
                          'DESIGN.md 4.2b); reported next to, never instead of, `value`; only with --mlp-dtype fp32')
     ap.add_argument('--unique', type=int, default=0, help='distinct synthetic graphs per GPU (0 = all)')
+    ap.add_argument('--planner-problems', type=int, default=8,
+                    help='host-loop planner problems timed next to the forward benchmark (0 = skip the planner leg)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -296,6 +360,8 @@ def main():
                          'frac': round(achieved / peak, 4), 'traffic': traffic if args.mlp_dtype == 'fp32' else None,
                          'launch_ms': round(ep_avg_ms, 4), 'algorithmic_flops_per_launch': ep_flops},
         }
+        if world == 1 and args.planner_problems > 0 and (args.env, args.mlp_dtype) == ('maze2', 'fp32'):
+            res['config']['planner'] = planner_leg(args.planner_problems, 512, dev)
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(args.env, args.nodes, args.k1, args.cpu_seconds, 1234)
         print(json.dumps(res), flush=True)
