@@ -364,8 +364,18 @@ void pack_explorer(const Blob& B, const gnnmp_explorer_dims& dm, gnnmp_explorer*
         for (int b = 0; b < 3; ++b) {
             const std::string p = sname + "." + std::to_string(b);
             float* a = att + (size_t)b * A::size;
-            tiles(W(p + ".attention.query.weight"), D, 0, a + A::wq);
-            tiles(W(p + ".attention.key.weight"), D, 0, a + A::wk);
+            // Wqk = Wq^T Wk (see AttBlob): [d, d], Wqk[i][j] = sum_c Wq[c][i] Wk[c][j]
+            std::vector<float> wqk((size_t)D * D);
+            {
+                const float *wq = W(p + ".attention.query.weight"), *wk = W(p + ".attention.key.weight");
+                for (int i = 0; i < D; ++i)
+                    for (int j = 0; j < D; ++j) {
+                        double acc = 0.0;
+                        for (int c2 = 0; c2 < D; ++c2) acc += (double)wq[(size_t)c2 * D + i] * (double)wk[(size_t)c2 * D + j];
+                        wqk[(size_t)i * D + j] = (float)acc;
+                    }
+            }
+            tiles(wqk.data(), D, 0, a + A::wqk);
             tiles(W(p + ".attention.value.weight"), D, 0, a + A::wv);
             vec(W(p + ".attention.layer_norm.weight"), a + A::ln1g);
             vec(W(p + ".attention.layer_norm.bias"), a + A::ln1b);
@@ -376,7 +386,7 @@ void pack_explorer(const Blob& B, const gnnmp_explorer_dims& dm, gnnmp_explorer*
             vec(W(p + ".map_feed.layer_norm.weight"), a + A::ln2g);
             vec(W(p + ".map_feed.layer_norm.bias"), a + A::ln2b);
             float* q = ob + L.blk0 + (size_t)b * L.blk_stride;
-            tiles(W(p + ".attention.key.weight"), D, 0, q + L.wk);
+            tiles(wqk.data(), D, 0, q + L.wk);                       // obstacle keys are premultiplied: K' = Wqk code
             tiles(W(p + ".attention.value.weight"), D, 0, q + L.wv);
             tiles(W(p + ".obs_feed.w_1.weight"), D, 0, q + L.fw1);
             vec(W(p + ".obs_feed.w_1.bias"), q + L.fb1);
@@ -631,7 +641,7 @@ struct PrePlan { int waves, ot_chunk, wregion; size_t lds_bytes; };
 // blob sizes by (d, precision): T = (d/32)^2 * tile_unit(P), V = d
 int out_e_size(int D, int P) { return 3 * tile_floats(D, P) + 2 * vec_floats(D); }
 int out_n_size(int D, int P) { return 5 * tile_floats(D, P) + 4 * vec_floats(D); }
-int att_staged(int D, int P) { return 5 * tile_floats(D, P); }
+int att_staged(int D, int P) { return 4 * tile_floats(D, P); }
 
 PrePlan plan_pre(int D, int P, int ot_max, int enc_size, int out_size, bool use_obs) {
     const int NT = D / 32;
@@ -760,8 +770,14 @@ int forward_impl(const gnnmp_explorer* h, const gnnmp_batch* b, int loop, int us
         p.tile_meta = q.tile_meta;
         p.G = c.G;
         const size_t res_bytes = ((size_t)3 * (att_staged(D, P) + 6 * vec_floats(D)) + (size_t)3 * c.kv_stride) * sizeof(float) + 64;
+        p.out_in_lds = 0;
         if (((D == 32 && P == 0) || P == 1) && use_obs && res_bytes <= 163840 && h->resident) {
-            HIP_TRY(launch_pre_resident(D, P, edge != 0, p, res_bytes, h->n_cu, st));
+            size_t lds_bytes = res_bytes;
+            if (res_bytes + (size_t)p.out_size * sizeof(float) <= 163840) {      // the epilogue weights fit as well
+                p.out_in_lds = 1;
+                lds_bytes += (size_t)p.out_size * sizeof(float);
+            }
+            HIP_TRY(launch_pre_resident(D, P, edge != 0, p, lds_bytes, h->n_cu, st));
             continue;
         }
         HIP_TRY(launch_pre(D, P, edge != 0, pl.waves, p, (edge ? c.Epad : c.Npad) / 32, pl.lds_bytes, st));

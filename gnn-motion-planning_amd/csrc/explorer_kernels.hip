@@ -452,22 +452,21 @@ __device__ __forceinline__ void attention_block(const float* wl, const float* wg
     using L = AttBlob<D, P>;
     const int h = lane >> 5;
     const int OT = (O + 31) / 32;
-    f32x16 Q[NT], acc[NT];
+    f32x16 acc[NT];
     float mx, psum;
+    BOp<P> mop[NT];                                             // one conversion / split of m feeds Wqk, Wv and the logits
+    make_ops<P, NT>(m, mop);
     {
-        f32x16 Km[NT];
+        f32x16 Tq[NT];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) { Q[t] = splat16(0.f); Km[t] = splat16(0.f); acc[t] = splat16(0.f); }
-        BOp<P> mop[NT];                                         // one conversion / split of m feeds Wq, Wk and Wv
-        make_ops<P, NT>(m, mop);
-        linear_acc_ops<P, NT, NT>(wl + L::wq, mop, Q, lane);
-        linear_acc_ops<P, NT, NT>(wl + L::wk, mop, Km, lane);
+        for (int t = 0; t < NT; ++t) { Tq[t] = splat16(0.f); acc[t] = splat16(0.f); }
+        linear_acc_ops<P, NT, NT>(wl + L::wqk, mop, Tq, lane);  // Wqk m: the self logit is m . (Wqk m)
         linear_acc_ops<P, NT, NT>(wl + L::wv, mop, acc, lane);  // acc starts as 1 * V_self
         float l0 = 0.f;
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) l0 = fmaf(Q[t][r], Km[t][r], l0);
+            for (int r = 0; r < 16; ++r) l0 = fmaf(m[t][r], Tq[t][r], l0);
         l0 = xsum(l0);
         // softmax(x / sqrt(d)) evaluated as exp2((x - max) * log2(e) / sqrt(d))
         mx = l0;
@@ -475,9 +474,7 @@ __device__ __forceinline__ void attention_block(const float* wl, const float* wg
     }
     const float cs = 1.4426950408889634f / sqrtf((float)D);
     const int chunk_floats = ot_chunk * NT * TF;
-    BOp<P> qop[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) qop[t] = BOp<P>(Q[t]);
+    const BOp<P> (&qop)[NT] = mop;                              // obstacle keys are premultiplied with Wqk (obs_kernel)
     for (int c0 = 0; c0 < OT; c0 += ot_chunk) {
         const int c1 = min(OT, c0 + ot_chunk);
         if (c0 > 0) {       // first chunk was staged together with the weights
@@ -673,6 +670,7 @@ __global__ __launch_bounds__(WAVES * 64) void pre_resident_kernel(PreParams p) {
     float* wl = lds;                                           // [3][AB::size]: matrices AND the six vectors of a block
     float* kvl = lds + 3 * AB::size;                           // [3][kv_stride]
     int* ctr = reinterpret_cast<int*>(kvl + 3 * (size_t)p.kv_stride);
+    float* outl = reinterpret_cast<float*>(ctr) + 16;          // epilogue blob, when the launch reserved room (p.out_in_lds)
     const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
     const int C = p.C;
     const int total = p.ptr_pad_total[p.G] / 32;               // padded 32-row tiles actually in use
@@ -683,6 +681,7 @@ __global__ __launch_bounds__(WAVES * 64) void pre_resident_kernel(PreParams p) {
     const int t1 = min(total, t0 + share);
     if (t0 >= t1) return;
     stage(wl, p.att, 3 * AB::size);
+    if (p.out_in_lds) stage(outl, p.out, p.out_size);
     const EncBlob E = p.encb;
     while (t0 < t1) {
         const int g = p.tile_graph[t0];
@@ -703,7 +702,7 @@ __global__ __launch_bounds__(WAVES * 64) void pre_resident_kernel(PreParams p) {
             // encoder / epilogue weights are MFMA operands read from global memory; laundering the pointers per tile
             // keeps the compiler from hoisting those loop-invariant loads out of the tile loop into dozens of registers
             const float* enc_w = p.enc;
-            const float* out_w = p.out;
+            const float* out_w = p.out_in_lds ? outl : p.out;
             if constexpr (D > 32) asm volatile("" : "+s"(enc_w), "+s"(out_w));    // d = 32: registers to spare, hoisting pays
             f32x16 m[NT], aux[NT];
             if constexpr (EDGE) {

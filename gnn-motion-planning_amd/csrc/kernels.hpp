@@ -54,6 +54,7 @@ struct PreParams {
     const int* tile_meta;       // per 32-edge tile (EDGE only)
     int G;
     int use_obstacles;
+    int out_in_lds;          // resident variant: the epilogue blob is staged into LDS too (it fits)
     float *o0, *o1, *o2, *o3, *o4;
     float* om;               // optional: the attention output itself (node_free_code / edge_free_code after the 3 blocks),
                              // row-major [rows of this launch's padded index space, d]: frozen input of the training path

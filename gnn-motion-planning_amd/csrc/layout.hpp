@@ -25,15 +25,17 @@ __host__ __device__ constexpr int small_floats(int D, int ksteps, int P = 0) {
     return (D / 32) * ksteps * (P == 0 ? 64 : (P == 1 ? 256 : 768));
 }
 
-// One attention Block (model.py:204-218).  The five DxD matrices come first and are what gets staged
-// into LDS (`staged` floats); the six D-vectors behind them are read straight from global memory
-// (768 B at d = 32: keeping them out of LDS is what lets three workgroups share a CU at O <= 128).
+// One attention Block (model.py:204-218).  The query and key projections only ever meet in inner products
+// (model.py:173-174: q . k_map and q . k_obstacle), so they are stored as ONE matrix Wqk = Wq^T Wk (product in double,
+// rounded once): logits = m . (Wqk code_o) against obstacle keys that obs_kernel premultiplies with the same matrix, self
+// logit = m . (Wqk m) -- one d x d product per row instead of two, with fewer roundings than the reference's
+// (Wq m) . (Wk m).  The four DxD matrices come first (`staged` floats), the six D-vectors behind them.
 template <int D, int P = 0>
 struct AttBlob {
     static constexpr int T = tile_floats(D, P), V = vec_floats(D);
-    static constexpr int wq = 0, wk = T, wv = 2 * T, w1 = 3 * T, w2 = 4 * T, staged = 5 * T;
-    static constexpr int ln1g = 5 * T, ln1b = 5 * T + V, b1 = 5 * T + 2 * V, b2 = 5 * T + 3 * V, ln2g = 5 * T + 4 * V,
-                         ln2b = 5 * T + 5 * V, size = 5 * T + 6 * V;
+    static constexpr int wqk = 0, wv = T, w1 = 2 * T, w2 = 3 * T, staged = 4 * T;
+    static constexpr int ln1g = 4 * T, ln1b = 4 * T + V, b1 = 4 * T + 2 * V, b2 = 4 * T + 3 * V, ln2g = 4 * T + 4 * V,
+                         ln2b = 4 * T + 5 * V, size = 4 * T + 6 * V;
 };
 
 // Two Seq(Lin, ReLU, Lin) encoders on raw inputs (node_code + node_free_code, or edge_code +

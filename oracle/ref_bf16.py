@@ -39,18 +39,22 @@ def _ffn(w, pre, x):
     return _ln(w, pre + '.layer_norm', y + x)
 
 
+def _wqk(w, a):
+    """The kernels' combined query-key matrix: Wq^T Wk, product in double, rounded to fp32 once (api.cpp)."""
+    return (w[a + '.query.weight'].double().T @ w[a + '.key.weight'].double()).float()
+
+
 def _attention(w, pre, m, ko, vo):
     """ko, vo: bf16-rounded obstacle keys / values [O, d] (as stored in the K/V slabs).  Online softmax over
     32-obstacle tiles exactly like attention_block (p is rounded relative to the running maximum)."""
     d = m.shape[1]
     a = pre + '.attention'
-    q = lin(m, w[a + '.query.weight'])
-    km = lin(m, w[a + '.key.weight'])
+    tq = lin(m, _wqk(w, a))                                  # Wqk m with Wqk = Wq^T Wk (layout.hpp AttBlob)
     acc = lin(m, w[a + '.value.weight'])
-    mx = (q * km).sum(-1)
+    mx = (m * tq).sum(-1)                                    # self logit m . (Wqk m)
     psum = torch.ones_like(mx)
     cs = math.log2(math.e) / math.sqrt(d)
-    qb = r(q)
+    qb = r(m)                                                # obstacle keys are premultiplied: ko = r(Wqk code)
     for o0 in range(0, ko.shape[0], 32):
         s = qb @ ko[o0:o0 + 32].T
         nmx = torch.maximum(mx, s.max(-1).values)
@@ -82,8 +86,8 @@ def explorer_forward_bf16(w, v, goal, obstacles, edge_index, loop, use_obstacles
         on, oe = _mlp2(w, 'obs_node_code', ob), _mlp2(w, 'obs_edge_code', ob)
         for b in range(3):
             pn, pe = 'node_attentions.%d' % b, 'edge_attentions.%d' % b
-            nf = _attention(w, pn, nf, r(lin(on, w[pn + '.attention.key.weight'])), r(lin(on, w[pn + '.attention.value.weight'])))
-            ef = _attention(w, pe, ef, r(lin(oe, w[pe + '.attention.key.weight'])), r(lin(oe, w[pe + '.attention.value.weight'])))
+            nf = _attention(w, pn, nf, r(lin(on, _wqk(w, pn + '.attention'))), r(lin(on, w[pn + '.attention.value.weight'])))
+            ef = _attention(w, pe, ef, r(lin(oe, _wqk(w, pe + '.attention'))), r(lin(oe, w[pe + '.attention.value.weight'])))
             on, oe = _ffn(w, pn + '.obs_feed', on), _ffn(w, pe + '.obs_feed', oe)
     gi = int(knn(v, g, 1)[1][0])
     we, wd, w1, p0, wl1 = (w['encoder.weight'], w['decoder.weight'], w['process.lin_0.0.weight'], w['policy.0.weight'],
