@@ -492,20 +492,45 @@ __device__ __forceinline__ void attention_block(const float* wl, const float* wg
             // fp32 MFMA and VALU share the SIMD's issue time (tools/microbench/mfma_chain.hip), so every VALU
             // instruction here costs MFMA throughput: mask only the one partial tile, fold the scale into an
             // fma, and skip the accumulator rescale while the running maximum does not move.
-            if ((ot + 1) * 32 > O) {                     // wave-uniform: only the last tile can hold padding obstacles
+            float nmx, ps;
+            if (P == 1 && O - ot * 32 <= 8) {
+                // wave-uniform: at most eight obstacles in this tile (the robot-arm environments have five boxes):
+                // obstacle phi(r, h) lives in registers 0..3 only, the softmax arithmetic runs on those four.  Compiled
+                // into the bf16 kernels only (the bf16 configs are the robot arms; in the fp32 maze kernel the extra
+                // branch cost 1.7 % through code layout alone)
+                float tmax = -INFINITY;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) s[r] = ((ot * 32 + phi(r, h)) < O) ? s[r] : -INFINITY;
+                for (int r = 0; r < 4; ++r) {
+                    s[r] = ((ot * 32 + phi(r, h)) < O) ? s[r] : -INFINITY;
+                    tmax = fmaxf(tmax, s[r]);
+                }
+                tmax = xmax(tmax);
+                nmx = fmaxf(mx, tmax);
+                const float off = -nmx * cs;
+                ps = 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], cs, off));
+                    ps += s[r];
+                }
+#pragma unroll
+                for (int r = 4; r < 16; ++r) s[r] = 0.f;
+            } else {
+                if ((ot + 1) * 32 > O) {                 // wave-uniform: only the last tile can hold padding obstacles
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s[r] = ((ot * 32 + phi(r, h)) < O) ? s[r] : -INFINITY;
+                }
+                float tmax = s[0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, s[r]);
+                tmax = xmax(tmax);
+                nmx = fmaxf(mx, tmax);
+                const float off = -nmx * cs;
+                s = s * cs + off;                           // packed fmas
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(s[r]);
+                ps = tree_sum(s);
             }
-            float tmax = s[0];
-#pragma unroll
-            for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, s[r]);
-            tmax = xmax(tmax);
-            const float nmx = fmaxf(mx, tmax);
-            const float off = -nmx * cs;
-            s = s * cs + off;                               // packed fmas
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(s[r]);
-            const float ps = tree_sum(s);
             const int nq = min(4, (O - ot * 32 + 7) >> 3);
             const BOp<P> pop(s);
             if (__builtin_amdgcn_ballot_w64(nmx != mx) != 0) {      // some row's maximum moved: rescale (alpha = 1 elsewhere)

@@ -1,8 +1,10 @@
 """Training path of the explorer: gradients of the HIP backward against torch.autograd
 through the CPU oracle with the reference's detach points (model.py:141,142,146), fp64-anchored:
 
-    |g_gpu - g_oracle64| <= 1e-4 * max|g_oracle64| + 1e-6    per parameter tensor   (fp32 sums of ~10^3-10^4 terms with
-                                                              float atomics; the fp32 oracle itself is at 1e-6..1e-5)
+    |g_gpu - g_oracle64| <= max(1e-4 * max|g_oracle64|, 4 * own) + 1e-6    per parameter tensor,
+    own = max|g_oracle32 - g_oracle64|: the same oracle run in fp32 (fp32 sums of ~10^3-10^4 terms with float atomics;
+    relu masks and the arg-max of the max-aggregation react to last-digit differences of the forward, so the fp32
+    oracle's own deviation is the natural unit, as for the forward bar)
 
 on the 64-node goldens of every checkpoint family, for a random linear loss and for the reference's loss form
 (-log_softmax over a frontier row set, train_explorer.py:174); frozen parameters get no gradient; the forward of the
@@ -66,6 +68,7 @@ def test_gradients_match_oracle(path):
         assert torch.allclose(s.detach(), s_inf, rtol=1e-5, atol=2e-5)      # same function as the inference path
         loss_fn(s).backward()
         _, g64 = _oracle_grads(w, r, L, loss_fn, torch.float64)
+        _, g32 = _oracle_grads(w, r, L, loss_fn, torch.float32)
         worst = 0.0
         for pname, p in m.named_parameters():
             top = pname.split('.')[0]
@@ -77,8 +80,9 @@ def test_gradients_match_oracle(path):
             assert p.grad is not None, pname
             scale = float(ref.abs().max())
             err = float((p.grad.cpu().double() - ref).abs().max())
+            own = float((g32[pname].double() - ref).abs().max())
             worst = max(worst, err / (scale + 1e-30))
-            assert err <= 1e-4 * scale + 1e-6, (name, pname, err, scale)
+            assert err <= max(1e-4 * scale, 4.0 * own) + 1e-6, (name, pname, err, scale, own)
         print('\n%s, %s loss: worst relative gradient error %.2e' % (os.path.basename(path), name, worst))
 
 
