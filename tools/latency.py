@@ -23,15 +23,20 @@ def model_for(env):
     return m, e
 
 
-def timeit(fn, n=30, warm=5):
+def timeit(fn, n=30, warm=5, reps=5):
+    """Median over `reps` timed blocks of n calls (this pool shows sporadic multi-millisecond stalls that are unrelated to
+    the kernels: round 1's "smoother bf16 C=14 batch 256 = 5.858 ms" line was one of them, tools/diag/smoother_c14.py)."""
     for _ in range(warm):
         fn()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(n):
-        fn()
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / n
+    ts = []
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) / n)
+    return sorted(ts)[len(ts) // 2]
 
 
 def single(env, n, k):
@@ -49,18 +54,19 @@ def single(env, n, k):
                                                                fb * 1e3, d2h * 1e3, rep * 1e3))
 
 
-def batched(env, n, k, G, uniq=16):
+def batched(env, n, k, G, uniq=16, dtype='fp32'):
     import gc
     gc.collect()
     torch.cuda.empty_cache()          # the previous configuration's workspace (GBs) must not be reclaimed inside the timing
     m, e = model_for(env)
+    m.mlp_dtype = dtype
     base = [synth_graph(env, n, k, seed=1234 + i) for i in range(uniq)]
     b = gnnmp.GraphBatch.from_graphs([base[i % uniq] for i in range(G)], e['S'], dev)
     m.profile(dev, True)
     t = timeit(lambda: m.forward_batch(b, 5), n=10, warm=5)
     prof = m.profile_read(dev)
-    print('%-7s N=%-5d k1=%-3d batch %-4d: %.3f ms/step = %.1f graphs/s   stages(ms/step): %s' %
-          (env, n, k, G, t * 1e3, G / t, {kk: round(v[0] / 15, 3) for kk, v in prof.items()}))
+    print('%-7s N=%-5d k1=%-3d %s batch %-4d: %.3f ms/step = %.1f graphs/s   stages(ms/step): %s' %
+          (env, n, k, dtype, G, t * 1e3, G / t, {kk: round(v[0] / max(v[1] // max(1, {'mp': 5}.get(kk, 1)), 1), 3) for kk, v in prof.items()}))
 
 
 def smoother(name, C, P=20, F=500, Co=500, B=256, scale=1.0):
@@ -94,6 +100,8 @@ if __name__ == '__main__':
     batched('maze2', 200, 6, 256)
     batched('kuka7', 2000, 10, 64)       # configs[2] shape (fp32 here)
     batched('kuka14', 5000, 16, 32, uniq=4)     # configs[4] shape (fp32 here)
+    batched('kuka7', 2000, 10, 64, dtype='bf16')       # configs[2]
+    batched('kuka14', 5000, 16, 32, uniq=4, dtype='bf16')     # configs[4]
     batched('ur5', 1000, 8, 256)
     batched('snake7', 1000, 8, 256)
     smoother('smooth_2d_attv3', 2)
