@@ -123,7 +123,7 @@ def planner_leg(n_host, n_device, dev):
         env = Maze2D(f['maps'], f['init_states'], f['goal_states'])
     m = gnnmp.EncoderProcessDecoder(2, 2, 32, 2)
     m.load_state_dict(load_weights('weights_maze'))
-    ms = gnnmp.ModelSmoother(workspace_size=2, config_size=2, embed_size=128, obs_size=6)
+    ms = gnnmp.ModelSmoother(workspace_size=2, config_size=2, embed_size=128, obs_size=6).eval()
     ms.load_state_dict(load_weights('smooth_2d_attv3'))
     np.random.seed(1234)
     env.init_new_problem(0)

@@ -82,6 +82,11 @@ def lib():
     L.gnnmp_explorer_workspace_bytes.argtypes = [vp, ctypes.POINTER(Batch), ctypes.POINTER(sz)]
     L.gnnmp_explorer_forward.argtypes = [vp, ctypes.POINTER(Batch), ctypes.c_int, ctypes.c_int, vp, vp, vp, sz, vp]
     L.gnnmp_explorer_debug_tap.argtypes = [vp, ctypes.POINTER(Batch), ctypes.c_int, vp, vp, sz, vp]
+    L.gnnmp_smoother_grad_floats.restype = ctypes.c_int64
+    L.gnnmp_smoother_grad_floats.argtypes = [vp]
+    L.gnnmp_smoother_train_workspace_bytes.argtypes = [vp, ctypes.POINTER(SmoothBatch), ctypes.c_int, ctypes.POINTER(sz)]
+    L.gnnmp_smoother_train_forward.argtypes = [vp, ctypes.POINTER(SmoothBatch), ctypes.c_int, vp, vp, vp, sz, vp]
+    L.gnnmp_smoother_train_backward.argtypes = [vp, ctypes.POINTER(SmoothBatch), ctypes.c_int, vp, vp, vp, sz, vp]
     L.gnnmp_explorer_grad_floats.restype = ctypes.c_int64
     L.gnnmp_explorer_grad_floats.argtypes = [vp]
     L.gnnmp_explorer_train_workspace_bytes.argtypes = [vp, ctypes.POINTER(Batch), ctypes.c_int, ctypes.POINTER(sz)]
@@ -138,3 +143,18 @@ def manifest(kind, dims):
         check(fn(ctypes.byref(dims), i, buf, 256, ctypes.byref(numel)), 'gnnmp_%s_manifest' % kind)
         out.append((buf.value.decode(), int(numel.value)))
     return out
+
+
+class NativeHandle:
+    """Owns one gnnmp_*_create handle: destroyed when the last reference goes (the module drops its reference when the
+    weights change; an autograd graph keeps the handle its forward ran with until its backward is done)."""
+
+    def __init__(self, ptr, destroy):
+        self._as_parameter_ = ptr            # ctypes passes this where a void* is expected
+        self._destroy = destroy
+
+    def __del__(self):
+        try:
+            self._destroy(self._as_parameter_)
+        except Exception:
+            pass

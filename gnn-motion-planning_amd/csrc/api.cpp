@@ -879,6 +879,10 @@ struct gnnmp_smoother {
     int device;
     float* w_dev;
     SmLayout L;
+    float* w_raw_dev;     // the caller's weight blob as given (training path)
+    std::vector<Entry> man;
+    std::vector<int64_t> man_off;
+    int64_t n_raw;
 };
 
 extern "C" int gnnmp_smoother_manifest(const gnnmp_smoother_dims* dims, int index, char* name, size_t name_cap,
@@ -911,6 +915,8 @@ extern "C" int gnnmp_smoother_create(gnnmp_smoother** out, const gnnmp_smoother_
     h->dims = *dims;
     h->device = device;
     h->w_dev = nullptr;
+    h->w_raw_dev = nullptr;
+    h->man = B.man; h->man_off = B.off; h->n_raw = tot;
     const int PR = dims->mlp_dtype;
     h->L = SmLayout::make(PR, D, C);
     const SmLayout& L = h->L;
@@ -969,6 +975,8 @@ extern "C" int gnnmp_smoother_create(gnnmp_smoother** out, const gnnmp_smoother_
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) e = hipMalloc((void**)&h->w_dev, P.size() * sizeof(float));
     if (e == hipSuccess) e = hipMemcpy(h->w_dev, P.data(), P.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc((void**)&h->w_raw_dev, (size_t)tot * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(h->w_raw_dev, weights_host, (size_t)tot * sizeof(float), hipMemcpyHostToDevice);
     if (prev_dev >= 0 && prev_dev != device) (void)hipSetDevice(prev_dev);
     if (e != hipSuccess) {
         if (h->w_dev) (void)hipFree(h->w_dev);
@@ -982,6 +990,7 @@ extern "C" int gnnmp_smoother_create(gnnmp_smoother** out, const gnnmp_smoother_
 extern "C" int gnnmp_smoother_destroy(gnnmp_smoother* h) {
     if (!h) return GNNMP_ERR_NULL;
     if (h->w_dev) (void)hipFree(h->w_dev);
+    if (h->w_raw_dev) (void)hipFree(h->w_raw_dev);
     delete h;
     return GNNMP_OK;
 }
@@ -1309,6 +1318,8 @@ extern "C" int gnnmp_explorer_train_forward(const gnnmp_explorer* h, const gnnmp
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     float* T = reinterpret_cast<float*>(static_cast<char*>(ws) + t.inf_bytes);
     const int d = h->dims.embed_size, C = h->dims.config_size, Np = c.Npad, Ep = c.Epad;
+    // rows of padding tiles no kernel writes must hold finite numbers: the weight gradients sum 0 * activation over them
+    HIP_TRY(hipMemsetAsync(T, 0, t.total_floats * sizeof(float), st));
     // frozen inputs (model.py:141,142,146 detach them): node_free_code / edge_free_code after the attention stacks
     const int rc = forward_impl(h, b, loop, use_obstacles, nullptr, nullptr, ws, t.inf_bytes, hip_stream, T + t.NF, T + t.EF, true);
     if (rc != GNNMP_OK) return rc;
@@ -1422,5 +1433,204 @@ extern "C" int gnnmp_explorer_train_backward(const gnnmp_explorer* h, const gnnm
     HIP_TRY(t_linear_dx(Np, d, d, T + t.dNC, nc2.w, T + t.dX, false, st));
     HIP_TRY(t_relu_bwd((size_t)Np * d, T + t.NCh, T + t.dX, st));
     HIP_TRY(t_linear_dw(Np, 4 * C, d, T + t.dX, T + t.NCin, nc0.gw, nc0.gb, st));
+    return GNNMP_OK;
+}
+
+// =============================================================================================
+// training path of the smoother (train_smoother.py:33-61; model_smoother.py:104-142 under model.train())
+// =============================================================================================
+namespace {
+
+struct SmTrainCarve {
+    size_t inf_bytes;
+    int Nn, K0, ecap;
+    // floats from the start of the train region
+    size_t states, it0, it_stride, Xin, X0, stats, X1, X, esrc, edst, ne, Zh, S, L1h, Hh;
+    size_t Zin, M, dZh, dZin, dX, dX1, dX0, dXin, dS, dL1h, dHh, prop, dprop, dpa, dpb, tmpP;
+    size_t total_floats;
+};
+
+bool sm_train_carve(const gnnmp_smoother* h, const gnnmp_smooth_batch* b, int loop, const SmCarve& c, SmTrainCarve& t) {
+    const size_t d = h->dims.embed_size, C = h->dims.config_size, P = b->total_path;
+    t.Nn = b->total_path + b->total_free + b->total_collided;
+    t.K0 = (int)C + 3;
+    t.ecap = c.ecap;
+    const size_t Nn = t.Nn, Ec = t.ecap, K0 = t.K0;
+    size_t o = 0;
+    auto take = [&](size_t n) { const size_t r = o; o += (n + 63) & ~(size_t)63; return r; };
+    t.inf_bytes = (c.total + 255) & ~(size_t)255;
+    t.states = take((size_t)(loop + 1) * P * C);
+    t.it0 = o;
+    t.Xin = take(Nn * K0) - t.it0; t.X0 = take(Nn * d) - t.it0; t.stats = take(3 * d) - t.it0; t.X1 = take(Nn * d) - t.it0;
+    t.X = take(Nn * d) - t.it0; t.esrc = take(Ec) - t.it0; t.edst = take(Ec) - t.it0; t.ne = take(64) - t.it0;
+    t.Zh = take(Ec * d) - t.it0; t.S = take(P * d) - t.it0; t.L1h = take(P * d) - t.it0; t.Hh = take(P * d) - t.it0;
+    t.it_stride = o - t.it0;
+    o = t.it0 + t.it_stride * (size_t)(loop > 0 ? loop : 1);
+    t.Zin = take(Ec * 3 * d); t.M = take(Ec * d); t.dZh = take(Ec * d); t.dZin = take(Ec * 3 * d);
+    t.dX = take(Nn * d); t.dX1 = take(Nn * d); t.dX0 = take(Nn * d); t.dXin = take(Nn * K0);
+    t.dS = take(P * d); t.dL1h = take(P * d); t.dHh = take(P * d); t.prop = take(P * C); t.dprop = take(P * C);
+    t.dpa = take(P * C); t.dpb = take(P * C); t.tmpP = take(P * d);
+    t.total_floats = o;
+    return true;
+}
+
+struct SmW { const float* w; const float* b; float* gw; float* gb; };
+SmW sm_wref(const gnnmp_smoother* h, float* grad, const std::string& name) {
+    SmW r{nullptr, nullptr, nullptr, nullptr};
+    for (size_t i = 0; i < h->man.size(); ++i) {
+        if (h->man[i].name == name + ".weight") { r.w = h->w_raw_dev + h->man_off[i]; r.gw = grad ? grad + h->man_off[i] : nullptr; }
+        if (h->man[i].name == name + ".bias") { r.b = h->w_raw_dev + h->man_off[i]; r.gb = grad ? grad + h->man_off[i] : nullptr; }
+    }
+    return r;
+}
+
+bool sm_train_ok(const gnnmp_smoother* h, const gnnmp_smooth_batch* b) {
+    return b->n_problems == 1 && b->total_path >= 1 && h->dims.mlp_dtype == GNNMP_F32 && b->max_samples <= 2048;
+}
+
+void sm_fill_params(const gnnmp_smoother* h, const gnnmp_smooth_batch* b, const SmCarve& c, void* ws, SmParams& p) {
+    p.B = 1; p.C = h->dims.config_size; p.total_path = b->total_path; p.total_edges = b->total_edges;
+    p.scale = h->dims.scale;
+    p.path = b->path; p.free_pts = b->free_pts; p.collided = b->collided;
+    p.edge_index = reinterpret_cast<const long long*>(b->edge_index);
+    p.path_ptr = b->path_ptr; p.free_ptr = b->free_ptr; p.coll_ptr = b->coll_ptr; p.edge_ptr = b->edge_ptr;
+    p.w = h->w_dev; p.L = h->L;
+    p.knn = at<int>(ws, c.knn);
+    p.e_src = at<int>(ws, c.e_src); p.e_dst = at<int>(ws, c.e_dst); p.e_count = at<int>(ws, c.e_count);
+    p.seg_beg = at<int>(ws, c.seg_beg); p.seg_cnt = at<int>(ws, c.seg_cnt);
+    p.etile_prob = at<int>(ws, c.etile); p.ptile_prob = at<int>(ws, c.ptile);
+    p.msg = at<float>(ws, c.msg);
+    p.cand_cap = b->max_edges + kSmK * b->max_path;
+    if (p.cand_cap < 1) p.cand_cap = 1;
+    p.n_etiles = c.ecap / 32; p.n_ptiles = c.pcap / 32;
+}
+
+}  // namespace
+
+extern "C" int64_t gnnmp_smoother_grad_floats(const gnnmp_smoother* h) { return h ? h->n_raw : GNNMP_ERR_NULL; }
+
+extern "C" int gnnmp_smoother_train_workspace_bytes(const gnnmp_smoother* h, const gnnmp_smooth_batch* shape, int loop, size_t* bytes) {
+    if (!h || !shape || !bytes) return GNNMP_ERR_NULL;
+    if (loop < 0) return GNNMP_ERR_ARG;
+    if (!sm_train_ok(h, shape)) return GNNMP_ERR_DIMS;
+    SmCarve c;
+    if (!sm_carve(h, shape, c)) return GNNMP_ERR_ARG;
+    SmTrainCarve t;
+    sm_train_carve(h, shape, loop, c, t);
+    *bytes = t.inf_bytes + t.total_floats * sizeof(float);
+    return GNNMP_OK;
+}
+
+extern "C" int gnnmp_smoother_train_forward(const gnnmp_smoother* h, const gnnmp_smooth_batch* b, int loop, float* out_path,
+                                            float* bn_stats, void* ws, size_t ws_bytes, void* hip_stream) {
+    if (!h || !b || !ws || !out_path) return GNNMP_ERR_NULL;
+    if (loop < 0) return GNNMP_ERR_ARG;
+    if (!sm_train_ok(h, b)) return GNNMP_ERR_DIMS;
+    SmCarve c;
+    if (!sm_carve(h, b, c)) return GNNMP_ERR_ARG;
+    SmTrainCarve t;
+    sm_train_carve(h, b, loop, c, t);
+    if (ws_bytes < t.inf_bytes + t.total_floats * sizeof(float) || (reinterpret_cast<uintptr_t>(ws) & 255)) return GNNMP_ERR_WORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    float* T = reinterpret_cast<float*>(static_cast<char*>(ws) + t.inf_bytes);
+    const int d = h->dims.embed_size, C = h->dims.config_size, P = b->total_path, F = b->total_free, Co = b->total_collided;
+    const int Nn = t.Nn, K0 = t.K0, Ec = t.ecap;
+    SmParams p;
+    sm_fill_params(h, b, c, ws, p);
+    if ((size_t)2 * p.cand_cap * sizeof(int) > 60000) return GNNMP_ERR_DIMS;
+    const SmW nc0 = sm_wref(h, nullptr, "node_code.0"), bn = sm_wref(h, nullptr, "node_code.1"), nc3 = sm_wref(h, nullptr, "node_code.3"),
+              l00 = sm_wref(h, nullptr, "process.lin_0.0"), l02 = sm_wref(h, nullptr, "process.lin_0.2"),
+              l10 = sm_wref(h, nullptr, "process.lin_1.0"), l12 = sm_wref(h, nullptr, "process.lin_1.2"), sn = sm_wref(h, nullptr, "smooth_node");
+    float* states = T + t.states;
+    HIP_TRY(hipMemsetAsync(T, 0, t.total_floats * sizeof(float), st));                         // edge slots past the count stay finite
+    HIP_TRY(launch_sm_init(P * C, p.scale, b->path, states, st));                              // model_smoother.py:118
+    for (int it = 0; it < loop; ++it) {
+        float* I = T + t.it0 + t.it_stride * (size_t)it;
+        float* cur = states + (size_t)it * P * C;
+        p.cur = cur; p.cur_next = cur;
+        HIP_TRY(hipMemsetAsync(at<char>(ws, c.ff_beg), 0xFF, c.ff_end - c.ff_beg, st));
+        HIP_TRY(launch_sm_knn_edges(p, st));                                                    // :125-128
+        HIP_TRY(hipMemcpyAsync(I + t.esrc, p.e_src, sizeof(int) * Ec, hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemcpyAsync(I + t.edst, p.e_dst, sizeof(int) * Ec, hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemcpyAsync(I + t.ne, p.e_count, sizeof(int), hipMemcpyDeviceToDevice, st));
+        const int* ne = reinterpret_cast<const int*>(I + t.ne);
+        const int* es = reinterpret_cast<const int*>(I + t.esrc);
+        const int* ed = reinterpret_cast<const int*>(I + t.edst);
+        HIP_TRY(t_sm_nodes_in(P, F, Co, C, p.scale, cur, b->free_pts, b->collided, I + t.Xin, st));   // :130-135
+        HIP_TRY(t_linear(Nn, K0, d, I + t.Xin, nc0.w, nc0.b, I + t.X0, false, st));
+        HIP_TRY(t_bn_fwd(Nn, d, I + t.X0, bn.w, bn.b, I + t.X1, I + t.stats, true, st));       // BatchNorm, batch statistics + ReLU
+        HIP_TRY(t_linear(Nn, d, d, I + t.X1, nc3.w, nc3.b, I + t.X, false, st));
+        HIP_TRY(t_sm_msg_in(ne, d, es, ed, I + t.X, T + t.Zin, Ec, st));                       // :36-37
+        HIP_TRY(t_linear(Ec, 3 * d, d, T + t.Zin, l00.w, l00.b, I + t.Zh, true, st));
+        HIP_TRY(t_linear(Ec, d, d, I + t.Zh, l02.w, l02.b, T + t.M, false, st));
+        HIP_TRY(t_fill((size_t)P * d, I + t.S, 0.f, st));
+        HIP_TRY(t_sm_scatter_add(ne, d, ed, T + t.M, I + t.S, Ec, st));                        // aggr = 'add' (:32)
+        HIP_TRY(t_linear(P, d, d, I + t.S, l10.w, l10.b, I + t.L1h, true, st));
+        HIP_TRY(t_linear(P, d, d, I + t.L1h, l12.w, l12.b, T + t.tmpP, false, st));
+        HIP_TRY(t_add_rows((size_t)P * d, I + t.X, T + t.tmpP, I + t.Hh, st));                 // x + lin_1(out) (:34), rows < P
+        HIP_TRY(t_linear(P, d, C, I + t.Hh, sn.w, sn.b, T + t.prop, false, st));
+        HIP_TRY(t_sm_path_update(P, C, cur, T + t.prop, cur + (size_t)P * C, st));             // :139
+        if (bn_stats) {
+            HIP_TRY(hipMemcpyAsync(bn_stats + (size_t)it * 2 * d, I + t.stats, sizeof(float) * d, hipMemcpyDeviceToDevice, st));
+            HIP_TRY(hipMemcpyAsync(bn_stats + (size_t)it * 2 * d + d, I + t.stats + 2 * d, sizeof(float) * d, hipMemcpyDeviceToDevice, st));
+        }
+    }
+    HIP_TRY(t_scale(P * C, p.scale, states + (size_t)loop * P * C, out_path, st));                  // :142
+    return GNNMP_OK;
+}
+
+extern "C" int gnnmp_smoother_train_backward(const gnnmp_smoother* h, const gnnmp_smooth_batch* b, int loop, const float* d_out_path,
+                                             float* grad, void* ws, size_t ws_bytes, void* hip_stream) {
+    if (!h || !b || !ws || !grad || !d_out_path) return GNNMP_ERR_NULL;
+    if (loop < 0) return GNNMP_ERR_ARG;
+    if (!sm_train_ok(h, b)) return GNNMP_ERR_DIMS;
+    SmCarve c;
+    if (!sm_carve(h, b, c)) return GNNMP_ERR_ARG;
+    SmTrainCarve t;
+    sm_train_carve(h, b, loop, c, t);
+    if (ws_bytes < t.inf_bytes + t.total_floats * sizeof(float)) return GNNMP_ERR_WORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    float* T = reinterpret_cast<float*>(static_cast<char*>(ws) + t.inf_bytes);
+    const int d = h->dims.embed_size, C = h->dims.config_size, P = b->total_path;
+    const int Nn = t.Nn, K0 = t.K0, Ec = t.ecap;
+    HIP_TRY(hipMemsetAsync(grad, 0, (size_t)h->n_raw * sizeof(float), st));
+    const SmW nc0 = sm_wref(h, grad, "node_code.0"), bn = sm_wref(h, grad, "node_code.1"), nc3 = sm_wref(h, grad, "node_code.3"),
+              l00 = sm_wref(h, grad, "process.lin_0.0"), l02 = sm_wref(h, grad, "process.lin_0.2"),
+              l10 = sm_wref(h, grad, "process.lin_1.0"), l12 = sm_wref(h, grad, "process.lin_1.2"), sn = sm_wref(h, grad, "smooth_node");
+    float* dcur = T + t.dpa;
+    float* dprev = T + t.dpb;
+    HIP_TRY(t_scale(P * C, h->dims.scale, d_out_path, dcur, st));
+    for (int it = loop - 1; it >= 0; --it) {
+        float* I = T + t.it0 + t.it_stride * (size_t)it;
+        const int* ne = reinterpret_cast<const int*>(I + t.ne);
+        const int* es = reinterpret_cast<const int*>(I + t.esrc);
+        const int* ed = reinterpret_cast<const int*>(I + t.edst);
+        HIP_TRY(t_sm_path_update_bwd(P, C, dcur, T + t.dprop, dprev, st));
+        HIP_TRY(t_linear_dw(P, d, C, T + t.dprop, I + t.Hh, sn.gw, sn.gb, st));
+        HIP_TRY(t_linear_dx(P, d, C, T + t.dprop, sn.w, T + t.dHh, false, st));
+        HIP_TRY(t_fill((size_t)Nn * d, T + t.dX, 0.f, st));
+        HIP_TRY(hipMemcpyAsync(T + t.dX, T + t.dHh, sizeof(float) * P * d, hipMemcpyDeviceToDevice, st));   // x + ...: identity branch
+        HIP_TRY(t_linear_dw(P, d, d, T + t.dHh, I + t.L1h, l12.gw, l12.gb, st));
+        HIP_TRY(t_linear_dx(P, d, d, T + t.dHh, l12.w, T + t.dL1h, false, st));
+        HIP_TRY(t_relu_bwd((size_t)P * d, I + t.L1h, T + t.dL1h, st));
+        HIP_TRY(t_linear_dw(P, d, d, T + t.dL1h, I + t.S, l10.gw, l10.gb, st));
+        HIP_TRY(t_linear_dx(P, d, d, T + t.dL1h, l10.w, T + t.dS, false, st));
+        HIP_TRY(t_sm_scatter_add_bwd(ne, d, ed, T + t.dS, T + t.M, Ec, st));                    // dM
+        HIP_TRY(t_linear_dw(Ec, d, d, T + t.M, I + t.Zh, l02.gw, l02.gb, st));
+        HIP_TRY(t_linear_dx(Ec, d, d, T + t.M, l02.w, T + t.dZh, false, st));
+        HIP_TRY(t_relu_bwd((size_t)Ec * d, I + t.Zh, T + t.dZh, st));
+        HIP_TRY(t_sm_msg_in(ne, d, es, ed, I + t.X, T + t.Zin, Ec, st));                        // Zin recomputed
+        HIP_TRY(t_linear_dw(Ec, 3 * d, d, T + t.dZh, T + t.Zin, l00.gw, l00.gb, st));
+        HIP_TRY(t_linear_dx(Ec, 3 * d, d, T + t.dZh, l00.w, T + t.dZin, false, st));
+        HIP_TRY(t_sm_msg_in_bwd(ne, d, es, ed, T + t.dZin, T + t.dX, Ec, st));
+        HIP_TRY(t_linear_dw(Nn, d, d, T + t.dX, I + t.X1, nc3.gw, nc3.gb, st));
+        HIP_TRY(t_linear_dx(Nn, d, d, T + t.dX, nc3.w, T + t.dX1, false, st));
+        HIP_TRY(t_relu_bwd((size_t)Nn * d, I + t.X1, T + t.dX1, st));
+        HIP_TRY(t_bn_bwd(Nn, d, I + t.X0, T + t.dX1, bn.w, I + t.stats, T + t.dX0, bn.gw, bn.gb, st));
+        HIP_TRY(t_linear_dw(Nn, K0, d, T + t.dX0, I + t.Xin, nc0.gw, nc0.gb, st));
+        HIP_TRY(t_linear_dx(Nn, K0, d, T + t.dX0, nc0.w, T + t.dXin, false, st));
+        HIP_TRY(t_sm_coords_bwd(P, C, T + t.dXin, dprev, st));                                  // nodes[:P] = path (:140)
+        float* sw = dcur; dcur = dprev; dprev = sw;
+    }
     return GNNMP_OK;
 }

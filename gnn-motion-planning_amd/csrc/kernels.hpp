@@ -173,6 +173,22 @@ hipError_t t_segment_max_bwd(int Npad, int D, const float* dA, const int* arg, f
 hipError_t t_scores_out(const TrainGeom& q, const float* slot_scores, float* out, hipStream_t st);
 hipError_t t_scores_in(const TrainGeom& q, const float* d_out, float* d_slot, hipStream_t st);
 
+hipError_t t_sm_nodes_in(int P, int F, int Co, int C, float scale, const float* cur, const float* free_pts, const float* coll, float* out,
+                         hipStream_t st);
+hipError_t t_bn_fwd(int N, int D, const float* x, const float* gamma, const float* beta, float* y, float* stats, bool relu, hipStream_t st);
+hipError_t t_bn_bwd(int N, int D, const float* x, const float* dy, const float* gamma, const float* stats, float* dx, float* dgamma,
+                    float* dbeta, hipStream_t st);
+hipError_t t_sm_msg_in(const int* n_edges, int D, const int* e_src, const int* e_dst, const float* X, float* out, int cap, hipStream_t st);
+hipError_t t_sm_msg_in_bwd(const int* n_edges, int D, const int* e_src, const int* e_dst, const float* dZ, float* dX, int cap, hipStream_t st);
+hipError_t t_sm_scatter_add(const int* n_edges, int D, const int* e_dst, const float* M, float* S, int cap, hipStream_t st);
+hipError_t t_sm_scatter_add_bwd(const int* n_edges, int D, const int* e_dst, const float* dS, float* dM, int cap, hipStream_t st);
+hipError_t t_add_rows(size_t n, const float* a, const float* b, float* out, hipStream_t st);
+hipError_t t_sm_path_update(int P, int C, const float* prev, const float* proposal, float* next, hipStream_t st);
+hipError_t t_sm_path_update_bwd(int P, int C, const float* d_next, float* d_proposal, float* d_prev, hipStream_t st);
+hipError_t t_sm_coords_bwd(int P, int C, const float* dXin, float* d_prev, hipStream_t st);
+hipError_t t_scale(int n, float s, const float* x, float* y, hipStream_t st);
+hipError_t launch_sm_knn_edges(const SmParams& p, hipStream_t st);      // kNN + coalesced edge list only (training path)
+
 hipError_t launch_prep(const PrepParams& q, hipStream_t st);
 hipError_t launch_obs(int D, int P, const ObsParams& p, int G, hipStream_t st);
 hipError_t launch_pre(int D, int P, bool edge, int waves, const PreParams& p, int n_tiles32, size_t lds_bytes, hipStream_t st);

@@ -339,6 +339,15 @@ static hipError_t launch_sm_iter_t(const SmParams& p, hipStream_t st) {
     return hipSuccess;
 }
 
+hipError_t launch_sm_knn_edges(const SmParams& p, hipStream_t st) {
+    hipLaunchKernelGGL(sm_knn_kernel, dim3((p.total_path + 3) / 4), dim3(256), 0, st, p);
+    LAUNCH_CHECK();
+    const size_t lds = (size_t)2 * p.cand_cap * sizeof(int);
+    hipLaunchKernelGGL(sm_edges_kernel, dim3(p.B), dim3(256), lds, st, p);
+    LAUNCH_CHECK();
+    return hipSuccess;
+}
+
 hipError_t launch_sm_iter(int D, int P, const SmParams& p, hipStream_t st) {
     switch (D) {
         case 32: return P ? launch_sm_iter_t<32, 1>(p, st) : launch_sm_iter_t<32, 0>(p, st);

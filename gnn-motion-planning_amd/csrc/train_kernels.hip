@@ -356,3 +356,213 @@ hipError_t t_scores_in(const TrainGeom& q, const float* d_out, float* d_slot, hi
 }
 
 }  // namespace gnnmp
+
+// =====================================================================================================================
+// smoother training path (train_smoother.py:33-61 through model_smoother.py:104-142 with model.train(): BatchNorm in
+// batch-statistics mode).  One problem per call, like the reference's training loop.
+// =====================================================================================================================
+namespace gnnmp {
+
+// Xin[n] = [coords of node n (path rows: current scaled path; samples: x / scale), one-hot(path, free, collided)]
+__global__ void sm_nodes_in_kernel(int P, int F, int Co, int C, float scale, const float* __restrict__ cur,
+                                   const float* __restrict__ free_pts, const float* __restrict__ coll, float* __restrict__ out) {
+    const int K = C + 3, Nn = P + F + Co;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Nn * K) return;
+    const int n = i / K, k = i % K;
+    const int kind = n < P ? 0 : (n < P + F ? 1 : 2);
+    float val;
+    if (k < C) val = kind == 0 ? cur[n * C + k] : (kind == 1 ? free_pts[(n - P) * C + k] / scale : coll[(n - P - F) * C + k] / scale);
+    else val = (k - C == kind) ? 1.f : 0.f;
+    out[i] = val;
+}
+
+// BatchNorm1d, training mode, one block per feature: y = (x - mean) * invstd * gamma + beta with the batch's biased
+// variance; stats[f] = mean, stats[D + f] = invstd, stats[2 D + f] = unbiased variance (for the running-stat update)
+__global__ __launch_bounds__(256) void bn_train_fwd_kernel(int N, int D, const float* __restrict__ x, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float eps, float* __restrict__ y,
+                                                           float* __restrict__ stats, int relu) {
+    __shared__ float red[256];
+    const int f = blockIdx.x, tid = threadIdx.x;
+    float s = 0.f;
+    for (int n = tid; n < N; n += 256) s += x[(size_t)n * D + f];
+    red[tid] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) { if (tid < off) red[tid] += red[tid + off]; __syncthreads(); }
+    const float mean = red[0] / N;
+    __syncthreads();
+    float q = 0.f;
+    for (int n = tid; n < N; n += 256) { const float dlt = x[(size_t)n * D + f] - mean; q = fmaf(dlt, dlt, q); }
+    red[tid] = q;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) { if (tid < off) red[tid] += red[tid + off]; __syncthreads(); }
+    const float var = red[0] / N;
+    const float invstd = 1.0f / sqrtf(var + eps);
+    if (tid == 0) { stats[f] = mean; stats[D + f] = invstd; stats[2 * D + f] = N > 1 ? red[0] / (N - 1) : var; }
+    const float g = gamma[f], b = beta[f];
+    for (int n = tid; n < N; n += 256) {
+        const float val = (x[(size_t)n * D + f] - mean) * invstd * g + b;
+        y[(size_t)n * D + f] = (relu && val < 0.f) ? 0.f : val;
+    }
+}
+// dx = gamma * invstd / N * (N dy - sum(dy) - xhat * sum(dy * xhat));  dgamma += sum(dy * xhat);  dbeta += sum(dy)
+__global__ __launch_bounds__(256) void bn_train_bwd_kernel(int N, int D, const float* __restrict__ x, const float* __restrict__ dy,
+                                                           const float* __restrict__ gamma, const float* __restrict__ stats,
+                                                           float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    __shared__ float r0[256], r1[256];
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const float mean = stats[f], invstd = stats[D + f];
+    float s0 = 0.f, s1 = 0.f;
+    for (int n = tid; n < N; n += 256) {
+        const float g = dy[(size_t)n * D + f];
+        s0 += g;
+        s1 = fmaf(g, (x[(size_t)n * D + f] - mean) * invstd, s1);
+    }
+    r0[tid] = s0; r1[tid] = s1;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) { if (tid < off) { r0[tid] += r0[tid + off]; r1[tid] += r1[tid + off]; } __syncthreads(); }
+    const float sum_dy = r0[0], sum_dyx = r1[0];
+    if (tid == 0) { atomicAdd(&dgamma[f], sum_dyx); atomicAdd(&dbeta[f], sum_dy); }
+    const float k = gamma[f] * invstd / N;
+    for (int n = tid; n < N; n += 256) {
+        const float xhat = (x[(size_t)n * D + f] - mean) * invstd;
+        dx[(size_t)n * D + f] = k * (N * dy[(size_t)n * D + f] - sum_dy - xhat * sum_dyx);
+    }
+}
+
+// Zin[e] = [X_s - X_t, X_s, X_t]  (model_smoother.py:36-37); edges [0, *n_edges)
+__global__ void sm_msg_in_kernel(const int* __restrict__ n_edges, int D, const int* __restrict__ e_src, const int* __restrict__ e_dst,
+                                 const float* __restrict__ X, float* __restrict__ out, int cap) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cap * 3 * D) return;
+    const int e = i / (3 * D), k = i % (3 * D);
+    float val = 0.f;
+    if (e < *n_edges) {
+        const int part = k / D, f = k % D;
+        const float xs = X[(size_t)e_src[e] * D + f], xt = X[(size_t)e_dst[e] * D + f];
+        val = part == 0 ? xs - xt : (part == 1 ? xs : xt);
+    }
+    out[i] = val;
+}
+__global__ void sm_msg_in_bwd_kernel(const int* __restrict__ n_edges, int D, const int* __restrict__ e_src, const int* __restrict__ e_dst,
+                                     const float* __restrict__ dZ, float* __restrict__ dX, int cap) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cap * D) return;
+    const int e = i / D, f = i % D;
+    if (e >= *n_edges) return;
+    const float* z = dZ + (size_t)e * 3 * D;
+    atomicAdd(&dX[(size_t)e_src[e] * D + f], z[f] + z[D + f]);
+    atomicAdd(&dX[(size_t)e_dst[e] * D + f], z[2 * D + f] - z[f]);
+}
+// S[dst] += M[e] (aggr = 'add'); adjoint dM[e] = dS[dst]
+__global__ void sm_scatter_add_kernel(const int* __restrict__ n_edges, int D, const int* __restrict__ e_dst, const float* __restrict__ M,
+                                      float* __restrict__ S, int cap) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cap * D) return;
+    const int e = i / D;
+    if (e < *n_edges) atomicAdd(&S[(size_t)e_dst[e] * D + i % D], M[i]);
+}
+__global__ void sm_scatter_add_bwd_kernel(const int* __restrict__ n_edges, int D, const int* __restrict__ e_dst, const float* __restrict__ dS,
+                                          float* __restrict__ dM, int cap) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cap * D) return;
+    const int e = i / D;
+    dM[i] = e < *n_edges ? dS[(size_t)e_dst[e] * D + i % D] : 0.f;
+}
+// z = x + y (rows R x D)
+__global__ void add_rows_kernel(size_t n, const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = a[i] + b[i];
+}
+// path_next = path_prev with rows 1 .. P-2 replaced by `proposal` (model_smoother.py:139)
+__global__ void sm_path_update_kernel(int P, int C, const float* __restrict__ prev, const float* __restrict__ proposal, float* __restrict__ next) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P * C) return;
+    const int n = i / C;
+    next[i] = (n >= 1 && n <= P - 2) ? proposal[i] : prev[i];
+}
+// adjoint: d_proposal = d_next on interior rows (0 elsewhere); d_prev = d_next on the two end rows (0 elsewhere)
+__global__ void sm_path_update_bwd_kernel(int P, int C, const float* __restrict__ d_next, float* __restrict__ d_proposal, float* __restrict__ d_prev) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P * C) return;
+    const int n = i / C;
+    const bool inner = n >= 1 && n <= P - 2;
+    d_proposal[i] = inner ? d_next[i] : 0.f;
+    d_prev[i] = inner ? 0.f : d_next[i];
+}
+// d_prev[n, c] += dXin[n, c] for path rows (the coordinates of the next iteration's path nodes ARE this path)
+__global__ void sm_coords_bwd_kernel(int P, int C, const float* __restrict__ dXin, float* __restrict__ d_prev) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P * C) return;
+    d_prev[i] += dXin[(size_t)(i / C) * (C + 3) + i % C];
+}
+__global__ void scale_rows_kernel(int n, float s, const float* __restrict__ x, float* __restrict__ y) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = x[i] * s;
+}
+
+hipError_t t_sm_nodes_in(int P, int F, int Co, int C, float scale, const float* cur, const float* free_pts, const float* coll, float* out,
+                         hipStream_t st) {
+    hipLaunchKernelGGL(sm_nodes_in_kernel, dim3(blocks((size_t)(P + F + Co) * (C + 3))), dim3(256), 0, st, P, F, Co, C, scale, cur, free_pts, coll, out);
+    TRAIN_LAUNCH_CHECK();
+    return hipSuccess;
+}
+hipError_t t_bn_fwd(int N, int D, const float* x, const float* gamma, const float* beta, float* y, float* stats, bool relu, hipStream_t st) {
+    hipLaunchKernelGGL(bn_train_fwd_kernel, dim3(D), dim3(256), 0, st, N, D, x, gamma, beta, 1e-5f, y, stats, relu ? 1 : 0);
+    TRAIN_LAUNCH_CHECK();
+    return hipSuccess;
+}
+hipError_t t_bn_bwd(int N, int D, const float* x, const float* dy, const float* gamma, const float* stats, float* dx, float* dgamma,
+                    float* dbeta, hipStream_t st) {
+    hipLaunchKernelGGL(bn_train_bwd_kernel, dim3(D), dim3(256), 0, st, N, D, x, dy, gamma, stats, dx, dgamma, dbeta);
+    TRAIN_LAUNCH_CHECK();
+    return hipSuccess;
+}
+hipError_t t_sm_msg_in(const int* n_edges, int D, const int* e_src, const int* e_dst, const float* X, float* out, int cap, hipStream_t st) {
+    hipLaunchKernelGGL(sm_msg_in_kernel, dim3(blocks((size_t)cap * 3 * D)), dim3(256), 0, st, n_edges, D, e_src, e_dst, X, out, cap);
+    TRAIN_LAUNCH_CHECK();
+    return hipSuccess;
+}
+hipError_t t_sm_msg_in_bwd(const int* n_edges, int D, const int* e_src, const int* e_dst, const float* dZ, float* dX, int cap, hipStream_t st) {
+    hipLaunchKernelGGL(sm_msg_in_bwd_kernel, dim3(blocks((size_t)cap * D)), dim3(256), 0, st, n_edges, D, e_src, e_dst, dZ, dX, cap);
+    TRAIN_LAUNCH_CHECK();
+    return hipSuccess;
+}
+hipError_t t_sm_scatter_add(const int* n_edges, int D, const int* e_dst, const float* M, float* S, int cap, hipStream_t st) {
+    hipLaunchKernelGGL(sm_scatter_add_kernel, dim3(blocks((size_t)cap * D)), dim3(256), 0, st, n_edges, D, e_dst, M, S, cap);
+    TRAIN_LAUNCH_CHECK();
+    return hipSuccess;
+}
+hipError_t t_sm_scatter_add_bwd(const int* n_edges, int D, const int* e_dst, const float* dS, float* dM, int cap, hipStream_t st) {
+    hipLaunchKernelGGL(sm_scatter_add_bwd_kernel, dim3(blocks((size_t)cap * D)), dim3(256), 0, st, n_edges, D, e_dst, dS, dM, cap);
+    TRAIN_LAUNCH_CHECK();
+    return hipSuccess;
+}
+hipError_t t_add_rows(size_t n, const float* a, const float* b, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(add_rows_kernel, dim3(blocks(n)), dim3(256), 0, st, n, a, b, out);
+    TRAIN_LAUNCH_CHECK();
+    return hipSuccess;
+}
+hipError_t t_sm_path_update(int P, int C, const float* prev, const float* proposal, float* next, hipStream_t st) {
+    hipLaunchKernelGGL(sm_path_update_kernel, dim3(blocks((size_t)P * C)), dim3(256), 0, st, P, C, prev, proposal, next);
+    TRAIN_LAUNCH_CHECK();
+    return hipSuccess;
+}
+hipError_t t_sm_path_update_bwd(int P, int C, const float* d_next, float* d_proposal, float* d_prev, hipStream_t st) {
+    hipLaunchKernelGGL(sm_path_update_bwd_kernel, dim3(blocks((size_t)P * C)), dim3(256), 0, st, P, C, d_next, d_proposal, d_prev);
+    TRAIN_LAUNCH_CHECK();
+    return hipSuccess;
+}
+hipError_t t_sm_coords_bwd(int P, int C, const float* dXin, float* d_prev, hipStream_t st) {
+    hipLaunchKernelGGL(sm_coords_bwd_kernel, dim3(blocks((size_t)P * C)), dim3(256), 0, st, P, C, dXin, d_prev);
+    TRAIN_LAUNCH_CHECK();
+    return hipSuccess;
+}
+hipError_t t_scale(int n, float s, const float* x, float* y, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(scale_rows_kernel, dim3(blocks((size_t)n)), dim3(256), 0, st, n, s, x, y);
+    TRAIN_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+}  // namespace gnnmp

@@ -154,9 +154,7 @@ class EncoderProcessDecoder(nn.Module):
 
     # ------------------------------------------------------------------ native handle
     def _drop_handle(self):
-        if getattr(self, '_handle', None):
-            _lib.lib().gnnmp_explorer_destroy(self._handle)
-        self._handle = None
+        self._handle = None                # _lib.NativeHandle: destroyed with its last reference
         self._handle_key = None
 
     def __del__(self):
@@ -230,6 +228,7 @@ class EncoderProcessDecoder(nn.Module):
         with torch.cuda.device(idx):            # the library also restores the caller's current device itself
             _lib.check(_lib.lib().gnnmp_explorer_create(ctypes.byref(h), ctypes.byref(dims), blob.data_ptr(),
                                                         blob.numel(), idx), 'gnnmp_explorer_create')
+        h = _lib.NativeHandle(h, _lib.lib().gnnmp_explorer_destroy)
         self._handle, self._handle_key = h, key
         return h
 

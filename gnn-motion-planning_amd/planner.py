@@ -262,6 +262,9 @@ def explore(env, model, model_s, smooth=True, batch=500, t_max=1000, k=30, smoot
 def eval_gnn(env, indexes, model, model_s, seed=1234, smooth=True, batch=500, t_max=500, k=30, device='cuda', **kw):
     """Counterpart of ``eval_gnn`` (eval_gnn.py:96-145): the seven per-problem numbers and their
     aggregates, same order as the reference's return tuple."""
+    model.eval()                       # eval_gnn.py:109-110
+    if model_s is not None:
+        model_s.eval()
     np.random.seed(seed)
     torch.manual_seed(seed)
     sol, paths, smooth_paths = [], [], []
@@ -317,6 +320,9 @@ def eval_gnn_device(env, indexes, model, model_s, seed=1234, batch=500, k=30, de
     ``shard = (rank, world)``: evaluate only this rank's contiguous block of ``indexes`` (``dist.shard_range``) after
     skipping the sampling of the blocks before it, so the union over ranks equals the sequential run problem by
     problem; the aggregates returned are those of the local block (gather with ``dist.gather_problem_results``)."""
+    model.eval()                       # eval_gnn.py:109-110
+    if model_s is not None:
+        model_s.eval()
     np.random.seed(seed)
     torch.manual_seed(seed)
     indexes = list(indexes)
@@ -620,6 +626,9 @@ def eval_gnn_device_rounds(env, indexes, model, model_s=None, seed=1234, batch=5
     and the problems behind it -- whose samples came from the wrong stream position -- are sampled and explored again
     from the position the sequential loop would have reached.  Per-problem outcomes therefore equal the one-by-one loop's
     (tests/test_planner_rounds_gpu.py against rows recorded from the unmodified reference)."""
+    model.eval()                       # eval_gnn.py:109-110
+    if model_s is not None:
+        model_s.eval()
     np.random.seed(seed)
     torch.manual_seed(seed)
     dim = env.config_dim

@@ -64,6 +64,67 @@ class SmoothBatch:
         return sb
 
 
+def _cbatch(sb):
+    return _lib.SmoothBatch(sb.n, sb.path.shape[0], sb.free.shape[0], sb.collided.shape[0], sb.edge_index.shape[1],
+                            sb.max_path, sb.max_samples, sb.max_edges, sb.path.data_ptr(),
+                            sb.free.data_ptr() if sb.free.numel() else None,
+                            sb.collided.data_ptr() if sb.collided.numel() else None,
+                            sb.edge_index.data_ptr() if sb.edge_index.numel() else None,
+                            sb.path_ptr.data_ptr(), sb.free_ptr.data_ptr(), sb.coll_ptr.data_ptr(), sb.edge_ptr.data_ptr())
+
+
+# parameters the reference's training loss reaches (train_smoother.py:33-61): everything forward() reads
+SMOOTHER_TRAINABLE = ('node_code.0.weight', 'node_code.0.bias', 'node_code.1.weight', 'node_code.1.bias', 'node_code.3.weight',
+                      'node_code.3.bias', 'process.lin_0.0.weight', 'process.lin_0.0.bias', 'process.lin_0.2.weight',
+                      'process.lin_0.2.bias', 'process.lin_1.0.weight', 'process.lin_1.0.bias', 'process.lin_1.2.weight',
+                      'process.lin_1.2.bias', 'smooth_node.weight', 'smooth_node.bias')
+
+
+class _TrainSmooth(torch.autograd.Function):
+    """New path [P, C] of ONE smoothing problem with gradients for the smoother's parameters, the way the reference
+    trains it (train_smoother.py:33-61, model.train()): BatchNorm with batch statistics, gradients through the loop's
+    in-place path updates.  Forward and backward run in libgnnmp.so (gnnmp_smoother_train_forward / _backward)."""
+
+    @staticmethod
+    def forward(ctx, model, sb, loop, *params):
+        dev = sb.path.device
+        h = model._native(dev)
+        cb = _cbatch(sb)
+        need = ctypes.c_size_t()
+        _lib.check(_lib.lib().gnnmp_smoother_train_workspace_bytes(h, ctypes.byref(cb), int(loop), ctypes.byref(need)),
+                   'gnnmp_smoother_train_workspace_bytes')
+        ws = torch.empty(need.value, dtype=torch.uint8, device=dev)
+        out = torch.empty_like(sb.path)
+        stats = torch.zeros(max(int(loop), 1), 2, model.embed_size, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            st = torch.cuda.current_stream().cuda_stream
+            _lib.check(_lib.lib().gnnmp_smoother_train_forward(h, ctypes.byref(cb), int(loop), out.data_ptr(), stats.data_ptr(),
+                                                               ws.data_ptr(), ws.numel(), st), 'gnnmp_smoother_train_forward')
+        ctx.model, ctx.sb, ctx.loop, ctx.ws, ctx.handle, ctx.names = model, sb, int(loop), ws, h, [n for n, _ in model._manifest]
+        ctx.mark_non_differentiable(stats)
+        return out, stats
+
+    @staticmethod
+    def backward(ctx, d_out, _d_stats):
+        model, sb, dev = ctx.model, ctx.sb, ctx.sb.path.device
+        cb = _cbatch(sb)
+        n = int(_lib.lib().gnnmp_smoother_grad_floats(ctx.handle))
+        grad = torch.empty(n, dtype=torch.float32, device=dev)
+        d_out = d_out.contiguous().float()
+        with torch.cuda.device(dev):
+            st = torch.cuda.current_stream().cuda_stream
+            _lib.check(_lib.lib().gnnmp_smoother_train_backward(ctx.handle, ctypes.byref(cb), ctx.loop, d_out.data_ptr(),
+                                                                grad.data_ptr(), ctx.ws.data_ptr(), ctx.ws.numel(), st),
+                       'gnnmp_smoother_train_backward')
+        sd = model.state_dict(keep_vars=True)
+        out, off = [], 0
+        for name, numel in model._manifest:
+            t = sd[name]
+            out.append(grad[off:off + numel].view_as(t).to(t.device) if name in SMOOTHER_TRAINABLE else None)
+            off += numel
+        return (None, None, None) + tuple(out)
+
+
 class ModelSmoother(nn.Module):
     """``ModelSmoother(workspace_size, config_size, obs_size, embed_size, scale=1.)``
     (model_smoother.py:51; ``scale=np.max(env.bound)`` only for ur5, str2name.py:40)."""
@@ -102,9 +163,7 @@ class ModelSmoother(nn.Module):
         self.register_load_state_dict_post_hook(lambda m, _k: m._drop_handle())
 
     def _drop_handle(self):
-        if getattr(self, '_handle', None):
-            _lib.lib().gnnmp_smoother_destroy(self._handle)
-        self._handle = None
+        self._handle = None                # _lib.NativeHandle: destroyed with its last reference
         self._handle_key = None
 
     def __del__(self):
@@ -148,6 +207,7 @@ class ModelSmoother(nn.Module):
         with torch.cuda.device(idx):
             _lib.check(_lib.lib().gnnmp_smoother_create(ctypes.byref(h), ctypes.byref(dims), blob.data_ptr(), blob.numel(),
                                                         idx), 'gnnmp_smoother_create')
+        h = _lib.NativeHandle(h, _lib.lib().gnnmp_smoother_destroy)
         self._handle, self._handle_key = h, key
         return h
 
@@ -158,13 +218,7 @@ class ModelSmoother(nn.Module):
         if dev.type != 'cuda':
             raise RuntimeError('gnnmp runs on the GPU only (got %s tensors); there is no CPU fallback' % dev)
         h = self._native(dev)
-        cb = _lib.SmoothBatch(sb.n, sb.path.shape[0], sb.free.shape[0], sb.collided.shape[0], sb.edge_index.shape[1],
-                              sb.max_path, sb.max_samples, sb.max_edges, sb.path.data_ptr(),
-                              sb.free.data_ptr() if sb.free.numel() else None,
-                              sb.collided.data_ptr() if sb.collided.numel() else None,
-                              sb.edge_index.data_ptr() if sb.edge_index.numel() else None,
-                              sb.path_ptr.data_ptr(), sb.free_ptr.data_ptr(), sb.coll_ptr.data_ptr(),
-                              sb.edge_ptr.data_ptr())
+        cb = _cbatch(sb)
         need = ctypes.c_size_t()
         _lib.check(_lib.lib().gnnmp_smoother_workspace_bytes(h, ctypes.byref(cb), ctypes.byref(need)),
                    'gnnmp_smoother_workspace_bytes')
@@ -178,10 +232,35 @@ class ModelSmoother(nn.Module):
                        'gnnmp_smoother_forward')
         return out
 
-    @torch.no_grad()
+    def forward_train(self, path, free, collided, obstacles=None, edge_index=None, loop=10, **kwargs):
+        """The reference's TRAINING call (train_smoother.py:52 under ``model.train()``): new path [P, C] with a
+        ``grad_fn``; BatchNorm (node_code.1) normalises with the statistics of this call's node rows in every loop
+        iteration and its running statistics are updated like torch.nn.BatchNorm1d does (momentum 0.1, unbiased
+        variance, one update per loop iteration).  fp32 only."""
+        if self.mlp_dtype != 'fp32':
+            raise RuntimeError('training runs in fp32 (mlp_dtype = %r)' % self.mlp_dtype)
+        if path.device.type != 'cuda':
+            raise RuntimeError('gnnmp runs on the GPU only (got %s tensors); there is no CPU fallback' % path.device)
+        sb = SmoothBatch([path], [free], [collided], [edge_index], path.device)
+        self._native(path.device)
+        sd = self.state_dict(keep_vars=True)
+        out, stats = _TrainSmooth.apply(self, sb, loop, *[sd[n] for n, _ in self._manifest])
+        bn = self.node_code[1]
+        with torch.no_grad():
+            for it in range(int(loop)):
+                m = 0.1 if bn.momentum is None else bn.momentum
+                bn.running_mean.mul_(1 - m).add_(stats[it, 0].to(bn.running_mean.device), alpha=m)
+                bn.running_var.mul_(1 - m).add_(stats[it, 1].to(bn.running_var.device), alpha=m)
+                bn.num_batches_tracked += 1
+        return out
+
     def forward(self, path, free, collided, obstacles=None, edge_index=None, loop=10, **kwargs):
         """Reference call (smoother.py:243): returns the new path [P, C]; ``obstacles`` and extra
         keywords are accepted and ignored like the reference does; the caller's ``path`` tensor is
-        never written (model_smoother.py:118)."""
-        sb = SmoothBatch([path], [free], [collided], [edge_index], path.device)
-        return self.forward_batch(sb, loop)
+        never written (model_smoother.py:118).  In ``train()`` mode with autograd enabled this is the training call
+        (:meth:`forward_train`); otherwise the inference kernels run (eval-mode BatchNorm, no graph)."""
+        if self.training and torch.is_grad_enabled():
+            return self.forward_train(path, free, collided, obstacles, edge_index, loop)
+        with torch.no_grad():
+            sb = SmoothBatch([path], [free], [collided], [edge_index], path.device)
+            return self.forward_batch(sb, loop)

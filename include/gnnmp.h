@@ -223,6 +223,22 @@ int gnnmp_smoother_forward(const gnnmp_smoother* h, const gnnmp_smooth_batch* ba
                            float* out_path, void* workspace, size_t workspace_bytes, void* hip_stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Training path of the smoother   (train_smoother.py:33-61 through model_smoother.py:104-142 under model.train())
+ * ------------------------------------------------------------------------------------------
+ * One problem per call (batch->n_problems == 1), fp32 handle.  The training forward differs from the inference one where
+ * the reference's does: BatchNorm (node_code.1) normalises with the statistics of THIS call's node rows (path + free +
+ * collided) in every loop iteration, and activations are kept.  bn_stats_or_null [loop][2][d] receives, per iteration, the
+ * batch mean and the UNBIASED batch variance (what a caller needs to update running_mean / running_var the way
+ * torch.nn.BatchNorm1d does).  train_backward: d loss / d out_path [P, C] -> d loss / d parameters in manifest order
+ * (gnnmp_smoother_grad_floats floats; running_mean / running_var entries stay zero).  Same workspace for both calls. */
+int64_t gnnmp_smoother_grad_floats(const gnnmp_smoother* h);
+int gnnmp_smoother_train_workspace_bytes(const gnnmp_smoother* h, const gnnmp_smooth_batch* shape, int loop, size_t* bytes);
+int gnnmp_smoother_train_forward(const gnnmp_smoother* h, const gnnmp_smooth_batch* batch, int loop, float* out_path,
+                                 float* bn_stats_or_null, void* workspace, size_t workspace_bytes, void* hip_stream);
+int gnnmp_smoother_train_backward(const gnnmp_smoother* h, const gnnmp_smooth_batch* batch, int loop, const float* d_out_path,
+                                  float* grad, void* workspace, size_t workspace_bytes, void* hip_stream);
+
+/* ------------------------------------------------------------------------------------------
  * Graph construction on the device   (create_data, eval_gnn.py:150-165; knn_graph :160,162; coalesce :164)
  * ---------------------------------------------------------------------------------------- */
 /* Graph g owns node rows [node_ptr[g], node_ptr[g+1]) of v; its first n_free[g] rows are the

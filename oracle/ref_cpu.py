@@ -229,8 +229,16 @@ def _explorer_forward(w, v, goal, obstacles, edge_index, loop, use_obstacles=Tru
 # --------------------------------------------------------------------------------------
 # smoother
 # --------------------------------------------------------------------------------------
-@torch.no_grad()
-def smoother_forward(w, path, free, collided, edge_index, loop=1, scale=1.0, taps=None, knn_input_dtype=False):
+def smoother_forward(w, path, free, collided, edge_index, loop=1, scale=1.0, taps=None, knn_input_dtype=False, training=False):
+    """Inference restatement (smoother.py:233 runs it under eval()); ``training`` = the reference's training call
+    (train_smoother.py:52 under model.train()): BatchNorm with batch statistics, autograd graph kept."""
+    if training:
+        return _smoother_forward(w, path, free, collided, edge_index, loop, scale, taps, knn_input_dtype, True)
+    with torch.no_grad():
+        return _smoother_forward(w, path, free, collided, edge_index, loop, scale, taps, knn_input_dtype, False)
+
+
+def _smoother_forward(w, path, free, collided, edge_index, loop=1, scale=1.0, taps=None, knn_input_dtype=False, training=False):
     """``ModelSmoother.forward`` (model_smoother.py:104-142); ``obstacles`` is accepted and
     ignored by the reference, so it is not a parameter here."""
     path = path / scale                                                       # :118
@@ -248,8 +256,13 @@ def smoother_forward(w, path, free, collided, edge_index, loop=1, scale=1.0, tap
         info[P:P + free.shape[0], 1] = 1
         info[P + free.shape[0]:, 2] = 1
         x = _lin(w, 'node_code.0', torch.cat((nodes, info), dim=-1))          # :135-136
-        x = F.batch_norm(x, w['node_code.1.running_mean'], w['node_code.1.running_var'],
-                         w['node_code.1.weight'], w['node_code.1.bias'], False, 0.0, 1e-5)
+        if training:
+            run = (taps or {}).get('bn_running')                                  # (mean, var) updated in place like nn.BatchNorm1d
+            x = F.batch_norm(x, run[0] if run else None, run[1] if run else None, w['node_code.1.weight'],
+                             w['node_code.1.bias'], True, 0.1, 1e-5)
+        else:
+            x = F.batch_norm(x, w['node_code.1.running_mean'], w['node_code.1.running_var'],
+                             w['node_code.1.weight'], w['node_code.1.bias'], False, 0.0, 1e-5)
         x = _lin(w, 'node_code.3', F.relu(x))
         s, t = ei[0], ei[1]
         xj, xi = x[s], x[t]

@@ -116,7 +116,7 @@ def test_cfg5_smoother_batch_both_modes():
     sb = SmoothBatch(paths, frees, colls, eis, DEV)
     outs = {}
     for dtype in ('fp32', 'bf16'):
-        ms = gnnmp.ModelSmoother(workspace_size=3, config_size=C, embed_size=128, obs_size=6, scale=1.0)
+        ms = gnnmp.ModelSmoother(workspace_size=3, config_size=C, embed_size=128, obs_size=6, scale=1.0).eval()
         ms.load_state_dict(w, strict=True)
         ms.mlp_dtype = dtype
         o1 = ms.forward_batch(sb, 1).clone()

@@ -28,7 +28,7 @@ def test_published_run_1000_problems():
     env = Maze2D(r['maps'], r['init_states'], r['goal_states'])
     m = gnnmp.EncoderProcessDecoder(2, 2, 32, 2)
     m.load_state_dict(load_weights('weights_maze'))
-    ms = gnnmp.ModelSmoother(workspace_size=2, config_size=2, embed_size=128, obs_size=6)
+    ms = gnnmp.ModelSmoother(workspace_size=2, config_size=2, embed_size=128, obs_size=6).eval()
     ms.load_state_dict(load_weights('smooth_2d_attv3'))
     rows = []
     out = planner.eval_gnn_device(env, range(1000), m, ms, seed=int(r['seed']), batch=int(r['batch']), k=int(r['k']),
@@ -67,7 +67,7 @@ def test_sharded_evaluation_equals_sequential():
     env = Maze2D(r['maps'], r['init_states'], r['goal_states'])
     m = gnnmp.EncoderProcessDecoder(2, 2, 32, 2)
     m.load_state_dict(load_weights('weights_maze'))
-    ms = gnnmp.ModelSmoother(workspace_size=2, config_size=2, embed_size=128, obs_size=6)
+    ms = gnnmp.ModelSmoother(workspace_size=2, config_size=2, embed_size=128, obs_size=6).eval()
     ms.load_state_dict(load_weights('smooth_2d_attv3'))
     whole, parts = [], []
     planner.eval_gnn_device(env, range(64), m, ms, device=DEV, rows_out=whole)
@@ -87,7 +87,7 @@ def test_second_setting_400_problems():
         ref, seed, batch, k = f['rows'], int(f['seed']), int(f['batch']), int(f['k'])
     m = gnnmp.EncoderProcessDecoder(2, 2, 32, 2)
     m.load_state_dict(load_weights('weights_maze'))
-    ms = gnnmp.ModelSmoother(workspace_size=2, config_size=2, embed_size=128, obs_size=6)
+    ms = gnnmp.ModelSmoother(workspace_size=2, config_size=2, embed_size=128, obs_size=6).eval()
     ms.load_state_dict(load_weights('smooth_2d_attv3'))
     rows = []
     planner.eval_gnn_device(env, range(ref.shape[0]), m, ms, seed=seed, batch=batch, k=k, device=DEV, rows_out=rows)

@@ -46,7 +46,7 @@ def test_device_explore_equals_host_counterpart_step_by_step():
         r = {k: f[k] for k in f.files}
     idx = [0, 3, 5]
     m = _models()
-    ms = gnnmp.ModelSmoother(workspace_size=2, config_size=2, embed_size=128, obs_size=6)
+    ms = gnnmp.ModelSmoother(workspace_size=2, config_size=2, embed_size=128, obs_size=6).eval()
     ms.load_state_dict(load_weights('smooth_2d_attv3'))
     problems = [dict(map=r['maps'][i], init_state=r['init_states'][i], goal_state=r['goal_states'][i]) for i in idx]
     np.random.seed(7)
@@ -81,7 +81,7 @@ def test_device_explore_equals_host_counterpart_step_by_step():
 
 
 def _smoother():
-    ms = gnnmp.ModelSmoother(workspace_size=2, config_size=2, embed_size=128, obs_size=6)
+    ms = gnnmp.ModelSmoother(workspace_size=2, config_size=2, embed_size=128, obs_size=6).eval()
     ms.load_state_dict(load_weights('smooth_2d_attv3'))
     return ms
 

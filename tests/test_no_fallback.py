@@ -28,7 +28,7 @@ def test_cpu_tensors_are_refused():
     ei = torch.tensor([[0, 1], [1, 0]])
     with pytest.raises(RuntimeError, match='no CPU fallback'):
         m(goal=v[1], loop=1, v=v, obstacles=torch.rand(3, 2), edge_index=ei)
-    s = gnnmp.ModelSmoother(2, 2, 6, 128)
+    s = gnnmp.ModelSmoother(2, 2, 6, 128).eval()
     with pytest.raises(RuntimeError, match='no CPU fallback'):
         s(path=v[:4], free=v, collided=v, edge_index=ei, loop=1)
 

@@ -24,7 +24,7 @@ def test_eval_set_matches_reference(sparse, gpu_graph):
     env = Maze2D(r['maps'], r['init_states'], r['goal_states'])
     m = gnnmp.EncoderProcessDecoder(2, 2, 32, 2)
     m.load_state_dict(load_weights('weights_maze'))
-    ms = gnnmp.ModelSmoother(workspace_size=2, config_size=2, embed_size=128, obs_size=6)
+    ms = gnnmp.ModelSmoother(workspace_size=2, config_size=2, embed_size=128, obs_size=6).eval()
     ms.load_state_dict(load_weights('smooth_2d_attv3'))
     np.random.seed(int(r['seed']))
     torch.manual_seed(int(r['seed']))

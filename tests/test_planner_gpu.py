@@ -29,7 +29,7 @@ def test_gpu_planner_reproduces_reference_run(path):
     env.init_new_problem(0)
     m = gnnmp.EncoderProcessDecoder(2, 2, 32, 2)
     m.load_state_dict(load_weights('weights_maze'))
-    ms = gnnmp.ModelSmoother(workspace_size=2, config_size=2, embed_size=128, obs_size=6)
+    ms = gnnmp.ModelSmoother(workspace_size=2, config_size=2, embed_size=128, obs_size=6).eval()
     ms.load_state_dict(load_weights('smooth_2d_attv3'))
     np.random.seed(int(r['seed']))
     torch.manual_seed(int(r['seed']))

@@ -40,7 +40,7 @@ def test_resample_rounds_150_problems():
     assert t_max == 3 * batch
     m = gnnmp.EncoderProcessDecoder(2, 2, 32, 2)
     m.load_state_dict(load_weights('weights_maze'))
-    ms = gnnmp.ModelSmoother(workspace_size=2, config_size=2, embed_size=128, obs_size=6)
+    ms = gnnmp.ModelSmoother(workspace_size=2, config_size=2, embed_size=128, obs_size=6).eval()
     ms.load_state_dict(load_weights('smooth_2d_attv3'))
     rows = []
     out = planner.eval_gnn_device_rounds(env, range(ref.shape[0]), m, ms, seed=seed, batch=batch, t_max=t_max, k=k, device=DEV,

@@ -1,0 +1,142 @@
+"""Training path of the smoother: the reference trains ModelSmoother under model.train()
+(train_smoother.py:33-61), i.e. BatchNorm with batch statistics inside every loop iteration and gradients through the
+loop's path updates.  The HIP forward/backward is compared with torch.autograd through the CPU oracle in training mode,
+fp64-anchored like the explorer's:
+
+    forward:   allclose(rtol 1e-5, atol 1e-5) against the oracle in fp32 and fp64
+    gradients: |g_gpu - g_oracle64| <= max(1e-4 * max|g_oracle64|, 4 * own) + 1e-6 per parameter tensor,
+               own = max|g_oracle32 - g_oracle64|
+    BatchNorm running statistics after the call = what nn.BatchNorm1d leaves (momentum 0.1, unbiased variance, one update
+    per loop iteration)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_files, load_weights
+import gnnmp
+from gnnmp.smoother import SMOOTHER_TRAINABLE
+from oracle import ref_cpu
+from test_smoother_parity import CONF, chain_edges, make
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+FILES = [p for p in golden_files('smoother_') if 'knn32' not in p]
+
+
+def _oracle(w, r, scale, loss_fn, dtype, loop):
+    wd = {k: (t.to(dtype).clone().requires_grad_(True) if t.is_floating_point() and 'running' not in k else t)
+          for k, t in w.items()}
+    run = (w['node_code.1.running_mean'].to(dtype).clone(), w['node_code.1.running_var'].to(dtype).clone())
+    taps = {'bn_running': run}
+    out = ref_cpu.smoother_forward(wd, torch.from_numpy(r['path']).to(dtype), torch.from_numpy(r['free']).to(dtype),
+                                   torch.from_numpy(r['collided']).to(dtype), torch.from_numpy(r['edge_index']), loop,
+                                   scale, taps=taps, training=True)
+    loss_fn(out).backward()
+    return out.detach(), {k: t.grad for k, t in wd.items() if torch.is_tensor(t) and t.requires_grad}, run
+
+
+@pytest.mark.parametrize('path', FILES, ids=os.path.basename)
+@pytest.mark.parametrize('loop_override', [None, 3])
+def test_gradients_match_oracle(path, loop_override):
+    with np.load(path) as f:
+        r = {k: f[k] for k in f.files}
+    name = os.path.basename(path).split('_P')[0].replace('smoother_', '')
+    loop = int(r['loop']) if loop_override is None else loop_override
+    if loop_override is not None and loop == int(r['loop']):
+        pytest.skip('same as the recorded loop count')
+    C, scale = CONF[name]
+    w = load_weights(name)
+    m = make(name)
+    m.train()
+    P = r['path'].shape[0]
+    target = torch.from_numpy(r['out_fp64'])                                 # any fixed target: the loss form of :59
+
+    def loss(o):
+        return torch.nn.functional.mse_loss(target.to(o.dtype).to(o.device)[1:-1], o[1:-1])
+
+    out = m(path=torch.from_numpy(r['path']).to(DEV), free=torch.from_numpy(r['free']).to(DEV),
+            collided=torch.from_numpy(r['collided']).to(DEV), obstacles=None,
+            edge_index=torch.from_numpy(r['edge_index']).to(DEV), loop=loop)
+    assert out.requires_grad and out.shape == (P, C)
+    loss(out).backward()
+    o64, g64, run64 = _oracle(w, r, scale, loss, torch.float64, loop)
+    o32, g32, _ = _oracle(w, r, scale, loss, torch.float32, loop)
+    e = (out.detach().cpu().double() - o64).abs().max().item()
+    assert torch.allclose(out.detach().cpu().double(), o64, rtol=1e-5, atol=1e-5), e
+    assert torch.allclose(out.detach().cpu(), o32, rtol=1e-5, atol=1e-5)
+    worst = 0.0
+    sd = m.state_dict(keep_vars=True)
+    trained = {id(sd[k]) for k in SMOOTHER_TRAINABLE}                        # bn2 IS node_code.1 (model_smoother.py:63,65)
+    for k, p in sd.items():
+        if not isinstance(p, torch.nn.Parameter) or (k not in SMOOTHER_TRAINABLE and id(p) in trained):
+            continue
+        if k not in SMOOTHER_TRAINABLE:
+            assert p.grad is None, k
+            continue
+        assert p.grad is not None, k
+        ref = g64[k]
+        own = (g32[k].double() - ref).abs().max().item()
+        bar = max(1e-4 * ref.abs().max().item(), 4 * own) + 1e-6
+        err = (p.grad.cpu().double() - ref).abs().max().item()
+        worst = max(worst, err / bar)
+        assert err <= bar, (k, err, bar, own)
+    print('\n%s loop %d: forward err %.2e, worst gradient err/bar %.2f' % (os.path.basename(path), loop, e, worst))
+    bn = m.node_code[1]
+    assert int(bn.num_batches_tracked) == int(w['node_code.1.num_batches_tracked']) + loop
+    assert torch.allclose(bn.running_mean.cpu().double(), run64[0], rtol=1e-5, atol=1e-6)
+    assert torch.allclose(bn.running_var.cpu().double(), run64[1], rtol=1e-5, atol=1e-6)
+
+
+def test_eval_mode_and_no_grad_take_the_inference_path():
+    path = FILES[0]
+    with np.load(path) as f:
+        r = {k: f[k] for k in f.files}
+    name = os.path.basename(path).split('_P')[0].replace('smoother_', '')
+    m = make(name)
+    args = dict(path=torch.from_numpy(r['path']).to(DEV), free=torch.from_numpy(r['free']).to(DEV),
+                collided=torch.from_numpy(r['collided']).to(DEV), obstacles=None,
+                edge_index=torch.from_numpy(r['edge_index']).to(DEV), loop=int(r['loop']))
+    m.eval()
+    a = m(**args)
+    assert not a.requires_grad
+    m.train()
+    with torch.no_grad():
+        b = m(**args)
+    assert torch.equal(a, b)                                                 # the reference's eval() numbers either way
+    c = m(**args)
+    assert c.requires_grad and not torch.equal(a, c)                         # batch statistics change the numbers
+
+
+def test_sgd_step_moves_the_loss_down():
+    """One optimizer step the way train_smoother.py:33-61 takes it (loss over a few problems, one backward)."""
+    name = 'smooth_2d_attv3'
+    m = make(name)
+    m.train()
+    sd = m.state_dict(keep_vars=True)
+    opt = torch.optim.SGD(list({id(sd[k]): sd[k] for k in SMOOTHER_TRAINABLE}.values()), lr=1e-3)
+    gen = torch.Generator().manual_seed(3)
+    probs = []
+    for P in (8, 12, 20):
+        path = torch.rand(P, 2, generator=gen) * 2 - 1
+        tgt = path.clone()
+        tgt[1:-1] = 0.5 * (path[:-2] + path[2:])
+        probs.append(dict(path=path.to(DEV), free=(torch.rand(60, 2, generator=gen) * 2 - 1).to(DEV),
+                          collided=(torch.rand(40, 2, generator=gen) * 2 - 1).to(DEV), obstacles=None,
+                          edge_index=chain_edges(P).to(DEV), loop=2, target=tgt.to(DEV)))
+
+    def total():
+        loss = 0.
+        for q in probs:
+            a = {k: v for k, v in q.items() if k != 'target'}
+            loss = loss + torch.nn.functional.mse_loss(q['target'][1:-1], m(**a)[1:-1])
+        return loss / len(probs)
+
+    before = total()
+    opt.zero_grad()
+    before.backward()
+    opt.step()
+    m.refresh_weights()
+    after = total()
+    assert after.item() < before.item(), (before.item(), after.item())

@@ -26,7 +26,7 @@ def test_bf16_smoother(path):
         r = {k: f[k] for k in f.files}
     name = os.path.basename(path).split('_P')[0].replace('smoother_', '')
     C, scale = CONF[name]
-    m = gnnmp.ModelSmoother(workspace_size=3, config_size=C, embed_size=128, obs_size=6, scale=scale)
+    m = gnnmp.ModelSmoother(workspace_size=3, config_size=C, embed_size=128, obs_size=6, scale=scale).eval()
     m.load_state_dict(load_weights(name))
     m.mlp_dtype = 'bf16'
     args = [torch.from_numpy(r[k]) for k in ('path', 'free', 'collided', 'edge_index')]

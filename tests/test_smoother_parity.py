@@ -19,7 +19,7 @@ CONF = {'smooth_2d_attv3': (2, 1.0), 'smooth_7d_attv3': (7, 1.0), 'smooth_ur5_at
 
 def make(name):
     C, scale = CONF[name]
-    m = gnnmp.ModelSmoother(workspace_size=3, config_size=C, embed_size=128, obs_size=6, scale=scale)
+    m = gnnmp.ModelSmoother(workspace_size=3, config_size=C, embed_size=128, obs_size=6, scale=scale).eval()
     m.load_state_dict(load_weights(name), strict=True)
     return m
 

@@ -14,7 +14,7 @@ for name, C in (('smooth_2d_attv3', 2), ('smooth_7d_attv3', 7), ('smooth_13d_att
         if only and ('%d%s' % (C, dtype)) not in only:
             continue
         gen = torch.Generator().manual_seed(3)
-        ms = gnnmp.ModelSmoother(workspace_size=3, config_size=C, embed_size=128, obs_size=6, scale=1.0)
+        ms = gnnmp.ModelSmoother(workspace_size=3, config_size=C, embed_size=128, obs_size=6, scale=1.0).eval()
         ms.load_state_dict(load_weights(name)); ms.mlp_dtype = dtype
         mk = lambda n: (torch.rand(n, C, generator=gen) * 2 - 1)
         B = 256

@@ -79,7 +79,7 @@ def smoother(name, C, P=20, F=500, Co=500, B=256, scale=1.0):
     torch.cuda.empty_cache()
     gen = torch.Generator().manual_seed(3)
     for dtype in ('fp32', 'bf16'):
-        ms = gnnmp.ModelSmoother(workspace_size=3, config_size=C, embed_size=128, obs_size=6, scale=scale)
+        ms = gnnmp.ModelSmoother(workspace_size=3, config_size=C, embed_size=128, obs_size=6, scale=scale).eval()
         ms.load_state_dict(load_weights(name))
         ms.mlp_dtype = dtype
         mk = lambda n: (torch.rand(n, C, generator=gen) * 2 - 1)          # noqa: E731

@@ -48,7 +48,7 @@ for path in sorted(glob.glob(os.path.join(REPO, 'tests', 'golden', 'smoother_*.n
     name = os.path.basename(path).split('_P')[0].replace('smoother_', '')
     C, scale = SM[name]
     for mode in [m for m in modes if m != 'bf16x3']:
-        m = gnnmp.ModelSmoother(workspace_size=3, config_size=C, embed_size=128, obs_size=6, scale=scale)
+        m = gnnmp.ModelSmoother(workspace_size=3, config_size=C, embed_size=128, obs_size=6, scale=scale).eval()
         m.load_state_dict(load_weights(name), strict=True)
         m.mlp_dtype = mode
         out = m(path=torch.from_numpy(r['path']).to(DEV), free=torch.from_numpy(r['free']).to(DEV),

@@ -41,7 +41,7 @@ def main():
     dev = 'cuda:0'
     m = gnnmp.EncoderProcessDecoder(2, 2, 32, 2)
     m.load_state_dict(load_weights('weights_maze'))
-    ms = gnnmp.ModelSmoother(workspace_size=2, config_size=2, embed_size=128, obs_size=6)
+    ms = gnnmp.ModelSmoother(workspace_size=2, config_size=2, embed_size=128, obs_size=6).eval()
     ms.load_state_dict(load_weights('smooth_2d_attv3'))
     if a.device_explore:
         probs = [dict(map=maps[i % maps.shape[0]], init_state=init[i % maps.shape[0]], goal_state=goal[i % maps.shape[0]])

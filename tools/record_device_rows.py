@@ -19,7 +19,7 @@ with np.load(os.path.join(REPO, 'tests', 'golden', 'evalset_mazehard_first1000.n
 env = Maze2D(r['maps'], r['init_states'], r['goal_states'])
 m = gnnmp.EncoderProcessDecoder(2, 2, 32, 2)
 m.load_state_dict(load_weights('weights_maze'))
-ms = gnnmp.ModelSmoother(workspace_size=2, config_size=2, embed_size=128, obs_size=6)
+ms = gnnmp.ModelSmoother(workspace_size=2, config_size=2, embed_size=128, obs_size=6).eval()
 ms.load_state_dict(load_weights('smooth_2d_attv3'))
 rows = []
 planner.eval_gnn_device(env, range(64), m, ms, seed=int(r['seed']), batch=int(r['batch']), k=int(r['k']), device='cuda:0',
