@@ -261,6 +261,7 @@ struct gnnmp_explorer {
     StageProf* prof;      // mutable side state (profiling is single-threaded by contract)
     int n_cu;             // compute units of the device (persistent-kernel grid)
     int resident;         // use pre_resident_kernel when it fits (GNNMP_RESIDENT=0 disables)
+    int resident_both;    // small batches: node and edge pre stages in one launch (GNNMP_PRE_BOTH=0 disables)
     float* w_raw_dev;     // the caller's weight blob as given (manifest order, torch row-major): the training path's view
     std::vector<Entry> man;
     std::vector<int64_t> man_off;
@@ -512,6 +513,8 @@ extern "C" int gnnmp_explorer_create(gnnmp_explorer** out, const gnnmp_explorer_
         if (h->n_cu < 8) h->n_cu = 8;
         const char* env = std::getenv("GNNMP_RESIDENT");
         h->resident = !(env && env[0] == '0');
+        const char* env2 = std::getenv("GNNMP_PRE_BOTH");
+        h->resident_both = !(env2 && env2[0] == '0');
     }
     if (e == hipSuccess) e = hipMalloc((void**)&h->w_dev, packed.size() * sizeof(float));
     if (e == hipSuccess) e = hipMemcpy(h->w_dev, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice);
@@ -710,9 +713,6 @@ int forward_impl(const gnnmp_explorer* h, const gnnmp_batch* b, int loop, int us
     PrepParams q;
     {
     StageScope sc(prof, GNNMP_STAGE_PREP, st);
-    HIP_TRY(hipMemsetAsync(at<char>(ws, c.zero_beg), 0, c.zero_end - c.zero_beg, st));
-    HIP_TRY(hipMemsetAsync(at<char>(ws, c.ff_beg), 0xFF, c.ff_end - c.ff_beg, st));
-
     q.G = c.G; q.E = b->total_edges; q.C = C;
     q.edge_index = reinterpret_cast<const long long*>(b->edge_index);
     q.node_ptr = b->node_ptr; q.edge_ptr = b->edge_ptr; q.v = b->v; q.goal = b->goal;
@@ -723,7 +723,8 @@ int forward_impl(const gnnmp_explorer* h, const gnnmp_batch* b, int loop, int us
     q.csr = at<int4>(ws, c.csr);
     q.goal_node = at<int>(ws, c.goal_node);
     q.tile_meta = at<int>(ws, c.tile_meta); q.n_etiles = c.Epad / 32;
-    HIP_TRY(launch_prep(q, st));
+    HIP_TRY(launch_prep(q, c.Npad, c.Epad, at<char>(ws, c.zero_beg), c.zero_end - c.zero_beg, at<char>(ws, c.ff_beg),
+                        c.ff_end - c.ff_beg, st));
     // zero-fill of policy_output (model.py:148); sum_g N_g^2 is read from dense_ptr[G] on the device
     if (dense) HIP_TRY(launch_zero_dense(dense, q.dense_ptr + c.G, st));
     }
@@ -740,8 +741,13 @@ int forward_impl(const gnnmp_explorer* h, const gnnmp_batch* b, int loop, int us
         HIP_TRY(launch_obs(D, P, op, c.G, st));
     }
 
+    PreParams pp[2];
+    PrePlan plan[2];
+    size_t res_lds[2] = {0, 0};                            // LDS bytes of the resident variant, 0 = not applicable
+    const size_t res_bytes = ((size_t)3 * (att_staged(D, P) + 6 * vec_floats(D)) + (size_t)3 * c.kv_stride) * sizeof(float) + 64;
+    const bool resident_ok = ((D == 32 && P == 0) || P == 1) && use_obs && res_bytes <= 163840 && h->resident;
     for (int edge = 0; edge < 2; ++edge) {
-        PreParams p;
+        PreParams& p = pp[edge];
         p.v = b->v; p.goal = b->goal; p.C = C;
         p.node_ptr = b->node_ptr; p.node_ptr_pad = q.node_ptr_pad;
         p.tile_graph = edge ? q.etile_graph : q.ntile_graph;
@@ -755,32 +761,45 @@ int forward_impl(const gnnmp_explorer* h, const gnnmp_batch* b, int loop, int us
         p.out_size = edge ? out_e_size(D, P) : out_n_size(D, P);
         p.kv = at<float>(ws, edge ? c.kv_e : c.kv_n);
         p.kv_stride = c.kv_stride; p.ot_max = c.ot_max;
-        const PrePlan pl = plan_pre(D, P, c.ot_max, p.encb.size, p.out_size, use_obs);
-        p.ot_chunk = pl.ot_chunk; p.wregion = pl.wregion; p.use_obstacles = use_obs ? 1 : 0;
+        plan[edge] = plan_pre(D, P, c.ot_max, p.encb.size, p.out_size, use_obs);
+        p.ot_chunk = plan[edge].ot_chunk; p.wregion = plan[edge].wregion; p.use_obstacles = use_obs ? 1 : 0;
         p.om = edge ? om_edges : om_nodes;
         if (edge) { p.o0 = at<float>(ws, c.Ke); p.o1 = at<float>(ws, c.PE); p.o2 = p.o3 = p.o4 = nullptr; }
         else {
             p.o0 = at<float>(ws, c.XI); p.o1 = at<float>(ws, c.X); p.o2 = at<float>(ws, c.A);
             p.o3 = at<float>(ws, c.B); p.o4 = at<float>(ws, c.DN);
         }
-        if (edge && b->total_edges == 0) continue;
-        StageScope sc(prof, edge ? GNNMP_STAGE_EDGE_PRE : GNNMP_STAGE_NODE_PRE, st);
         // resident variant: all three blocks' weights + the graph's K/V for all three blocks in LDS
         p.ptr_pad_total = edge ? q.edge_ptr_pad : q.node_ptr_pad;
         p.tile_meta = q.tile_meta;
         p.G = c.G;
-        const size_t res_bytes = ((size_t)3 * (att_staged(D, P) + 6 * vec_floats(D)) + (size_t)3 * c.kv_stride) * sizeof(float) + 64;
         p.out_in_lds = 0;
-        if (((D == 32 && P == 0) || P == 1) && use_obs && res_bytes <= 163840 && h->resident) {
-            size_t lds_bytes = res_bytes;
+        if (resident_ok) {
+            res_lds[edge] = res_bytes;
             if (res_bytes + (size_t)p.out_size * sizeof(float) <= 163840) {      // the epilogue weights fit as well
                 p.out_in_lds = 1;
-                lds_bytes += (size_t)p.out_size * sizeof(float);
+                res_lds[edge] += (size_t)p.out_size * sizeof(float);
             }
-            HIP_TRY(launch_pre_resident(D, P, edge != 0, p, lds_bytes, h->n_cu, st));
-            continue;
         }
-        HIP_TRY(launch_pre(D, P, edge != 0, pl.waves, p, (edge ? c.Epad : c.Npad) / 32, pl.lds_bytes, st));
+    }
+    // small batches: both stages in one launch, side by side (see pre_resident_both_kernel); `share` 32-row tiles per
+    // 12-wave workgroup, as few as keep all workgroups of both roles resident at once
+    bool both_done = false;
+    if (resident_ok && D == 32 && b->total_edges > 0 && h->resident_both) {
+        const int nt = c.Npad / 32, et = c.Epad / 32;
+        for (int share = 1; share <= 12 && !both_done; ++share) {
+            const int nb = ((nt + share - 1) / share + 7) & ~7, eb = ((et + share - 1) / share + 7) & ~7;
+            if (nb + eb > h->n_cu) continue;
+            StageScope sc(prof, GNNMP_STAGE_EDGE_PRE, st);
+            HIP_TRY(launch_pre_resident_both(D, P, pp[0], pp[1], res_lds[0] > res_lds[1] ? res_lds[0] : res_lds[1], nb, eb, st));
+            both_done = true;
+        }
+    }
+    for (int edge = 0; edge < 2 && !both_done; ++edge) {
+        if (edge && b->total_edges == 0) continue;
+        StageScope sc(prof, edge ? GNNMP_STAGE_EDGE_PRE : GNNMP_STAGE_NODE_PRE, st);
+        if (res_lds[edge]) HIP_TRY(launch_pre_resident(D, P, edge != 0, pp[edge], res_lds[edge], h->n_cu, st));
+        else HIP_TRY(launch_pre(D, P, edge != 0, plan[edge].waves, pp[edge], (edge ? c.Epad : c.Npad) / 32, plan[edge].lds_bytes, st));
     }
 
     if (pre_only) return GNNMP_OK;

@@ -98,14 +98,12 @@ __device__ __forceinline__ int find_graph(const int* __restrict__ ptr, int G, in
 constexpr int kCoopMaxTiles = 1024;     // up to this many 32-node tiles, mp_fused runs one tile per workgroup of 8 waves
 constexpr int kPrepCap = 8192;
 constexpr int kPrepGraphMin = 64;      // batches of at least this many graphs take the per-graph kernel
+constexpr int kPrepSmallEdges = 24576; // smaller batches: single-launch prep up to this many edges per graph on average
 
-__global__ __launch_bounds__(1024) void prep_graph_kernel(PrepParams q) {
-    extern __shared__ int prep_lds[];                  // cnt[kPrepCap], rb[kPrepCap], scan[1024]
-    __shared__ int carry;
-    const int g = blockIdx.x, tid = threadIdx.x;
-    const int n0 = q.node_ptr_pad[g], Np = q.node_ptr_pad[g + 1] - n0;
+__device__ __forceinline__ void prep_graph_body(const PrepParams& q, int g, int n0, int Np, int e0, int e1, int* prep_lds) {
+    __shared__ int carry;                              // prep_lds: cnt[kPrepCap], rb[kPrepCap], scan[1024]
+    const int tid = threadIdx.x;
     const int c0 = q.edge_ptr[g], Eg = q.edge_ptr[g + 1] - c0;            // caller columns of this graph
-    const int e0 = q.edge_ptr_pad[g], e1 = q.edge_ptr_pad[g + 1];
     const bool in_lds = Np <= kPrepCap;
     int* cnt = in_lds ? prep_lds : q.deg + n0;
     int* rb = in_lds ? prep_lds + kPrepCap : q.row_beg + n0;
@@ -184,6 +182,88 @@ __global__ __launch_bounds__(1024) void prep_graph_kernel(PrepParams q) {
             meta = 4 | (rb[d0] < start ? 1 : 0) | (rb[dl] + cnt[dl] > start + 32 ? 2 : 0);
         }
         q.tile_meta[t] = meta;
+    }
+}
+
+__global__ __launch_bounds__(1024) void prep_graph_kernel(PrepParams q) {
+    extern __shared__ int prep_lds[];
+    const int g = blockIdx.x;
+    const int n0 = q.node_ptr_pad[g];
+    prep_graph_body(q, g, n0, q.node_ptr_pad[g + 1] - n0, q.edge_ptr_pad[g], q.edge_ptr_pad[g + 1], prep_lds);
+}
+
+// goal node of graph g: argmin_i |v_i - goal|^2, lowest index on ties (model.py:132); any power-of-two workgroup
+__device__ __forceinline__ void goal_body(int C, const float* __restrict__ v, const float* __restrict__ goal,
+                                          const int* __restrict__ node_ptr, int g, int n0_pad, int* __restrict__ goal_node) {
+    __shared__ float s_d[1024];
+    __shared__ int s_i[1024];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int n0 = node_ptr[g], n = node_ptr[g + 1] - n0;
+    float best = INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = tid; i < n; i += nt) {
+        float d = 0.f;
+        for (int c = 0; c < C; ++c) {
+            const float x = v[(size_t)(n0 + i) * C + c] - goal[(size_t)g * C + c];
+            d = fmaf(x, x, d);
+        }
+        if (d < best) { best = d; bi = i; }
+    }
+    s_d[tid] = best; s_i[tid] = bi;
+    __syncthreads();
+    for (int off = nt >> 1; off > 0; off >>= 1) {
+        if (tid < off) {
+            const float od = s_d[tid + off];
+            const int oi = s_i[tid + off];
+            if (od < s_d[tid] || (od == s_d[tid] && oi < s_i[tid])) { s_d[tid] = od; s_i[tid] = oi; }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) goal_node[g] = (n > 0) ? n0_pad + s_i[0] : -1;
+}
+
+// -----------------------------------------------------------------------------------------------------
+// Small batches (G < kPrepGraphMin graphs of moderate size -- the reference's own call pattern is ONE graph per
+// forward, eval_gnn.py:194): the whole prep stage in ONE launch.  A dependent launch costs ~5 us on this part whatever
+// it does, and the stage used to be eight of them (two fills, prefix arrays, count, scan, fill, tile metadata, goal
+// node).  Workgroup g: padded prefix arrays (every workgroup recomputes the < 64 entries it needs, workgroup 0 writes
+// them), CSR build of graph g, goal node of graph g; the last workgroup marks the tiles / slots / nodes behind the
+// last graph as unused (what the two fills were for).
+// -----------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void prep_small_kernel(PrepParams q, int Npad, int Epad) {
+    extern __shared__ int prep_lds[];
+    __shared__ int sp_n[65], sp_e[65];
+    __shared__ long long sp_d[65];
+    const int g = blockIdx.x, tid = threadIdx.x;
+    if (tid < 64) {                                    // wave 0: inclusive scans over the (< 64) graphs
+        int n = 0, e = 0;
+        long long dd = 0;
+        if (tid < q.G) {
+            const int ng = q.node_ptr[tid + 1] - q.node_ptr[tid];
+            n = round_up(ng, kPad);
+            e = round_up(q.edge_ptr[tid + 1] - q.edge_ptr[tid], kPad);
+            dd = (long long)ng * ng;
+        }
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int an = __shfl_up(n, off), ae = __shfl_up(e, off);
+            const long long ad = __shfl_up(dd, off);
+            if (tid >= off) { n += an; e += ae; dd += ad; }
+        }
+        sp_n[tid + 1] = n; sp_e[tid + 1] = e; sp_d[tid + 1] = dd;
+        if (tid == 0) { sp_n[0] = 0; sp_e[0] = 0; sp_d[0] = 0; }
+    }
+    __syncthreads();
+    if (g == 0 && tid <= q.G) { q.node_ptr_pad[tid] = sp_n[tid]; q.edge_ptr_pad[tid] = sp_e[tid]; q.dense_ptr[tid] = sp_d[tid]; }
+    const int n0 = sp_n[g], e0 = sp_e[g], e1 = sp_e[g + 1];
+    prep_graph_body(q, g, n0, sp_n[g + 1] - n0, e0, e1, prep_lds);
+    goal_body(q.C, q.v, q.goal, q.node_ptr, g, n0, q.goal_node);
+    if (g == q.G - 1) {
+        const int n_end = sp_n[q.G], e_end = sp_e[q.G];
+        for (int i = n_end + tid; i < Npad; i += 1024) { q.deg[i] = 0; q.row_beg[i] = e_end; }
+        for (int t = n_end / 32 + tid; t < Npad / 32; t += 1024) q.ntile_graph[t] = -1;
+        for (int t = e_end / 32 + tid; t < Epad / 32; t += 1024) { q.etile_graph[t] = -1; q.tile_meta[t] = -1; }
+        for (int sl = e_end + tid; sl < Epad; sl += 1024) q.csr[sl] = make_int4(-1, -1, -1, -1);
     }
 }
 
@@ -282,31 +362,7 @@ __global__ void prep_tilemeta_kernel(int n_tiles, const int4* __restrict__ csr, 
 __global__ void goal_kernel(int C, const float* __restrict__ v, const float* __restrict__ goal,
                             const int* __restrict__ node_ptr, const int* __restrict__ node_ptr_pad,
                             int* __restrict__ goal_node) {
-    __shared__ float s_d[256];
-    __shared__ int s_i[256];
-    const int g = blockIdx.x, tid = threadIdx.x;
-    const int n0 = node_ptr[g], n = node_ptr[g + 1] - n0;
-    float best = INFINITY;
-    int bi = 0x7fffffff;
-    for (int i = tid; i < n; i += 256) {
-        float d = 0.f;
-        for (int c = 0; c < C; ++c) {
-            const float x = v[(size_t)(n0 + i) * C + c] - goal[(size_t)g * C + c];
-            d = fmaf(x, x, d);
-        }
-        if (d < best) { best = d; bi = i; }
-    }
-    s_d[tid] = best; s_i[tid] = bi;
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-        if (tid < off) {
-            const float od = s_d[tid + off];
-            const int oi = s_i[tid + off];
-            if (od < s_d[tid] || (od == s_d[tid] && oi < s_i[tid])) { s_d[tid] = od; s_i[tid] = oi; }
-        }
-        __syncthreads();
-    }
-    if (tid == 0) goal_node[g] = (n > 0) ? node_ptr_pad[g] + s_i[0] : -1;
+    goal_body(C, v, goal, node_ptr, blockIdx.x, node_ptr_pad[blockIdx.x], goal_node);
 }
 
 // =====================================================================================================
@@ -340,7 +396,7 @@ __device__ __forceinline__ void ffn_(const float* w1, const float* b1, const flo
 }
 
 // =====================================================================================================
-// obs_kernel: one workgroup (4 waves) per graph; wave w owns obstacle tiles w, w+4, ...
+// obs_kernel: one workgroup (4 waves) per (graph, side); wave w owns obstacle tiles w, w+4, ...
 // Weights are read straight from global memory (this stage is ~0.1 % of the work).
 // For side in {node, edge}: code = MLP2(ob); for b in 0..2: K = Wk code, V = Wv code -> KV slab;
 // code = FFN_obs_b(code).
@@ -350,13 +406,16 @@ template <int D, int P>
 __global__ __launch_bounds__(256) void obs_kernel(ObsParams p) {
     constexpr int NT = D / 32;
     constexpr int TF = Prec<P>::TF;
-    const int g = blockIdx.x;
+    // workgroup (g, side): the node-side and edge-side obstacle stacks are independent chains of ~14 dependent layers
+    // each; side by side they halve the latency of the stage for a single graph and double the workgroups of a batch
+    const int g = blockIdx.x >> 1;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
     // max_obstacles is a caller promise; clamp so a too-small value truncates the obstacle set instead of
     // writing past the K/V slab (documented in gnnmp.h)
     const int o0 = p.obs_ptr[g], O = min(p.obs_ptr[g + 1] - o0, p.ot_max * 32);
     const int OT = (O + 31) / 32;
-    for (int side = 0; side < 2; ++side) {
+    {
+        const int side = blockIdx.x & 1;
         const float* W = p.w[side];
         const ObsBlob L = p.blob;
         float* kv_side = p.kv[side];
@@ -687,7 +746,7 @@ __global__ __launch_bounds__(WAVES * 64) void pre_kernel(PreParams p) {
 // Encoder / epilogue weights (22 KB) are read as MFMA A operands straight from global memory (L1/L2).
 // =====================================================================================================
 template <int D, int P, bool EDGE, int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void pre_resident_kernel(PreParams p) {
+__device__ __forceinline__ void pre_resident_body(const PreParams& p, const int vblock, const int vgrid) {
     constexpr int NT = D / 32;
     constexpr bool kRecomputeAux = EDGE && D == 64;
     using AB = AttBlob<D, P>;
@@ -699,9 +758,9 @@ __global__ __launch_bounds__(WAVES * 64) void pre_resident_kernel(PreParams p) {
     const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
     const int C = p.C;
     const int total = p.ptr_pad_total[p.G] / 32;               // padded 32-row tiles actually in use
-    const int nb = gridDim.x >> 3;
-    const int wg = (blockIdx.x & 7) * nb + (blockIdx.x >> 3);   // XCD-contiguous order
-    const int share = (total + gridDim.x - 1) / gridDim.x;
+    const int nb = vgrid >> 3;
+    const int wg = (vblock & 7) * nb + (vblock >> 3);           // XCD-contiguous order
+    const int share = (total + vgrid - 1) / vgrid;
     int t0 = wg * share;
     const int t1 = min(total, t0 + share);
     if (t0 >= t1) return;
@@ -828,6 +887,21 @@ __global__ __launch_bounds__(WAVES * 64) void pre_resident_kernel(PreParams p) {
     }
 }
 
+template <int D, int P, bool EDGE, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void pre_resident_kernel(PreParams p) {
+    pre_resident_body<D, P, EDGE, WAVES>(p, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// Small batches: the node and the edge pre stages are independent (both need the CSR and the K/V slabs only) and
+// neither fills the device, so ONE launch runs them side by side: workgroups [0, node_blocks) take the node role,
+// the rest the edge role.  For one 1000-node graph each stage is a ~30 us dependent chain (a wave's 32-row tile is
+// ~700 MFMAs in a row) and the two launches used to run back to back.
+template <int D, int P, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void pre_resident_both_kernel(PreParams pn, PreParams pe, int node_blocks) {
+    if ((int)blockIdx.x < node_blocks) pre_resident_body<D, P, false, WAVES>(pn, (int)blockIdx.x, node_blocks);
+    else pre_resident_body<D, P, true, WAVES>(pe, (int)blockIdx.x - node_blocks, (int)gridDim.x - node_blocks);
+}
+
 // Grid-stride over tile groups with an XCD-aware order: workgroup b runs on XCD b % 8 (observed
 // dispatch rule; used for speed only), so XCD x walks the contiguous eighth [x*per, (x+1)*per) of the
 // group space.  Consecutive groups belong to the same graphs, hence each XCD's private L2 only ever
@@ -882,6 +956,32 @@ __device__ __forceinline__ void load_edge_slot_tile(const float* base_f32_units,
         const f32x8 a = __builtin_convertvector(lo, f32x8), c = __builtin_convertvector(hi, f32x8);
 #pragma unroll
         for (int r = 0; r < 8; ++r) { x[r] = a[r]; x[8 + r] = c[r]; }
+    }
+}
+
+// the same tile kept as loaded (bf16 tiles stay packed: 8 registers instead of 16 while they wait in the prefetch queue)
+template <int P> struct KeRaw { f32x16 v; };
+template <> struct KeRaw<1> { bf16x8 lo, hi; };
+template <int P, int NT>
+__device__ __forceinline__ void load_edge_slot_raw(const float* base_f32_units, int slot, int h, int t, KeRaw<P>& r) {
+    if constexpr (P != 1) {
+        load_edge_slot_tile<P, NT>(base_f32_units, slot, h, t, r.v);
+    } else {
+        const size_t tile = (size_t)(slot >> 5);
+        const int ln = (slot & 31) + 32 * h;
+        const __bf16* b = reinterpret_cast<const __bf16*>(base_f32_units) + tile * NT * 1024 + ln * 8;
+        r.lo = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(b + (t * 2 + 0) * 512));
+        r.hi = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(b + (t * 2 + 1) * 512));
+    }
+}
+template <int P>
+__device__ __forceinline__ void expand_raw(const KeRaw<P>& r, f32x16& x) {
+    if constexpr (P != 1) {
+        x = r.v;
+    } else {
+        const f32x8 a = __builtin_convertvector(r.lo, f32x8), c = __builtin_convertvector(r.hi, f32x8);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { x[q] = a[q]; x[8 + q] = c[q]; }
     }
 }
 
@@ -1049,14 +1149,24 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((P == 2 |
         constexpr int STEP = 32 * COOP;
         const int first = beg + (kCoop ? 32 * wave : 0);
         auto src_row = [&](int rec, bool valid) { return valid ? n0 + (rec & 0x7ffffff) : t0; };
+        // K_e streams from HBM: PF tiles of a chunk are requested KD chunks ahead and wait in registers
+        constexpr int PF = (P == 1) ? NT : 1;                    // prefetched tiles per chunk (the rest is loaded in place)
+        constexpr int KD = (P == 1) ? 2 : 1;                     // chunks ahead
         int rec_c = 0, rec_n = 0;
         if (first + j < end) rec_c = p.rec32[first + j];
         if (first + STEP + j < end) rec_n = p.rec32[first + STEP + j];
-        f32x16 ke_n;
+        KeRaw<P> ke_q[KD][PF];
+        auto ke_fetch = [&](int cc, KeRaw<P> (&dst)[PF]) {      // wave-uniform cc
+            if (cc < end && !(p.dbg & 4)) {
+#pragma unroll
+                for (int t = 0; t < PF; ++t) load_edge_slot_raw<P, NT>(p.Ke, cc + j < end ? cc + j : beg, h, t, dst[t]);
+            }
+        };
         if (first < end) {
             const int mine_row = src_row(rec_c, first + j < end);
-            dma_rows<D, P>(p.A, [&](int sr) { return __builtin_amdgcn_ds_bpermute(sr * 4, mine_row); }, astage, lane);
-            load_edge_slot_tile<P, NT>(p.Ke, first + j < end ? first + j : beg, h, 0, ke_n);
+            if (!(p.dbg & 2)) dma_rows<D, P>(p.A, [&](int sr) { return __builtin_amdgcn_ds_bpermute(sr * 4, mine_row); }, astage, lane);
+#pragma unroll
+            for (int k = 0; k < KD; ++k) ke_fetch(first + k * STEP, ke_q[k]);
         }
         for (int c0 = first; c0 < end; c0 += STEP) {
             const int slot = c0 + j;
@@ -1064,16 +1174,25 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((P == 2 |
             const int rec = rec_c;
             const int dloc = valid ? ((rec >> 27) & 31) : 0;
             const int eslot = valid ? slot : beg;
-            const f32x16 ke0 = ke_n;
+            KeRaw<P> ke0[PF];
+#pragma unroll
+            for (int t = 0; t < PF; ++t) ke0[t] = ke_q[0][t];
             if (h == 0) dl[j] = dloc * D;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this chunk's A rows (and the job's B rows) have landed
+            // this chunk's A rows (and the job's B rows) have landed; with KD = 2 the next chunk's K_e tiles, requested
+            // AFTER them, may still be in flight (vector memory returns in order)
+            if constexpr (KD == 2) {
+                if (c0 + STEP < end) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PF) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
             f32x16 M[NT];
 #pragma unroll
             for (int ot = 0; ot < NT; ++ot) M[ot] = splat16(bias[ot]);
             // hidden = relu(A[src] + B[dst] + K_e), one 32-feature tile at a time, straight into the swapped MFMA
             linear_acc_stream<P, NT, true>(wl + LE::w2, [&](int it, f32x16& x) {
                 f32x16 a, b;
-                if (it == 0) x = ke0; else load_edge_slot_tile<P, NT>(p.Ke, eslot, h, it, x);
+                if (it < PF) expand_raw<P>(ke0[it < PF ? it : 0], x); else load_edge_slot_tile<P, NT>(p.Ke, eslot, h, it, x);
                 read_stage_tile<D, P>(astage, j, h, it, a);
                 read_stage_tile<D, P>(btile, dloc, h, it, b);
                 if (it == NT - 1) {
@@ -1082,10 +1201,14 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((P == 2 |
                     rec_c = rec_n;
                     if (c0 + STEP < end) {                                     // wave-uniform
                         const int mine_row = src_row(rec_c, c0 + STEP + j < end);
-                        dma_rows<D, P>(p.A, [&](int sr) { return __builtin_amdgcn_ds_bpermute(sr * 4, mine_row); }, astage, lane);
-                        load_edge_slot_tile<P, NT>(p.Ke, c0 + STEP + j < end ? c0 + STEP + j : beg, h, 0, ke_n);
+                        if (!(p.dbg & 2)) dma_rows<D, P>(p.A, [&](int sr) { return __builtin_amdgcn_ds_bpermute(sr * 4, mine_row); }, astage, lane);
                         if (c0 + 2 * STEP + j < end) rec_n = p.rec32[c0 + 2 * STEP + j];
                     }
+#pragma unroll
+                    for (int k = 0; k + 1 < KD; ++k)
+#pragma unroll
+                        for (int t = 0; t < PF; ++t) ke_q[k][t] = ke_q[k + 1][t];
+                    ke_fetch(c0 + KD * STEP, ke_q[KD - 1]);
                 }
                 x += a + b;
 #pragma unroll
@@ -1108,6 +1231,7 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((P == 2 |
                 const int4 o = *reinterpret_cast<const int4*>(dl + 8 * g4 + 4 * h);
                 off[g4 * 4 + 0] = o.x; off[g4 * 4 + 1] = o.y; off[g4 * 4 + 2] = o.z; off[g4 * 4 + 3] = o.w;
             }
+            if (!(p.dbg & 1))
 #pragma unroll
             for (int ot = 0; ot < NT; ++ot)
 #pragma unroll
@@ -1125,6 +1249,7 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((P == 2 |
         // ---- node phase.  X and R rows of the tile (contiguous, fp32) come through the two stages as well; the weights
         // (MpNBlob) are read from global memory as MFMA operands (at d = 64 the pointer is laundered per job so that the
         // compiler does not hoist those loop-invariant loads out of the job loop into ~70 registers)
+        if (p.dbg & 8) continue;
         const float* wn = p.wn;
         asm volatile("" : "+s"(wn));
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1277,7 +1402,20 @@ static hipError_t set_lds(K kernel, size_t bytes) {
                                (int)bytes);
 }
 
-hipError_t launch_prep(const PrepParams& q, hipStream_t st) {
+hipError_t launch_prep(const PrepParams& q, int Npad, int Epad, void* zero_ptr, size_t zero_bytes, void* ff_ptr, size_t ff_bytes,
+                       hipStream_t st) {
+    const size_t glds = (size_t)(2 * kPrepCap + 1024) * sizeof(int);
+    if (q.G < kPrepGraphMin && (long long)q.E <= (long long)q.G * kPrepSmallEdges) {
+        const hipError_t attr = set_lds(prep_small_kernel, glds);
+        if (attr != hipSuccess) return attr;
+        hipLaunchKernelGGL(prep_small_kernel, dim3(q.G), dim3(1024), glds, st, q, Npad, Epad);
+        LAUNCH_CHECK();
+        return hipSuccess;
+    }
+    hipError_t me = hipMemsetAsync(zero_ptr, 0, zero_bytes, st);
+    if (me != hipSuccess) return me;
+    me = hipMemsetAsync(ff_ptr, 0xFF, ff_bytes, st);
+    if (me != hipSuccess) return me;
     hipLaunchKernelGGL(prep_ptrs_kernel, dim3(1), dim3(256), 0, st, q.G, q.node_ptr, q.edge_ptr, q.node_ptr_pad,
                        q.edge_ptr_pad, q.dense_ptr);
     LAUNCH_CHECK();
@@ -1314,7 +1452,7 @@ hipError_t launch_prep(const PrepParams& q, hipStream_t st) {
 
 template <int D, int P>
 static hipError_t launch_obs_t(const ObsParams& p, int G, hipStream_t st) {
-    hipLaunchKernelGGL((obs_kernel<D, P>), dim3(G), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((obs_kernel<D, P>), dim3(2 * G), dim3(256), 0, st, p);
     LAUNCH_CHECK();
     return hipSuccess;
 }
@@ -1363,6 +1501,22 @@ static hipError_t launch_pre_resident_t(const PreParams& p, size_t lds_bytes, in
     hipLaunchKernelGGL((pre_resident_kernel<D, P, EDGE, WAVES>), dim3(n_cu), dim3(WAVES * 64), lds_bytes, st, p);
     LAUNCH_CHECK();
     return hipSuccess;
+}
+template <int D, int P>
+static hipError_t launch_pre_resident_both_t(const PreParams& pn, const PreParams& pe, size_t lds_bytes, int node_blocks, int edge_blocks,
+                                             hipStream_t st) {
+    hipError_t e = set_lds(pre_resident_both_kernel<D, P, 12>, lds_bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((pre_resident_both_kernel<D, P, 12>), dim3(node_blocks + edge_blocks), dim3(12 * 64), lds_bytes, st, pn, pe, node_blocks);
+    LAUNCH_CHECK();
+    return hipSuccess;
+}
+// both block counts are multiples of 8 (XCD walk of the body)
+hipError_t launch_pre_resident_both(int D, int P, const PreParams& pn, const PreParams& pe, size_t lds_bytes, int node_blocks,
+                                    int edge_blocks, hipStream_t st) {
+    if (D == 32 && P == 0) return launch_pre_resident_both_t<32, 0>(pn, pe, lds_bytes, node_blocks, edge_blocks, st);
+    if (D == 32 && P == 1) return launch_pre_resident_both_t<32, 1>(pn, pe, lds_bytes, node_blocks, edge_blocks, st);
+    return hipErrorInvalidValue;
 }
 // d = 32: 12 waves (3 per SIMD, <= 168 VGPRs); d = 64 (bf16 operands only -- fp32 weights do not fit): 8 waves
 hipError_t launch_pre_resident(int D, int P, bool edge, const PreParams& p, size_t lds_bytes, int n_cu, hipStream_t st) {

@@ -1,1 +1,1 @@
-for d in 0 1 2 4 8; do echo -n "dbg=$d "; GNNMP_MP_DBG=$d python bench.py --no-cpu-baseline --planner-problems 0 --pcie-steps 0 --dense-steps 0 --bf16x3-steps 0 --env kuka7 --nodes 2000 --k1 10 --graphs 64 --mlp-dtype bf16 2>&1 | tail -1 | python -c "import sys,json; r=json.loads(sys.stdin.read()); print(r['config']['stage_ms_per_step'])"; done
+for d in 0 1 2 4 8 6 7 15; do echo -n "dbg=$d "; GNNMP_MP_DBG=$d tools/cfg3.sh "$@"; done
