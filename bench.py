@@ -173,6 +173,7 @@ def main():
     ap.add_argument('--bf16x3-steps', type=int, default=5,
                     help='extra steps timed in the opt-in bf16x3 mode (fp32-class results from the bf16 matrix pipe, '
                          'DESIGN.md 4.2b); reported next to, never instead of, `value`; only with --mlp-dtype fp32')
+    ap.add_argument('--single-steps', type=int, default=50, help='single-graph latency: calls per timed block (0 = skip)')
     ap.add_argument('--unique', type=int, default=0, help='distinct synthetic graphs per GPU (0 = all)')
     ap.add_argument('--planner-problems', type=int, default=8,
                     help='host-loop planner problems timed next to the forward benchmark (0 = skip the planner leg)')
@@ -293,6 +294,30 @@ def main():
         x3_rate = G * args.bf16x3_steps / (time.perf_counter() - t1)
         model.mlp_dtype = args.mlp_dtype
 
+    # secondary: the call the reference itself makes (eval_gnn.py:194: ONE graph per forward).  Median of 5 blocks of 50
+    # back-to-back calls: prebuilt one-graph batch with per-edge scores, and the drop-in module call with the dense
+    # [N, N] result.
+    single_us = None
+    if args.single_steps > 0:
+        g0 = graphs[0]
+        b1 = model._single(g0['goal'], g0['v'], g0['obstacles'], g0['edge_index'])
+
+        def med(fn):
+            for _ in range(10):
+                fn()
+            ts = []
+            for _ in range(5):
+                torch.cuda.synchronize(dev)
+                t1 = time.perf_counter()
+                for _ in range(args.single_steps):
+                    fn()
+                torch.cuda.synchronize(dev)
+                ts.append((time.perf_counter() - t1) / args.single_steps)
+            return round(sorted(ts)[2] * 1e6, 1)
+        single_us = {'sparse_scores': med(lambda: model.forward_batch(b1, args.loop)),
+                     'dense_drop_in_call': med(lambda: model(goal=g0['goal'], loop=args.loop, v=g0['v'], obstacles=g0['obstacles'],
+                                                             edge_index=g0['edge_index']))}
+
     # final result gather (the only collective of the job): per-rank edge scores -> every rank
     checksum = float(scores.double().sum().item())
     if use_dist:
@@ -354,7 +379,8 @@ def main():
                        'pcie_inclusive_graphs_per_s_per_gpu': None if e2e is None else round(e2e, 1),
                        'pcie_inclusive_one_batch_at_a_time': None if e2e_serial is None else round(e2e_serial, 1),
                        'dense_output_graphs_per_s_per_gpu': None if dense_rate is None else round(dense_rate, 1),
-                       'bf16x3_mode_graphs_per_s_per_gpu': None if x3_rate is None else round(x3_rate, 1)},
+                       'bf16x3_mode_graphs_per_s_per_gpu': None if x3_rate is None else round(x3_rate, 1),
+                       'single_graph_us': single_us},
             'roofline': {'kernel': 'pre_resident_kernel<%d,%s,EDGE> (edge encoders + 3 obstacle-attention blocks)' % (e['d'], args.mlp_dtype),
                          'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
                          'frac': round(achieved / peak, 4), 'traffic': traffic if args.mlp_dtype == 'fp32' else None,

@@ -10,11 +10,14 @@ class GraphBatch:
     """Device-resident concatenation of G graphs: v [sumN, C], goal [G, C], obstacles [sumO, S],
     edge_index [2, sumE] (graph-local ids), node_ptr / edge_ptr / obs_ptr int32 [G+1]."""
 
-    def __init__(self, v, goal, obstacles, edge_index, node_ptr, edge_ptr, obs_ptr, max_obstacles):
+    def __init__(self, v, goal, obstacles, edge_index, node_ptr, edge_ptr, obs_ptr, max_obstacles, dense_floats=None):
         self.v, self.goal, self.obstacles, self.edge_index = v, goal, obstacles, edge_index
         self.node_ptr, self.edge_ptr, self.obs_ptr = node_ptr, edge_ptr, obs_ptr
         self.max_obstacles = int(max_obstacles)
-        self.n_graphs = int(node_ptr.numel() - 1)
+        # node_ptr None: ONE graph described by the tensor shapes alone (no prefix arrays on the device, gnnmp.h)
+        self.n_graphs = 1 if node_ptr is None else int(node_ptr.numel() - 1)
+        # sum_g N_g^2 when the host knows it (sizes the dense output without reading node_ptr back from the device)
+        self.dense_floats = int(v.shape[0]) ** 2 if (node_ptr is None and dense_floats is None) else dense_floats
 
     @property
     def total_nodes(self):
@@ -47,9 +50,12 @@ class GraphBatch:
             torch.cat(vs).contiguous().to(device), torch.cat(goals).contiguous().to(device),
             torch.cat(obs).contiguous().to(device), torch.cat(eis, dim=1).contiguous().to(device),
             prefix([x.shape[0] for x in vs]).to(device), prefix([x.shape[1] for x in eis]).to(device),
-            prefix([x.shape[0] for x in obs]).to(device), max([x.shape[0] for x in obs] + [0]))
+            prefix([x.shape[0] for x in obs]).to(device), max([x.shape[0] for x in obs] + [0]),
+            dense_floats=sum(int(x.shape[0]) ** 2 for x in vs))
 
     def split_edges(self, scores):
         """Per-graph views of a [sumE] score vector."""
+        if self.edge_ptr is None:
+            return [scores]
         ptr = self.edge_ptr.tolist()
         return [scores[ptr[i]:ptr[i + 1]] for i in range(self.n_graphs)]

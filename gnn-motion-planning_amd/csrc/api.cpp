@@ -583,7 +583,7 @@ struct Carve {
     // sizes
     int G, Npad, Epad, ot_max, kv_stride, D;
     // offsets in bytes
-    size_t node_ptr_pad, edge_ptr_pad, goal_node, dense_ptr;
+    size_t node_ptr_pad, edge_ptr_pad, goal_node, dense_ptr, in_ptrs;
     size_t zero_beg, deg, cursor, zero_end;
     size_t ff_beg, ntile_graph, etile_graph, csr, ff_end, tile_meta, rec32;
     size_t row_beg;
@@ -613,6 +613,7 @@ bool carve(const gnnmp_explorer* h, const gnnmp_batch* b, Carve& c) {
     c.edge_ptr_pad = take(sizeof(int) * (c.G + 1));
     c.goal_node = take(sizeof(int) * c.G);
     c.dense_ptr = take(sizeof(long long) * (c.G + 1));
+    c.in_ptrs = take(sizeof(int) * 6);          // prefix arrays of a single graph given by its totals (NULL prefix pointers)
     c.zero_beg = o;
     c.deg = take(sizeof(int) * c.Npad);
     c.zero_end = o;
@@ -698,7 +699,11 @@ namespace {
 int forward_impl(const gnnmp_explorer* h, const gnnmp_batch* b, int loop, int use_obstacles, float* edge_scores, float* dense,
                  void* ws, size_t ws_bytes, void* hip_stream, float* om_nodes, float* om_edges, bool pre_only) {
     if (!h || !b || !ws) return GNNMP_ERR_NULL;
-    if (!b->v || !b->goal || !b->node_ptr || !b->edge_ptr || !b->obs_ptr) return GNNMP_ERR_NULL;
+    if (!b->v || !b->goal) return GNNMP_ERR_NULL;
+    // ONE graph may be given by its totals alone (all three prefix pointers NULL): the reference's call (model.py:115)
+    // has no prefix arrays, and building them on the device costs the caller three host-to-device copies per call
+    const bool implicit = !b->node_ptr && !b->edge_ptr && !b->obs_ptr;
+    if (implicit ? b->n_graphs != 1 : (!b->node_ptr || !b->edge_ptr || !b->obs_ptr)) return GNNMP_ERR_NULL;
     if (b->total_edges > 0 && (!b->edge_index || (!edge_scores && !pre_only))) return GNNMP_ERR_NULL;
     if (use_obstacles && b->total_obstacles > 0 && !b->obstacles) return GNNMP_ERR_NULL;
     if (loop < 1) return GNNMP_ERR_ARG;                    // model.py:139-145: decode unbound for loop = 0
@@ -711,11 +716,16 @@ int forward_impl(const gnnmp_explorer* h, const gnnmp_batch* b, int loop, int us
 
     StageProf* prof = h->prof;
     PrepParams q;
+    const int* node_ptr = implicit ? at<int>(ws, c.in_ptrs) : b->node_ptr;
+    const int* edge_ptr = implicit ? at<int>(ws, c.in_ptrs) + 2 : b->edge_ptr;
+    const int* obs_ptr = implicit ? at<int>(ws, c.in_ptrs) + 4 : b->obs_ptr;
     {
     StageScope sc(prof, GNNMP_STAGE_PREP, st);
     q.G = c.G; q.E = b->total_edges; q.C = C;
     q.edge_index = reinterpret_cast<const long long*>(b->edge_index);
-    q.node_ptr = b->node_ptr; q.edge_ptr = b->edge_ptr; q.v = b->v; q.goal = b->goal;
+    q.single_out = implicit ? at<int>(ws, c.in_ptrs) : nullptr;
+    q.single_n = b->total_nodes; q.single_e = b->total_edges; q.single_o = b->total_obstacles;
+    q.node_ptr = node_ptr; q.edge_ptr = edge_ptr; q.v = b->v; q.goal = b->goal;
     q.node_ptr_pad = at<int>(ws, c.node_ptr_pad); q.edge_ptr_pad = at<int>(ws, c.edge_ptr_pad);
     q.dense_ptr = at<long long>(ws, c.dense_ptr);
     q.deg = at<int>(ws, c.deg); q.cursor = at<int>(ws, c.cursor); q.row_beg = at<int>(ws, c.row_beg);
@@ -732,7 +742,7 @@ int forward_impl(const gnnmp_explorer* h, const gnnmp_batch* b, int loop, int us
     const bool use_obs = use_obstacles != 0;
     if (use_obs) {
         ObsParams op;
-        op.obstacles = b->obstacles; op.obs_ptr = b->obs_ptr; op.S = h->dims.obs_size;
+        op.obstacles = b->obstacles; op.obs_ptr = obs_ptr; op.S = h->dims.obs_size;
         op.w[0] = W + h->off.obs_n; op.w[1] = W + h->off.obs_e;
         op.blob = h->obs;
         op.kv[0] = at<float>(ws, c.kv_n); op.kv[1] = at<float>(ws, c.kv_e);
@@ -749,11 +759,11 @@ int forward_impl(const gnnmp_explorer* h, const gnnmp_batch* b, int loop, int us
     for (int edge = 0; edge < 2; ++edge) {
         PreParams& p = pp[edge];
         p.v = b->v; p.goal = b->goal; p.C = C;
-        p.node_ptr = b->node_ptr; p.node_ptr_pad = q.node_ptr_pad;
+        p.node_ptr = node_ptr; p.node_ptr_pad = q.node_ptr_pad;
         p.tile_graph = edge ? q.etile_graph : q.ntile_graph;
         p.csr = q.csr;
         p.rec32 = at<int>(ws, c.rec32);
-        p.obs_ptr = b->obs_ptr; p.goal_node = q.goal_node;
+        p.obs_ptr = obs_ptr; p.goal_node = q.goal_node;
         p.enc = W + (edge ? h->off.enc_e : h->off.enc_n);
         p.encb = edge ? h->enc_e : h->enc_n;
         p.att = W + (edge ? h->off.att_e : h->off.att_n);
@@ -826,7 +836,7 @@ int forward_impl(const gnnmp_explorer* h, const gnnmp_batch* b, int loop, int us
     if (b->total_edges > 0) {
         PolicyParams p;
         p.csr = q.csr; p.etile_graph = q.etile_graph;
-        p.node_ptr = b->node_ptr; p.node_ptr_pad = q.node_ptr_pad; p.dense_ptr = q.dense_ptr;
+        p.node_ptr = node_ptr; p.node_ptr_pad = q.node_ptr_pad; p.dense_ptr = q.dense_ptr;
         p.PS = Abuf[cur]; p.PT = at<float>(ws, c.B); p.PE = at<float>(ws, c.PE);
         p.w = W + h->off.pol;
         p.scores = edge_scores; p.dense = dense;
@@ -856,7 +866,8 @@ extern "C" int gnnmp_explorer_debug_tap(const gnnmp_explorer* h, const gnnmp_bat
             return GNNMP_OK;
         default: return GNNMP_ERR_ARG;
     }
-    HIP_TRY(launch_unpad_rows(c.G, b->total_nodes, D, b->node_ptr, at<int>(ws, c.node_ptr_pad), at<float>(ws, src), dst, st));
+    HIP_TRY(launch_unpad_rows(c.G, b->total_nodes, D, b->node_ptr ? b->node_ptr : at<int>(ws, c.in_ptrs), at<int>(ws, c.node_ptr_pad),
+                              at<float>(ws, src), dst, st));
     return GNNMP_OK;
 }
 
@@ -1327,6 +1338,7 @@ extern "C" int gnnmp_explorer_train_workspace_bytes(const gnnmp_explorer* h, con
 extern "C" int gnnmp_explorer_train_forward(const gnnmp_explorer* h, const gnnmp_batch* b, int loop, int use_obstacles,
                                             float* edge_scores, void* ws, size_t ws_bytes, void* hip_stream) {
     if (!h || !b || !ws || (b->total_edges > 0 && !edge_scores)) return GNNMP_ERR_NULL;
+    if (!b->node_ptr || !b->edge_ptr || !b->obs_ptr) return GNNMP_ERR_NULL;     // the training path takes explicit prefix arrays
     if (loop < 1) return GNNMP_ERR_ARG;
     if (h->dims.mlp_dtype != GNNMP_F32) return GNNMP_ERR_DIMS;
     Carve c;
@@ -1382,6 +1394,7 @@ extern "C" int gnnmp_explorer_train_forward(const gnnmp_explorer* h, const gnnmp
 extern "C" int gnnmp_explorer_train_backward(const gnnmp_explorer* h, const gnnmp_batch* b, int loop, const float* d_edge_scores,
                                              float* grad, void* ws, size_t ws_bytes, void* hip_stream) {
     if (!h || !b || !ws || !grad || (b->total_edges > 0 && !d_edge_scores)) return GNNMP_ERR_NULL;
+    if (!b->node_ptr || !b->edge_ptr || !b->obs_ptr) return GNNMP_ERR_NULL;
     if (loop < 1) return GNNMP_ERR_ARG;
     Carve c;
     if (!carve(h, b, c)) return GNNMP_ERR_ARG;

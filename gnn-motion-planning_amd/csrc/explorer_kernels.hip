@@ -222,6 +222,11 @@ __device__ __forceinline__ void goal_body(int C, const float* __restrict__ v, co
     if (tid == 0) goal_node[g] = (n > 0) ? n0_pad + s_i[0] : -1;
 }
 
+__global__ void single_ptrs_kernel(int* out, int n, int e, int o) {
+    const int tid = threadIdx.x;
+    if (tid < 6) out[tid] = (tid & 1) ? (tid == 1 ? n : (tid == 3 ? e : o)) : 0;
+}
+
 // -----------------------------------------------------------------------------------------------------
 // Small batches (G < kPrepGraphMin graphs of moderate size -- the reference's own call pattern is ONE graph per
 // forward, eval_gnn.py:194): the whole prep stage in ONE launch.  A dependent launch costs ~5 us on this part whatever
@@ -235,6 +240,11 @@ __global__ __launch_bounds__(1024) void prep_small_kernel(PrepParams q, int Npad
     __shared__ int sp_n[65], sp_e[65];
     __shared__ long long sp_d[65];
     const int g = blockIdx.x, tid = threadIdx.x;
+    if (q.single_out) {                                // one graph given by its totals: its prefix arrays come first
+        if (tid < 6) q.single_out[tid] = (tid & 1) ? (tid == 1 ? q.single_n : (tid == 3 ? q.single_e : q.single_o)) : 0;
+        __threadfence();
+        __syncthreads();
+    }
     if (tid < 64) {                                    // wave 0: inclusive scans over the (< 64) graphs
         int n = 0, e = 0;
         long long dd = 0;
@@ -1157,14 +1167,14 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((P == 2 |
         if (first + STEP + j < end) rec_n = p.rec32[first + STEP + j];
         KeRaw<P> ke_q[KD][PF];
         auto ke_fetch = [&](int cc, KeRaw<P> (&dst)[PF]) {      // wave-uniform cc
-            if (cc < end && !(p.dbg & 4)) {
+            if (cc < end) {
 #pragma unroll
                 for (int t = 0; t < PF; ++t) load_edge_slot_raw<P, NT>(p.Ke, cc + j < end ? cc + j : beg, h, t, dst[t]);
             }
         };
         if (first < end) {
             const int mine_row = src_row(rec_c, first + j < end);
-            if (!(p.dbg & 2)) dma_rows<D, P>(p.A, [&](int sr) { return __builtin_amdgcn_ds_bpermute(sr * 4, mine_row); }, astage, lane);
+            dma_rows<D, P>(p.A, [&](int sr) { return __builtin_amdgcn_ds_bpermute(sr * 4, mine_row); }, astage, lane);
 #pragma unroll
             for (int k = 0; k < KD; ++k) ke_fetch(first + k * STEP, ke_q[k]);
         }
@@ -1201,7 +1211,7 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((P == 2 |
                     rec_c = rec_n;
                     if (c0 + STEP < end) {                                     // wave-uniform
                         const int mine_row = src_row(rec_c, c0 + STEP + j < end);
-                        if (!(p.dbg & 2)) dma_rows<D, P>(p.A, [&](int sr) { return __builtin_amdgcn_ds_bpermute(sr * 4, mine_row); }, astage, lane);
+                        dma_rows<D, P>(p.A, [&](int sr) { return __builtin_amdgcn_ds_bpermute(sr * 4, mine_row); }, astage, lane);
                         if (c0 + 2 * STEP + j < end) rec_n = p.rec32[c0 + 2 * STEP + j];
                     }
 #pragma unroll
@@ -1231,7 +1241,6 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((P == 2 |
                 const int4 o = *reinterpret_cast<const int4*>(dl + 8 * g4 + 4 * h);
                 off[g4 * 4 + 0] = o.x; off[g4 * 4 + 1] = o.y; off[g4 * 4 + 2] = o.z; off[g4 * 4 + 3] = o.w;
             }
-            if (!(p.dbg & 1))
 #pragma unroll
             for (int ot = 0; ot < NT; ++ot)
 #pragma unroll
@@ -1249,7 +1258,6 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((P == 2 |
         // ---- node phase.  X and R rows of the tile (contiguous, fp32) come through the two stages as well; the weights
         // (MpNBlob) are read from global memory as MFMA operands (at d = 64 the pointer is laundered per job so that the
         // compiler does not hoist those loop-invariant loads out of the job loop into ~70 registers)
-        if (p.dbg & 8) continue;
         const float* wn = p.wn;
         asm volatile("" : "+s"(wn));
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1411,6 +1419,10 @@ hipError_t launch_prep(const PrepParams& q, int Npad, int Epad, void* zero_ptr, 
         hipLaunchKernelGGL(prep_small_kernel, dim3(q.G), dim3(1024), glds, st, q, Npad, Epad);
         LAUNCH_CHECK();
         return hipSuccess;
+    }
+    if (q.single_out) {
+        hipLaunchKernelGGL(single_ptrs_kernel, dim3(1), dim3(64), 0, st, q.single_out, q.single_n, q.single_e, q.single_o);
+        LAUNCH_CHECK();
     }
     hipError_t me = hipMemsetAsync(zero_ptr, 0, zero_bytes, st);
     if (me != hipSuccess) return me;
@@ -1583,9 +1595,7 @@ static hipError_t launch_mp_fused_dp(const MpFusedParams& p, hipStream_t st) {
     return coop ? launch_mp_fused_t<D, P, 8>(p, st) : launch_mp_fused_t<D, P, 1>(p, st);
 }
 hipError_t launch_mp_fused(int D, int P, const MpFusedParams& p_in, hipStream_t st) {
-    MpFusedParams p = p_in;
-    static const int dbg = getenv("GNNMP_MP_DBG") ? atoi(getenv("GNNMP_MP_DBG")) : 0;
-    p.dbg = dbg;
+    const MpFusedParams& p = p_in;
     GNNMP_DISPATCH_DP(D, P, (launch_mp_fused_dp<DD, PP>(p, st)));
 }
 

@@ -17,6 +17,8 @@ struct PrepParams {
     int4* csr;                                   // [Epad] {source, target, caller column, 0}; -1 = pad slot
     int* goal_node;                              // [G] padded node id
     int* tile_meta;                              // per 32-edge tile, see prep_graph_kernel
+    int* single_out;                             // non-null: ONE graph given by its totals; node_ptr / edge_ptr / obs_ptr point here
+    int single_n, single_e, single_o;            //           ([0,N | 0,E | 0,O], written by the prep stage before anything reads them)
     int n_etiles;
 };
 
@@ -68,7 +70,6 @@ struct MpFusedParams {
     float *Hout, *Xout, *Aout, *Bout;
     int n_tiles;                 // 32-node tiles of the padded node space
     int store_h;
-    int dbg;
 };
 
 struct PolicyParams {

@@ -6,6 +6,7 @@ Same constructor signature, same parameter / buffer names (so ``load_state_dict`
 ``torch.nn`` layers below are parameter containers only; this class never calls them.
 """
 import ctypes
+import operator
 
 import torch
 from torch import nn
@@ -46,6 +47,9 @@ class _MPNN(nn.Module):                           # model.py:22-28
         self.lin_0 = Seq(Lin(d * 5, d), ReLU(), Lin(d, d))
         self.lin_1 = Lin(d * 2, d)
         self.bn = nn.BatchNorm1d(d)
+
+
+_VERSION = operator.attrgetter('_version')
 
 
 class _TrainScores(torch.autograd.Function):
@@ -212,8 +216,12 @@ class EncoderProcessDecoder(nn.Module):
         parameters were reloaded, moved, replaced or modified in place)."""
         wt = self._live_weights()
         idx = self._device_index(device)
-        key = (idx, self.mlp_dtype, tuple((id(t), t._version) for t in wt))
-        if self._handle is not None and key == self._handle_key:
+        # staleness check on every call, kept cheap (C-level loops; ~30 us for the 142 tensors): same tensor objects, same
+        # autograd version counters, same device / operand mode
+        key = (idx, self.mlp_dtype, list(map(_VERSION, wt)), wt)
+        hk = self._handle_key
+        if self._handle is not None and hk[0] == idx and hk[1] == key[1] and hk[2] == key[2] and len(hk[3]) == len(wt) \
+                and all(map(operator.is_, hk[3], wt)):
             return self._handle
         self._drop_handle()
         parts = []
@@ -236,8 +244,10 @@ class EncoderProcessDecoder(nn.Module):
     def _cbatch(b):
         return _lib.Batch(b.n_graphs, b.total_nodes, b.total_edges, b.total_obstacles, b.max_obstacles,
                           b.v.data_ptr(), b.goal.data_ptr(), b.obstacles.data_ptr() if b.total_obstacles else None,
-                          b.edge_index.data_ptr() if b.total_edges else None, b.node_ptr.data_ptr(),
-                          b.edge_ptr.data_ptr(), b.obs_ptr.data_ptr())
+                          b.edge_index.data_ptr() if b.total_edges else None,
+                          None if b.node_ptr is None else b.node_ptr.data_ptr(),
+                          None if b.edge_ptr is None else b.edge_ptr.data_ptr(),
+                          None if b.obs_ptr is None else b.obs_ptr.data_ptr())
 
     def _workspace(self, h, cb, device):
         need = ctypes.c_size_t()
@@ -278,8 +288,11 @@ class EncoderProcessDecoder(nn.Module):
         scores = torch.empty(batch.total_edges, dtype=torch.float32, device=dev) if out is None else out[:batch.total_edges]
         dn = None
         if dense:
-            n = (batch.node_ptr[1:] - batch.node_ptr[:-1]).to(torch.int64)
-            dn = torch.empty(int((n * n).sum()), dtype=torch.float32, device=dev)
+            total = batch.dense_floats
+            if total is None:                                  # hand-built batch: read the node counts back
+                n = (batch.node_ptr[1:] - batch.node_ptr[:-1]).to(torch.int64)
+                total = int((n * n).sum())
+            dn = torch.empty(total, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             st = torch.cuda.current_stream().cuda_stream
             _lib.check(_lib.lib().gnnmp_explorer_forward(
@@ -363,20 +376,26 @@ class EncoderProcessDecoder(nn.Module):
         P = scores.new_zeros(v.shape[0], v.shape[0])
         return P.index_put((edge_index[1], edge_index[0]), scores)
 
-    def _single(self, goal, v, obstacles, edge_index):
+    def _single(self, goal, v, obstacles, edge_index, prefix_arrays=True):
+        """One graph as a :class:`GraphBatch`.  ``prefix_arrays=False``: no node_ptr / edge_ptr / obs_ptr tensors -- the
+        library takes the single graph's sizes from the totals (gnnmp.h), which saves the three small host-to-device
+        copies per call that building them costs (inference entry points only)."""
         dev = v.device
         S = self.obs_size
         obs = obstacles.reshape(-1, S).float() if (obstacles is not None and self.use_obstacles) else \
             torch.zeros(0, S, device=dev)
+        if not prefix_arrays:
+            return GraphBatch(v.float().contiguous(), goal.reshape(1, -1).float().contiguous(), obs.contiguous(),
+                              edge_index.long().contiguous(), None, None, None, obs.shape[0])
         i32 = lambda *a: torch.tensor(a, dtype=torch.int32, device=dev)      # noqa: E731
         return GraphBatch(v.float().contiguous(), goal.reshape(1, -1).float().contiguous(), obs.contiguous(),
                           edge_index.long().contiguous(), i32(0, v.shape[0]), i32(0, edge_index.shape[1]),
-                          i32(0, obs.shape[0]), obs.shape[0])
+                          i32(0, obs.shape[0]), obs.shape[0], dense_floats=int(v.shape[0]) ** 2)
 
     @torch.no_grad()
     def edge_scores(self, goal, loop, v, obstacles, edge_index, **_ignored):
         """Sparse form of :meth:`forward`: scores [E] in ``edge_index`` column order."""
-        return self.forward_batch(self._single(goal, v, obstacles, edge_index), loop)
+        return self.forward_batch(self._single(goal, v, obstacles, edge_index, prefix_arrays=False), loop)
 
     # ------------------------------------------------------------------ reference signature
     @torch.no_grad()
@@ -385,5 +404,5 @@ class EncoderProcessDecoder(nn.Module):
         ``P[target, source] = score`` (model.py:148-149).  ``free``, ``collided``, ``k``, ``labels``
         and any other extra keyword are accepted and ignored exactly like the reference does
         (model.py:115)."""
-        _, dn = self.forward_batch(self._single(goal, v, obstacles, edge_index), loop, dense=True)
+        _, dn = self.forward_batch(self._single(goal, v, obstacles, edge_index, prefix_arrays=False), loop, dense=True)
         return dn.view(v.shape[0], v.shape[0])

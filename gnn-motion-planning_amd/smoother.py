@@ -5,6 +5,7 @@ shipped ``smooth_*_attv3.pt`` files works) and ``forward`` keyword signature; th
 in libgnnmp.so's HIP kernels.  The ``torch.nn`` layers are parameter containers only.
 """
 import ctypes
+import operator
 
 import torch
 from torch import nn
@@ -62,6 +63,9 @@ class SmoothBatch:
         sb.max_edges = max(edge_counts)
         sb.path_counts = list(path_counts)
         return sb
+
+
+_VERSION = operator.attrgetter('_version')
 
 
 def _cbatch(sb):
@@ -197,8 +201,9 @@ class ModelSmoother(nn.Module):
         wt = [sd[n] for n, _ in self._manifest]
         dev = torch.device(device)
         idx = dev.index if dev.index is not None else torch.cuda.current_device()
-        key = (idx, float(self.scale), self.mlp_dtype, tuple((id(t), t._version) for t in wt))
-        if self._handle is not None and key == self._handle_key:
+        key = (idx, float(self.scale), self.mlp_dtype, list(map(_VERSION, wt)), wt)
+        hk = self._handle_key
+        if self._handle is not None and hk[:4] == key[:4] and len(hk[4]) == len(wt) and all(map(operator.is_, hk[4], wt)):
             return self._handle
         self._drop_handle()
         blob = torch.cat([t.detach().to('cpu', torch.float32).reshape(-1) for t in wt]).contiguous()

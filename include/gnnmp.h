@@ -97,7 +97,9 @@ int gnnmp_explorer_destroy(gnnmp_explorer* h);
  * obstacles.  edge_index holds GRAPH-LOCAL node ids (what each problem's create_data produced),
  * row 0 = message source j, row 1 = message target i (PyG flow source_to_target); any order,
  * duplicates allowed (each column is scored independently).  Node ids must lie in [0, N_g): like
- * the reference's tensor indexing, out-of-range ids are not checked on the device. */
+ * the reference's tensor indexing, out-of-range ids are not checked on the device.
+ * One graph (G = 1, the reference's own call, model.py:115) may leave node_ptr, edge_ptr and obs_ptr all NULL: the
+ * three totals describe it (inference entry points only; the training entry points take explicit prefix arrays). */
 typedef struct {
     int32_t n_graphs;            /* G >= 1                                                    */
     int32_t total_nodes;         /* sum_g N_g                                                 */
@@ -110,7 +112,7 @@ typedef struct {
     const float* goal;           /* [G, C]                                                    */
     const float* obstacles;      /* [total_obstacles, S]                                      */
     const int64_t* edge_index;   /* [2, total_edges]                                          */
-    const int32_t* node_ptr;     /* [G+1]                                                     */
+    const int32_t* node_ptr;     /* [G+1]   (or all three NULL when G == 1)                   */
     const int32_t* edge_ptr;     /* [G+1]                                                     */
     const int32_t* obs_ptr;      /* [G+1]                                                     */
 } gnnmp_batch;

@@ -227,3 +227,28 @@ def test_deepcopy_after_forward():
     assert torch.equal(a, b)
     del m
     assert torch.equal(b, m2.edge_scores(g['goal'], 3, g['v'], g['obstacles'], g['edge_index']))
+
+
+@pytest.mark.parametrize('n,k', [(64, 4), (1000, 8), (3000, 12)])
+def test_single_graph_without_prefix_arrays(n, k):
+    """gnnmp.h: one graph may be handed over by its totals alone (node_ptr = edge_ptr = obs_ptr = NULL, what the drop-in
+    forward() does); same bits as the explicit one-graph batch (small graphs take the one-launch prep stage, the
+    3000-node one the multi-pass one), and the library refuses NULL prefix arrays for more than one graph."""
+    import ctypes
+    from gnnmp import _lib
+    m = make_model('maze2')
+    d = to_dev(synth_graph('maze2', n, k, seed=n))
+    explicit = m._single(d['goal'], d['v'], d['obstacles'], d['edge_index'])
+    implicit = m._single(d['goal'], d['v'], d['obstacles'], d['edge_index'], prefix_arrays=False)
+    assert implicit.node_ptr is None and implicit.n_graphs == 1 and implicit.dense_floats == n * n
+    s_e, dn_e = m.forward_batch(explicit, 3, dense=True)
+    s_i, dn_i = m.forward_batch(implicit, 3, dense=True)
+    assert torch.equal(s_e, s_i) and torch.equal(dn_e, dn_i)
+    assert torch.equal(m(goal=d['goal'], loop=3, v=d['v'], obstacles=d['obstacles'], edge_index=d['edge_index']),
+                       dn_e.view(n, n))
+    assert torch.equal(m.debug_tap(implicit, 1), m.debug_tap(explicit, 1))
+    cb = m._cbatch(implicit)
+    cb.n_graphs = 2
+    rc = _lib.lib().gnnmp_explorer_forward(m._native(DEV), ctypes.byref(cb), 3, 1, s_i.data_ptr(), None, m._ws.data_ptr(),
+                                           m._ws.numel(), None)
+    assert rc == -1                                   # GNNMP_ERR_NULL
