@@ -348,6 +348,28 @@ void pack_explorer(const Blob& B, const gnnmp_explorer_dims& dm, gnnmp_explorer*
         vec(W(n1 + ".2.bias"), dst + e.c1);
     };
     enc(h->enc_e, PK + o.enc_e, "edge_code", 2 * C, "edge_free_code", 2 * C);
+    {
+        // edge_code is consumed by ONE matrix only: K_e = W1d.EF + W1e.EC + b1 with EC = W2.relu(..) + c (model.py:120, :38).
+        // The edge kernels therefore produce W1e.EC + b1 directly: second encoder layer F = W1e.W2, bias W1e.c + b1
+        // (products in double), one d x d product per edge less.  OutEBlob::w1e / b1 stay in the layout, unused.
+        const float* w1m = W("process.lin_0.0.weight");             // [d, 5d]: columns 4d.. multiply edge_code
+        const float* w2 = W("edge_code.2.weight");
+        const float* c2 = W("edge_code.2.bias");
+        const float* b1m = W("process.lin_0.0.bias");
+        std::vector<float> F((size_t)D * D), cF(D);
+        for (int i = 0; i < D; ++i) {
+            for (int j = 0; j < D; ++j) {
+                double acc = 0.0;
+                for (int k = 0; k < D; ++k) acc += (double)w1m[(size_t)i * 5 * D + 4 * D + k] * (double)w2[(size_t)k * D + j];
+                F[(size_t)i * D + j] = (float)acc;
+            }
+            double acc = (double)b1m[i];
+            for (int k = 0; k < D; ++k) acc += (double)w1m[(size_t)i * 5 * D + 4 * D + k] * (double)c2[k];
+            cF[i] = (float)acc;
+        }
+        tiles(F.data(), D, 0, PK + o.enc_e + h->enc_e.a0);
+        vec(cF.data(), PK + o.enc_e + h->enc_e.c0);
+    }
     enc(h->enc_n, PK + o.enc_n, "node_code", 4 * C, "node_free_code", C);
 
     // --- attention blocks (map side) and obstacle side

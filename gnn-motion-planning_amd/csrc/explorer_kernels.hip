@@ -709,9 +709,9 @@ __global__ __launch_bounds__(WAVES * 64) void pre_kernel(PreParams p) {
         f32x16 y[NT];
         BOp<P> mop[NT];
         make_ops<P, NT>(m, mop);
-        load_vec<NT>(wl + L::b1, y, lane);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) y[t] = aux[t];                          // aux = W1e.edge_code + b1 (folded at pack time)
         linear_acc_ops<P, NT, NT>(wl + L::w1d, mop, y, lane);
-        linear_acc_p<P, NT, NT>(wl + L::w1e, aux, y, lane);
         store_tile_p<P, NT>(p.o0 + (size_t)tile * NT * kETile, y, lane);     // K_e
         load_vec<NT>(wl + L::bp0, y, lane);
         linear_acc_ops<P, NT, NT>(wl + L::wpc, mop, y, lane);
@@ -845,7 +845,9 @@ __device__ __forceinline__ void pre_resident_body(const PreParams& p, const int 
                 f32x16 y[NT];
                 BOp<P> mop[NT];
                 make_ops<P, NT>(m, mop);
-                load_vec<NT>(out_w + L::b1, y, lane);
+                // aux = W1e.edge_code + b1 (the product is folded into the encoder's second layer at pack time)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) y[t] = kRecomputeAux ? splat16(0.f) : aux[t];
                 linear_acc_ops<P, NT, NT>(out_w + L::w1d, mop, y, lane);
                 if constexpr (kRecomputeAux) {
                     const int4 rec = p.csr[row];
@@ -859,8 +861,9 @@ __device__ __forceinline__ void pre_resident_body(const PreParams& p, const int 
                         return ok ? x : 0.f;
                     };
                     mlp2_in<NT, P>(enc_w + E.as0, E.ks0, enc_w + E.b0, enc_w + E.a0, enc_w + E.c0, getin, aux, lane);
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) y[t] += aux[t];
                 }
-                linear_acc_p<P, NT, NT>(out_w + L::w1e, aux, y, lane);
                 store_tile_p<P, NT>(p.o0 + (size_t)tile * NT * kETile, y, lane);
                 load_vec<NT>(out_w + L::bp0, y, lane);
                 linear_acc_ops<P, NT, NT>(out_w + L::wpc, mop, y, lane);

@@ -31,12 +31,22 @@ class SmoothBatch:
             return p.to(torch.int32).to(device)
         f32 = lambda ts: torch.cat([t.float().reshape(t.shape[0], -1) for t in ts]).contiguous().to(device)  # noqa: E731
         self.n = len(paths)
-        self.path, self.free, self.collided = f32(paths), f32(frees), f32(collideds)
-        self.edge_index = torch.cat([e.long() for e in edge_indexes], dim=1).contiguous().to(device)
-        self.path_ptr = prefix([t.shape[0] for t in paths])
-        self.free_ptr = prefix([t.shape[0] for t in frees])
-        self.coll_ptr = prefix([t.shape[0] for t in collideds])
-        self.edge_ptr = prefix([e.shape[1] for e in edge_indexes])
+        if self.n == 1:
+            # the reference's call (one problem, smoother.py:243): no concatenations, and the four prefix arrays travel
+            # as ONE small host-to-device copy instead of four
+            one = lambda t: t.float().reshape(t.shape[0], -1).contiguous().to(device)  # noqa: E731
+            self.path, self.free, self.collided = one(paths[0]), one(frees[0]), one(collideds[0])
+            self.edge_index = edge_indexes[0].long().contiguous().to(device)
+            ptrs = torch.tensor([0, paths[0].shape[0], 0, frees[0].shape[0], 0, collideds[0].shape[0], 0,
+                                 edge_indexes[0].shape[1]], dtype=torch.int32).to(device)
+            self.path_ptr, self.free_ptr, self.coll_ptr, self.edge_ptr = ptrs[0:2], ptrs[2:4], ptrs[4:6], ptrs[6:8]
+        else:
+            self.path, self.free, self.collided = f32(paths), f32(frees), f32(collideds)
+            self.edge_index = torch.cat([e.long() for e in edge_indexes], dim=1).contiguous().to(device)
+            self.path_ptr = prefix([t.shape[0] for t in paths])
+            self.free_ptr = prefix([t.shape[0] for t in frees])
+            self.coll_ptr = prefix([t.shape[0] for t in collideds])
+            self.edge_ptr = prefix([e.shape[1] for e in edge_indexes])
         self.max_path = max(t.shape[0] for t in paths)
         self.max_samples = max(f.shape[0] + c.shape[0] for f, c in zip(frees, collideds))
         self.max_edges = max(e.shape[1] for e in edge_indexes)

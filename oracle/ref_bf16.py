@@ -77,7 +77,11 @@ def explorer_forward_bf16(w, v, goal, obstacles, edge_index, loop, use_obstacles
     g = goal.view(-1, C)
     nc = _mlp2(w, 'node_code', torch.cat((v, g.repeat(n, 1), (v - g) ** 2, v - g), dim=-1))
     pair = torch.cat((v[s], v[t]), dim=-1)
-    ec = _mlp2(w, 'edge_code', pair)
+    # W1e . edge_code + b1 with the product folded into the encoder's second layer in double (api.cpp pack_explorer)
+    w1e = w['process.lin_0.0.weight'][:, 4 * d:].double()
+    fold = (w1e @ w['edge_code.2.weight'].double()).float()
+    fold_b = (w1e @ w['edge_code.2.bias'].double() + w['process.lin_0.0.bias'].double()).float()
+    ec = lin(F.relu(lin(pair, w['edge_code.0.weight'], w['edge_code.0.bias'])), fold, fold_b)
     nf = _mlp2(w, 'node_free_code', v)
     ef = _mlp2(w, 'edge_free_code', pair)
     if use_obstacles:
@@ -104,7 +108,7 @@ def explorer_forward_bf16(w, v, goal, obstacles, edge_index, loop, use_obstacles
     # A, B, K_e, PE (and the policy's node terms) are STORED in bf16 in this mode (chain.hpp store_*_p)
     A, B = r(lin(x, wsrc)), r(lin(x, wdst))
     dn = lin(nc, wd[:, :d]) + w['decoder.bias']
-    ke = r(lin(ef, w1[:, 3 * d:4 * d]) + lin(ec, w1[:, 4 * d:]) + w['process.lin_0.0.bias'])
+    ke = r(lin(ef, w1[:, 3 * d:4 * d]) + ec)
     pe_ = r(lin(ef, p0[:, 2 * d:]) + w['policy.0.bias'])
     for it in range(loop):
         hid = F.relu(A[s] + B[t] + ke)
