@@ -97,8 +97,8 @@ __device__ __forceinline__ int find_graph(const int* __restrict__ ptr, int G, in
 // =====================================================================================================
 constexpr int kCoopMaxTiles = 1024;     // up to this many 32-node tiles, mp_fused runs one tile per workgroup of 8 waves
 constexpr int kPrepCap = 8192;
-constexpr int kPrepGraphMin = 64;      // batches of at least this many graphs take the per-graph kernel
-constexpr int kPrepSmallEdges = 24576; // smaller batches: single-launch prep up to this many edges per graph on average
+constexpr int kPrepGraphMin = 64;      // batches of at least this many graphs: one workgroup per graph (prep_small_kernel)
+constexpr int kPrepSmallEdges = 24576; // smaller batches: the same up to this many edges per graph on average
 
 __device__ __forceinline__ void prep_graph_body(const PrepParams& q, int g, int n0, int Np, int e0, int e1, int* prep_lds) {
     __shared__ int carry;                              // prep_lds: cnt[kPrepCap], rb[kPrepCap], scan[1024]
@@ -185,13 +185,6 @@ __device__ __forceinline__ void prep_graph_body(const PrepParams& q, int g, int 
     }
 }
 
-__global__ __launch_bounds__(1024) void prep_graph_kernel(PrepParams q) {
-    extern __shared__ int prep_lds[];
-    const int g = blockIdx.x;
-    const int n0 = q.node_ptr_pad[g];
-    prep_graph_body(q, g, n0, q.node_ptr_pad[g + 1] - n0, q.edge_ptr_pad[g], q.edge_ptr_pad[g + 1], prep_lds);
-}
-
 // goal node of graph g: argmin_i |v_i - goal|^2, lowest index on ties (model.py:132); any power-of-two workgroup
 __device__ __forceinline__ void goal_body(int C, const float* __restrict__ v, const float* __restrict__ goal,
                                           const int* __restrict__ node_ptr, int g, int n0_pad, int* __restrict__ goal_node) {
@@ -228,48 +221,50 @@ __global__ void single_ptrs_kernel(int* out, int n, int e, int o) {
 }
 
 // -----------------------------------------------------------------------------------------------------
-// Small batches (G < kPrepGraphMin graphs of moderate size -- the reference's own call pattern is ONE graph per
-// forward, eval_gnn.py:194): the whole prep stage in ONE launch.  A dependent launch costs ~5 us on this part whatever
-// it does, and the stage used to be eight of them (two fills, prefix arrays, count, scan, fill, tile metadata, goal
-// node).  Workgroup g: padded prefix arrays (every workgroup recomputes the < 64 entries it needs, workgroup 0 writes
-// them), CSR build of graph g, goal node of graph g; the last workgroup marks the tiles / slots / nodes behind the
-// last graph as unused (what the two fills were for).
+// The whole prep stage in ONE launch, one workgroup per graph: padded prefix arrays (every workgroup reduces the
+// entries before its own graph itself), CSR build of graph g, goal node of graph g; the last workgroup marks the
+// tiles / slots / nodes behind the last graph as unused.  A dependent launch costs ~5 us on this part whatever it
+// does, and the stage used to be six to eight of them (two fills of up to 40 MB, prefix arrays, count, scan, fill,
+// tile metadata, goal node): 31 -> 19 us for the reference's own call pattern (ONE graph per forward, eval_gnn.py:194).
+// Used for batches of at least kPrepGraphMin graphs and for smaller batches of moderate graphs; a few large graphs
+// take the device-wide passes below.
 // -----------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void prep_small_kernel(PrepParams q, int Npad, int Epad) {
     extern __shared__ int prep_lds[];
-    __shared__ int sp_n[65], sp_e[65];
-    __shared__ long long sp_d[65];
+    __shared__ long long red[3][16];
     const int g = blockIdx.x, tid = threadIdx.x;
     if (q.single_out) {                                // one graph given by its totals: its prefix arrays come first
         if (tid < 6) q.single_out[tid] = (tid & 1) ? (tid == 1 ? q.single_n : (tid == 3 ? q.single_e : q.single_o)) : 0;
         __threadfence();
         __syncthreads();
     }
-    if (tid < 64) {                                    // wave 0: inclusive scans over the (< 64) graphs
-        int n = 0, e = 0;
-        long long dd = 0;
-        if (tid < q.G) {
-            const int ng = q.node_ptr[tid + 1] - q.node_ptr[tid];
-            n = round_up(ng, kPad);
-            e = round_up(q.edge_ptr[tid + 1] - q.edge_ptr[tid], kPad);
-            dd = (long long)ng * ng;
-        }
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int an = __shfl_up(n, off), ae = __shfl_up(e, off);
-            const long long ad = __shfl_up(dd, off);
-            if (tid >= off) { n += an; e += ae; dd += ad; }
-        }
-        sp_n[tid + 1] = n; sp_e[tid + 1] = e; sp_d[tid + 1] = dd;
-        if (tid == 0) { sp_n[0] = 0; sp_e[0] = 0; sp_d[0] = 0; }
+    // padded prefix sums over the graphs before this one: every workgroup reduces them itself (G loads spread over
+    // 1024 threads) instead of waiting for a separate scan launch
+    long long an = 0, ae = 0, ad = 0;
+    for (int t = tid; t < g; t += 1024) {
+        const int ng = q.node_ptr[t + 1] - q.node_ptr[t];
+        an += round_up(ng, kPad);
+        ae += round_up(q.edge_ptr[t + 1] - q.edge_ptr[t], kPad);
+        ad += (long long)ng * ng;
     }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { an += __shfl_down(an, off); ae += __shfl_down(ae, off); ad += __shfl_down(ad, off); }
+    if ((tid & 63) == 0) { red[0][tid >> 6] = an; red[1][tid >> 6] = ae; red[2][tid >> 6] = ad; }
     __syncthreads();
-    if (g == 0 && tid <= q.G) { q.node_ptr_pad[tid] = sp_n[tid]; q.edge_ptr_pad[tid] = sp_e[tid]; q.dense_ptr[tid] = sp_d[tid]; }
-    const int n0 = sp_n[g], e0 = sp_e[g], e1 = sp_e[g + 1];
-    prep_graph_body(q, g, n0, sp_n[g + 1] - n0, e0, e1, prep_lds);
+    an = 0; ae = 0; ad = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { an += red[0][w]; ae += red[1][w]; ad += red[2][w]; }
+    const int ng_own = q.node_ptr[g + 1] - q.node_ptr[g];
+    const int n0 = (int)an, e0 = (int)ae;
+    const int n1 = n0 + round_up(ng_own, kPad), e1 = e0 + round_up(q.edge_ptr[g + 1] - q.edge_ptr[g], kPad);
+    if (tid == 0) {
+        if (g == 0) { q.node_ptr_pad[0] = 0; q.edge_ptr_pad[0] = 0; q.dense_ptr[0] = 0; }
+        q.node_ptr_pad[g + 1] = n1; q.edge_ptr_pad[g + 1] = e1; q.dense_ptr[g + 1] = ad + (long long)ng_own * ng_own;
+    }
+    prep_graph_body(q, g, n0, n1 - n0, e0, e1, prep_lds);
     goal_body(q.C, q.v, q.goal, q.node_ptr, g, n0, q.goal_node);
     if (g == q.G - 1) {
-        const int n_end = sp_n[q.G], e_end = sp_e[q.G];
+        const int n_end = n1, e_end = e1;
         for (int i = n_end + tid; i < Npad; i += 1024) { q.deg[i] = 0; q.row_beg[i] = e_end; }
         for (int t = n_end / 32 + tid; t < Npad / 32; t += 1024) q.ntile_graph[t] = -1;
         for (int t = e_end / 32 + tid; t < Epad / 32; t += 1024) { q.etile_graph[t] = -1; q.tile_meta[t] = -1; }
@@ -279,7 +274,7 @@ __global__ __launch_bounds__(1024) void prep_small_kernel(PrepParams q, int Npad
 
 // -----------------------------------------------------------------------------------------------------
 // Device-wide form of the same build (count -> scan -> fill -> tile metadata, one thread per edge), used for
-// small batches: a single graph with 56 k edges would keep one workgroup busy for ~90 us in prep_graph_kernel,
+// small batches: a single graph with 56 k edges would keep one workgroup busy for ~90 us in the per-graph kernel,
 // while these four passes spread it over the device in ~25 us.
 // -----------------------------------------------------------------------------------------------------
 // graph of caller column e: one binary search per workgroup (first column), then a short walk
@@ -1416,7 +1411,8 @@ static hipError_t set_lds(K kernel, size_t bytes) {
 hipError_t launch_prep(const PrepParams& q, int Npad, int Epad, void* zero_ptr, size_t zero_bytes, void* ff_ptr, size_t ff_bytes,
                        hipStream_t st) {
     const size_t glds = (size_t)(2 * kPrepCap + 1024) * sizeof(int);
-    if (q.G < kPrepGraphMin && (long long)q.E <= (long long)q.G * kPrepSmallEdges) {
+    static const int prep_mode = getenv("GNNMP_PREP_MODE") ? atoi(getenv("GNNMP_PREP_MODE")) : 0;   // experiments: 1 one launch, 2 device-wide
+    if (prep_mode ? prep_mode == 1 : (q.G >= kPrepGraphMin || (long long)q.E <= (long long)q.G * kPrepSmallEdges)) {
         const hipError_t attr = set_lds(prep_small_kernel, glds);
         if (attr != hipSuccess) return attr;
         hipLaunchKernelGGL(prep_small_kernel, dim3(q.G), dim3(1024), glds, st, q, Npad, Epad);
@@ -1434,13 +1430,7 @@ hipError_t launch_prep(const PrepParams& q, int Npad, int Epad, void* zero_ptr, 
     hipLaunchKernelGGL(prep_ptrs_kernel, dim3(1), dim3(256), 0, st, q.G, q.node_ptr, q.edge_ptr, q.node_ptr_pad,
                        q.edge_ptr_pad, q.dense_ptr);
     LAUNCH_CHECK();
-    if (q.G >= kPrepGraphMin) {                        // one workgroup per graph
-        const size_t lds = (size_t)(2 * kPrepCap + 1024) * sizeof(int);
-        const hipError_t attr = set_lds(prep_graph_kernel, lds);      // per launch: the attribute is per device
-        if (attr != hipSuccess) return attr;
-        hipLaunchKernelGGL(prep_graph_kernel, dim3(q.G), dim3(1024), lds, st, q);
-        LAUNCH_CHECK();
-    } else {                                           // few graphs: one thread per edge across the device
+    {                                                  // few, large graphs: one thread per edge across the device
         if (q.E > 0) {
             hipLaunchKernelGGL(prep_count_kernel, dim3((q.E + 255) / 256), dim3(256), 0, st, q.G, q.E, q.edge_index,
                                q.edge_ptr, q.node_ptr_pad, q.deg, q.cursor);

@@ -16,7 +16,7 @@ struct PrepParams {
     int *ntile_graph, *etile_graph;              // per 32-row tile
     int4* csr;                                   // [Epad] {source, target, caller column, 0}; -1 = pad slot
     int* goal_node;                              // [G] padded node id
-    int* tile_meta;                              // per 32-edge tile, see prep_graph_kernel
+    int* tile_meta;                              // per 32-edge tile, see prep_graph_body
     int* single_out;                             // non-null: ONE graph given by its totals; node_ptr / edge_ptr / obs_ptr point here
     int single_n, single_e, single_o;            //           ([0,N | 0,E | 0,O], written by the prep stage before anything reads them)
     int n_etiles;
