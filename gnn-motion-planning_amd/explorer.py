@@ -7,6 +7,7 @@ Same constructor signature, same parameter / buffer names (so ``load_state_dict`
 """
 import ctypes
 import operator
+import os
 
 import torch
 from torch import nn
@@ -50,6 +51,23 @@ class _MPNN(nn.Module):                           # model.py:22-28
 
 
 _VERSION = operator.attrgetter('_version')
+# GNNMP_CHECK_EDGE_INDEX=1: validate edge_index against the node counts before every forward (one device read-back per
+# call).  Like the reference's tensor indexing on the GPU, the kernels themselves do not check node ids (gnnmp.h).
+_CHECK_IDS = os.environ.get('GNNMP_CHECK_EDGE_INDEX', '0') not in ('', '0')
+
+
+def _check_edge_ids(batch):
+    if batch.total_edges == 0:
+        return
+    ei = batch.edge_index
+    if batch.node_ptr is None:
+        n_of_edge = batch.total_nodes
+    else:
+        counts = (batch.node_ptr[1:] - batch.node_ptr[:-1]).long()
+        per_graph = (batch.edge_ptr[1:] - batch.edge_ptr[:-1]).long()
+        n_of_edge = torch.repeat_interleave(counts, per_graph).unsqueeze(0)
+    if bool(((ei < 0) | (ei >= n_of_edge)).any()):
+        raise IndexError('edge_index holds node ids outside [0, N_g) of their graph')
 
 
 class _TrainScores(torch.autograd.Function):
@@ -281,6 +299,8 @@ class EncoderProcessDecoder(nn.Module):
         if int(loop) < 1:
             raise ValueError('loop must be >= 1: the reference binds `decode` only inside the loop '
                              '(model.py:139-145)')
+        if _CHECK_IDS:
+            _check_edge_ids(batch)
         h = self._native(dev)
         cb = self._cbatch(batch)
         if ws is None:

@@ -94,6 +94,22 @@ SMOOTHER_TRAINABLE = ('node_code.0.weight', 'node_code.0.bias', 'node_code.1.wei
                       'process.lin_1.2.bias', 'smooth_node.weight', 'smooth_node.bias')
 
 
+MAX_SAMPLES = 2048          # free + collided samples per problem (the kNN kernel keeps <= 32 samples per lane)
+MAX_CANDIDATES = 7500       # caller edges + 10 kNN edges per waypoint of one problem (sorted in LDS)
+
+
+def _check_limits(sb):
+    """The kernels' per-problem limits (gnnmp.h); the reference's planner stays far inside them (500 + 500 samples,
+    paths of a few dozen waypoints), direct callers get the limit by name instead of GNNMP_ERR_DIMS."""
+    if sb.max_samples > MAX_SAMPLES:
+        raise ValueError('a smoothing problem has %d free + collided samples; the HIP smoother takes at most %d per problem'
+                         % (sb.max_samples, MAX_SAMPLES))
+    if sb.max_edges + 10 * sb.max_path > MAX_CANDIDATES:
+        raise ValueError('a smoothing problem has %d caller edges and %d waypoints: edges + 10 * waypoints = %d exceeds the HIP '
+                         "smoother's limit of %d candidate edges per problem"
+                         % (sb.max_edges, sb.max_path, sb.max_edges + 10 * sb.max_path, MAX_CANDIDATES))
+
+
 class _TrainSmooth(torch.autograd.Function):
     """New path [P, C] of ONE smoothing problem with gradients for the smoother's parameters, the way the reference
     trains it (train_smoother.py:33-61, model.train()): BatchNorm with batch statistics, gradients through the loop's
@@ -102,6 +118,7 @@ class _TrainSmooth(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, sb, loop, *params):
         dev = sb.path.device
+        _check_limits(sb)
         h = model._native(dev)
         cb = _cbatch(sb)
         need = ctypes.c_size_t()
@@ -232,6 +249,7 @@ class ModelSmoother(nn.Module):
         dev = sb.path.device
         if dev.type != 'cuda':
             raise RuntimeError('gnnmp runs on the GPU only (got %s tensors); there is no CPU fallback' % dev)
+        _check_limits(sb)
         h = self._native(dev)
         cb = _cbatch(sb)
         need = ctypes.c_size_t()

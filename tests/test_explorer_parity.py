@@ -252,3 +252,23 @@ def test_single_graph_without_prefix_arrays(n, k):
     rc = _lib.lib().gnnmp_explorer_forward(m._native(DEV), ctypes.byref(cb), 3, 1, s_i.data_ptr(), None, m._ws.data_ptr(),
                                            m._ws.numel(), None)
     assert rc == -1                                   # GNNMP_ERR_NULL
+
+
+def test_optional_edge_index_range_check(monkeypatch):
+    """GNNMP_CHECK_EDGE_INDEX=1 (read at import; here the module flag is flipped): ids outside [0, N_g) raise IndexError
+    like the reference's tensor indexing would, instead of reading device memory out of bounds."""
+    from gnnmp import explorer as E
+    monkeypatch.setattr(E, '_CHECK_IDS', True)
+    m = make_model('maze2')
+    graphs = [synth_graph('maze2', 64, 4, seed=1), synth_graph('maze2', 40, 3, seed=2)]
+    b = gnnmp.GraphBatch.from_graphs(graphs, 2, DEV)
+    m.forward_batch(b, 2)                                          # valid ids pass
+    bad = gnnmp.GraphBatch.from_graphs(graphs, 2, DEV)
+    bad.edge_index[0, -1] = 40                                     # second graph has nodes 0..39
+    with pytest.raises(IndexError):
+        m.forward_batch(bad, 2)
+    d = to_dev(graphs[0])
+    ei = d['edge_index'].clone()
+    ei[1, 0] = -1
+    with pytest.raises(IndexError):
+        m(goal=d['goal'], loop=2, v=d['v'], obstacles=d['obstacles'], edge_index=ei)

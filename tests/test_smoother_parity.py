@@ -138,5 +138,19 @@ def test_limits_fail_loudly():
     m = make('smooth_2d_attv3')
     gen = torch.Generator().manual_seed(1)
     path, free, coll = (torch.rand(n, 2, generator=gen).to(DEV) for n in (6, 1500, 700))
-    with pytest.raises(RuntimeError, match='gnnmp_smoother_forward'):
+    with pytest.raises(ValueError, match='at most 2048'):                 # the Python wrapper names the limit
         m(path=path, free=free, collided=coll, edge_index=chain_edges(6).to(DEV), loop=1)
+    import ctypes
+    from gnnmp import smoother as S
+    sb = S.SmoothBatch([path], [free], [coll], [chain_edges(6).to(DEV)], DEV)
+    cb = S._cbatch(sb)
+    need = ctypes.c_size_t()
+    L, h = S._lib.lib(), m._native(DEV)
+    assert L.gnnmp_smoother_workspace_bytes(h, ctypes.byref(cb), ctypes.byref(need)) == 0
+    ws = torch.empty(need.value, dtype=torch.uint8, device=DEV)
+    out = torch.empty_like(sb.path)
+    rc = L.gnnmp_smoother_forward(h, ctypes.byref(cb), 1, out.data_ptr(), ws.data_ptr(), ws.numel(), None)
+    assert rc != 0 and b'dimensions' in L.gnnmp_status_string(rc)        # the C ABI refuses it as well (GNNMP_ERR_DIMS)
+    long_path = torch.rand(800, 2, generator=gen).to(DEV)                # 3 * 800 chain edges + 10 * 800 kNN candidates
+    with pytest.raises(ValueError, match='candidate edges'):
+        m(path=long_path, free=free[:500], collided=coll[:500], edge_index=chain_edges(800).to(DEV), loop=1)
