@@ -1092,7 +1092,11 @@ extern "C" int gnnmp_smoother_workspace_bytes(const gnnmp_smoother* h, const gnn
 extern "C" int gnnmp_smoother_forward(const gnnmp_smoother* h, const gnnmp_smooth_batch* b, int loop, float* out_path,
                                       void* ws, size_t ws_bytes, void* hip_stream) {
     if (!h || !b || !ws || !out_path) return GNNMP_ERR_NULL;
-    if (!b->path || !b->path_ptr || !b->free_ptr || !b->coll_ptr || !b->edge_ptr) return GNNMP_ERR_NULL;
+    if (!b->path) return GNNMP_ERR_NULL;
+    // ONE problem may be given by its totals alone (the four prefix pointers NULL): the reference's call has no prefix
+    // arrays (model_smoother.py:104) and building them costs the caller a host-to-device copy per call
+    const bool implicit = !b->path_ptr && !b->free_ptr && !b->coll_ptr && !b->edge_ptr;
+    if (implicit ? b->n_problems != 1 : (!b->path_ptr || !b->free_ptr || !b->coll_ptr || !b->edge_ptr)) return GNNMP_ERR_NULL;
     if ((b->total_free > 0 && !b->free_pts) || (b->total_collided > 0 && !b->collided) ||
         (b->total_edges > 0 && !b->edge_index))
         return GNNMP_ERR_NULL;
@@ -1120,12 +1124,19 @@ extern "C" int gnnmp_smoother_forward(const gnnmp_smoother* h, const gnnmp_smoot
     if (p.cand_cap < 1) p.cand_cap = 1;
     if ((size_t)2 * p.cand_cap * sizeof(int) > 60000) return GNNMP_ERR_DIMS;
     p.n_etiles = c.ecap / 32; p.n_ptiles = c.pcap / 32;
-    HIP_TRY(launch_sm_init(b->total_path * C, p.scale, b->path, p.cur, st));
+    p.one_free = b->total_free; p.one_coll = b->total_collided;
+    if (loop == 0) {                                         // nothing moves: out = (path / scale) * scale
+        HIP_TRY(launch_sm_init(b->total_path * C, p.scale, b->path, p.cur, st));
+        HIP_TRY(launch_sm_final(b->total_path * C, p.scale, p.cur, out_path, st));
+        return GNNMP_OK;
+    }
+    // four launches per iteration (kNN, edge list, messages, path update): the scaled working copy is written by the
+    // first kNN launch, the tile maps by the edge-list kernel, the result by the last path-update launch
     for (int it = 0; it < loop; ++it) {
-        HIP_TRY(hipMemsetAsync(at<char>(ws, c.ff_beg), 0xFF, c.ff_end - c.ff_beg, st));
+        p.init_from_path = it == 0 ? 1 : 0;
+        p.out = it == loop - 1 ? out_path : nullptr;
         HIP_TRY(launch_sm_iter(D, h->dims.mlp_dtype, p, st));
     }
-    HIP_TRY(launch_sm_final(b->total_path * C, p.scale, p.cur, out_path, st));
     return GNNMP_OK;
 }
 
@@ -1539,7 +1550,7 @@ SmW sm_wref(const gnnmp_smoother* h, float* grad, const std::string& name) {
 }
 
 bool sm_train_ok(const gnnmp_smoother* h, const gnnmp_smooth_batch* b) {
-    return b->n_problems == 1 && b->total_path >= 1 && h->dims.mlp_dtype == GNNMP_F32 && b->max_samples <= 2048;
+    return b->path_ptr && b->free_ptr && b->coll_ptr && b->edge_ptr && b->n_problems == 1 && b->total_path >= 1 && h->dims.mlp_dtype == GNNMP_F32 && b->max_samples <= 2048;
 }
 
 void sm_fill_params(const gnnmp_smoother* h, const gnnmp_smooth_batch* b, const SmCarve& c, void* ws, SmParams& p) {
@@ -1557,6 +1568,7 @@ void sm_fill_params(const gnnmp_smoother* h, const gnnmp_smooth_batch* b, const 
     p.cand_cap = b->max_edges + kSmK * b->max_path;
     if (p.cand_cap < 1) p.cand_cap = 1;
     p.n_etiles = c.ecap / 32; p.n_ptiles = c.pcap / 32;
+    p.one_free = b->total_free; p.one_coll = b->total_collided; p.init_from_path = 0; p.out = nullptr;
 }
 
 }  // namespace

@@ -96,6 +96,9 @@ struct SmParams {
     int *etile_prob, *ptile_prob;     // tile -> problem (-1 unused)
     float* msg;                       // [edge capacity, d]
     int cand_cap, n_etiles, n_ptiles;
+    int one_free, one_coll;           // path_ptr == nullptr: ONE problem, its sample counts (waypoints / edges: total_path / total_edges)
+    int init_from_path;               // first iteration: the knn kernel also writes cur = path / scale
+    float* out;                       // last iteration: the node kernel also writes out = cur * scale (else nullptr)
 };
 
 hipError_t launch_sm_init(int n, float scale, const float* path, float* cur, hipStream_t st);

@@ -25,9 +25,14 @@ namespace gnnmp {
 
 __device__ __forceinline__ int sm_round32(int x) { return (x + 31) & ~31; }
 // start of problem b in the padded path-node / edge index spaces (no scan needed)
-__device__ __forceinline__ int sm_poff(const int* path_ptr, int b) { return sm_round32(path_ptr[b]) + 32 * b; }
-__device__ __forceinline__ int sm_eoff(const int* edge_ptr, const int* path_ptr, int b) {
-    return sm_round32(edge_ptr[b] + kSmK * path_ptr[b]) + 32 * b;
+// prefix arrays; ONE problem may be given by its totals alone (all four pointers NULL, gnnmp.h)
+__device__ __forceinline__ int sm_pp(const SmParams& p, int i) { return p.path_ptr ? p.path_ptr[i] : (i > 0 ? p.total_path : 0); }
+__device__ __forceinline__ int sm_fp(const SmParams& p, int i) { return p.path_ptr ? p.free_ptr[i] : (i > 0 ? p.one_free : 0); }
+__device__ __forceinline__ int sm_cp(const SmParams& p, int i) { return p.path_ptr ? p.coll_ptr[i] : (i > 0 ? p.one_coll : 0); }
+__device__ __forceinline__ int sm_ep(const SmParams& p, int i) { return p.path_ptr ? p.edge_ptr[i] : (i > 0 ? p.total_edges : 0); }
+__device__ __forceinline__ int sm_poff(const SmParams& p, int b) { return sm_round32(sm_pp(p, b)) + 32 * b; }
+__device__ __forceinline__ int sm_eoff(const SmParams& p, int b) {
+    return sm_round32(sm_ep(p, b) + kSmK * sm_pp(p, b)) + 32 * b;
 }
 
 // path_cur = path / scale     (model_smoother.py:118)
@@ -51,13 +56,18 @@ __global__ __launch_bounds__(256) void sm_knn_kernel(SmParams p) {
     const int node = blockIdx.x * 4 + wave;               // global path row
     if (node >= p.total_path) return;
     int lo = 0, hi = p.B;                                  // problem of this path row
-    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (p.path_ptr[mid] <= node) lo = mid; else hi = mid; }
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (sm_pp(p, mid) <= node) lo = mid; else hi = mid; }
     const int b = lo;
     const int C = p.C;
-    const int f0 = p.free_ptr[b], F = p.free_ptr[b + 1] - f0;
-    const int c0 = p.coll_ptr[b], Co = p.coll_ptr[b + 1] - c0;
+    const int f0 = sm_fp(p, b), F = sm_fp(p, b + 1) - f0;
+    const int c0 = sm_cp(p, b), Co = sm_cp(p, b + 1) - c0;
     const int ns = F + Co;
-    const float* q = p.cur + (size_t)node * C;
+    // first iteration: the scaled working copy of the path (model_smoother.py:118) is written here, not by a launch of
+    // its own; this wave reads its row from the caller's path (same arithmetic, path / scale)
+    const bool first = p.init_from_path != 0;
+    const float* q = first ? p.path + (size_t)node * C : p.cur + (size_t)node * C;
+    const float qdiv = first ? p.scale : 1.0f;
+    if (first && lane < C) p.cur[(size_t)node * C + lane] = q[lane] / p.scale;
     constexpr int kMaxPerLane = 32;                        // up to 2048 samples per problem
     float dist[kMaxPerLane];
 #pragma unroll
@@ -68,7 +78,7 @@ __global__ __launch_bounds__(256) void sm_knn_kernel(SmParams p) {
             const float* x = (s < F) ? p.free_pts + (size_t)(f0 + s) * C : p.collided + (size_t)(c0 + s - F) * C;
             d = 0.f;
             for (int c = 0; c < C; ++c) {
-                const float df = x[c] / p.scale - q[c];
+                const float df = x[c] / p.scale - (first ? q[c] / qdiv : q[c]);
                 d = fmaf(df, df, d);
             }
         }
@@ -107,10 +117,10 @@ __global__ __launch_bounds__(256) void sm_knn_kernel(SmParams p) {
 __global__ __launch_bounds__(256) void sm_edges_kernel(SmParams p) {
     extern __shared__ int sm_lds[];
     const int b = blockIdx.x, tid = threadIdx.x;
-    const int p0 = p.path_ptr[b], P = p.path_ptr[b + 1] - p0;
-    const int F = p.free_ptr[b + 1] - p.free_ptr[b], Co = p.coll_ptr[b + 1] - p.coll_ptr[b];
+    const int p0 = sm_pp(p, b), P = sm_pp(p, b + 1) - p0;
+    const int F = sm_fp(p, b + 1) - sm_fp(p, b), Co = sm_cp(p, b + 1) - sm_cp(p, b);
     const int M = P + F + Co;
-    const int e0 = p.edge_ptr[b], ne = p.edge_ptr[b + 1] - e0;
+    const int e0 = sm_ep(p, b), ne = sm_ep(p, b + 1) - e0;
     const int ncand = ne + kSmK * P;
     int* key = sm_lds;                    // [cap]
     int* sorted = sm_lds + p.cand_cap;    // [cap]
@@ -141,8 +151,8 @@ __global__ __launch_bounds__(256) void sm_edges_kernel(SmParams p) {
         sorted[rank] = kc;
     }
     __syncthreads();
-    const int eoff = sm_eoff(p.edge_ptr, p.path_ptr, b);
-    const int poff = sm_poff(p.path_ptr, b);
+    const int eoff = sm_eoff(p, b);
+    const int poff = sm_poff(p, b);
     if (tid == 0) s_carry = 0;
     for (int i = tid; i < sm_round32(P); i += 256) { p.seg_beg[poff + i] = 0; p.seg_cnt[poff + i] = 0; }
     __syncthreads();
@@ -174,8 +184,13 @@ __global__ __launch_bounds__(256) void sm_edges_kernel(SmParams p) {
     }
     const int n = s_carry;
     if (tid == 0) p.e_count[b] = n;
-    for (int t = eoff / 32 + tid; t < (eoff + sm_round32(n)) / 32; t += 256) p.etile_prob[t] = b;
-    for (int t = poff / 32 + tid; t < (poff + sm_round32(P)) / 32; t += 256) p.ptile_prob[t] = b;
+    // tile -> problem maps of this problem's whole capacity range (-1 = unused tile; no separate fill launch): the range
+    // ends where the next problem's begins, the last problem's at the end of the tile space
+    const int et_used = (eoff + sm_round32(n)) / 32, pt_used = (poff + sm_round32(P)) / 32;
+    const int et_end = b + 1 < p.B ? sm_eoff(p, b + 1) / 32 : p.n_etiles;
+    const int pt_end = b + 1 < p.B ? sm_poff(p, b + 1) / 32 : p.n_ptiles;
+    for (int t = eoff / 32 + tid; t < et_end; t += 256) p.etile_prob[t] = t < et_used ? b : -1;
+    for (int t = poff / 32 + tid; t < pt_end; t += 256) p.ptile_prob[t] = t < pt_used ? b : -1;
 }
 
 // node features [coords / scale (path rows are already scaled), one-hot(kind)]   model_smoother.py:130-135
@@ -191,9 +206,9 @@ struct SmNodeIn {
 };
 
 __device__ __forceinline__ SmNodeIn sm_node_in(const SmParams& p, int b, int n) {
-    const int p0 = p.path_ptr[b], P = p.path_ptr[b + 1] - p0;
-    const int f0 = p.free_ptr[b], F = p.free_ptr[b + 1] - f0;
-    const int c0 = p.coll_ptr[b];
+    const int p0 = sm_pp(p, b), P = sm_pp(p, b + 1) - p0;
+    const int f0 = sm_fp(p, b), F = sm_fp(p, b + 1) - f0;
+    const int c0 = sm_cp(p, b);
     SmNodeIn in;
     in.C = p.C; in.scale = p.scale;
     if (n < P) { in.row = p.cur + (size_t)(p0 + n) * p.C; in.kind = 0; in.inv_is_path = 1.f; }
@@ -225,7 +240,7 @@ __global__ __launch_bounds__(256) void sm_msg_kernel(SmParams p) {
     if (tile >= p.n_etiles) return;
     const int b = p.etile_prob[tile];
     if (b < 0) return;
-    const int eoff = sm_eoff(p.edge_ptr, p.path_ptr, b);
+    const int eoff = sm_eoff(p, b);
     const int e = tile * 32 + j;
     const bool valid = (e - eoff) < p.e_count[b];
     const int src = valid ? p.e_src[e] : 0, dst = valid ? p.e_dst[e] : 0;
@@ -260,8 +275,8 @@ __global__ __launch_bounds__(256) void sm_node_kernel(SmParams p) {
     if (tile >= p.n_ptiles) return;
     const int b = p.ptile_prob[tile];
     if (b < 0) return;
-    const int poff = sm_poff(p.path_ptr, b);
-    const int p0 = p.path_ptr[b], PN = p.path_ptr[b + 1] - p0;
+    const int poff = sm_poff(p, b);
+    const int p0 = sm_pp(p, b), PN = sm_pp(p, b + 1) - p0;
     const int n = tile * 32 + j - poff;                  // local path index
     const bool valid = n < PN;
     const float* W = p.w;
@@ -295,11 +310,149 @@ __global__ __launch_bounds__(256) void sm_node_kernel(SmParams p) {
     f32x16 o[1];
     load_vec<1>(W + p.L.bs, o, lane);
     linear_acc_p<P, 1, NT>(W + p.L.ws, y, o, lane);            // smooth_node (out features padded to 32)
-    if (valid && n >= 1 && n <= PN - 2) {                  // path[1:-1] = ...       model_smoother.py:139
+    const bool interior = valid && n >= 1 && n <= PN - 2;  // path[1:-1] = ...       model_smoother.py:139
+    if (interior || (valid && p.out != nullptr)) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int f = phi(r, h);
-            if (f < p.C) p.cur_next[(size_t)(p0 + n) * p.C + f] = o[0][r];
+            if (f < p.C) {
+                const size_t at = (size_t)(p0 + n) * p.C + f;
+                const float val = interior ? o[0][r] : p.cur[at];
+                if (interior) p.cur_next[at] = val;
+                if (p.out) p.out[at] = val * p.scale;      // last iteration: out = path_cur * scale (model_smoother.py:142)
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Few tiles (the reference's call: ONE problem, ~9 edge tiles and one path tile): a tile's layers are a chain of
+// ~1300 exact-fp32 MFMAs for one wave (34 us at 64 cycles each).  Here a tile belongs to a WORKGROUP of NT waves and
+// wave w computes output tile w (32 features) of every layer, i.e. a quarter of the MFMAs at d = 128; the waves
+// exchange their tiles through LDS between layers (all waves share the row <-> lane mapping, so the exchange is a
+// plain register dump and reload).  Every output element is accumulated in the same order as in the one-wave kernels:
+// the results are bit-identical.
+// ---------------------------------------------------------------------------------------------------
+template <int NT>
+__device__ __forceinline__ void sm_exchange(float* buf, int wave, const f32x16& mine, f32x16 (&all)[NT], int lane) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) buf[(wave * 16 + r) * 64 + lane] = mine[r];
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) all[t][r] = buf[(t * 16 + r) * 64 + lane];
+}
+
+// tile `wave` of x = node_code(in): layer 0 (a few MFMAs from the raw inputs) is computed whole by every wave
+template <int NT, int P>
+__device__ __forceinline__ void sm_node_code_tile(const SmParams& p, const SmNodeIn& in, int wave, f32x16& x, int lane) {
+    const float* W = p.w;
+    f32x16 hdn[NT];
+    load_vec<NT>(W + p.L.b0, hdn, lane);
+    linear_in_p<P, NT>(W + p.L.as0, p.L.ks, in, hdn, lane);
+    relu_<NT>(hdn);
+    f32x16 y[1];
+    load_vec<1>(W + p.L.b3 + wave * 32, y, lane);
+    linear_acc_p<P, 1, NT>(W + p.L.w3 + (size_t)wave * NT * Prec<P>::TF, hdn, y, lane);
+    x = y[0];
+}
+
+template <int D, int P>
+__global__ __launch_bounds__(D * 2) void sm_msg_split_kernel(SmParams p) {
+    constexpr int NT = D / 32;
+    __shared__ float xbuf[2][NT * 16 * 64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
+    const int tile = blockIdx.x;
+    const int b = p.etile_prob[tile];
+    if (b < 0) return;                                   // workgroup-uniform
+    const int eoff = sm_eoff(p, b);
+    const int e = tile * 32 + j;
+    const bool valid = (e - eoff) < p.e_count[b];
+    const int src = valid ? p.e_src[e] : 0, dst = valid ? p.e_dst[e] : 0;
+    const float* W = p.w;
+    constexpr size_t TF = Prec<P>::TF;
+    f32x16 z[1];
+    load_vec<1>(W + p.L.b00 + wave * 32, z, lane);
+    {
+        f32x16 mine, x[NT];
+        sm_node_code_tile<NT, P>(p, sm_node_in(p, b, dst), wave, mine, lane);      // x_i (target)
+        sm_exchange<NT>(xbuf[0], wave, mine, x, lane);
+        linear_acc_p<P, 1, NT>(W + p.L.wdst + (size_t)wave * NT * TF, x, z, lane);   // (W_c - W_a) x_i
+    }
+    {
+        f32x16 mine, x[NT];
+        sm_node_code_tile<NT, P>(p, sm_node_in(p, b, src), wave, mine, lane);      // x_j (source)
+        sm_exchange<NT>(xbuf[1], wave, mine, x, lane);
+        linear_acc_p<P, 1, NT>(W + p.L.wsrc + (size_t)wave * NT * TF, x, z, lane);   // (W_a + W_b) x_j
+    }
+    relu_<1>(z);
+    f32x16 zall[NT], m[1];
+    sm_exchange<NT>(xbuf[0], wave, z[0], zall, lane);
+    load_vec<1>(W + p.L.b02 + wave * 32, m, lane);
+    linear_acc_p<P, 1, NT>(W + p.L.w02 + (size_t)wave * NT * TF, zall, m, lane);
+    store_row<1>(p.msg + (size_t)e * D + wave * 32, m, h);
+}
+
+template <int D, int P>
+__global__ __launch_bounds__(D * 2) void sm_node_split_kernel(SmParams p) {
+    constexpr int NT = D / 32;
+    __shared__ float xbuf[2][NT * 16 * 64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
+    const int tile = blockIdx.x;
+    const int b = p.ptile_prob[tile];
+    if (b < 0) return;
+    const int poff = sm_poff(p, b);
+    const int p0 = sm_pp(p, b), PN = sm_pp(p, b + 1) - p0;
+    const int n = tile * 32 + j - poff;                  // local path index
+    const bool valid = n < PN;
+    const float* W = p.w;
+    constexpr size_t TF = Prec<P>::TF;
+    f32x16 S[NT];
+    {
+        f32x16 mine = splat16(0.f);
+        if (valid) {
+            const int beg = p.seg_beg[poff + n], cnt = p.seg_cnt[poff + n];
+            for (int i = 0; i < cnt; ++i) {              // coalesced edge order: increasing source id
+                f32x16 m[1];
+                load_row<1>(p.msg + (size_t)(beg + i) * D + wave * 32, m, h);
+                mine += m[0];
+            }
+        }
+        sm_exchange<NT>(xbuf[0], wave, mine, S, lane);
+    }
+    f32x16 y[1];
+    {
+        f32x16 hw[1], hdn[NT];
+        load_vec<1>(W + p.L.b10 + wave * 32, hw, lane);
+        linear_acc_p<P, 1, NT>(W + p.L.w10 + (size_t)wave * NT * TF, S, hw, lane);
+        relu_<1>(hw);
+        sm_exchange<NT>(xbuf[1], wave, hw[0], hdn, lane);
+        load_vec<1>(W + p.L.b12 + wave * 32, y, lane);
+        linear_acc_p<P, 1, NT>(W + p.L.w12 + (size_t)wave * NT * TF, hdn, y, lane);
+    }
+    {
+        f32x16 x;
+        sm_node_code_tile<NT, P>(p, sm_node_in(p, b, valid ? n : 0), wave, x, lane);
+        y[0] += x;                                        // h = x + lin_1(S)      model_smoother.py:34
+    }
+    f32x16 yall[NT];
+    sm_exchange<NT>(xbuf[0], wave, y[0], yall, lane);
+    if (wave != 0) return;                                // smooth_node: one output tile, accumulated in tile order
+    f32x16 o[1];
+    load_vec<1>(W + p.L.bs, o, lane);
+    linear_acc_p<P, 1, NT>(W + p.L.ws, yall, o, lane);
+    const bool interior = valid && n >= 1 && n <= PN - 2;  // path[1:-1] = ...       model_smoother.py:139
+    if (interior || (valid && p.out != nullptr)) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int f = phi(r, h);
+            if (f < p.C) {
+                const size_t at = (size_t)(p0 + n) * p.C + f;
+                const float val = interior ? o[0][r] : p.cur[at];
+                if (interior) p.cur_next[at] = val;
+                if (p.out) p.out[at] = val * p.scale;      // last iteration: out = path_cur * scale (model_smoother.py:142)
+            }
         }
     }
 }
@@ -325,6 +478,8 @@ hipError_t launch_sm_final(int n, float scale, const float* cur, float* out, hip
     return hipSuccess;
 }
 
+constexpr int kSmSplitMaxTiles = 512;   // up to this many 32-edge tiles the split kernels run (one workgroup per tile)
+
 template <int D, int P>
 static hipError_t launch_sm_iter_t(const SmParams& p, hipStream_t st) {
     hipLaunchKernelGGL(sm_knn_kernel, dim3((p.total_path + 3) / 4), dim3(256), 0, st, p);
@@ -332,6 +487,16 @@ static hipError_t launch_sm_iter_t(const SmParams& p, hipStream_t st) {
     const size_t lds = (size_t)2 * p.cand_cap * sizeof(int);
     hipLaunchKernelGGL(sm_edges_kernel, dim3(p.B), dim3(256), lds, st, p);
     LAUNCH_CHECK();
+    // few tiles: one tile per workgroup, its layers split over D / 32 waves (bit-identical, a quarter of the chain depth)
+    static const int split_env = getenv("GNNMP_SM_SPLIT") ? atoi(getenv("GNNMP_SM_SPLIT")) : -1;
+    const bool split = D >= 64 && (split_env >= 0 ? split_env != 0 : p.n_etiles <= kSmSplitMaxTiles);
+    if (split) {
+        hipLaunchKernelGGL((sm_msg_split_kernel<D, P>), dim3(p.n_etiles), dim3(D * 2), 0, st, p);
+        LAUNCH_CHECK();
+        hipLaunchKernelGGL((sm_node_split_kernel<D, P>), dim3(p.n_ptiles), dim3(D * 2), 0, st, p);
+        LAUNCH_CHECK();
+        return hipSuccess;
+    }
     hipLaunchKernelGGL((sm_msg_kernel<D, P>), dim3((p.n_etiles + 3) / 4), dim3(256), 0, st, p);
     LAUNCH_CHECK();
     hipLaunchKernelGGL((sm_node_kernel<D, P>), dim3((p.n_ptiles + 3) / 4), dim3(256), 0, st, p);

@@ -24,7 +24,7 @@ class _MPNN(nn.Module):                            # model_smoother.py:22-28
 class SmoothBatch:
     """Device-resident concatenation of B smoothing problems (see gnnmp_smooth_batch in gnnmp.h)."""
 
-    def __init__(self, paths, frees, collideds, edge_indexes, device):
+    def __init__(self, paths, frees, collideds, edge_indexes, device, prefix_arrays=True):
         def prefix(counts):
             p = torch.zeros(len(counts) + 1, dtype=torch.int64)
             p[1:] = torch.tensor(counts, dtype=torch.int64).cumsum(0)
@@ -37,9 +37,12 @@ class SmoothBatch:
             one = lambda t: t.float().reshape(t.shape[0], -1).contiguous().to(device)  # noqa: E731
             self.path, self.free, self.collided = one(paths[0]), one(frees[0]), one(collideds[0])
             self.edge_index = edge_indexes[0].long().contiguous().to(device)
-            ptrs = torch.tensor([0, paths[0].shape[0], 0, frees[0].shape[0], 0, collideds[0].shape[0], 0,
-                                 edge_indexes[0].shape[1]], dtype=torch.int32).to(device)
-            self.path_ptr, self.free_ptr, self.coll_ptr, self.edge_ptr = ptrs[0:2], ptrs[2:4], ptrs[4:6], ptrs[6:8]
+            if prefix_arrays:
+                ptrs = torch.tensor([0, paths[0].shape[0], 0, frees[0].shape[0], 0, collideds[0].shape[0], 0,
+                                     edge_indexes[0].shape[1]], dtype=torch.int32).to(device)
+                self.path_ptr, self.free_ptr, self.coll_ptr, self.edge_ptr = ptrs[0:2], ptrs[2:4], ptrs[4:6], ptrs[6:8]
+            else:       # the library takes the single problem's sizes from the totals (gnnmp.h): no host-to-device copy
+                self.path_ptr = self.free_ptr = self.coll_ptr = self.edge_ptr = None
         else:
             self.path, self.free, self.collided = f32(paths), f32(frees), f32(collideds)
             self.edge_index = torch.cat([e.long() for e in edge_indexes], dim=1).contiguous().to(device)
@@ -84,7 +87,8 @@ def _cbatch(sb):
                             sb.free.data_ptr() if sb.free.numel() else None,
                             sb.collided.data_ptr() if sb.collided.numel() else None,
                             sb.edge_index.data_ptr() if sb.edge_index.numel() else None,
-                            sb.path_ptr.data_ptr(), sb.free_ptr.data_ptr(), sb.coll_ptr.data_ptr(), sb.edge_ptr.data_ptr())
+                            *((None,) * 4 if sb.path_ptr is None else
+                              (sb.path_ptr.data_ptr(), sb.free_ptr.data_ptr(), sb.coll_ptr.data_ptr(), sb.edge_ptr.data_ptr())))
 
 
 # parameters the reference's training loss reaches (train_smoother.py:33-61): everything forward() reads
@@ -295,5 +299,5 @@ class ModelSmoother(nn.Module):
         if self.training and torch.is_grad_enabled():
             return self.forward_train(path, free, collided, obstacles, edge_index, loop)
         with torch.no_grad():
-            sb = SmoothBatch([path], [free], [collided], [edge_index], path.device)
+            sb = SmoothBatch([path], [free], [collided], [edge_index], path.device, prefix_arrays=False)
             return self.forward_batch(sb, loop)

@@ -218,6 +218,8 @@ typedef struct {
 int gnnmp_smoother_workspace_bytes(const gnnmp_smoother* h, const gnnmp_smooth_batch* shape, size_t* bytes);
 
 /* out_path [total_path, C]: the new waypoints (end points copied through, model_smoother.py:139).
+ * ONE problem (n_problems == 1, the reference's own call) may leave path_ptr, free_ptr, coll_ptr and edge_ptr all NULL:
+ * the totals describe it (inference entry point only).
  * Per-problem limits of the kernels (GNNMP_ERR_DIMS beyond them, nothing is silently truncated): at most 2048 samples
  * (free + collided; the reference's planner passes at most 500 + 500, smoother.py:57-58) and at most 7500 candidate
  * edges (caller edges + 10 kNN edges per waypoint). */

@@ -103,6 +103,29 @@ def test_batch_equals_single_bitwise():
         off += path.shape[0]
 
 
+@pytest.mark.parametrize('mode', ['fp32', 'bf16'])
+def test_split_kernels_equal_wave_kernels_bitwise(mode):
+    """Few edge tiles (a single call) run the tile-per-workgroup kernels (a tile's layers split over four waves), large
+    batches (> 512 edge tiles) the tile-per-wave kernels: same bits, in both operand modes."""
+    gen = torch.Generator().manual_seed(17)
+    name = 'smooth_7d_attv3'
+    m = make(name)
+    m.mlp_dtype = mode
+    probs = []
+    for i in range(72):                                  # ~9-14 edge tiles each: > 512 tiles in the batch
+        P = 20 + (i % 5) * 4
+        probs.append((torch.rand(P, 7, generator=gen) * 2 - 1, torch.rand(150, 7, generator=gen) * 2 - 1,
+                      torch.rand(100, 7, generator=gen) * 2 - 1, chain_edges(P)))
+    sb = gnnmp.SmoothBatch([p[0] for p in probs], [p[1] for p in probs], [p[2] for p in probs], [p[3] for p in probs], DEV)
+    assert sum((p[3].shape[1] + 10 * p[0].shape[0] + 31) // 32 for p in probs) > 512
+    out = m.forward_batch(sb, 2)
+    off = 0
+    for path, free, coll, ei in probs[:12]:
+        single = m(path=path.to(DEV), free=free.to(DEV), collided=coll.to(DEV), edge_index=ei.to(DEV), loop=2)
+        assert torch.equal(single, out[off:off + path.shape[0]])
+        off += path.shape[0]
+
+
 @pytest.mark.parametrize('seed', range(8))
 def test_random_problems(seed):
     """Structure fuzz: random waypoint counts (incl. paths longer than one 32-row tile), sample counts from fewer than
