@@ -605,7 +605,7 @@ struct Carve {
     // sizes
     int G, Npad, Epad, ot_max, kv_stride, D;
     // offsets in bytes
-    size_t node_ptr_pad, edge_ptr_pad, goal_node, dense_ptr, in_ptrs;
+    size_t node_ptr_pad, edge_ptr_pad, goal_node, dense_ptr, in_ptrs, prep_hist;
     size_t zero_beg, deg, cursor, zero_end;
     size_t ff_beg, ntile_graph, etile_graph, csr, ff_end, tile_meta, rec32;
     size_t row_beg;
@@ -648,6 +648,10 @@ bool carve(const gnnmp_explorer* h, const gnnmp_batch* b, Carve& c) {
     c.ff_end = o;
     c.rec32 = take(sizeof(int) * (size_t)c.Epad);
     c.row_beg = take(sizeof(int) * c.Npad);
+    {   // per-part target histograms + first slots of the prep stage's two-launch form (large graphs only)
+        const int parts = prep_parts(c.G, b->total_edges);
+        c.prep_hist = take(parts > 1 ? sizeof(int) * 2 * (size_t)parts * c.Npad : 0);
+    }
     const size_t nrow = sizeof(float) * (size_t)c.Npad * D, erow = sizeof(float) * (size_t)c.Epad * D;
     c.XI = take(nrow); c.X = take(nrow); c.A = take(nrow); c.A2 = take(nrow); c.B = take(nrow); c.DN = take(nrow);
     c.H = take(nrow);
@@ -755,8 +759,7 @@ int forward_impl(const gnnmp_explorer* h, const gnnmp_batch* b, int loop, int us
     q.csr = at<int4>(ws, c.csr);
     q.goal_node = at<int>(ws, c.goal_node);
     q.tile_meta = at<int>(ws, c.tile_meta); q.n_etiles = c.Epad / 32;
-    HIP_TRY(launch_prep(q, c.Npad, c.Epad, at<char>(ws, c.zero_beg), c.zero_end - c.zero_beg, at<char>(ws, c.ff_beg),
-                        c.ff_end - c.ff_beg, st));
+    HIP_TRY(launch_prep(q, c.Npad, c.Epad, at<int>(ws, c.prep_hist), st));
     // zero-fill of policy_output (model.py:148); sum_g N_g^2 is read from dense_ptr[G] on the device
     if (dense) HIP_TRY(launch_zero_dense(dense, q.dense_ptr + c.G, st));
     }

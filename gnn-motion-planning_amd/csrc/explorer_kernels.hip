@@ -2,7 +2,7 @@
 // EncoderProcessDecoder.forward of the reference (model.py:115-150), restructured for MI355X:
 //
 //   prep_*        caller edge list -> CSR-by-destination in a per-graph padded index space
-//   goal_kernel   goal node = argmin_i |v_i - goal|                         (model.py:132)
+//   (prep stage)  goal node = argmin_i |v_i - goal|                         (model.py:132)
 //   obs_kernel    obstacle codes, their 3+3 FFN stages and the K/V projections of all six
 //                 attention blocks, written as ready-made MFMA A operands   (model.py:126-130, obstacle rows)
 //   pre_kernel    per node / per edge: encoders + 3 obstacle cross-attention blocks, all in
@@ -36,48 +36,6 @@ namespace gnnmp {
 // =====================================================================================================
 __device__ __forceinline__ int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
-// one workgroup: node_ptr_pad / edge_ptr_pad / dense_ptr prefix arrays
-__global__ void prep_ptrs_kernel(int G, const int* __restrict__ node_ptr, const int* __restrict__ edge_ptr,
-                                 int* __restrict__ node_ptr_pad, int* __restrict__ edge_ptr_pad,
-                                 long long* __restrict__ dense_ptr) {
-    __shared__ int s_n[256], s_e[256];
-    __shared__ long long s_d[256];
-    __shared__ int carry_n, carry_e;
-    __shared__ long long carry_d;
-    const int tid = threadIdx.x;
-    if (tid == 0) { carry_n = 0; carry_e = 0; carry_d = 0; node_ptr_pad[0] = 0; edge_ptr_pad[0] = 0; dense_ptr[0] = 0; }
-    __syncthreads();
-    for (int base = 0; base < G; base += 256) {
-        const int g = base + tid;
-        int n = 0, e = 0;
-        long long dd = 0;
-        if (g < G) {
-            const int ng = node_ptr[g + 1] - node_ptr[g];
-            n = round_up(ng, kPad);
-            e = round_up(edge_ptr[g + 1] - edge_ptr[g], kPad);
-            dd = (long long)ng * ng;
-        }
-        s_n[tid] = n; s_e[tid] = e; s_d[tid] = dd;
-        __syncthreads();
-        for (int off = 1; off < 256; off <<= 1) {     // Hillis-Steele inclusive scan
-            int an = 0, ae = 0;
-            long long ad = 0;
-            if (tid >= off) { an = s_n[tid - off]; ae = s_e[tid - off]; ad = s_d[tid - off]; }
-            __syncthreads();
-            s_n[tid] += an; s_e[tid] += ae; s_d[tid] += ad;
-            __syncthreads();
-        }
-        if (g < G) {
-            node_ptr_pad[g + 1] = carry_n + s_n[tid];
-            edge_ptr_pad[g + 1] = carry_e + s_e[tid];
-            dense_ptr[g + 1] = carry_d + s_d[tid];
-        }
-        __syncthreads();
-        if (tid == 255) { carry_n += s_n[255]; carry_e += s_e[255]; carry_d += s_d[255]; }
-        __syncthreads();
-    }
-}
-
 __device__ __forceinline__ int find_graph(const int* __restrict__ ptr, int G, int x) {
     int lo = 0, hi = G;            // largest g with ptr[g] <= x
     while (hi - lo > 1) {
@@ -97,36 +55,55 @@ __device__ __forceinline__ int find_graph(const int* __restrict__ ptr, int G, in
 // =====================================================================================================
 constexpr int kCoopMaxTiles = 1024;     // up to this many 32-node tiles, mp_fused runs one tile per workgroup of 8 waves
 constexpr int kPrepCap = 8192;
-constexpr int kPrepGraphMin = 64;      // batches of at least this many graphs: one workgroup per graph (prep_small_kernel)
-constexpr int kPrepSmallEdges = 24576; // smaller batches: the same up to this many edges per graph on average
+constexpr int kPrepEdgesPerPart = 8192;  // prep stage: one workgroup per this many edges of a graph (at least one, at most kPrepMaxParts)
 
-__device__ __forceinline__ void prep_graph_body(const PrepParams& q, int g, int n0, int Np, int e0, int e1, int* prep_lds) {
+// Workgroup `part` of `parts` builds the CSR rows of the target nodes [lo, hi) of graph g (a slice of its padded node
+// range): it walks ALL edge columns of the graph, counts the ones whose target lies below its slice (that count is where
+// its slice starts in the slot space -- no communication between the parts) and ranks / scatters the ones inside.
+__device__ __forceinline__ void prep_graph_body(const PrepParams& q, int g, int part, int parts, int n0, int Np, int e0, int e1,
+                                                int* prep_lds) {
     __shared__ int carry;                              // prep_lds: cnt[kPrepCap], rb[kPrepCap], scan[1024]
+    __shared__ int below_w[16];
     const int tid = threadIdx.x;
     const int c0 = q.edge_ptr[g], Eg = q.edge_ptr[g + 1] - c0;            // caller columns of this graph
-    const bool in_lds = Np <= kPrepCap;
-    int* cnt = in_lds ? prep_lds : q.deg + n0;
-    int* rb = in_lds ? prep_lds + kPrepCap : q.row_beg + n0;
+    const int span = ((Np + parts - 1) / parts + 31) & ~31;
+    const int lo = min(part * span, Np), hi = min(lo + span, Np), Nown = hi - lo;
+    const bool in_lds = Nown <= kPrepCap;
+    int* cnt = in_lds ? prep_lds : q.deg + n0 + lo;
+    int* rb = in_lds ? prep_lds + kPrepCap : q.row_beg + n0 + lo;
     int* scan = prep_lds + 2 * kPrepCap;
     const long long* srcs = q.edge_index + c0;
     const long long* dsts = q.edge_index + (size_t)q.E + c0;
-    for (int i = tid; i < Np; i += 1024) cnt[i] = 0;
-    if (tid == 0) carry = e0;
+    for (int i = tid; i < Nown; i += 1024) cnt[i] = 0;
     __syncthreads();
     // arrival order inside the destination's segment (any order is fine: max-aggregation is order-free);
     // four independent columns per thread and trip so their loads are in flight together
-    for (int c = tid; c < Eg; c += 4096) {
-        int d[4];
+    int below = 0;
+    constexpr int U = 16;                               // independent columns per thread and trip: the loop is latency-bound
+    for (int c = tid; c < Eg; c += U * 1024) {
+        int d[U];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) d[u] = (c + u * 1024 < Eg) ? (int)dsts[c + u * 1024] : -1;
+        for (int u = 0; u < U; ++u) d[u] = (c + u * 1024 < Eg) ? (int)dsts[c + u * 1024] : 0x7fffffff;
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (d[u] >= 0) q.cursor[c0 + c + u * 1024] = atomicAdd(&cnt[d[u]], 1);
+        for (int u = 0; u < U; ++u) {
+            if (d[u] < lo) ++below;
+            else if (d[u] < hi) q.cursor[c0 + c + u * 1024] = atomicAdd(&cnt[d[u] - lo], 1);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) below += __shfl_down(below, off);
+    if ((tid & 63) == 0) below_w[tid >> 6] = below;
+    __syncthreads();
+    if (tid == 0) {
+        int sum = e0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) sum += below_w[w];
+        carry = sum;
     }
     __syncthreads();
-    for (int base = 0; base < Np; base += 1024) {      // exclusive scan -> absolute first slot of every node
+    for (int base = 0; base < Nown; base += 1024) {    // exclusive scan -> absolute first slot of every node
         const int i = base + tid;
-        const int d = (i < Np) ? cnt[i] : 0;
+        const int d = (i < Nown) ? cnt[i] : 0;
         scan[tid] = d;
         __syncthreads();
         for (int off = 1; off < 1024; off <<= 1) {
@@ -136,52 +113,41 @@ __device__ __forceinline__ void prep_graph_body(const PrepParams& q, int g, int 
             scan[tid] += a;
             __syncthreads();
         }
-        if (i < Np) {
+        if (i < Nown) {
             const int r = carry + scan[tid] - d;
             rb[i] = r;
-            if (in_lds) { q.row_beg[n0 + i] = r; q.deg[n0 + i] = d; }
+            if (in_lds) { q.row_beg[n0 + lo + i] = r; q.deg[n0 + lo + i] = d; }
         }
         __syncthreads();
         if (tid == 1023) carry += scan[1023];
         __syncthreads();
     }
-    for (int c = tid; c < Eg; c += 4096) {
-        int sv[4], tv[4], rk[4];
+    for (int c = tid; c < Eg; c += U * 1024) {
+        int sv[U], tv[U], rk[U];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < U; ++u) {
             const int cc = c + u * 1024;
-            const bool ok = cc < Eg;
-            sv[u] = ok ? (int)srcs[cc] : 0;
-            tv[u] = ok ? (int)dsts[cc] : -1;
-            rk[u] = ok ? q.cursor[c0 + cc] : 0;
+            tv[u] = cc < Eg ? (int)dsts[cc] : -1;
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (tv[u] >= 0)                                              // {source, target, caller column}
-                q.csr[rb[tv[u]] + rk[u]] = make_int4(n0 + sv[u], n0 + tv[u], c0 + c + u * 1024, 0);
-    }
-    for (int sl = e0 + Eg + tid; sl < e1; sl += 1024) q.csr[sl] = make_int4(-1, -1, -1, -1);
-    for (int t = n0 / 32 + tid; t < (n0 + Np) / 32; t += 1024) q.ntile_graph[t] = g;
-    for (int t = e0 / 32 + tid; t < e1 / 32; t += 1024) {
-        q.etile_graph[t] = g;
-        // bit0 = first segment starts in an earlier tile, bit1 = last segment continues in a later tile,
-        // bit2 = tile holds at least one edge (the edge pre kernel skips tiles of pure padding)
-        const int start = t * 32;
-        int meta = 0;
-        if (start < e0 + Eg) {
-            auto owner = [&](int slot) {               // largest node i with rb[i] <= slot
-                int lo = 0, hi = Np;
-                while (hi - lo > 1) {
-                    const int mid = (lo + hi) >> 1;
-                    if (rb[mid] <= slot) lo = mid; else hi = mid;
-                }
-                return lo;
-            };
-            const int lastslot = min(start + 31, e0 + Eg - 1);
-            const int d0 = owner(start), dl = owner(lastslot);
-            meta = 4 | (rb[d0] < start ? 1 : 0) | (rb[dl] + cnt[dl] > start + 32 ? 2 : 0);
+        for (int u = 0; u < U; ++u) {
+            const int cc = c + u * 1024;
+            const bool mine = tv[u] >= lo && tv[u] < hi;
+            sv[u] = mine ? (int)srcs[cc] : 0;
+            rk[u] = mine ? q.cursor[c0 + cc] : 0;
+            if (!mine) tv[u] = -1;
         }
-        q.tile_meta[t] = meta;
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (tv[u] >= 0)                                              // {source, target, caller column}
+                q.csr[rb[tv[u] - lo] + rk[u]] = make_int4(n0 + sv[u], n0 + tv[u], c0 + c + u * 1024, 0);
+    }
+    // pad slots and the per-tile maps of the graph, shared out over its parts
+    for (int sl = e0 + Eg + part * 1024 + tid; sl < e1; sl += parts * 1024) q.csr[sl] = make_int4(-1, -1, -1, -1);
+    for (int t = (n0 + lo) / 32 + tid; t < (n0 + hi) / 32; t += 1024) q.ntile_graph[t] = g;
+    for (int t = e0 / 32 + part * 1024 + tid; t < e1 / 32; t += parts * 1024) {
+        q.etile_graph[t] = g;
+        q.tile_meta[t] = t * 32 < e0 + Eg ? 4 : 0;     // 4 = tile holds at least one edge (the edge pre kernel skips pure padding)
     }
 }
 
@@ -215,31 +181,24 @@ __device__ __forceinline__ void goal_body(int C, const float* __restrict__ v, co
     if (tid == 0) goal_node[g] = (n > 0) ? n0_pad + s_i[0] : -1;
 }
 
-__global__ void single_ptrs_kernel(int* out, int n, int e, int o) {
-    const int tid = threadIdx.x;
-    if (tid < 6) out[tid] = (tid & 1) ? (tid == 1 ? n : (tid == 3 ? e : o)) : 0;
-}
-
 // -----------------------------------------------------------------------------------------------------
-// The whole prep stage in ONE launch, one workgroup per graph: padded prefix arrays (every workgroup reduces the
-// entries before its own graph itself), CSR build of graph g, goal node of graph g; the last workgroup marks the
-// tiles / slots / nodes behind the last graph as unused.  A dependent launch costs ~5 us on this part whatever it
-// does, and the stage used to be six to eight of them (two fills of up to 40 MB, prefix arrays, count, scan, fill,
-// tile metadata, goal node): 31 -> 19 us for the reference's own call pattern (ONE graph per forward, eval_gnn.py:194).
-// Used for batches of at least kPrepGraphMin graphs and for smaller batches of moderate graphs; a few large graphs
-// take the device-wide passes below.
+// The whole prep stage in ONE launch, `parts` workgroups per graph (1 for graphs up to ~12 k edges, up to 16 for large
+// ones): padded prefix arrays (every workgroup reduces the entries before its own graph itself), CSR rows of its slice
+// of the graph's target nodes, goal node of the graph (part 0); the last workgroup marks the tiles / slots / nodes
+// behind the last graph as unused.  A dependent launch costs ~5 us on this part whatever it does, and the stage used
+// to be six to eight of them (two fills of up to 40 MB, prefix arrays, count, scan, fill, tile metadata, goal node):
+// 31 -> 19 us for the reference's own call pattern (ONE graph per forward, eval_gnn.py:194).
 // -----------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void prep_small_kernel(PrepParams q, int Npad, int Epad) {
-    extern __shared__ int prep_lds[];
+// padded prefix sums over the graphs before graph g (every workgroup reduces them itself -- G loads spread over 1024
+// threads -- instead of waiting for a separate scan launch); part 0 publishes the entries of its graph
+__device__ __forceinline__ void prep_prefix(const PrepParams& q, int g, int part, int& n0, int& n1, int& e0, int& e1) {
     __shared__ long long red[3][16];
-    const int g = blockIdx.x, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     if (q.single_out) {                                // one graph given by its totals: its prefix arrays come first
         if (tid < 6) q.single_out[tid] = (tid & 1) ? (tid == 1 ? q.single_n : (tid == 3 ? q.single_e : q.single_o)) : 0;
         __threadfence();
         __syncthreads();
     }
-    // padded prefix sums over the graphs before this one: every workgroup reduces them itself (G loads spread over
-    // 1024 threads) instead of waiting for a separate scan launch
     long long an = 0, ae = 0, ad = 0;
     for (int t = tid; t < g; t += 1024) {
         const int ng = q.node_ptr[t + 1] - q.node_ptr[t];
@@ -255,119 +214,142 @@ __global__ __launch_bounds__(1024) void prep_small_kernel(PrepParams q, int Npad
 #pragma unroll
     for (int w = 0; w < 16; ++w) { an += red[0][w]; ae += red[1][w]; ad += red[2][w]; }
     const int ng_own = q.node_ptr[g + 1] - q.node_ptr[g];
-    const int n0 = (int)an, e0 = (int)ae;
-    const int n1 = n0 + round_up(ng_own, kPad), e1 = e0 + round_up(q.edge_ptr[g + 1] - q.edge_ptr[g], kPad);
-    if (tid == 0) {
+    n0 = (int)an; e0 = (int)ae;
+    n1 = n0 + round_up(ng_own, kPad); e1 = e0 + round_up(q.edge_ptr[g + 1] - q.edge_ptr[g], kPad);
+    if (tid == 0 && part == 0) {
         if (g == 0) { q.node_ptr_pad[0] = 0; q.edge_ptr_pad[0] = 0; q.dense_ptr[0] = 0; }
         q.node_ptr_pad[g + 1] = n1; q.edge_ptr_pad[g + 1] = e1; q.dense_ptr[g + 1] = ad + (long long)ng_own * ng_own;
     }
-    prep_graph_body(q, g, n0, n1 - n0, e0, e1, prep_lds);
-    goal_body(q.C, q.v, q.goal, q.node_ptr, g, n0, q.goal_node);
-    if (g == q.G - 1) {
-        const int n_end = n1, e_end = e1;
-        for (int i = n_end + tid; i < Npad; i += 1024) { q.deg[i] = 0; q.row_beg[i] = e_end; }
-        for (int t = n_end / 32 + tid; t < Npad / 32; t += 1024) q.ntile_graph[t] = -1;
-        for (int t = e_end / 32 + tid; t < Epad / 32; t += 1024) { q.etile_graph[t] = -1; q.tile_meta[t] = -1; }
-        for (int sl = e_end + tid; sl < Epad; sl += 1024) q.csr[sl] = make_int4(-1, -1, -1, -1);
-    }
+}
+
+// tiles / slots / nodes behind the last graph are unused (the padded totals are upper bounds)
+__device__ __forceinline__ void prep_trailing(const PrepParams& q, int n_end, int e_end, int Npad, int Epad) {
+    const int tid = threadIdx.x;
+    for (int i = n_end + tid; i < Npad; i += 1024) { q.deg[i] = 0; q.row_beg[i] = e_end; }
+    for (int t = n_end / 32 + tid; t < Npad / 32; t += 1024) q.ntile_graph[t] = -1;
+    for (int t = e_end / 32 + tid; t < Epad / 32; t += 1024) { q.etile_graph[t] = -1; q.tile_meta[t] = -1; }
+    for (int sl = e_end + tid; sl < Epad; sl += 1024) q.csr[sl] = make_int4(-1, -1, -1, -1);
+}
+
+__global__ __launch_bounds__(1024) void prep_small_kernel(PrepParams q, int Npad, int Epad, int parts) {
+    extern __shared__ int prep_lds[];
+    const int g = blockIdx.x / parts, part = blockIdx.x - g * parts;
+    int n0, n1, e0, e1;
+    prep_prefix(q, g, part, n0, n1, e0, e1);
+    prep_graph_body(q, g, part, parts, n0, n1 - n0, e0, e1, prep_lds);
+    if (part == 0) goal_body(q.C, q.v, q.goal, q.node_ptr, g, n0, q.goal_node);
+    if (g == q.G - 1 && part == parts - 1) prep_trailing(q, n1, e1, Npad, Epad);
 }
 
 // -----------------------------------------------------------------------------------------------------
-// Device-wide form of the same build (count -> scan -> fill -> tile metadata, one thread per edge), used for
-// small batches: a single graph with 56 k edges would keep one workgroup busy for ~90 us in the per-graph kernel,
-// while these four passes spread it over the device in ~25 us.
+// Large graphs (more than ~12 k edges on average): one workgroup walking all edge columns of a graph is a long
+// latency-bound loop (kuka14, 5000 nodes, k = 16: 80 k columns per graph, 32 graphs = 32 busy CUs).  Two launches with
+// the COLUMNS of a graph split over `parts` workgroups instead:
+//   prep_hist     part p histograms the targets of its column slice (LDS atomics; the returned count is the column's
+//                 rank among the slice's columns with that target) and publishes the histogram H[p][node];
+//                 plus prefix arrays, goal node, tile maps, pad records
+//   prep_scatter  every part sums the histograms (node totals -> scan -> first slot of every node; columns of earlier
+//                 parts come first inside a node's run) and scatters the records of its slice
 // -----------------------------------------------------------------------------------------------------
-// graph of caller column e: one binary search per workgroup (first column), then a short walk
-__device__ __forceinline__ int find_graph_wg(const int* __restrict__ ptr, int G, int e) {
-    __shared__ int s_g0;
-    if (threadIdx.x == 0) s_g0 = find_graph(ptr, G, blockIdx.x * blockDim.x);
+__global__ __launch_bounds__(1024) void prep_hist_kernel(PrepParams q, int Npad, int Epad, int parts, int* __restrict__ H) {
+    extern __shared__ int prep_lds[];
+    // all parts of a graph run on ONE XCD (workgroup b runs on XCD b % 8): they scatter into the same CSR rows, and lines
+    // written piecewise from several XCDs' L2s reach HBM as that many partial writes
+    const int idx = blockIdx.x >> 3, g = (idx / parts) * 8 + (blockIdx.x & 7), part = idx % parts, tid = threadIdx.x;
+    if (g >= q.G) return;
+    int n0, n1, e0, e1;
+    prep_prefix(q, g, part, n0, n1, e0, e1);
+    const int Np = n1 - n0;
+    const int c0 = q.edge_ptr[g], Eg = q.edge_ptr[g + 1] - c0;
+    const int cs = (int)((long long)Eg * part / parts), ce = (int)((long long)Eg * (part + 1) / parts);
+    int* hslice = H + (size_t)n0 * parts + (size_t)part * Np;
+    const bool in_lds = Np <= kPrepCap;
+    int* cnt = in_lds ? prep_lds : hslice;
+    const long long* dsts = q.edge_index + (size_t)q.E + c0;
+    for (int i = tid; i < Np; i += 1024) cnt[i] = 0;
     __syncthreads();
-    int g = s_g0;
-    while (g + 1 < G && e >= ptr[g + 1]) ++g;
-    return g;
+    constexpr int U = 16;
+    for (int c = cs + tid; c < ce; c += U * 1024) {
+        int d[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) d[u] = (c + u * 1024 < ce) ? (int)dsts[c + u * 1024] : -1;
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (d[u] >= 0) q.cursor[c0 + c + u * 1024] = atomicAdd(&cnt[d[u]], 1);
+    }
+    __syncthreads();
+    if (in_lds)
+        for (int i = tid; i < Np; i += 1024) hslice[i] = cnt[i];
+    // pad slots and the per-tile maps of the graph, shared out over its parts
+    for (int sl = e0 + Eg + part * 1024 + tid; sl < e1; sl += parts * 1024) q.csr[sl] = make_int4(-1, -1, -1, -1);
+    for (int t = n0 / 32 + part * 1024 + tid; t < n1 / 32; t += parts * 1024) q.ntile_graph[t] = g;
+    for (int t = e0 / 32 + part * 1024 + tid; t < e1 / 32; t += parts * 1024) {
+        q.etile_graph[t] = g;
+        q.tile_meta[t] = t * 32 < e0 + Eg ? 4 : 0;
+    }
+    if (part == parts - 1) goal_body(q.C, q.v, q.goal, q.node_ptr, g, n0, q.goal_node);
+    if (g == q.G - 1 && part == 0) prep_trailing(q, n1, e1, Npad, Epad);
 }
 
-__global__ void prep_count_kernel(int G, int E, const long long* __restrict__ edge_index, const int* __restrict__ edge_ptr,
-                                  const int* __restrict__ node_ptr_pad, int* __restrict__ deg, int* __restrict__ rank) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    const int g = find_graph_wg(edge_ptr, G, e < E ? e : E - 1);
-    if (e >= E) return;
-    const int dst = node_ptr_pad[g] + (int)edge_index[(size_t)E + e];
-    rank[e] = atomicAdd(&deg[dst], 1);        // arrival order inside the destination's segment (any order is fine:
-}                                             // max-aggregation is order-free and per-edge results do not depend on position)
-
-// one workgroup per graph: exclusive scan of deg over the graph's padded node range
-__global__ void prep_scan_kernel(const int* __restrict__ node_ptr_pad, const int* __restrict__ edge_ptr_pad,
-                                 const int* __restrict__ deg, int* __restrict__ row_beg,
-                                 int* __restrict__ ntile_graph, int* __restrict__ etile_graph) {
-    __shared__ int s[256];
+__global__ __launch_bounds__(1024) void prep_scatter_kernel(PrepParams q, int parts, const int* __restrict__ H, int* __restrict__ Bs) {
+    extern __shared__ int prep_lds[];
     __shared__ int carry;
-    const int g = blockIdx.x, tid = threadIdx.x;
-    const int n0 = node_ptr_pad[g], n1 = node_ptr_pad[g + 1];
-    const int e0 = edge_ptr_pad[g], e1 = edge_ptr_pad[g + 1];
+    const int idx = blockIdx.x >> 3, g = (idx / parts) * 8 + (blockIdx.x & 7), part = idx % parts, tid = threadIdx.x;
+    if (g >= q.G) return;
+    const int n0 = q.node_ptr_pad[g], Np = q.node_ptr_pad[g + 1] - n0, e0 = q.edge_ptr_pad[g];
+    const int c0 = q.edge_ptr[g], Eg = q.edge_ptr[g + 1] - c0;
+    const int cs = (int)((long long)Eg * part / parts), ce = (int)((long long)Eg * (part + 1) / parts);
+    const int* hg = H + (size_t)n0 * parts;
+    int* bs = Np <= kPrepCap ? prep_lds : Bs + (size_t)n0 * parts + (size_t)part * Np;     // first slot of my columns per node
+    int* scan = prep_lds + kPrepCap;
     if (tid == 0) carry = e0;
     __syncthreads();
-    for (int base = n0; base < n1; base += 256) {
+    for (int base = 0; base < Np; base += 1024) {
         const int i = base + tid;
-        const int d = (i < n1) ? deg[i] : 0;
-        s[tid] = d;
+        int tot = 0, mine = 0;
+        if (i < Np)
+            for (int pp = 0; pp < parts; ++pp) {
+                const int hv = hg[(size_t)pp * Np + i];
+                tot += hv;
+                mine += pp < part ? hv : 0;
+            }
+        scan[tid] = tot;
         __syncthreads();
-        for (int off = 1; off < 256; off <<= 1) {
+        for (int off = 1; off < 1024; off <<= 1) {
             int a = 0;
-            if (tid >= off) a = s[tid - off];
+            if (tid >= off) a = scan[tid - off];
             __syncthreads();
-            s[tid] += a;
+            scan[tid] += a;
             __syncthreads();
         }
-        if (i < n1) row_beg[i] = carry + s[tid] - d;
+        if (i < Np) {
+            const int r = carry + scan[tid] - tot;
+            bs[i] = r + mine;
+            if (part == 0) { q.row_beg[n0 + i] = r; q.deg[n0 + i] = tot; }
+        }
         __syncthreads();
-        if (tid == 255) carry += s[255];
+        if (tid == 1023) carry += scan[1023];
         __syncthreads();
     }
-    for (int t = n0 / 32 + tid; t < n1 / 32; t += 256) ntile_graph[t] = g;
-    for (int t = e0 / 32 + tid; t < e1 / 32; t += 256) etile_graph[t] = g;
-}
-
-__global__ void prep_fill_kernel(int G, int E, const long long* __restrict__ edge_index, const int* __restrict__ edge_ptr,
-                                 const int* __restrict__ node_ptr_pad, const int* __restrict__ row_beg,
-                                 const int* __restrict__ rank, int4* __restrict__ csr) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    const int g = find_graph_wg(edge_ptr, G, e < E ? e : E - 1);
-    if (e >= E) return;
-    const int base = node_ptr_pad[g];
-    const int src = base + (int)edge_index[e];
-    const int dst = base + (int)edge_index[(size_t)E + e];
-    const int pos = row_beg[dst] + rank[e];
-    csr[pos] = make_int4(src, dst, e, 0);      // one 16-byte record per edge: {source, target, caller column}
-}
-
-// per 32-edge tile: bit0 = its first segment starts in an earlier tile, bit1 = its last segment
-// continues in a later tile, bit2 = tile holds at least one edge; -1 = unused tile.  Lets the edge kernels skip
-// its segments without any dependent row_beg/deg loads.
-__global__ void prep_tilemeta_kernel(int n_tiles, const int4* __restrict__ csr, const int* __restrict__ row_beg,
-                                     const int* __restrict__ deg, const int* __restrict__ etile_graph,
-                                     int* __restrict__ tile_meta) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_tiles) return;
-    if (etile_graph[t] < 0) { tile_meta[t] = -1; return; }
-    const int start = t * 32;
-    const int d0 = csr[start].y;
-    if (d0 < 0) { tile_meta[t] = 0; return; }
-    int last = 31;
-    while (last > 0 && csr[start + last].y < 0) --last;
-    const int dl = csr[start + last].y;
-    const int first_open = row_beg[d0] < start;
-    const int last_open = row_beg[dl] + deg[dl] > start + 32;
-    tile_meta[t] = 4 | first_open | (last_open << 1);
-}
-
-// =====================================================================================================
-// goal node: argmin_i |v_i - goal|^2, lowest index on ties; one workgroup per graph
-// =====================================================================================================
-__global__ void goal_kernel(int C, const float* __restrict__ v, const float* __restrict__ goal,
-                            const int* __restrict__ node_ptr, const int* __restrict__ node_ptr_pad,
-                            int* __restrict__ goal_node) {
-    goal_body(C, v, goal, node_ptr, blockIdx.x, node_ptr_pad[blockIdx.x], goal_node);
+    __threadfence_block();
+    const long long* srcs = q.edge_index + c0;
+    const long long* dsts = q.edge_index + (size_t)q.E + c0;
+    constexpr int U = 8;
+    for (int c = cs + tid; c < ce; c += U * 1024) {
+        int sv[U], tv[U], rk[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int cc = c + u * 1024;
+            const bool ok = cc < ce;
+            sv[u] = ok ? (int)srcs[cc] : 0;
+            tv[u] = ok ? (int)dsts[cc] : -1;
+            rk[u] = ok ? q.cursor[c0 + cc] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (tv[u] >= 0)                                              // {source, target, caller column}
+                q.csr[bs[tv[u]] + rk[u]] = make_int4(n0 + sv[u], n0 + tv[u], c0 + c + u * 1024, 0);
+    }
 }
 
 // =====================================================================================================
@@ -1410,48 +1392,36 @@ static hipError_t set_lds(K kernel, size_t bytes) {
                                (int)bytes);
 }
 
-hipError_t launch_prep(const PrepParams& q, int Npad, int Epad, void* zero_ptr, size_t zero_bytes, void* ff_ptr, size_t ff_bytes,
-                       hipStream_t st) {
+int prep_parts(int G, int E) {
+    static const int parts_env = getenv("GNNMP_PREP_PARTS") ? atoi(getenv("GNNMP_PREP_PARTS")) : 0;    // experiments
+    const long long g = G > 0 ? G : 1;
+    long long parts = (long long)E / (g * kPrepEdgesPerPart);                 // by graph size ...
+    if (parts > 256 / g) parts = 256 / g;                                     // ... but no more workgroups than fill the device once
+    if (parts_env > 0) parts = parts_env;
+    if (parts < 1) parts = 1;
+    if (parts > kPrepMaxParts) parts = kPrepMaxParts;
+    return (int)parts;
+}
+
+// `hist`: 2 * prep_parts * Npad ints of workspace when prep_parts > 1 (unused otherwise)
+hipError_t launch_prep(const PrepParams& q, int Npad, int Epad, int* hist, hipStream_t st) {
     const size_t glds = (size_t)(2 * kPrepCap + 1024) * sizeof(int);
-    static const int prep_mode = getenv("GNNMP_PREP_MODE") ? atoi(getenv("GNNMP_PREP_MODE")) : 0;   // experiments: 1 one launch, 2 device-wide
-    if (prep_mode ? prep_mode == 1 : (q.G >= kPrepGraphMin || (long long)q.E <= (long long)q.G * kPrepSmallEdges)) {
+    const int parts = prep_parts(q.G, q.E);
+    if (parts == 1) {
         const hipError_t attr = set_lds(prep_small_kernel, glds);
         if (attr != hipSuccess) return attr;
-        hipLaunchKernelGGL(prep_small_kernel, dim3(q.G), dim3(1024), glds, st, q, Npad, Epad);
+        hipLaunchKernelGGL(prep_small_kernel, dim3(q.G), dim3(1024), glds, st, q, Npad, Epad, 1);
         LAUNCH_CHECK();
         return hipSuccess;
     }
-    if (q.single_out) {
-        hipLaunchKernelGGL(single_ptrs_kernel, dim3(1), dim3(64), 0, st, q.single_out, q.single_n, q.single_e, q.single_o);
-        LAUNCH_CHECK();
-    }
-    hipError_t me = hipMemsetAsync(zero_ptr, 0, zero_bytes, st);
-    if (me != hipSuccess) return me;
-    me = hipMemsetAsync(ff_ptr, 0xFF, ff_bytes, st);
-    if (me != hipSuccess) return me;
-    hipLaunchKernelGGL(prep_ptrs_kernel, dim3(1), dim3(256), 0, st, q.G, q.node_ptr, q.edge_ptr, q.node_ptr_pad,
-                       q.edge_ptr_pad, q.dense_ptr);
+    hipError_t attr = set_lds(prep_hist_kernel, glds);
+    if (attr != hipSuccess) return attr;
+    attr = set_lds(prep_scatter_kernel, glds);
+    if (attr != hipSuccess) return attr;
+    const unsigned grid = (unsigned)(((q.G + 7) / 8) * 8 * parts);            // (graph, part) -> workgroup: see prep_hist_kernel
+    hipLaunchKernelGGL(prep_hist_kernel, dim3(grid), dim3(1024), glds, st, q, Npad, Epad, parts, hist);
     LAUNCH_CHECK();
-    {                                                  // few, large graphs: one thread per edge across the device
-        if (q.E > 0) {
-            hipLaunchKernelGGL(prep_count_kernel, dim3((q.E + 255) / 256), dim3(256), 0, st, q.G, q.E, q.edge_index,
-                               q.edge_ptr, q.node_ptr_pad, q.deg, q.cursor);
-            LAUNCH_CHECK();
-        }
-        hipLaunchKernelGGL(prep_scan_kernel, dim3(q.G), dim3(256), 0, st, q.node_ptr_pad, q.edge_ptr_pad, q.deg, q.row_beg,
-                           q.ntile_graph, q.etile_graph);
-        LAUNCH_CHECK();
-        if (q.E > 0) {
-            hipLaunchKernelGGL(prep_fill_kernel, dim3((q.E + 255) / 256), dim3(256), 0, st, q.G, q.E, q.edge_index,
-                               q.edge_ptr, q.node_ptr_pad, q.row_beg, q.cursor, q.csr);
-            LAUNCH_CHECK();
-        }
-        hipLaunchKernelGGL(prep_tilemeta_kernel, dim3((q.n_etiles + 255) / 256), dim3(256), 0, st, q.n_etiles, q.csr,
-                           q.row_beg, q.deg, q.etile_graph, q.tile_meta);
-        LAUNCH_CHECK();
-    }
-    hipLaunchKernelGGL(goal_kernel, dim3(q.G), dim3(256), 0, st, q.C, q.v, q.goal, q.node_ptr, q.node_ptr_pad,
-                       q.goal_node);
+    hipLaunchKernelGGL(prep_scatter_kernel, dim3(grid), dim3(1024), glds, st, q, parts, hist, hist + (size_t)parts * Npad);
     LAUNCH_CHECK();
     return hipSuccess;
 }

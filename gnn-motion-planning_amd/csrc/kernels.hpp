@@ -193,8 +193,8 @@ hipError_t t_sm_coords_bwd(int P, int C, const float* dXin, float* d_prev, hipSt
 hipError_t t_scale(int n, float s, const float* x, float* y, hipStream_t st);
 hipError_t launch_sm_knn_edges(const SmParams& p, hipStream_t st);      // kNN + coalesced edge list only (training path)
 
-hipError_t launch_prep(const PrepParams& q, int Npad, int Epad, void* zero_ptr, size_t zero_bytes, void* ff_ptr, size_t ff_bytes,
-                       hipStream_t st);
+int prep_parts(int G, int E);
+hipError_t launch_prep(const PrepParams& q, int Npad, int Epad, int* hist, hipStream_t st);
 hipError_t launch_obs(int D, int P, const ObsParams& p, int G, hipStream_t st);
 hipError_t launch_pre(int D, int P, bool edge, int waves, const PreParams& p, int n_tiles32, size_t lds_bytes, hipStream_t st);
 hipError_t launch_pre_resident_both(int D, int P, const PreParams& pn, const PreParams& pe, size_t lds_bytes, int node_blocks,

@@ -7,6 +7,7 @@
 
 namespace gnnmp {
 
+constexpr int kPrepMaxParts = 16;   // workgroups per graph of the prep stage's two-launch form
 constexpr int kPad = 256;          // per-graph padding granularity of the node and edge index spaces
 constexpr int kRowsPerWave = 32;
 
