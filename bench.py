@@ -175,7 +175,7 @@ def main():
                          'DESIGN.md 4.2b); reported next to, never instead of, `value`; only with --mlp-dtype fp32')
     ap.add_argument('--single-steps', type=int, default=50, help='single-graph latency: calls per timed block (0 = skip)')
     ap.add_argument('--unique', type=int, default=0, help='distinct synthetic graphs per GPU (0 = all)')
-    ap.add_argument('--planner-problems', type=int, default=8,
+    ap.add_argument('--planner-problems', type=int, default=16,
                     help='host-loop planner problems timed next to the forward benchmark (0 = skip the planner leg)')
     args = ap.parse_args()
 

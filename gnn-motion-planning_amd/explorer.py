@@ -272,7 +272,11 @@ class EncoderProcessDecoder(nn.Module):
         _lib.check(_lib.lib().gnnmp_explorer_workspace_bytes(h, ctypes.byref(cb), ctypes.byref(need)),
                    'gnnmp_explorer_workspace_bytes')
         if self._ws is None or self._ws.numel() < need.value or self._ws.device != torch.device(device):
-            self._ws = torch.empty(need.value, dtype=torch.uint8, device=device)
+            # grown with head room: a planner calls with a slightly different edge count every time, and every
+            # re-allocation is a device malloc of tens of MB (milliseconds)
+            grow = 0 if self._ws is None or self._ws.device != torch.device(device) else need.value // 3
+            self._ws = None
+            self._ws = torch.empty(need.value + grow, dtype=torch.uint8, device=device)
         return self._ws
 
     # ------------------------------------------------------------------ batched entry points

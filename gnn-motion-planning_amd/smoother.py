@@ -260,7 +260,9 @@ class ModelSmoother(nn.Module):
         _lib.check(_lib.lib().gnnmp_smoother_workspace_bytes(h, ctypes.byref(cb), ctypes.byref(need)),
                    'gnnmp_smoother_workspace_bytes')
         if self._ws is None or self._ws.numel() < need.value or self._ws.device != dev:
-            self._ws = torch.empty(need.value, dtype=torch.uint8, device=dev)
+            grow = 0 if self._ws is None or self._ws.device != dev else need.value // 3      # see EncoderProcessDecoder._workspace
+            self._ws = None
+            self._ws = torch.empty(need.value + grow, dtype=torch.uint8, device=dev)
         out = torch.empty_like(sb.path)
         with torch.cuda.device(dev):
             st = torch.cuda.current_stream().cuda_stream
