@@ -1088,7 +1088,9 @@ __host__ __device__ constexpr int mp_lds_floats() {
 // wave 0 runs the node phase.  A single 1000-node graph has 32 tiles of ~12 chunks: 25 us per launch with one wave
 // per tile, ~9 us with eight.
 template <int D, int P, int COOP>
-__global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((P == 2 || D > 32) ? 2 : 3) : 1) void mp_fused_kernel(MpFusedParams p) {
+// d = 64 with fp32 / bf16x3 operands: the LDS tiles leave ONE 4-wave workgroup per CU anyway, so the wave may use the whole
+// register file (no spills)
+__global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 && P != 1) ? 1 : ((P == 2 || D > 32) ? 2 : 3)) : 1) void mp_fused_kernel(MpFusedParams p) {
     constexpr int NT = D / 32;
     constexpr bool kCoop = COOP > 1;
     using LE = MpEBlob<D, P>;
