@@ -885,7 +885,9 @@ extern "C" int gnnmp_explorer_debug_tap(const gnnmp_explorer* h, const gnnmp_bat
     switch (which) {
         case 0: src = c.XI; break;
         case 1: src = c.H; break;
-        case 2: src = c.X; break;
+        case 2:
+            if (h->dims.mlp_dtype == GNNMP_BF16) return GNNMP_ERR_DIMS;      // X rows are stored in bf16 in that mode
+            src = c.X; break;
         case 3:
             HIP_TRY(launch_goal_tap(c.G, at<int>(ws, c.goal_node), at<int>(ws, c.node_ptr_pad), dst, st));
             return GNNMP_OK;

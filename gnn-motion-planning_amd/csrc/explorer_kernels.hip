@@ -707,7 +707,7 @@ __global__ __launch_bounds__(WAVES * 64) void pre_kernel(PreParams p) {
         load_vec<NT>(wl + L::wehg, tmp, lane);
 #pragma unroll
         for (int t = 0; t < NT; ++t) xi[t] += isgoal ? tmp[t] : splat16(0.f);
-        store_row<NT>(p.o1 + (size_t)row * D, xi, h);                         // X_0
+        store_row_p<P == 1 ? 1 : 0, NT>(p.o1, (size_t)row, xi, h);                // X_0 (bf16 rows in the bf16 mode: its only reader is an MFMA operand)
 #pragma unroll
         for (int t = 0; t < NT; ++t) y[t] = splat16(0.f);
         linear_acc_p<P, NT, NT>(wl + L::wsrc, xi, y, lane);
@@ -859,7 +859,7 @@ __device__ __forceinline__ void pre_resident_body(const PreParams& p, const int 
                 load_vec<NT>(out_w + L::wehg, tmp, lane);
 #pragma unroll
                 for (int t = 0; t < NT; ++t) xi[t] += isgoal ? tmp[t] : splat16(0.f);
-                store_row<NT>(p.o1 + (size_t)row * D, xi, h);
+                store_row_p<P == 1 ? 1 : 0, NT>(p.o1, (size_t)row, xi, h);
 #pragma unroll
                 for (int t = 0; t < NT; ++t) y[t] = splat16(0.f);
                 linear_acc_p<P, NT, NT>(out_w + L::wsrc, xi, y, lane);
@@ -1254,7 +1254,7 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
         if constexpr (P != 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         linear_acc_stream<P, NT, false>(wn + LN::wlx, [&](int it, f32x16& x) {
             if constexpr (P != 1) read_stage_tile<D, 0>(astage, j, h, it, x);
-            else load_row_tile<0, NT>(p.X, (size_t)node, h, it, x);
+            else load_row_tile<1, NT>(p.X, (size_t)node, h, it, x);          // bf16 mode: X rows are stored in bf16
         }, H, lane);
         linear_acc_stream<P, NT, false>(wn + LN::wla, [&](int it, f32x16& x) {
 #pragma unroll
@@ -1275,7 +1275,7 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
                 load_row<NT>(p.R + (size_t)node * D, y, h);
             }
             linear_acc_p<P, NT, NT>(wn + LN::m1, H, y, lane);
-            store_row<NT>(p.Xout + (size_t)node * D, y, h);
+            store_row_p<P == 1 ? 1 : 0, NT>(p.Xout, (size_t)node, y, h);        // X is only ever read as an MFMA operand: bf16 rows lose nothing
             make_ops<P, NT>(y, yop);
         }
         {

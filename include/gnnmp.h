@@ -152,7 +152,8 @@ int gnnmp_explorer_profile_read(gnnmp_explorer* h, double* ms_sum /* [GNNMP_N_ST
 /* Test hook: after a forward, copy an intermediate out of `workspace` into `dst` (device, fp32,
  * row-major, caller node/edge order).  which: 0 = loop-invariant part of the encoder output [total_nodes, d]
  * (model.py:141 without the h_i term), 1 = final h_i [total_nodes, d] (model.py:142), 2 = decode [total_nodes, d]
- * (model.py:143), 3 = goal node per graph as float [G].  Returns GNNMP_ERR_ARG if unknown. */
+ * (model.py:143), 3 = goal node per graph as float [G].  Returns GNNMP_ERR_ARG if unknown; tap 2 is kept in bf16 in the
+ * GNNMP_BF16 mode (its only reader is an MFMA operand) and returns GNNMP_ERR_DIMS there. */
 int gnnmp_explorer_debug_tap(const gnnmp_explorer* h, const gnnmp_batch* batch, int which, float* dst,
                              void* workspace, size_t workspace_bytes, void* hip_stream);
 
