@@ -126,8 +126,9 @@ def planner_leg(n_host, n_device, dev):
     ms = gnnmp.ModelSmoother(workspace_size=2, config_size=2, embed_size=128, obs_size=6).eval()
     ms.load_state_dict(load_weights('smooth_2d_attv3'))
     np.random.seed(1234)
-    env.init_new_problem(0)
-    planner.explore(env, m, ms, True, batch=500, t_max=500, k=30, device=dev)                    # warm-up
+    for i in range(3):                                                                           # warm-up (first use of every kernel variant)
+        env.init_new_problem(i)
+        planner.explore(env, m, ms, True, batch=500, t_max=500, k=30, device=dev)
     fwd = tot = 0.0
     checks = 0
     t0 = time.perf_counter()
