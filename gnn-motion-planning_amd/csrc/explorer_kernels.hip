@@ -46,12 +46,11 @@ __device__ __forceinline__ int find_graph(const int* __restrict__ ptr, int G, in
 }
 
 // =====================================================================================================
-// prep_graph: the whole CSR-by-destination build of ONE graph in one 1024-thread workgroup (graphs are independent
-// and their caller columns contiguous): in-degree histogram + arrival rank with LDS atomics, block scan, scatter of
-// the int4 records, pad records, tile -> graph maps and the per-tile segment metadata (owner of a slot = binary
-// search in the LDS copy of row_beg).  Replaces the device-wide count / scan / fill / tilemeta passes (2.9 M global
-// returning atomics at cfg 2).  Graphs beyond kPrepCap padded nodes keep their counters in global memory
-// (same code through flat pointers).
+// prep stage: CSR-by-destination build in a per-graph padded index space.  Graphs are independent and their caller
+// columns contiguous, so a graph is built by one 1024-thread workgroup (prep_small_kernel: in-degree histogram + arrival
+// rank with LDS atomics, block scan, scatter of the int4 records, pad records, tile -> graph maps, goal node) or, when it
+// has more than ~16 k edges, by up to 16 workgroups that split its columns (prep_hist_kernel + prep_scatter_kernel).
+// Graphs beyond kPrepCap padded nodes keep their counters in global memory (same code through flat pointers).
 // =====================================================================================================
 constexpr int kCoopMaxTiles = 1024;     // up to this many 32-node tiles, mp_fused runs one tile per workgroup of 8 waves
 constexpr int kPrepCap = 8192;
@@ -922,7 +921,7 @@ struct XcdWalk {
 //                private [32 nodes][D] tile: order-free, exact, conflict-free (lanes hit consecutive banks), no
 //                transpose, no segment walk, no partial maxima across tile boundaries, no agg round trip to HBM.
 //   node phase   agg tile (0 for nodes without incoming edges: torch_scatter) -> H = Wlx X + Wla agg + bl,
-//                Y = R + M1 H, A' = M2 Y, B' = M3 Y  (the former mp_node; weights read as MFMA operands from L1/L2).
+//                Y = R + M1 H, A' = M2 Y, B' = M3 Y  (weights read as MFMA operands from L1/L2).
 // A' goes to the OTHER A buffer: other jobs still gather this iteration's A rows.
 // =====================================================================================================
 // one 32-feature tile `t` of edge slot `slot` (per-edge tiles are stored tile-native, [slot / 32][NT][...][64 lanes][...],

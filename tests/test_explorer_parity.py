@@ -272,3 +272,27 @@ def test_optional_edge_index_range_check(monkeypatch):
     ei[1, 0] = -1
     with pytest.raises(IndexError):
         m(goal=d['goal'], loop=2, v=d['v'], obstacles=d['obstacles'], edge_index=ei)
+
+
+def test_large_graph_prep_paths():
+    """A graph with more than 8192 nodes (counters of the CSR build in global memory instead of LDS) and ~100 k edges (its
+    columns split over several workgroups, prep_hist / prep_scatter).  The full graph is too slow for the fp64 oracle, so
+    the check is invariance, bitwise: the scores do not depend on how the build was split -- alone (12 parts) or batched
+    with a small graph (6 parts) -- nor on the caller's column order (a different arrival rank for every edge).  Values
+    against the oracle at a multi-part size: test_single_graph_without_prefix_arrays[3000-12] and the full-size tests."""
+    m = make_model('maze2')
+    big = synth_graph('maze2', 9000, 8, seed=77)
+    small = synth_graph('maze2', 64, 4, seed=78)
+    d = to_dev(big)
+    E = d['edge_index'].shape[1]
+    assert d['v'].shape[0] > 8192 and E > 8 * 8192
+    alone = m.edge_scores(d['goal'], 2, d['v'], d['obstacles'], d['edge_index'])
+    assert bool(torch.isfinite(alone).all())
+    b = gnnmp.GraphBatch.from_graphs([big, small], 2, DEV)
+    both = b.split_edges(m.forward_batch(b, 2))
+    assert torch.equal(both[0], alone)
+    ds = to_dev(small)
+    assert torch.equal(both[1], m.edge_scores(ds['goal'], 2, ds['v'], ds['obstacles'], ds['edge_index']))
+    perm = torch.randperm(E, generator=torch.Generator().manual_seed(5)).to(DEV)
+    shuffled = m.edge_scores(d['goal'], 2, d['v'], d['obstacles'], d['edge_index'][:, perm])
+    assert torch.equal(shuffled, alone[perm])
