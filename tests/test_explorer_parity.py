@@ -279,7 +279,7 @@ def test_large_graph_prep_paths():
     columns split over several workgroups, prep_hist / prep_scatter).  The full graph is too slow for the fp64 oracle, so
     the check is invariance, bitwise: the scores do not depend on how the build was split -- alone (12 parts) or batched
     with a small graph (6 parts) -- nor on the caller's column order (a different arrival rank for every edge).  Values
-    against the oracle at a multi-part size: test_single_graph_without_prefix_arrays[3000-12] and the full-size tests."""
+    against the oracle at a multi-part size: the full-size tests (30 k- and 80 k-edge graphs, tests/test_full_size_bf16_gpu.py)."""
     m = make_model('maze2')
     big = synth_graph('maze2', 9000, 8, seed=77)
     small = synth_graph('maze2', 64, 4, seed=78)
