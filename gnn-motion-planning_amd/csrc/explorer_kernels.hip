@@ -52,7 +52,9 @@ __device__ __forceinline__ int find_graph(const int* __restrict__ ptr, int G, in
 // has more than ~16 k edges, by up to 16 workgroups that split its columns (prep_hist_kernel + prep_scatter_kernel).
 // Graphs beyond kPrepCap padded nodes keep their counters in global memory (same code through flat pointers).
 // =====================================================================================================
-constexpr int kCoopMaxTiles = 1024;     // up to this many 32-node tiles, mp_fused runs one tile per workgroup of 8 waves
+// up to this many 32-node tiles mp_fused runs one tile per workgroup of 8 waves (measured crossovers: 12-16 graphs of
+// 1000 nodes at d = 32, 8-12 graphs of 2000 nodes at d = 64)
+constexpr int kCoopMaxTiles32 = 384, kCoopMaxTiles64 = 600;
 constexpr int kPrepCap = 8192;
 constexpr int kPrepEdgesPerPart = 8192;  // prep stage: one workgroup per this many edges of a graph (at least one, at most kPrepMaxParts)
 
@@ -1557,7 +1559,7 @@ static hipError_t launch_mp_fused_t(const MpFusedParams& p, hipStream_t st) {
 template <int D, int P>
 static hipError_t launch_mp_fused_dp(const MpFusedParams& p, hipStream_t st) {
     static const int forced = getenv("GNNMP_MP_COOP") ? atoi(getenv("GNNMP_MP_COOP")) : -1;
-    const bool coop = forced >= 0 ? forced != 0 : p.n_tiles <= kCoopMaxTiles;
+    const bool coop = forced >= 0 ? forced != 0 : p.n_tiles <= (D > 32 ? kCoopMaxTiles64 : kCoopMaxTiles32);
     return coop ? launch_mp_fused_t<D, P, 8>(p, st) : launch_mp_fused_t<D, P, 1>(p, st);
 }
 hipError_t launch_mp_fused(int D, int P, const MpFusedParams& p_in, hipStream_t st) {
