@@ -326,8 +326,8 @@ __global__ __launch_bounds__(256) void sm_node_kernel(SmParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Few tiles (the reference's call: ONE problem, ~9 edge tiles and one path tile): a tile's layers are a chain of
-// ~1300 exact-fp32 MFMAs for one wave (34 us at 64 cycles each).  Here a tile belongs to a WORKGROUP of NT waves and
+// A tile's layers are a chain of ~1300 exact-fp32 MFMAs for one wave (34 us at 64 cycles each; the reference's call is ONE
+// problem, ~9 edge tiles and one path tile).  Here a tile belongs to a WORKGROUP of NT waves and
 // wave w computes output tile w (32 features) of every layer, i.e. a quarter of the MFMAs at d = 128; the waves
 // exchange their tiles through LDS between layers (all waves share the row <-> lane mapping, so the exchange is a
 // plain register dump and reload).  Every output element is accumulated in the same order as in the one-wave kernels:
@@ -478,7 +478,7 @@ hipError_t launch_sm_final(int n, float scale, const float* cur, float* out, hip
     return hipSuccess;
 }
 
-constexpr int kSmSplitMaxTiles = 512;   // up to this many 32-edge tiles the split kernels run (one workgroup per tile)
+constexpr int kSmSplitMaxTilesBf16 = 2048;   // bf16 operands: the split kernels up to this many 32-edge tiles
 
 template <int D, int P>
 static hipError_t launch_sm_iter_t(const SmParams& p, hipStream_t st) {
@@ -487,9 +487,11 @@ static hipError_t launch_sm_iter_t(const SmParams& p, hipStream_t st) {
     const size_t lds = (size_t)2 * p.cand_cap * sizeof(int);
     hipLaunchKernelGGL(sm_edges_kernel, dim3(p.B), dim3(256), lds, st, p);
     LAUNCH_CHECK();
-    // few tiles: one tile per workgroup, its layers split over D / 32 waves (bit-identical, a quarter of the chain depth)
+    // one tile per workgroup, its layers split over D / 32 waves (bit-identical, a quarter of the chain depth): measured
+    // faster at EVERY batch size with exact-fp32 MFMAs (1 problem 143 -> 88 us, 256 problems 313 -> 238 us, 2048 problems
+    // 1.67 -> 1.43 ms) and up to ~250 problems with bf16 operands (beyond that the tile-per-wave kernels win by 5-10 %)
     static const int split_env = getenv("GNNMP_SM_SPLIT") ? atoi(getenv("GNNMP_SM_SPLIT")) : -1;
-    const bool split = D >= 64 && (split_env >= 0 ? split_env != 0 : p.n_etiles <= kSmSplitMaxTiles);
+    const bool split = D >= 64 && (split_env >= 0 ? split_env != 0 : (P == 0 || p.n_etiles <= kSmSplitMaxTilesBf16));
     if (split) {
         hipLaunchKernelGGL((sm_msg_split_kernel<D, P>), dim3(p.n_etiles), dim3(D * 2), 0, st, p);
         LAUNCH_CHECK();

@@ -105,19 +105,21 @@ def test_batch_equals_single_bitwise():
 
 @pytest.mark.parametrize('mode', ['fp32', 'bf16'])
 def test_split_kernels_equal_wave_kernels_bitwise(mode):
-    """Few edge tiles (a single call) run the tile-per-workgroup kernels (a tile's layers split over four waves), large
-    batches (> 512 edge tiles) the tile-per-wave kernels: same bits, in both operand modes."""
+    """The tile-per-workgroup kernels (a tile's layers split over four waves; all fp32 batches, bf16 up to 2048 edge
+    tiles) and the tile-per-wave kernels (larger bf16 batches): same bits.  bf16: a > 2048-tile batch against single calls;
+    fp32: the same comparison exercises batched vs single launches of the split kernels (the wave kernels are compared
+    in tests/test_smoother_wave_kernels_gpu.py through the GNNMP_SM_SPLIT switch)."""
     gen = torch.Generator().manual_seed(17)
     name = 'smooth_7d_attv3'
     m = make(name)
     m.mlp_dtype = mode
     probs = []
-    for i in range(72):                                  # ~9-14 edge tiles each: > 512 tiles in the batch
+    for i in range(240):                                 # ~9-14 edge tiles each: > 2048 tiles in the batch
         P = 20 + (i % 5) * 4
         probs.append((torch.rand(P, 7, generator=gen) * 2 - 1, torch.rand(150, 7, generator=gen) * 2 - 1,
                       torch.rand(100, 7, generator=gen) * 2 - 1, chain_edges(P)))
     sb = gnnmp.SmoothBatch([p[0] for p in probs], [p[1] for p in probs], [p[2] for p in probs], [p[3] for p in probs], DEV)
-    assert sum((p[3].shape[1] + 10 * p[0].shape[0] + 31) // 32 for p in probs) > 512
+    assert sum((p[3].shape[1] + 10 * p[0].shape[0] + 31) // 32 for p in probs) > 2048
     out = m.forward_batch(sb, 2)
     off = 0
     for path, free, coll, ei in probs[:12]:
