@@ -1547,7 +1547,14 @@ static hipError_t launch_mp_fused_t(const MpFusedParams& p, hipStream_t st) {
     hipError_t e = set_lds(mp_fused_kernel<D, P, COOP>, lds);
     if (e != hipSuccess) return e;
     if (COOP == 1) {
-        hipLaunchKernelGGL((mp_fused_kernel<D, P, COOP>), dim3(grid_for(mp_fused_kernel<D, P, COOP>, lds, p.n_tiles, 2)), dim3(256), lds, st, p);
+        // one workgroup per group of four tiles, NOT capped at what is resident: the hardware dispatcher hands the next
+        // group to whichever CU frees up first, which balances the uneven tiles better than a static share per resident
+        // workgroup did (five launches: cfg 2 0.952 -> 0.910 ms, kuka7 bf16 0.72 -> 0.70, kuka14 bf16 0.633 -> 0.592;
+        // a grid of 1.5x the resident workgroups is the worst case: 1.087 ms at cfg 2)
+        static const int forced = getenv("GNNMP_WGS_PER_CU") ? atoi(getenv("GNNMP_WGS_PER_CU")) : 0;      // experiments
+        int grid = ((p.n_tiles + 3) / 4 + 7) & ~7;
+        if (forced > 0) grid = grid_for(mp_fused_kernel<D, P, COOP>, lds, p.n_tiles, forced);
+        hipLaunchKernelGGL((mp_fused_kernel<D, P, COOP>), dim3(grid < 8 ? 8 : grid), dim3(256), lds, st, p);
     } else {
         const int grid = ((p.n_tiles + 7) & ~7) < 8 ? 8 : ((p.n_tiles + 7) & ~7);          // one workgroup per tile
         hipLaunchKernelGGL((mp_fused_kernel<D, P, COOP>), dim3(grid), dim3(COOP * 64), lds, st, p);
