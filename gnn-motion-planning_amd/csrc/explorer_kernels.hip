@@ -1303,35 +1303,70 @@ template <int D, int P>
 __global__ __launch_bounds__(256) void policy_kernel(PolicyParams p) {
     constexpr int NT = D / 32;
     using L = PolBlob<D, P>;
+    using G = RowGeom<D, P>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* wl = lds;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
+    // per wave: the PS rows of the tile's 32 sources and the PT rows of its 32 targets, gathered through LDS-DMA in the
+    // quad-coalesced layout of the message kernel (a chain-layout gather is one L1 access per lane)
+    float* sstage = lds + ((L::size + 3) & ~3) + wave * 2 * G::STAGE_FLOATS;
+    float* tstage = sstage + G::STAGE_FLOATS;
     stage(wl, p.w, L::size);
     __syncthreads();
     XcdWalk wk((p.n_tiles + 3) / 4);
-    int4 rec_n = make_int4(-1, -1, -1, 0);
-    int g_n = -1;
-    auto fetch = [&](int grp) {
-        const int tl = grp * 4 + wave;
-        g_n = -1;
-        if (tl < p.n_tiles) {
-            g_n = p.etile_graph[tl];
-            rec_n = p.csr[tl * 32 + j];
+    // software pipeline over this wave's tiles: while tile i is multiplied, the rows and the PE tile of tile i+1 are in
+    // flight and the records of tile i+2 are requested
+    int4 rec_c = make_int4(-1, -1, -1, 0), rec_n = make_int4(-1, -1, -1, 0);
+    int g_c = -1, g_n = -1, tile_c = -1, tile_n = -1;
+    auto fetch = [&](int grp, int4& rec, int& g, int& tile) {
+        tile = grp * 4 + wave;
+        g = -1;
+        rec = make_int4(-1, -1, -1, 0);
+        if (tile < p.n_tiles) {
+            g = p.etile_graph[tile];
+            rec = p.csr[tile * 32 + j];
         }
     };
-    if (wk.valid()) fetch(wk.cur);
-    while (wk.valid()) {
-        const int tile = wk.cur * 4 + wave;
-        const int4 rec = rec_n;
-        const int g = __builtin_amdgcn_readfirstlane(g_n);
+    f32x16 hid_n[NT];
+    auto issue = [&](const int4& rec, int g, int tile) {      // rows + PE tile of a fetched tile (g wave-uniform after the wait)
+        if (g < 0) return;
+        const int srow = rec.x >= 0 ? rec.x : 0, trow = rec.y >= 0 ? rec.y : 0;
+        dma_rows<D, P>(p.PS, [&](int sr) { return __builtin_amdgcn_ds_bpermute(sr * 4, srow); }, sstage, lane);
+        dma_rows<D, P>(p.PT, [&](int sr) { return __builtin_amdgcn_ds_bpermute(sr * 4, trow); }, tstage, lane);
+        load_tile_nt_p<P, NT>(p.PE + (size_t)tile * NT * kETile, hid_n, lane);
+    };
+    if (wk.valid()) {
+        fetch(wk.cur, rec_c, g_c, tile_c);
         wk.next();
-        if (wk.valid()) fetch(wk.cur);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        g_c = __builtin_amdgcn_readfirstlane(g_c);
+        issue(rec_c, g_c, tile_c);
+        if (wk.valid()) fetch(wk.cur, rec_n, g_n, tile_n);
+    }
+    while (tile_c >= 0) {
+        const int4 rec = rec_c;
+        const int g = g_c;
+        f32x16 hid[NT], a[NT], b[NT];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this tile's rows and PE tile (and the next records) have landed
+        if (g >= 0) {
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt) {
+                hid[tt] = hid_n[tt];
+                read_stage_tile<D, P>(sstage, j, h, tt, a[tt]);
+                read_stage_tile<D, P>(tstage, j, h, tt, b[tt]);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the stages have been read: the next tile may overwrite them
+        // advance the pipeline
+        rec_c = rec_n; tile_c = wk.valid() ? tile_n : -1;
+        g_c = tile_c >= 0 ? __builtin_amdgcn_readfirstlane(g_n) : -1;
+        if (tile_c >= 0) {
+            wk.next();
+            issue(rec_c, g_c, tile_c);
+            if (wk.valid()) fetch(wk.cur, rec_n, g_n, tile_n);
+        }
         if (g < 0) continue;
         const int s = rec.x, t = rec.y;
-        f32x16 hid[NT], a[NT], b[NT];
-        load_tile_nt_p<P, NT>(p.PE + (size_t)tile * NT * kETile, hid, lane);
-        load_row_p<P, NT>(p.PS, (size_t)(s >= 0 ? s : 0), a, h);
-        load_row_p<P, NT>(p.PT, (size_t)(t >= 0 ? t : 0), b, h);
 #pragma unroll
         for (int tt = 0; tt < NT; ++tt) hid[tt] += a[tt] - b[tt];
         relu_<NT>(hid);
@@ -1576,7 +1611,7 @@ hipError_t launch_mp_fused(int D, int P, const MpFusedParams& p_in, hipStream_t 
 
 template <int D, int P>
 static hipError_t launch_policy_t(const PolicyParams& p, hipStream_t st) {
-    const size_t lds = (size_t)PolBlob<D, P>::size * sizeof(float);
+    const size_t lds = (size_t)(((PolBlob<D, P>::size + 3) & ~3) + 4 * 2 * RowGeom<D, P>::STAGE_FLOATS) * sizeof(float);
     hipError_t e = set_lds(policy_kernel<D, P>, lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((policy_kernel<D, P>), dim3(grid_for(policy_kernel<D, P>, lds, p.n_tiles, 3)), dim3(256), lds, st, p);
