@@ -86,9 +86,9 @@ def test_star_graph_hub_spans_many_tiles():
 
 
 def test_per_graph_csr_build_ragged_batch():
-    """Batches of >= 64 graphs take the one-workgroup-per-graph CSR build (prep_graph_kernel; smaller batches the
-    device-wide passes): 80 random graphs incl. empty edge lists, single nodes and hubs, and bit-equality with the
-    same graphs scored one by one (device-wide path)."""
+    """80 random graphs incl. empty edge lists, single nodes and hubs in one batch (one workgroup per graph in the CSR
+    build, tile-per-wave message kernel) and bit-equality with the same graphs scored one by one (tile-per-workgroup
+    message kernel, both pre stages in one launch)."""
     gen = torch.Generator().manual_seed(31)
     w = load_weights('weights_maze')
     m = gnnmp.EncoderProcessDecoder(2, 2, 32, 2)
@@ -111,8 +111,8 @@ def test_per_graph_csr_build_ragged_batch():
 
 
 def test_graph_beyond_the_lds_share_of_the_csr_build():
-    """9 000 nodes inside a 66-graph batch: the per-graph CSR build keeps this graph's counters in global memory
-    instead of LDS (kPrepCap = 8192), the 65 small graphs next to it take the LDS path."""
+    """9 000 nodes inside a 66-graph batch: the CSR build keeps this graph's counters in global memory instead of LDS
+    (kPrepCap = 8192), the 65 small graphs next to it take the LDS path."""
     gen = torch.Generator().manual_seed(77)
     w = load_weights('weights_maze')
     m = gnnmp.EncoderProcessDecoder(2, 2, 32, 2)
@@ -159,3 +159,50 @@ def test_random_graphs_other_kernels(mode, seed):
         else:
             err = (part - ref).abs()
             assert err.mean().item() <= 0.03 and err.max().item() <= 0.25, (err.mean().item(), err.max().item())
+
+
+@pytest.mark.parametrize('tiles', [376, 384, 392])
+def test_message_kernel_form_boundary(tiles):
+    """The message kernel switches from one tile per workgroup to one tile per wave above 384 32-node tiles (d = 32): batches
+    just below, at and above the switch give the same bits as their graphs scored one by one, and match the oracle."""
+    gen = torch.Generator().manual_seed(tiles)
+    w = load_weights('weights_maze')
+    m = gnnmp.EncoderProcessDecoder(2, 2, 32, 2)
+    m.load_state_dict(w)
+    graphs, have = [], 0
+    while have < tiles:                                   # every graph occupies a multiple of 8 tiles (256-node padding)
+        want = min(tiles - have, 8 * int(torch.randint(1, 4, (1,), generator=gen)))
+        n = want * 32 - int(torch.randint(0, 200, (1,), generator=gen))
+        graphs.append(random_graph(gen, n, int(torch.randint(n, 4 * n, (1,), generator=gen)), int(torch.randint(0, 60, (1,), generator=gen))))
+        have += want
+    b = gnnmp.GraphBatch.from_graphs(graphs, 2, DEV)
+    parts = b.split_edges(m.forward_batch(b, 3))
+    for i, (g, part) in enumerate(zip(graphs, parts)):
+        one = m.edge_scores(g['goal'].to(DEV), 3, g['v'].to(DEV), g['obstacles'].to(DEV), g['edge_index'].to(DEV))
+        assert torch.equal(part, one), i
+    check(parts[0].cpu(), w, graphs[0], 3)
+    check(parts[-1].cpu(), w, graphs[-1], 3)
+
+
+def test_column_split_csr_build_ragged_batch():
+    """Graphs averaging more than 8 k edges take the two-launch CSR build (edge columns of a graph split over several
+    workgroups): a ragged batch with large graphs, an edge-less graph, a single-node graph and a hub; bit-equality with
+    the graphs scored one by one (other part counts, or the one-launch build) and the oracle on the small ones."""
+    gen = torch.Generator().manual_seed(909)
+    w = load_weights('weights_maze')
+    m = gnnmp.EncoderProcessDecoder(2, 2, 32, 2)
+    m.load_state_dict(w)
+    graphs = [random_graph(gen, 2500, 40000, 30, hub=500), random_graph(gen, 40, 0, 5), random_graph(gen, 1, 3, 0),
+              random_graph(gen, 3000, 52000, 90), random_graph(gen, 150, 600, 116, hub=90), random_graph(gen, 1800, 25000, 1)]
+    b = gnnmp.GraphBatch.from_graphs(graphs, 2, DEV)
+    assert b.total_edges // b.n_graphs > 2 * 8192
+    parts = b.split_edges(m.forward_batch(b, 2))
+    for i, (g, part) in enumerate(zip(graphs, parts)):
+        if g['edge_index'].shape[1] == 0:
+            assert part.numel() == 0
+            continue
+        one = m.edge_scores(g['goal'].to(DEV), 2, g['v'].to(DEV), g['obstacles'].to(DEV), g['edge_index'].to(DEV))
+        assert torch.equal(part, one), i
+    check(parts[2].cpu(), w, graphs[2], 2)
+    check(parts[4].cpu(), w, graphs[4], 2)
+    check(parts[5].cpu(), w, graphs[5], 2)
