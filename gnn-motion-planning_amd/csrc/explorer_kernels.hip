@@ -81,14 +81,30 @@ __device__ __forceinline__ void prep_graph_body(const PrepParams& q, int g, int 
     // four independent columns per thread and trip so their loads are in flight together
     int below = 0;
     constexpr int U = 16;                               // independent columns per thread and trip: the loop is latency-bound
-    for (int c = tid; c < Eg; c += U * 1024) {
-        int d[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) d[u] = (c + u * 1024 < Eg) ? (int)dsts[c + u * 1024] : 0x7fffffff;
+    // graphs of up to U * 1024 columns built by one workgroup: every thread keeps its columns (source, target, arrival
+    // rank) in registers between the ranking and the scatter -- edge_index is read once and the rank never goes to memory
+    const bool in_regs = parts == 1 && Eg <= U * 1024;
+    int sv_r[U], tv_r[U], rk_r[U];
+    if (in_regs) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            if (d[u] < lo) ++below;
-            else if (d[u] < hi) q.cursor[c0 + c + u * 1024] = atomicAdd(&cnt[d[u] - lo], 1);
+            const int cc = tid + u * 1024;
+            const bool ok = cc < Eg;
+            tv_r[u] = ok ? (int)dsts[cc] : -1;
+            sv_r[u] = ok ? (int)srcs[cc] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) rk_r[u] = tv_r[u] >= 0 ? atomicAdd(&cnt[tv_r[u]], 1) : 0;
+    } else {
+        for (int c = tid; c < Eg; c += U * 1024) {
+            int d[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) d[u] = (c + u * 1024 < Eg) ? (int)dsts[c + u * 1024] : 0x7fffffff;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (d[u] < lo) ++below;
+                else if (d[u] < hi) q.cursor[c0 + c + u * 1024] = atomicAdd(&cnt[d[u] - lo], 1);
+            }
         }
     }
 #pragma unroll
@@ -123,25 +139,32 @@ __device__ __forceinline__ void prep_graph_body(const PrepParams& q, int g, int 
         if (tid == 1023) carry += scan[1023];
         __syncthreads();
     }
-    for (int c = tid; c < Eg; c += U * 1024) {
-        int sv[U], tv[U], rk[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int cc = c + u * 1024;
-            tv[u] = cc < Eg ? (int)dsts[cc] : -1;
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int cc = c + u * 1024;
-            const bool mine = tv[u] >= lo && tv[u] < hi;
-            sv[u] = mine ? (int)srcs[cc] : 0;
-            rk[u] = mine ? q.cursor[c0 + cc] : 0;
-            if (!mine) tv[u] = -1;
-        }
+    if (in_regs) {
 #pragma unroll
         for (int u = 0; u < U; ++u)
-            if (tv[u] >= 0)                                              // {source, target, caller column}
-                q.csr[rb[tv[u] - lo] + rk[u]] = make_int4(n0 + sv[u], n0 + tv[u], c0 + c + u * 1024, 0);
+            if (tv_r[u] >= 0)                                            // {source, target, caller column}
+                q.csr[rb[tv_r[u]] + rk_r[u]] = make_int4(n0 + sv_r[u], n0 + tv_r[u], c0 + tid + u * 1024, 0);
+    } else {
+        for (int c = tid; c < Eg; c += U * 1024) {
+            int sv[U], tv[U], rk[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int cc = c + u * 1024;
+                tv[u] = cc < Eg ? (int)dsts[cc] : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int cc = c + u * 1024;
+                const bool mine = tv[u] >= lo && tv[u] < hi;
+                sv[u] = mine ? (int)srcs[cc] : 0;
+                rk[u] = mine ? q.cursor[c0 + cc] : 0;
+                if (!mine) tv[u] = -1;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (tv[u] >= 0)                                          // {source, target, caller column}
+                    q.csr[rb[tv[u] - lo] + rk[u]] = make_int4(n0 + sv[u], n0 + tv[u], c0 + c + u * 1024, 0);
+        }
     }
     // pad slots and the per-tile maps of the graph, shared out over its parts
     for (int sl = e0 + Eg + part * 1024 + tid; sl < e1; sl += parts * 1024) q.csr[sl] = make_int4(-1, -1, -1, -1);
