@@ -58,6 +58,31 @@ constexpr int kCoopMaxTiles32 = 384, kCoopMaxTiles64 = 600;
 constexpr int kPrepCap = 8192;
 constexpr int kPrepEdgesPerPart = 8192;  // prep stage: one workgroup per this many edges of a graph (at least one, at most kPrepMaxParts)
 
+// inclusive prefix sum over the 1024 threads of a workgroup: wave-level shuffles, then the 16 wave totals through LDS
+// (three barriers instead of the twenty of a Hillis-Steele scan in LDS); `wsum` holds 16 ints.  Returns the inclusive
+// prefix of `v`; `total` = sum over the workgroup.
+__device__ __forceinline__ int block_scan_1024(int v, int* wsum, int& total) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int x = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int y = __shfl_up(x, off);
+        if (lane >= off) x += y;
+    }
+    __syncthreads();                                   // wsum of the previous call has been read
+    if (lane == 63) wsum[wave] = x;
+    __syncthreads();
+    int before = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        const int t = wsum[w];
+        before += w < wave ? t : 0;
+        all += t;
+    }
+    total = all;
+    return x + before;
+}
+
 // Workgroup `part` of `parts` builds the CSR rows of the target nodes [lo, hi) of graph g (a slice of its padded node
 // range): it walks ALL edge columns of the graph, counts the ones whose target lies below its slice (that count is where
 // its slice starts in the slot space -- no communication between the parts) and ranks / scatters the ones inside.
@@ -118,27 +143,20 @@ __device__ __forceinline__ void prep_graph_body(const PrepParams& q, int g, int 
         carry = sum;
     }
     __syncthreads();
+    int carry_run = carry;                             // every thread carries the running offset itself
     for (int base = 0; base < Nown; base += 1024) {    // exclusive scan -> absolute first slot of every node
         const int i = base + tid;
         const int d = (i < Nown) ? cnt[i] : 0;
-        scan[tid] = d;
-        __syncthreads();
-        for (int off = 1; off < 1024; off <<= 1) {
-            int a = 0;
-            if (tid >= off) a = scan[tid - off];
-            __syncthreads();
-            scan[tid] += a;
-            __syncthreads();
-        }
+        int chunk_total;
+        const int incl = block_scan_1024(d, scan, chunk_total);
         if (i < Nown) {
-            const int r = carry + scan[tid] - d;
+            const int r = carry_run + incl - d;
             rb[i] = r;
             if (in_lds) { q.row_beg[n0 + lo + i] = r; q.deg[n0 + lo + i] = d; }
         }
-        __syncthreads();
-        if (tid == 1023) carry += scan[1023];
-        __syncthreads();
+        carry_run += chunk_total;
     }
+    __syncthreads();                                   // rb is complete
     if (in_regs) {
 #pragma unroll
         for (int u = 0; u < U; ++u)
@@ -317,7 +335,6 @@ __global__ __launch_bounds__(1024) void prep_hist_kernel(PrepParams q, int Npad,
 
 __global__ __launch_bounds__(1024) void prep_scatter_kernel(PrepParams q, int parts, const int* __restrict__ H, int* __restrict__ Bs) {
     extern __shared__ int prep_lds[];
-    __shared__ int carry;
     const int idx = blockIdx.x >> 3, g = (idx / parts) * 8 + (blockIdx.x & 7), part = idx % parts, tid = threadIdx.x;
     if (g >= q.G) return;
     const int n0 = q.node_ptr_pad[g], Np = q.node_ptr_pad[g + 1] - n0, e0 = q.edge_ptr_pad[g];
@@ -326,8 +343,7 @@ __global__ __launch_bounds__(1024) void prep_scatter_kernel(PrepParams q, int pa
     const int* hg = H + (size_t)n0 * parts;
     int* bs = Np <= kPrepCap ? prep_lds : Bs + (size_t)n0 * parts + (size_t)part * Np;     // first slot of my columns per node
     int* scan = prep_lds + kPrepCap;
-    if (tid == 0) carry = e0;
-    __syncthreads();
+    int carry_run = e0;
     for (int base = 0; base < Np; base += 1024) {
         const int i = base + tid;
         int tot = 0, mine = 0;
@@ -337,25 +353,17 @@ __global__ __launch_bounds__(1024) void prep_scatter_kernel(PrepParams q, int pa
                 tot += hv;
                 mine += pp < part ? hv : 0;
             }
-        scan[tid] = tot;
-        __syncthreads();
-        for (int off = 1; off < 1024; off <<= 1) {
-            int a = 0;
-            if (tid >= off) a = scan[tid - off];
-            __syncthreads();
-            scan[tid] += a;
-            __syncthreads();
-        }
+        int chunk_total;
+        const int incl = block_scan_1024(tot, scan, chunk_total);
         if (i < Np) {
-            const int r = carry + scan[tid] - tot;
+            const int r = carry_run + incl - tot;
             bs[i] = r + mine;
             if (part == 0) { q.row_beg[n0 + i] = r; q.deg[n0 + i] = tot; }
         }
-        __syncthreads();
-        if (tid == 1023) carry += scan[1023];
-        __syncthreads();
+        carry_run += chunk_total;
     }
     __threadfence_block();
+    __syncthreads();                                   // bs is complete
     const long long* srcs = q.edge_index + c0;
     const long long* dsts = q.edge_index + (size_t)q.E + c0;
     constexpr int U = 8;
