@@ -273,6 +273,7 @@ def main():
     # secondary: drop-in output format (the reference's zero-filled dense [N, N] block per graph, model.py:148-149)
     dense_rate = None
     if args.dense_steps > 0:
+        torch.cuda.empty_cache()          # the 1 GB output block must come out of the allocator's cache on every step, not from a fresh device malloc
         model.forward_batch(batch, args.loop, dense=True)
         torch.cuda.synchronize(dev)
         t1 = time.perf_counter()
