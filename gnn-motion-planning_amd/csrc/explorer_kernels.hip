@@ -1138,6 +1138,11 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
     int* dl = reinterpret_cast<int*>(mine);                      // [32] agg row offsets (floats) of this chunk's targets
     float* astage = mine + 32;                                   // gathered A rows of the current chunk
     stage(wl, p.we, LE::size);
+    // d = 32: the node phase's weights (MpNBlob, 20 KB) fit next to the tiles -- staged once per workgroup instead of read
+    // from L1 / L2 as MFMA operands by every tile (five launches at cfg 2: 0.910 -> 0.872 ms)
+    constexpr bool kNodeWInLds = D == 32;
+    float* wnl = lds + ((LE::size + 3) & ~3) + mp_lds_floats<D, P, COOP>();
+    if constexpr (kNodeWInLds) stage(wnl, p.wn, LN::size);
     __syncthreads();
     // b2 of the lane's feature(s): packed vectors are in register order, vec[(t*2 + h')*16 + r'] = b[32 t + phi(r', h')]
     float bias[NT];
@@ -1274,8 +1279,8 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
         // ---- node phase.  X and R rows of the tile (contiguous, fp32) come through the two stages as well; the weights
         // (MpNBlob) are read from global memory as MFMA operands (at d = 64 the pointer is laundered per job so that the
         // compiler does not hoist those loop-invariant loads out of the job loop into ~70 registers)
-        const float* wn = p.wn;
-        asm volatile("" : "+s"(wn));
+        const float* wn = kNodeWInLds ? wnl : p.wn;
+        if constexpr (!kNodeWInLds) asm volatile("" : "+s"(wn));
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if constexpr (P != 1) {                                  // fp32 rows fill a whole stage each
             dma_rows<D, 0>(p.X, [&](int sr) { return t0 + sr; }, astage, lane);
@@ -1609,7 +1614,7 @@ static int grid_for(K kernel, size_t lds_bytes, int n_tiles, int max_per_cu) {
 
 template <int D, int P, int COOP>
 static hipError_t launch_mp_fused_t(const MpFusedParams& p, hipStream_t st) {
-    const size_t lds = (size_t)(((MpEBlob<D, P>::size + 3) & ~3) + mp_lds_floats<D, P, COOP>()) * sizeof(float);
+    const size_t lds = (size_t)(((MpEBlob<D, P>::size + 3) & ~3) + mp_lds_floats<D, P, COOP>() + (D == 32 ? ((MpNBlob<D, P>::size + 3) & ~3) : 0)) * sizeof(float);
     hipError_t e = set_lds(mp_fused_kernel<D, P, COOP>, lds);
     if (e != hipSuccess) return e;
     if (COOP == 1) {
