@@ -806,7 +806,7 @@ __device__ __forceinline__ void pre_resident_body(const PreParams& p, const int 
             // keeps the compiler from hoisting those loop-invariant loads out of the tile loop into dozens of registers
             const float* enc_w = p.enc;
             const float* out_w = p.out_in_lds ? outl : p.out;
-            if constexpr (D > 32) asm volatile("" : "+s"(enc_w), "+s"(out_w));    // d = 32: registers to spare, hoisting pays
+            if constexpr (D > 32 || !EDGE) asm volatile("" : "+s"(enc_w), "+s"(out_w));    // d = 32 edge kernel: registers to spare, hoisting pays
             f32x16 m[NT], aux[NT];
             if constexpr (EDGE) {
                 const int4 rec = p.csr[row];
