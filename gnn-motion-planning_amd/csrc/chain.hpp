@@ -327,15 +327,23 @@ __device__ __forceinline__ void layer_norm_(f32x16 (&x)[NT], const float* gamma,
     f32x16 acc = x[0];
 #pragma unroll
     for (int t = 1; t < NT; ++t) acc += x[t];
-    const float mean = xsum(tree_sum(acc)) * inv_d;
+    float mean = xsum(tree_sum(acc)) * inv_d;
+    // keep the mean a value of its own: fused into the subtraction (x - sum * (1/d)) it becomes 16 unpacked fmas per tile
+    // instead of 8 packed adds
+    asm volatile("" : "+v"(mean));
     f32x16 sq = splat16(0.f);
+    const float nmean = -mean;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        x[t] -= mean;
+        x[t] += nmean;                                  // packed adds with the negated mean broadcast
         sq += x[t] * x[t];
     }
     const float v = xsum(tree_sum(sq));
-    const float rstd = 1.0f / sqrtf(v * inv_d + eps);
+    // 1 / sqrt: hardware estimate + one Newton step (full fp32 accuracy, 5 instructions instead of the ~20 of the IEEE
+    // square root and division sequences)
+    const float var = v * inv_d + eps;
+    float rstd = __builtin_amdgcn_rsqf(var);
+    rstd = rstd * (1.5f - 0.5f * var * rstd * rstd);
     f32x16 g[NT], b[NT];
     load_vec<NT>(gamma, g, lane);
     load_vec<NT>(beta, b, lane);

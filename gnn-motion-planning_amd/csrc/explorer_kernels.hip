@@ -623,7 +623,9 @@ __device__ __forceinline__ void attention_block(const float* wl, const float* wg
             mx = nmx;
         }
     }
-    const float inv = 1.0f / xsum(psum);
+    const float den = xsum(psum);                                // reciprocal: hardware estimate + one Newton step
+    float inv = __builtin_amdgcn_rcpf(den);
+    inv = inv * (2.0f - den * inv);
 #pragma unroll
     for (int t = 0; t < NT; ++t) m[t] = acc[t] * inv + m[t];         // value mix + residual
     layer_norm_<NT>(m, wg + L::ln1g, wg + L::ln1b, 1e-6f, lane);        // vectors: global (L1/L2 hits)
