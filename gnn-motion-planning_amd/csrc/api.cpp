@@ -208,6 +208,19 @@ extern "C" int64_t gnnmp_pack_a_small(const float* w, int out_f, int ld, int col
     return (int64_t)nto * ks * 64;
 }
 
+extern "C" int64_t gnnmp_pack_f64_ops(const float* w, int out_f, int ld, int col0, int n_in, int row_perm, float* dst) {
+    if (!w || !dst || out_f < 16 || out_f % 16 || n_in < 1) return GNNMP_ERR_ARG;
+    const int nks = (n_in + 3) / 4;
+    for (int ob = 0; ob < out_f / 16; ++ob)
+        for (int ks = 0; ks < nks; ++ks)
+            for (int l = 0; l < 64; ++l) {
+                const int k = 4 * ks + (l >> 4), i = l & 15;
+                const int row = 16 * ob + (row_perm ? 4 * (i & 3) + (i >> 2) : i);
+                dst[((size_t)ob * nks + ks) * 64 + l] = k < n_in ? w[(size_t)row * ld + col0 + k] : 0.f;
+            }
+    return (int64_t)(out_f / 16) * nks * 64;
+}
+
 extern "C" int64_t gnnmp_pack_vec(const float* b, int n, float* dst) {
     const int nt = n / 32;
     for (int t = 0; t < nt; ++t)
@@ -262,6 +275,7 @@ struct gnnmp_explorer {
     int n_cu;             // compute units of the device (persistent-kernel grid)
     int resident;         // use pre_resident_kernel when it fits (GNNMP_RESIDENT=0 disables)
     int resident_both;    // small batches: node and edge pre stages in one launch (GNNMP_PRE_BOTH=0 disables)
+    int node_f64;         // node side block 0 in double precision (fp32-class modes; GNNMP_NODE_F64=0 disables, for attribution runs)
     float* w_raw_dev;     // the caller's weight blob as given (manifest order, torch row-major): the training path's view
     std::vector<Entry> man;
     std::vector<int64_t> man_off;
@@ -320,6 +334,7 @@ void pack_explorer(const Blob& B, const gnnmp_explorer_dims& dm, gnnmp_explorer*
     o.pol = take(PolBlob<D, P>::size);
     o.obs_e = take(h->obs.size);
     o.obs_n = take(h->obs.size);
+    o.f64 = take(F64Blob::make(D, C).size);
     o.total = cur;
     out.assign(cur, 0.f);
     float* PK = out.data();
@@ -400,6 +415,19 @@ void pack_explorer(const Blob& B, const gnnmp_explorer_dims& dm, gnnmp_explorer*
             }
             tiles(wqk.data(), D, 0, a + A::wqk);
             tiles(W(p + ".attention.value.weight"), D, 0, a + A::wv);
+            if (side == 1 && b == 0) {
+                // node side, block 0 in fp64 (node_f64_body): node_free_code's encoder + this block's Wqk, Wv, LayerNorm
+                const F64Blob F = F64Blob::make(D, C);
+                float* f = PK + o.f64;
+                gnnmp_pack_f64_ops(W("node_free_code.0.weight"), D, C, 0, C, 0, f + F.w1);
+                std::memcpy(f + F.b1, W("node_free_code.0.bias"), sizeof(float) * D);
+                gnnmp_pack_f64_ops(W("node_free_code.2.weight"), D, D, 0, D, 0, f + F.w2);
+                std::memcpy(f + F.b2, W("node_free_code.2.bias"), sizeof(float) * D);
+                gnnmp_pack_f64_ops(wqk.data(), D, D, 0, D, 1, f + F.wqk);               // these two run on the f32 instruction
+                gnnmp_pack_f64_ops(W(p + ".attention.value.weight"), D, D, 0, D, 1, f + F.wv);
+                std::memcpy(f + F.lng, W(p + ".attention.layer_norm.weight"), sizeof(float) * D);
+                std::memcpy(f + F.lnb, W(p + ".attention.layer_norm.bias"), sizeof(float) * D);
+            }
             vec(W(p + ".attention.layer_norm.weight"), a + A::ln1g);
             vec(W(p + ".attention.layer_norm.bias"), a + A::ln1b);
             tiles(W(p + ".map_feed.w_1.weight"), D, 0, a + A::w1);
@@ -537,6 +565,8 @@ extern "C" int gnnmp_explorer_create(gnnmp_explorer** out, const gnnmp_explorer_
         h->resident = !(env && env[0] == '0');
         const char* env2 = std::getenv("GNNMP_PRE_BOTH");
         h->resident_both = !(env2 && env2[0] == '0');
+        const char* env3 = std::getenv("GNNMP_NODE_F64");
+        h->node_f64 = !(env3 && env3[0] == '0');
     }
     if (e == hipSuccess) e = hipMalloc((void**)&h->w_dev, packed.size() * sizeof(float));
     if (e == hipSuccess) e = hipMemcpy(h->w_dev, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice);
@@ -609,7 +639,7 @@ struct Carve {
     size_t zero_beg, deg, cursor, zero_end;
     size_t ff_beg, ntile_graph, etile_graph, csr, ff_end, tile_meta, rec32;
     size_t row_beg;
-    size_t XI, X, A, A2, B, DN, H, Ke, PE, kv_e, kv_n;
+    size_t XI, X, A, A2, B, DN, H, Ke, PE, kv_e, kv_n, M0;
     size_t total;
 };
 
@@ -655,6 +685,7 @@ bool carve(const gnnmp_explorer* h, const gnnmp_batch* b, Carve& c) {
     const size_t nrow = sizeof(float) * (size_t)c.Npad * D, erow = sizeof(float) * (size_t)c.Epad * D;
     c.XI = take(nrow); c.X = take(nrow); c.A = take(nrow); c.A2 = take(nrow); c.B = take(nrow); c.DN = take(nrow);
     c.H = take(nrow);
+    c.M0 = take(h->dims.mlp_dtype == GNNMP_BF16 ? 0 : nrow);      // node_f64_body -> node pre kernel (fp32-class modes)
     c.Ke = take(erow); c.PE = take(erow);
     c.kv_e = take(sizeof(float) * (size_t)c.G * 3 * c.kv_stride);
     c.kv_n = take(sizeof(float) * (size_t)c.G * 3 * c.kv_stride);
@@ -765,6 +796,7 @@ int forward_impl(const gnnmp_explorer* h, const gnnmp_batch* b, int loop, int us
     }
 
     const bool use_obs = use_obstacles != 0;
+    bool use_m0 = false;
     if (use_obs) {
         ObsParams op;
         op.obstacles = b->obstacles; op.obs_ptr = obs_ptr; op.S = h->dims.obs_size;
@@ -772,8 +804,15 @@ int forward_impl(const gnnmp_explorer* h, const gnnmp_batch* b, int loop, int us
         op.blob = h->obs;
         op.kv[0] = at<float>(ws, c.kv_n); op.kv[1] = at<float>(ws, c.kv_e);
         op.kv_stride = c.kv_stride; op.ot_max = c.ot_max;
+        NodeF64Params nq;
+        nq.v = b->v; nq.C = C; nq.node_ptr = node_ptr; nq.node_ptr_pad = q.node_ptr_pad; nq.ntile_graph = q.ntile_graph;
+        nq.w = W + h->off.f64; nq.blob = F64Blob::make(D, C);
+        nq.m0 = at<float>(ws, c.M0);
+        nq.groups = c.Npad / 64 > 2 * h->n_cu ? 4 : 1;                          // kPad = 256 rows = 4 groups
+        nq.n_wg = (P != GNNMP_BF16 && h->node_f64) ? c.Npad / (64 * nq.groups) : 0;
+        use_m0 = nq.n_wg > 0;
         StageScope sc(prof, GNNMP_STAGE_OBS, st);
-        HIP_TRY(launch_obs(D, P, op, c.G, st));
+        HIP_TRY(launch_obs(D, P, op, nq, c.G, st));
     }
 
     PreParams pp[2];
@@ -799,6 +838,7 @@ int forward_impl(const gnnmp_explorer* h, const gnnmp_batch* b, int loop, int us
         plan[edge] = plan_pre(D, P, c.ot_max, p.encb.size, p.out_size, use_obs);
         p.ot_chunk = plan[edge].ot_chunk; p.wregion = plan[edge].wregion; p.use_obstacles = use_obs ? 1 : 0;
         p.om = edge ? om_edges : om_nodes;
+        p.m0 = (!edge && use_m0) ? at<float>(ws, c.M0) : nullptr;
         if (edge) { p.o0 = at<float>(ws, c.Ke); p.o1 = at<float>(ws, c.PE); p.o2 = p.o3 = p.o4 = nullptr; }
         else {
             p.o0 = at<float>(ws, c.XI); p.o1 = at<float>(ws, c.X); p.o2 = at<float>(ws, c.A);

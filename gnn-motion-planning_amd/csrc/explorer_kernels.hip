@@ -422,19 +422,19 @@ __device__ __forceinline__ void ffn_(const float* w1, const float* b1, const flo
 // KV slab of (graph, block): Ko A-tiles [ot][ft][1024] then Vo A-tiles [ot][ft][1024] (stride ot_max).
 // =====================================================================================================
 template <int D, int P>
-__global__ __launch_bounds__(256) void obs_kernel(ObsParams p) {
+__device__ __forceinline__ void obs_body(const ObsParams& p, const int vblock) {
     constexpr int NT = D / 32;
     constexpr int TF = Prec<P>::TF;
     // workgroup (g, side): the node-side and edge-side obstacle stacks are independent chains of ~14 dependent layers
     // each; side by side they halve the latency of the stage for a single graph and double the workgroups of a batch
-    const int g = blockIdx.x >> 1;
+    const int g = vblock >> 1;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
     // max_obstacles is a caller promise; clamp so a too-small value truncates the obstacle set instead of
     // writing past the K/V slab (documented in gnnmp.h)
     const int o0 = p.obs_ptr[g], O = min(p.obs_ptr[g + 1] - o0, p.ot_max * 32);
     const int OT = (O + 31) / 32;
     {
-        const int side = blockIdx.x & 1;
+        const int side = vblock & 1;
         const float* W = p.w[side];
         const ObsBlob L = p.blob;
         float* kv_side = p.kv[side];
@@ -518,16 +518,313 @@ __global__ __launch_bounds__(256) void obs_kernel(ObsParams p) {
     }
 }
 
+
+// =====================================================================================================
+// node_f64_body: the node side's node_free_code encoder (model.py:122) and the attention sub-block of node block 0
+// (model.py:164-181 for node_attentions.0) in DOUBLE precision -- the one stretch of the forward where fp32 rounding is
+// amplified: obstacle logits of block 0 are nearly uniform (|x| < 0.3), the attended value is close to a plain average,
+// and the LayerNorm behind it divides by the small spread of (average + node_free_code); with fp32 there the scores move
+// by ~1e-5 (the reference's own fp32-vs-fp64 distance on the 116-obstacle mazes is made of exactly this,
+// tools/diag/parity_sensitivity*.py), everything else contributes <= 3e-6.  The node side is 1/11 of the rows and this is
+// one of its three blocks, so double precision here costs a few per cent of the step.
+//
+// v_mfma_f64_16x16x4_f64 (64 cycles, probed with tools/microbench/mfma_f64_probe.hip): A[i][k] in lane i + 16 k,
+// B[k][j] in lane j + 16 k, D[i][j] in lane j + 16 (i % 4), register i / 4.  One wave owns 16 nodes; a node's features live
+// in the four lanes j, j+16, j+32, j+48: lane (j, g) holds feature 16 b + 4 r + g in register r of block b -- which is what
+// the next layer's B operand needs at k-step r (k slot g <-> input feature 4 r + g), so chains of layers run in registers
+// in the natural feature order.  Softmax weights come out as lane (j, g), register r <-> obstacle 16 ob + 4 r + g: the B
+// operand of P.V with the same rule.
+// Workgroup = 4 waves = 64 padded node rows of ONE graph; it builds the graph's node-side block-0 obstacle operands
+// K' = Wqk code, V = Wv code itself (fp32 chain code of obs_body, f64_obs_chunk obstacles at a time into LDS) so that the role has
+// no dependency on the obstacle role and both run in the same launch.
+// =====================================================================================================
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ double gsum4(double x) {
+    x += __shfl_xor(x, 16, 64);
+    x += __shfl_xor(x, 32, 64);
+    return x;
+}
+// max over the four lanes of a node on the VALU (gfx950 v_permlane16_swap / v_permlane32_swap: no LDS round trip in the
+// per-block critical path): swapping a value with itself leaves {rows 0,0,2,2} and {rows 1,1,3,3} (then {halves 0,0} and {1,1})
+__device__ __forceinline__ float gmax4f(float x) {
+    const unsigned u = __float_as_uint(x);
+    const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    const float m = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    const unsigned v = __float_as_uint(m);
+    const auto b = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+
+// exp(x) for x <= 0 (softmax weights relative to the running maximum), double precision: x = n ln2 + r, |r| <= 0.347,
+// Taylor polynomial of degree 10 (remainder < 3e-13 relative: six digits beyond fp32), scaled by 2^n.  Written with
+// full-rate instructions only: n by the 1.5 * 2^52 trick (its integer value is the low word of the sum), the scaling by an
+// integer add into the exponent field (the polynomial is in [0.7, 1.42] and n >= -1010 after the clamp, so the result stays
+// normal).  A masked obstacle (-inf) comes out as e^-700 = 1e-304: nothing, next to a denominator >= 1.
+__device__ __forceinline__ double exp_nonpos(double x) {
+    x = fmax(x, -700.0);
+    const double t = fma(x, 1.4426950408889634, 6755399441055744.0);
+    const double n = t - 6755399441055744.0;
+    double r = fma(-n, 6.93147180369123816490e-01, x);
+    r = fma(-n, 1.90821492927058770002e-10, r);
+    double p = 1.0 / 3628800.0;
+    p = fma(p, r, 1.0 / 362880.0);
+    p = fma(p, r, 1.0 / 40320.0);
+    p = fma(p, r, 1.0 / 5040.0);
+    p = fma(p, r, 1.0 / 720.0);
+    p = fma(p, r, 1.0 / 120.0);
+    p = fma(p, r, 1.0 / 24.0);
+    p = fma(p, r, 1.0 / 6.0);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    const int ni = __double2loint(t);
+    return __hiloint2double(__double2hiint(p) + (ni << 20), __double2loint(p));
+}
+
+// y[ob] += sum_ib A[ob][ib] . x[ib]   (A: [NB][NB][4][64] floats)
+template <int NB>
+__device__ __forceinline__ void lin64(const float* A, const f64x4 (&x)[NB], f64x4 (&y)[NB], int lane) {
+#pragma unroll
+    for (int ib = 0; ib < NB; ++ib)
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+#pragma unroll
+            for (int ob = 0; ob < NB; ++ob)
+                y[ob] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)A[((ob * NB + ib) * 4 + st) * 64 + lane], x[ib][st], y[ob], 0, 0, 0);
+}
+
+template <int NB>
+__device__ __forceinline__ void vec64(const float* b, f64x4 (&y)[NB], int g) {
+#pragma unroll
+    for (int ob = 0; ob < NB; ++ob)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) y[ob][r] = (double)b[16 * ob + 4 * r + g];
+}
+
+template <int D, int P>
+__device__ __forceinline__ void node_f64_body(const ObsParams& p, const NodeF64Params& q, const int vblock) {
+    constexpr int NB = D / 16, NT = D / 32, OC = f64_obs_chunk(D);
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const F64Blob L = q.blob;
+    float* wl = lds;
+    float* kd = lds + ((L.size + 3) & ~3);
+    float* vd = kd + OC * D;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j16 = lane & 15, g = lane >> 4;
+    // a workgroup owns q.groups consecutive 64-row groups of ONE graph's padded node range (kPad is a multiple of 64 *
+    // groups): the obstacle operands are built once per workgroup
+    const int row00 = vblock * 64 * q.groups;
+    const int gr = q.ntile_graph[row00 >> 5];
+    if (gr < 0) return;
+    stage(wl, q.w, L.size);
+    const int o0 = p.obs_ptr[gr], O = min(p.obs_ptr[gr + 1] - o0, p.ot_max * 32);
+    const int OT = (O + 31) / 32;
+    const int C = q.C;
+    const int nbase_pad = q.node_ptr_pad[gr], nbase = q.node_ptr[gr], ng = q.node_ptr[gr + 1] - nbase;
+    const bool single_chunk = O <= OC;
+    const double isd = 1.0 / sqrt((double)D);
+    for (int grp = 0; grp < q.groups; ++grp) {
+    const int row0 = row00 + grp * 64;
+    if (row0 - nbase_pad >= ng) {                          // (uniform) nothing but padding rows from here on: finite rows, no work
+        for (int i = threadIdx.x; i < (q.groups - grp) * 64 * D; i += 256) q.m0[(size_t)row0 * D + i] = 0.f;
+        break;
+    }
+    const int row = row0 + wave * 16 + j16, local = row - nbase_pad;
+    const float* vr = q.v + (size_t)(nbase + (local < ng ? local : 0)) * C;
+
+    f64x4 x[NB], acc[NB];
+    float xf[NB][4];
+    float mxs = 0.f, l0s = 0.f;
+    double den = 0.0;
+    for (int oc0 = 0; oc0 == 0 || oc0 < O; oc0 += OC) {
+        if (oc0 > 0 || (grp > 0 && !single_chunk)) __syncthreads();    // everybody is done with the previous chunk's operands
+        if (grp == 0 || !single_chunk)
+        {   // obstacle operands of this chunk: wave w owns the 32-obstacle tiles oc0/32 + w, ... (obs_body's arithmetic for b = 0)
+            const float* W = p.w[0];
+            const ObsBlob Lo = p.blob;
+            const int h = lane >> 5, j = lane & 31, S = p.S;
+            for (int ot = (oc0 >> 5) + wave; ot < min(OT, (oc0 + OC) >> 5); ot += 4) {
+                const int o = ot * 32 + j;
+                const bool valid = o < O;
+                const float* orow = p.obstacles + (size_t)(o0 + (valid ? o : 0)) * S;
+                f32x16 code[NT], K[NT], V[NT];
+                mlp2_in<NT, P>(W + Lo.as0, Lo.ks, W + Lo.b0, W + Lo.a0, W + Lo.c0,
+                               [&](int k) { const bool ok = k < S; const float xx = orow[ok ? k : 0]; return ok ? xx : 0.f; }, code, lane);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) { K[t] = splat16(0.f); V[t] = splat16(0.f); }
+                linear_acc_p<P, NT, NT>(W + Lo.blk0 + Lo.wk, code, K, lane);
+                linear_acc_p<P, NT, NT>(W + Lo.blk0 + Lo.wv, code, V, lane);
+                const int oo = o - oc0;
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int f = 32 * t + phi(r, h);
+                        kd[(((oo >> 4) * NB + (f >> 4)) * 4 + ((f & 15) >> 2)) * 64 + (oo & 15) + 16 * (f & 3)] = valid ? K[t][r] : 0.f;
+                        vd[(((oo >> 4) * NB + (f >> 4)) * 4 + (oo & 3)) * 64 + (f & 15) + 16 * ((oo & 15) >> 2)] = valid ? V[t][r] : 0.f;
+                    }
+            }
+        }
+        if (grp == 0 || !single_chunk) __syncthreads();    // operands (and, the first time, the staged weights) are in LDS
+        if (oc0 == 0) {
+            // node_free_code = W2 relu(W1 v + b1) + b2
+            f64x4 hdn[NB];
+            vec64<NB>(wl + L.b1, hdn, g);
+            for (int st = 0; st < L.ks; ++st) {
+                const int k = 4 * st + g;
+                const double xin = k < C ? (double)vr[k] : 0.0;
+#pragma unroll
+                for (int ob = 0; ob < NB; ++ob)
+                    hdn[ob] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)wl[L.w1 + (ob * L.ks + st) * 64 + lane], xin, hdn[ob], 0, 0, 0);
+            }
+#pragma unroll
+            for (int ob = 0; ob < NB; ++ob)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) hdn[ob][r] = fmax(hdn[ob][r], 0.0);
+            vec64<NB>(wl + L.b2, x, g);
+            lin64<NB>(wl + L.w2, hdn, x, lane);
+            // self term: logit m . (Wqk m), value Wv m with weight exp(0)
+#pragma unroll
+            for (int ob = 0; ob < NB; ++ob)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xf[ob][r] = (float)x[ob][r];
+            // Wqk m and Wv m on the fp32 pipe (neither is sensitive: 4e-9 / 2e-7 on the scores when rounded to fp32); the rows of
+            // these two operands are packed permuted so that the f32 result layout (feature 4 g + r) lands on the f64 one (4 r + g)
+            f32x4 tq[NB], mv[NB];
+#pragma unroll
+            for (int ob = 0; ob < NB; ++ob) { tq[ob] = f32x4{0.f, 0.f, 0.f, 0.f}; mv[ob] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+            for (int ib = 0; ib < NB; ++ib)
+#pragma unroll
+                for (int st = 0; st < 4; ++st)
+#pragma unroll
+                    for (int ob = 0; ob < NB; ++ob) {
+                        tq[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[L.wqk + ((ob * NB + ib) * 4 + st) * 64 + lane], xf[ib][st], tq[ob], 0, 0, 0);
+                        mv[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[L.wv + ((ob * NB + ib) * 4 + st) * 64 + lane], xf[ib][st], mv[ob], 0, 0, 0);
+                    }
+            double l0 = 0.0;
+#pragma unroll
+            for (int ob = 0; ob < NB; ++ob)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    l0 = fma(x[ob][r], (double)tq[ob][r], l0);
+                    acc[ob][r] = (double)mv[ob][r];
+                }
+            l0s = (float)gsum4(l0);                        // UNSCALED self logit, in float like the obstacle logits
+        }
+        // Softmax over the chunk in two passes (its logits stay in registers): no rescaling of the accumulators between
+        // blocks, so they stay in the matrix pipe's registers, and one exp per weight.  Across chunks (O > 128): online.
+        // pass 1: logits on the fp32 matrix pipe (v_mfma_f32_16x16x4_f32, half the time of the f64 one): a logit error of
+        // 1e-7 moves a softmax weight by 1e-7 relative, no more -- the sensitive quantities are the weights' OWN rounding,
+        // the weighted sum and the LayerNorm input, which stay in double.  Result layout of the f32 instruction: lane
+        // (j, g), register r <-> obstacle 16 ob + 4 g + r (the f64 one has 4 r + g); vd is packed to match.
+        const int nblk = (min(O, oc0 + OC) - oc0 + 15) >> 4;
+        f32x4 sl[OC / 16];
+        float lmax = -INFINITY;
+#pragma unroll
+        for (int ob = 0; ob < OC / 16; ++ob) {
+            f32x4 sv = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            if (ob < nblk) {
+                sv = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ib = 0; ib < NB; ++ib)
+#pragma unroll
+                    for (int st = 0; st < 4; ++st)
+                        sv = __builtin_amdgcn_mfma_f32_16x16x4f32(kd[((ob * NB + ib) * 4 + st) * 64 + lane], xf[ib][st], sv, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    sv[r] = (oc0 + 16 * ob + 4 * g + r < O) ? sv[r] : -INFINITY;
+                    lmax = fmaxf(lmax, sv[r]);
+                }
+            }
+            sl[ob] = sv;
+        }
+        const float nmxs = fmaxf(oc0 == 0 ? l0s : mxs, gmax4f(lmax));
+        {
+            // first chunk: the self term enters with weight exp(self - max); later chunks: rescale what has been summed
+            const double alpha = exp_nonpos(((double)(oc0 == 0 ? l0s : mxs) - (double)nmxs) * isd);
+            den = (oc0 == 0) ? (g == 0 ? alpha : 0.0) : den * alpha;     // lane-local share of the denominator, summed over g at the end
+#pragma unroll
+            for (int fb = 0; fb < NB; ++fb) acc[fb] *= alpha;
+        }
+        mxs = nmxs;
+#pragma unroll
+        for (int ob = 0; ob < OC / 16; ++ob) {
+            if (ob < nblk) {
+                f64x4 pr;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    pr[r] = exp_nonpos(((double)sl[ob][r] - (double)nmxs) * isd);     // 0 for the padding obstacles
+                    den += pr[r];
+                }
+#pragma unroll
+                for (int st = 0; st < 4; ++st)
+#pragma unroll
+                    for (int fb = 0; fb < NB; ++fb)
+                        acc[fb] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)vd[((ob * NB + fb) * 4 + st) * 64 + lane], pr[st], acc[fb], 0, 0, 0);
+            }
+        }
+    }
+    // value mix + residual + LayerNorm (biased variance, eps 1e-6 inside the root: model.py:181), rounded to fp32 once
+    const double inv = 1.0 / gsum4(den);
+    double sum = 0.0;
+#pragma unroll
+    for (int ob = 0; ob < NB; ++ob)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            x[ob][r] = fma(acc[ob][r], inv, x[ob][r]);
+            sum += x[ob][r];
+        }
+    const double mean = gsum4(sum) * (1.0 / D);
+    double sq = 0.0;
+#pragma unroll
+    for (int ob = 0; ob < NB; ++ob)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            x[ob][r] -= mean;
+            sq = fma(x[ob][r], x[ob][r], sq);
+        }
+    const double rstd = 1.0 / sqrt(gsum4(sq) * (1.0 / D) + 1e-6);
+    float* out = q.m0 + (size_t)row * D;
+#pragma unroll
+    for (int ob = 0; ob < NB; ++ob)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int f = 16 * ob + 4 * r + g;
+            out[f] = (float)(x[ob][r] * rstd * (double)wl[L.lng + f] + (double)wl[L.lnb + f]);
+        }
+    }   // 64-row group
+}
+
+// the obstacle launch: workgroups [0, f64_blocks) run node_f64_body (fp32-class modes only), the rest obs_body
+template <int D, int P>
+__global__ __launch_bounds__(256) void obs_kernel(ObsParams p, NodeF64Params q, int f64_blocks) {
+    // the (few, short) obstacle workgroups first: the edge side's K/V is what the next launch waits for
+    const int obs_blocks = (int)gridDim.x - f64_blocks;
+    if constexpr (P != 1) {
+        if ((int)blockIdx.x >= obs_blocks) {
+            node_f64_body<D, P>(p, q, (int)blockIdx.x - obs_blocks);
+            return;
+        }
+    }
+    obs_body<D, P>(p, (int)blockIdx.x);
+}
+
 // =====================================================================================================
 // attention Block on the map rows held in registers (model.py:164-181 + map_feed :212-216).
 // wl: LDS copy of AttBlob<D>; kvl: LDS K/V chunk region; kvg: this (graph, block)'s slab in global.
 // =====================================================================================================
-template <int D, int P>
+// MAYSKIP && skip (workgroup-uniform): m already went through the attention sub-block (node_f64_body), only map_feed runs
+template <int D, int P, bool MAYSKIP = false>
 __device__ __forceinline__ void attention_block(const float* wl, const float* wg, float* kvl, const float* kvg, int O,
-                                                int ot_max, int ot_chunk, f32x16 (&m)[D / 32], int lane) {
+                                                int ot_max, int ot_chunk, f32x16 (&m)[D / 32], int lane, bool skip = false) {
     constexpr int NT = D / 32;
     constexpr int TF = Prec<P>::TF;
     using L = AttBlob<D, P>;
+    if (MAYSKIP && skip) {
+        ffn_<NT, P>(wl + L::w1, wg + L::b1, wl + L::w2, wg + L::b2, wg + L::ln2g, wg + L::ln2b, m, lane);
+        return;
+    }
     const int h = lane >> 5;
     const int OT = (O + 31) / 32;
     f32x16 acc[NT];
@@ -691,7 +988,8 @@ __global__ __launch_bounds__(WAVES * 64) void pre_kernel(PreParams p) {
         };
         auto getin_nf = [&](int k) { const bool ok = k < C; const float x = vr[ok ? k : 0]; return ok ? x : 0.f; };
         mlp2_in<NT, P>(wl + E.as0, E.ks0, wl + E.b0, wl + E.a0, wl + E.c0, getin_nc, aux, lane);  // node_code
-        mlp2_in<NT, P>(wl + E.as1, E.ks1, wl + E.b1, wl + E.a1, wl + E.c1, getin_nf, m, lane);    // node_free_code
+        if (p.m0) load_row<NT>(p.m0 + (size_t)row * D, m, h);                                     // node_f64_body's rows
+        else mlp2_in<NT, P>(wl + E.as1, E.ks1, wl + E.b1, wl + E.a1, wl + E.c1, getin_nf, m, lane);    // node_free_code
     }
 
     if (p.use_obstacles) {
@@ -707,7 +1005,7 @@ __global__ __launch_bounds__(WAVES * 64) void pre_kernel(PreParams p) {
             stage(kvl, kvg, c1 * NT * TF);
             stage(kvl + chunk_floats, kvg + (size_t)p.ot_max * NT * TF, c1 * NT * TF);
             __syncthreads();
-            attention_block<D, P>(wl, attg, kvl, kvg, O, p.ot_max, p.ot_chunk, m, lane);
+            attention_block<D, P, !EDGE>(wl, attg, kvl, kvg, O, p.ot_max, p.ot_chunk, m, lane, !EDGE && b == 0 && p.m0 != nullptr);
         }
     }
 
@@ -845,11 +1143,12 @@ __device__ __forceinline__ void pre_resident_body(const PreParams& p, const int 
                 };
                 auto getin_nf = [&](int k) { const bool ok = k < C; const float x = vr[ok ? k : 0]; return ok ? x : 0.f; };
                 mlp2_in<NT, P>(enc_w + E.as0, E.ks0, enc_w + E.b0, enc_w + E.a0, enc_w + E.c0, getin_nc, aux, lane);
-                mlp2_in<NT, P>(enc_w + E.as1, E.ks1, enc_w + E.b1, enc_w + E.a1, enc_w + E.c1, getin_nf, m, lane);
+                if (p.m0) load_row<NT>(p.m0 + (size_t)row * D, m, h);                              // node_f64_body's rows
+                else mlp2_in<NT, P>(enc_w + E.as1, E.ks1, enc_w + E.b1, enc_w + E.a1, enc_w + E.c1, getin_nf, m, lane);
             }
             for (int b = 0; b < 3; ++b)
-                attention_block<D, P>(wl + b * AB::size, wl + b * AB::size, kvl + (size_t)b * p.kv_stride, nullptr,
-                                   O, p.ot_max, p.ot_max, m, lane);
+                attention_block<D, P, !EDGE>(wl + b * AB::size, wl + b * AB::size, kvl + (size_t)b * p.kv_stride, nullptr,
+                                   O, p.ot_max, p.ot_max, m, lane, !EDGE && b == 0 && p.m0 != nullptr);
             if (p.om) store_row<NT>(p.om + (size_t)row * D, m, h);       // training path: frozen node_/edge_free_code
             if constexpr (EDGE) {
                 using L = OutEBlob<D, P>;
@@ -1504,8 +1803,14 @@ hipError_t launch_prep(const PrepParams& q, int Npad, int Epad, int* hist, hipSt
 
 
 template <int D, int P>
-static hipError_t launch_obs_t(const ObsParams& p, int G, hipStream_t st) {
-    hipLaunchKernelGGL((obs_kernel<D, P>), dim3(2 * G), dim3(256), 0, st, p);
+static hipError_t launch_obs_t(const ObsParams& p, const NodeF64Params& q, int G, hipStream_t st) {
+    const int f64_blocks = P == 1 ? 0 : q.n_wg;
+    const size_t lds = f64_blocks ? (size_t)(((q.blob.size + 3) & ~3) + 2 * f64_obs_chunk(D) * D) * sizeof(float) : 0;
+    if (lds) {
+        const hipError_t e = set_lds(obs_kernel<D, P>, lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((obs_kernel<D, P>), dim3(f64_blocks + 2 * G), dim3(256), lds, st, p, q, f64_blocks);
     LAUNCH_CHECK();
     return hipSuccess;
 }
@@ -1521,8 +1826,8 @@ static hipError_t launch_obs_t(const ObsParams& p, int G, hipStream_t st) {
         return hipErrorInvalidValue;                                                         \
     } while (0)
 
-hipError_t launch_obs(int D, int P, const ObsParams& p, int G, hipStream_t st) {
-    GNNMP_DISPATCH_DP(D, P, (launch_obs_t<DD, PP>(p, G, st)));
+hipError_t launch_obs(int D, int P, const ObsParams& p, const NodeF64Params& q, int G, hipStream_t st) {
+    GNNMP_DISPATCH_DP(D, P, (launch_obs_t<DD, PP>(p, q, G, st)));
 }
 
 template <int D, int P, bool EDGE, int WAVES>

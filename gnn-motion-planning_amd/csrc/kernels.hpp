@@ -33,6 +33,18 @@ struct ObsParams {
     int ot_max;
 };
 
+// node side, block 0 in fp64: extra workgroups of the obstacle launch (node_f64_body)
+struct NodeF64Params {
+    const float* v;
+    int C;
+    const int *node_ptr, *node_ptr_pad, *ntile_graph;      // ntile_graph: graph of every 32-row tile of the padded node space
+    const float* w;          // F64Blob
+    F64Blob blob;
+    float* m0;               // out [Npad, d]: node_free_code after the attention sub-block of block 0 (input of its map_feed)
+    int n_wg;                // workgroups of this role (64 * groups padded node rows each); 0 = role not used
+    int groups;              // 64-row groups per workgroup: 1 (few graphs: shortest chains) or 4 (obstacle operands built once per 256 rows)
+};
+
 struct PreParams {
     const float *v, *goal;
     int C;
@@ -58,6 +70,8 @@ struct PreParams {
     int use_obstacles;
     int out_in_lds;          // resident variant: the epilogue blob is staged into LDS too (it fits)
     float *o0, *o1, *o2, *o3, *o4;
+    const float* m0;         // NODE only, optional: rows produced by node_f64_body; the kernel then skips node_free_code's encoder
+                             // and the attention sub-block of block 0
     float* om;               // optional: the attention output itself (node_free_code / edge_free_code after the 3 blocks),
                              // row-major [rows of this launch's padded index space, d]: frozen input of the training path
 };
@@ -195,7 +209,7 @@ hipError_t launch_sm_knn_edges(const SmParams& p, hipStream_t st);      // kNN +
 
 int prep_parts(int G, int E);
 hipError_t launch_prep(const PrepParams& q, int Npad, int Epad, int* hist, hipStream_t st);
-hipError_t launch_obs(int D, int P, const ObsParams& p, int G, hipStream_t st);
+hipError_t launch_obs(int D, int P, const ObsParams& p, const NodeF64Params& q, int G, hipStream_t st);
 hipError_t launch_pre(int D, int P, bool edge, int waves, const PreParams& p, int n_tiles32, size_t lds_bytes, hipStream_t st);
 hipError_t launch_pre_resident_both(int D, int P, const PreParams& pn, const PreParams& pe, size_t lds_bytes, int node_blocks,
                                     int edge_blocks, hipStream_t st);

@@ -125,6 +125,32 @@ struct ObsBlob {
     }
 };
 
+// Node side, block 0, in fp64 (node_f64_body, explorer_kernels.hip): node_free_code encoder + the attention sub-block
+// through its LayerNorm, computed with v_mfma_f64_16x16x4_f64.  Matrices are stored as that instruction's A operands,
+// fp32 values (converted on load): [out/16][ceil(in/4)][64 lanes], lane l of k-step s holding W[16 ob + l%16][4 s + l/16]
+// (0 beyond the input width); vectors in plain feature order.  gnnmp_pack_f64_ops in gnnmp.h.
+struct F64Blob {
+    int w1, b1, w2, b2, wqk, wv, lng, lnb, size, ks;
+    __host__ __device__ static F64Blob make(int D, int C) {
+        F64Blob e;
+        int o = 0;
+        e.ks = (C + 3) / 4;
+        e.w1 = o; o += (D / 16) * e.ks * 64;
+        e.b1 = o; o += D;
+        e.w2 = o; o += D * D;
+        e.b2 = o; o += D;
+        e.wqk = o; o += D * D;
+        e.wv = o; o += D * D;
+        e.lng = o; o += D;
+        e.lnb = o; o += D;
+        e.size = o;
+        return e;
+    }
+};
+// obstacles whose K'/V operands sit in LDS -- and whose logits sit in registers -- at a time (node_f64_body): 128 at d = 32;
+// 32 at d = 64, where the register file is the limit (and the d = 64 checkpoints are the robot arms with five boxes)
+__host__ __device__ constexpr int f64_obs_chunk(int D) { return D == 32 ? 128 : 32; }
+
 // ---- smoother (ModelSmoother, model_smoother.py:46-142)
 constexpr int kSmK = 10;            // knn(..., k=10) at model_smoother.py:125
 
@@ -162,7 +188,7 @@ struct SmLayout {
 
 // Offsets of every blob inside the device weight buffer of an explorer handle.
 struct ExplorerOffsets {
-    int enc_e, enc_n, att_e, att_n, out_e, out_n, mpn, mpn_last, mpe, pol, obs_e, obs_n, total;
+    int enc_e, enc_n, att_e, att_n, out_e, out_n, mpn, mpn_last, mpe, pol, obs_e, obs_n, f64, total;
 };
 
 }  // namespace gnnmp

@@ -343,6 +343,12 @@ int64_t gnnmp_pack_a_tiles(const float* w, int out_f, int ld, int col0, int n_in
 int64_t gnnmp_pack_a_small(const float* w, int out_f, int ld, int col0, int n_in, float* dst);
 /* Per-feature vector in register order: dst[(t*2 + h)*16 + r] = b[32*t + phi(r,h)]. */
 int64_t gnnmp_pack_vec(const float* b, int n, float* dst);
+/* A operands of v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32 for the double-precision stretch of the node side
+ * (node_free_code encoder and the attention sub-block of node_attentions.0, reference model.py:122,164-181):
+ * dst[(ob*ceil(n_in/4) + ks)*64 + lane] = W[16*ob + i'][col0 + 4*ks + (lane>>4)] (0 beyond n_in) with i = lane&15 and
+ * i' = i, or i' = 4*(i%4) + i/4 when row_perm (matrices multiplied by the f32 instruction, whose result register r of lane
+ * group g is row 4g + r where the f64 instruction's is 4r + g).  Returns the floats written; out_f a multiple of 16. */
+int64_t gnnmp_pack_f64_ops(const float* w, int out_f, int ld, int col0, int n_in, int row_perm, float* dst);
 
 #ifdef __cplusplus
 }
