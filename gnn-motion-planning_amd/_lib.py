@@ -105,6 +105,8 @@ def lib():
     L.gnnmp_pack_a_tiles.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp]
     L.gnnmp_pack_a_small.restype = ctypes.c_int64
     L.gnnmp_pack_a_small.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp]
+    L.gnnmp_pack_f64_ops.restype = ctypes.c_int64
+    L.gnnmp_pack_f64_ops.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp]
     L.gnnmp_pack_vec.restype = ctypes.c_int64
     L.gnnmp_pack_vec.argtypes = [vp, ctypes.c_int, vp]
     for name in ('gnnmp_smoother_manifest', 'gnnmp_smoother_create', 'gnnmp_smoother_destroy',

@@ -4,7 +4,7 @@
 
 Tolerance (north_star: "within 1e-5 fp32"; SURVEY.md finding 0.7): the per-fixture bar of tests/parity_bar.py --
     atol = max(1e-5, 1.25 * own),  own = max|ref_fp32 - ref_fp64| of the reference itself on that fixture,
-    |gpu - ref_fp32| <= atol + 1e-5 |ref|   and   |gpu - ref_fp64| <= atol + 1e-5 |ref|   elementwise.
+    |gpu - ref_fp64| <= atol   and   |gpu - ref_fp32| <= atol + own   elementwise, no relative term.
 profiles/r02_parity.txt lists every fixture's three maxima and which ones meet the bare 1e-5."""
 import os
 
@@ -83,17 +83,39 @@ def test_golden_taps(path):
     dec = m.debug_tap(b, 2).cpu()
     gi = int(m.debug_tap(b, 3).cpu()[0])
     w = load_weights(ENVS[env]['ckpt'])
-    taps = {}
-    ref_cpu.explorer_forward(w, torch.from_numpy(r['v']), torch.from_numpy(r['goal']), torch.from_numpy(r['obstacles']),
-                             torch.from_numpy(r['edge_index']), L, taps=taps)
+    taps, taps64 = {}, {}
+    args = (torch.from_numpy(r['v']), torch.from_numpy(r['goal']), torch.from_numpy(r['obstacles']))
+    ref_cpu.explorer_forward(w, *args, torch.from_numpy(r['edge_index']), L, taps=taps)
+    w64 = {k: (t.double() if t.is_floating_point() else t) for k, t in w.items()}
+    ref_cpu.explorer_forward(w64, *[a.double() for a in args], torch.from_numpy(r['edge_index']), L, taps=taps64)
     assert gi == int(taps['goal_index'][0])
-    assert torch.allclose(h, torch.from_numpy(r['tap_h'][L - 1]), rtol=1e-4, atol=2e-5)
-    assert torch.allclose(dec, torch.from_numpy(r['tap_decode']), rtol=1e-4, atol=2e-5)
+    # intermediates on the scores' bar (absolute, no relative term): the recorded reference hook (fp32) and the oracle's fp64
+    # run of it.  Hidden rows reach |h| ~ 50 where the scores stay within [-32, 12], so the margin over the reference's own
+    # fp32 error is 1.5 instead of 1.25 (measured worst case: 1.30 on snake7 h_3)
+    TAPF = 1.5
+    assert_fp32_parity(h.reshape(-1), torch.from_numpy(r['tap_h'][L - 1]).reshape(-1), taps64['h'][L - 1].reshape(-1), 'h_L', TAPF)
+    assert_fp32_parity(dec.reshape(-1), torch.from_numpy(r['tap_decode']).reshape(-1), taps64['decode'].reshape(-1), 'decode', TAPF)
     # every intermediate h_i via shorter loops
     for li in range(1, L):
         m.forward_batch(b, li)
         hi = m.debug_tap(b, 1).cpu()
-        assert torch.allclose(hi, torch.from_numpy(r['tap_h'][li - 1]), rtol=1e-4, atol=2e-5), li
+        assert_fp32_parity(hi.reshape(-1), torch.from_numpy(r['tap_h'][li - 1]).reshape(-1), taps64['h'][li - 1].reshape(-1), 'h_%d' % li, TAPF)
+
+
+@pytest.mark.parametrize('path', golden_files('explorer_'), ids=os.path.basename)
+def test_golden_bare_1e5(path):
+    """north_star's bare figure: |gpu - ref_fp32| <= 1e-5 on every golden on which the reference's own fp32 run is within 1e-5
+    of its fp64 run (elsewhere it is not a meaningful target: tests/parity_bar.py), and |gpu - ref_fp64| <= 1e-5 everywhere."""
+    r = _load(path)
+    env = env_of(path)
+    m = make_model(env, bool(r['use_obstacles']))
+    s = m.edge_scores(torch.from_numpy(r['goal']).to(DEV), int(r['loop']), torch.from_numpy(r['v']).to(DEV),
+                      torch.from_numpy(r['obstacles']).to(DEV), torch.from_numpy(r['edge_index']).to(DEV)).cpu().double()
+    ref32, ref64 = torch.from_numpy(r['scores_fp32']).double(), torch.from_numpy(r['scores_fp64'])
+    own = float((ref32 - ref64).abs().max())
+    assert float((s - ref64).abs().max()) <= 1e-5, (own, float((s - ref64).abs().max()))
+    if own <= 1e-5:
+        assert float((s - ref32).abs().max()) <= 1e-5, (own, float((s - ref32).abs().max()))
 
 
 def test_dense_is_reference_layout():
@@ -168,7 +190,7 @@ def test_degenerate_graphs(case):
     m = make_model('maze2')
     s = m.edge_scores(v[1].to(DEV), 5, v.to(DEV), obstacles.to(DEV), ei.to(DEV)).cpu()
     ref32, ref64 = explorer_oracle_pair(w, dict(v=v, goal=v[1].clone(), obstacles=obstacles, edge_index=ei), 5)
-    assert_fp32_parity(s, ref32, ref64, 'structure case', own_factor=2.5)
+    assert_fp32_parity(s, ref32, ref64, 'structure case')
 
 
 @pytest.mark.parametrize('n_obs', [0, 1, 31, 32, 33, 128, 129, 300])
@@ -183,7 +205,7 @@ def test_obstacle_counts(n_obs):
     m = make_model('maze2')
     s = m.edge_scores(v[1].to(DEV), 5, v.to(DEV), obstacles.to(DEV), ei.to(DEV)).cpu()
     ref32, ref64 = explorer_oracle_pair(w, dict(v=v, goal=v[1].clone(), obstacles=obstacles, edge_index=ei), 5)
-    assert_fp32_parity(s, ref32, ref64, 'structure case', own_factor=2.5)
+    assert_fp32_parity(s, ref32, ref64, 'structure case')
 
 
 def test_use_obstacles_toggle_and_loop_validation():

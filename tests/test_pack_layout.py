@@ -115,3 +115,62 @@ def test_obstacle_value_transpose_rule():
     for j in range(32):
         hp, rp = (j >> 2) & 1, (j & 3) + 4 * (j >> 3)
         assert phi(rp, hp) == j
+
+
+# ---- v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32 operands of the double-precision node stretch (gnnmp_pack_f64_ops).
+# Layouts probed on the MI355X with tools/microbench/mfma_f64_probe.hip: A[i][k] in lane i + 16 k, B[k][j] in lane j + 16 k;
+# D[i][j] of the f64 instruction in lane j + 16 (i % 4), register i / 4; of the f32 one in lane j + 16 (i / 4), register i % 4.
+def mfma16(a, b, acc, f64):
+    A = np.zeros((16, 4)); B = np.zeros((4, 16))
+    A[LANE & 15, LANE >> 4] = a
+    B[LANE >> 4, LANE & 15] = b
+    Dm = A @ B
+    for r in range(4):
+        i = 4 * r + (LANE >> 4) if f64 else 4 * (LANE >> 4) + r
+        acc[r] += Dm[i, LANE & 15]
+    return acc
+
+
+def pack_f64(W, n_in, row_perm):
+    out_f, ld = W.shape
+    nks = (n_in + 3) // 4
+    dst = np.zeros((out_f // 16) * nks * 64, dtype=np.float32)
+    Wc = np.ascontiguousarray(W, dtype=np.float32)
+    n = _lib.lib().gnnmp_pack_f64_ops(Wc.ctypes.data, out_f, ld, 0, n_in, row_perm, dst.ctypes.data)
+    assert n == dst.size
+    return dst.reshape(out_f // 16, nks, 64)
+
+
+@pytest.mark.parametrize('D,C', [(32, 2), (64, 7), (32, 14)])
+def test_f64_chain_layout(D, C):
+    """node_f64_body's chain: first layer on C raw inputs, a d x d layer on the f64 instruction, and a d x d layer on the f32
+    instruction with row-permuted operands landing in the f64 register layout -- all equal to plain matrix products."""
+    rng = np.random.default_rng(D + C)
+    NB = D // 16
+    X = rng.standard_normal((16, C)).astype(np.float32)                 # 16 nodes
+    W1 = rng.standard_normal((D, C)).astype(np.float32)
+    W2 = rng.standard_normal((D, D)).astype(np.float32)
+    W3 = rng.standard_normal((D, D)).astype(np.float32)
+    j, g = LANE & 15, LANE >> 4
+    A1 = pack_f64(W1, C, 0)
+    h = np.zeros((NB, 4, 64))
+    for st in range(A1.shape[1]):
+        k = 4 * st + g
+        xin = np.where(k < C, X[j, np.minimum(k, C - 1)], 0.0)
+        for ob in range(NB):
+            mfma16(A1[ob, st].astype(np.float64), xin, h[ob], True)
+    ref1 = X.astype(np.float64) @ W1.T.astype(np.float64)
+    for ob in range(NB):
+        for r in range(4):
+            assert np.allclose(h[ob, r], ref1[j, 16 * ob + 4 * r + g], rtol=1e-12, atol=1e-12)
+    for perm, f64 in ((0, True), (1, False)):
+        A = pack_f64(W2 if f64 else W3, D, perm).reshape(NB, NB, 4, 64)
+        y = np.zeros((NB, 4, 64))
+        for ib in range(NB):
+            for st in range(4):
+                for ob in range(NB):
+                    mfma16(A[ob, ib, st].astype(np.float64), h[ib, st], y[ob], f64)
+        ref = ref1 @ (W2 if f64 else W3).T.astype(np.float64)
+        for ob in range(NB):
+            for r in range(4):                                         # both land in the f64 layout: feature 16 ob + 4 r + g
+                assert np.allclose(y[ob, r], ref[j, 16 * ob + 4 * r + g], rtol=1e-12, atol=1e-9)
