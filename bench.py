@@ -46,13 +46,22 @@ def edge_pre_flops(E, O, C, d):
     return 2 * 2 * E * (2 * C * d + d * d) + 3 * E * (10 * d * d + 4 * d * (O + 1))
 
 
+def mp_fused_bytes(N, E, d, bf16):
+    """HBM bytes one mp_fused launch (one message-passing iteration, model.py:139-143) has to move for one graph: the
+    per-edge first-layer constant K_e and the packed edge record stream in once; every node row of A (gathered by source:
+    the gather itself is served by L2, its first touch is HBM), B, X and R is read once and X', A', B' are written once.
+    bf16 mode stores K_e, A, B and X in bf16."""
+    se = 2 if bf16 else 4
+    return E * (d * se + 4) + N * d * (3 * se + 4) + N * d * 3 * se
+
+
 def algorithmic_bytes(N, E, O, C, S):
     """SURVEY.md section 8(d) B_sparse: v, goal, obstacles, int32 edge pairs, scores out."""
     return 4 * N * C + 4 * C + 4 * O * S + 8 * E + 4 * E
 
 
 def kernel_source_hash():
-    """sha256 over the sources of the dominant kernel (what profiles/edge_pre_traffic.json was measured on)."""
+    """sha256 over the sources of the dominant kernel (what the entries of profiles/kernel_traffic.json were measured on)."""
     import hashlib
     hsh = hashlib.sha256()
     for f in ('chain.hpp', 'layout.hpp', 'kernels.hpp', 'explorer_kernels.hip'):
@@ -121,7 +130,7 @@ def planner_leg(n_host, n_device, dev):
     from gnnmp.weights import load_weights
     with np.load(os.path.join(REPO, 'tests', 'golden', 'evalset_mazehard_first1000.npz')) as f:
         env = Maze2D(f['maps'], f['init_states'], f['goal_states'])
-    m = gnnmp.EncoderProcessDecoder(2, 2, 32, 2)
+    m = gnnmp.EncoderProcessDecoder(2, 2, 32, 2).eval()
     m.load_state_dict(load_weights('weights_maze'))
     ms = gnnmp.ModelSmoother(workspace_size=2, config_size=2, embed_size=128, obs_size=6).eval()
     ms.load_state_dict(load_weights('smooth_2d_attv3'))
@@ -207,7 +216,7 @@ def main():
     base = synth_batch_gpu(args.env, args.nodes, args.k1, uniq, dev, seed0=1234 + rank * G)
     graphs = [base[i % uniq] for i in range(G)]
     batch = gnnmp.GraphBatch.from_graphs(graphs, e['S'], dev)
-    model = gnnmp.EncoderProcessDecoder(e['workspace'], e['C'], e['d'], e['S'])
+    model = gnnmp.EncoderProcessDecoder(e['workspace'], e['C'], e['d'], e['S']).eval()
     model.load_state_dict(load_weights(e['ckpt']), strict=True)
     model.mlp_dtype = args.mlp_dtype
 
@@ -323,15 +332,9 @@ def main():
     # final result gather (the only collective of the job): per-rank edge scores -> every rank
     checksum = float(scores.double().sum().item())
     if use_dist:
-        n = torch.tensor([scores.numel()], dtype=torch.int64, device=dev)
-        sizes = [torch.zeros_like(n) for _ in range(world)]
-        dist.all_gather(sizes, n)
-        cap = int(max(int(s.item()) for s in sizes))
-        pad = torch.zeros(cap, dtype=torch.float32, device=dev)
-        pad[:scores.numel()] = scores
-        out = [torch.empty_like(pad) for _ in range(world)]
-        dist.all_gather(out, pad)
-        checksum = float(sum(o[:int(s.item())].double().sum().item() for o, s in zip(out, sizes)))
+        from gnnmp.dist import gather_variable
+        parts = gather_variable(scores)                    # one padded buffer, all_gather_into_tensor (RCCL)
+        checksum = float(torch.stack([p_.double().sum() for p_ in parts]).sum().item())
 
     if rank == 0:
         Ns = [int(g['v'].shape[0]) for g in graphs]
@@ -343,19 +346,47 @@ def main():
         ep_ms, ep_n = prof['edge_pre']
         ep_avg_ms = ep_ms / max(ep_n, 1)
         achieved = ep_flops / (ep_avg_ms * 1e-3) / 1e12 if ep_avg_ms > 0 else 0.0
-        peak = PEAK_BF16_TFLOPS if args.mlp_dtype == 'bf16' else PEAK_FP32_TFLOPS
-        # HBM bytes of the dominant kernel come from separate rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE cannot be
-        # read inside this process); the summary tool stamps the file with a hash of the kernel sources it measured,
-        # and the number is reported only while that hash still matches the sources of the library in use
-        traffic = None
-        tpath = os.path.join(REPO, 'profiles', 'edge_pre_traffic.json')
+        # the roofline block describes the DOMINANT kernel of this workload: the stage with the largest share of the step
+        stage_tot = {k: v[0] for k, v in prof.items()}
+        dom = max(stage_tot, key=stage_tot.get)
+        if dom not in ('edge_pre', 'mp'):
+            dom = 'edge_pre'
+        pname = {'fp32': '0', 'bf16': '1', 'bf16x3': '2'}[args.mlp_dtype]
+        if dom == 'mp':
+            mp_ms, mp_n = prof['mp']
+            mp_avg_ms = mp_ms / max(mp_n, 1)
+            mp_bytes = sum(mp_fused_bytes(n, m, e['d'], args.mlp_dtype == 'bf16') for n, m in zip(Ns, Es))
+            roof = {'kernel': 'mp_fused_kernel<%d, %s, ...> (one message-passing iteration: edge MLP second layer, max aggregation, '
+                              'node update; %d launches per step)' % (e['d'], pname, args.loop),
+                    'kernel_like': 'mp_fused_kernel<%d, %s' % (e['d'], pname),
+                    'bound': 'hbm', 'achieved': round(mp_bytes / (mp_avg_ms * 1e-3) / 1e9, 1) if mp_avg_ms > 0 else 0.0,
+                    'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'launch_ms': round(mp_avg_ms, 4), 'algorithmic_bytes_per_launch': mp_bytes}
+        else:
+            peak = PEAK_BF16_TFLOPS if args.mlp_dtype == 'bf16' else PEAK_FP32_TFLOPS
+            roof = {'kernel': 'pre_resident_kernel<%d, %s, EDGE> (edge encoders + 3 obstacle-attention blocks)' % (e['d'], pname),
+                    'kernel_like': 'pre_resident_kernel<%d, %s, true' % (e['d'], pname),
+                    'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
+                    'launch_ms': round(ep_avg_ms, 4), 'algorithmic_flops_per_launch': ep_flops}
+        roof['frac'] = round(roof['achieved'] / roof['peak'], 4)
+        # HBM bytes per launch of that kernel come from separate rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE cannot be
+        # read inside this process; tools/traffic_json.py writes profiles/kernel_traffic.json): every entry carries the
+        # workload it was measured on, the date of the pass and a hash of the kernel sources; the number is reported only
+        # for the same workload and while that hash still matches the sources of the library in use
+        wkey = '%s N=%d k1=%d graphs=%d %s' % (args.env, args.nodes, args.k1, G, args.mlp_dtype)
+        roof['traffic'] = None
+        tpath = os.path.join(REPO, 'profiles', 'kernel_traffic.json')
         if os.path.exists(tpath):
             try:
-                tj = json.load(open(tpath))
-                if tj.get('kernel_source_sha256') == kernel_source_hash():
-                    traffic = tj.get('hbm_bytes_per_launch')
+                for tj in json.load(open(tpath)):
+                    if tj.get('kernel_like') == roof['kernel_like'] and tj.get('workload') == wkey:
+                        fresh = tj.get('kernel_source_sha256') == kernel_source_hash()
+                        roof['traffic'] = tj.get('hbm_bytes_per_launch') if fresh else None
+                        roof['traffic_source'] = {'file': 'profiles/kernel_traffic.json', 'measured': tj.get('measured'),
+                                                  'kernel_source_sha256': tj.get('kernel_source_sha256', '')[:16],
+                                                  'stale': not fresh, 'how': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, '
+                                                  'gfx950 corrections of MI355X_MICROARCH.md'}
             except Exception:
-                traffic = None
+                pass
         cfg_name = 'BASELINE configs[1]' if (args.env, args.nodes, args.k1, G, args.mlp_dtype) == ('maze2', 1000, 8, 256, 'fp32') \
             else ('BASELINE configs[2] shape' if (args.env, args.nodes, args.k1, args.mlp_dtype) == ('kuka7', 2000, 10, 'bf16')
                   else 'custom workload')
@@ -383,10 +414,7 @@ def main():
                        'dense_output_graphs_per_s_per_gpu': None if dense_rate is None else round(dense_rate, 1),
                        'bf16x3_mode_graphs_per_s_per_gpu': None if x3_rate is None else round(x3_rate, 1),
                        'single_graph_us': single_us},
-            'roofline': {'kernel': 'pre_resident_kernel<%d,%s,EDGE> (edge encoders + 3 obstacle-attention blocks)' % (e['d'], args.mlp_dtype),
-                         'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
-                         'frac': round(achieved / peak, 4), 'traffic': traffic if args.mlp_dtype == 'fp32' else None,
-                         'launch_ms': round(ep_avg_ms, 4), 'algorithmic_flops_per_launch': ep_flops},
+            'roofline': roof,
         }
         if world == 1 and args.planner_problems > 0 and (args.env, args.mlp_dtype) == ('maze2', 'fp32'):
             res['config']['planner'] = planner_leg(args.planner_problems, 512, dev)

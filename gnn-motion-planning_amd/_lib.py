@@ -4,7 +4,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libgnnmp.so')
+LIB_PATH = os.environ.get('GNNMP_LIB') or os.path.join(_HERE, 'libgnnmp.so')      # GNNMP_LIB: an experiment build (tools/diag/build_variant.sh)
 
 c_float_p = ctypes.POINTER(ctypes.c_float)
 c_int32_p = ctypes.POINTER(ctypes.c_int32)

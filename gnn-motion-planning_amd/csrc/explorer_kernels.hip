@@ -1423,7 +1423,13 @@ __host__ __device__ constexpr int mp_lds_floats() {
 template <int D, int P, int COOP>
 // d = 64 with fp32 / bf16x3 operands: the LDS tiles leave ONE 4-wave workgroup per CU anyway, so the wave may use the whole
 // register file (no spills)
-__global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 && P != 1) ? 1 : ((P == 2 || D > 32) ? 2 : 3)) : 1) void mp_fused_kernel(MpFusedParams p) {
+#ifndef GNNMP_MP_WGS32
+#define GNNMP_MP_WGS32 3
+#endif
+#ifndef GNNMP_MP_DEEP32
+#define GNNMP_MP_DEEP32 0
+#endif
+__global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 && P != 1) ? 1 : ((P == 2 || D > 32) ? 2 : GNNMP_MP_WGS32)) : 1) void mp_fused_kernel(MpFusedParams p) {
     constexpr int NT = D / 32;
     constexpr bool kCoop = COOP > 1;
     using LE = MpEBlob<D, P>;
@@ -1480,7 +1486,7 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
         const int first = beg + (kCoop ? 32 * wave : 0);
         auto src_row = [&](int rec, bool valid) { return valid ? n0 + (rec & 0x7ffffff) : t0; };
         // K_e streams from HBM: PF tiles of a chunk are requested KD chunks ahead and wait in registers
-        constexpr bool kDeep = P == 1;                           // packed bf16 tiles are cheap to hold (fp32, d = 32: measured 0.95 -> 0.99 ms)
+        constexpr bool kDeep = P == 1 || (GNNMP_MP_DEEP32 && P == 0 && D == 32 && COOP == 1);   // packed bf16 tiles are cheap to hold (fp32, d = 32: measured 0.95 -> 0.99 ms)
         constexpr int PF = kDeep ? NT : 1;                       // prefetched tiles per chunk (the rest is loaded in place)
         constexpr int KD = kDeep ? 2 : 1;                        // chunks ahead
         constexpr int LPT = P == 1 ? 2 : 4;                      // load instructions per tile

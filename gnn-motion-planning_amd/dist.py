@@ -3,9 +3,10 @@
 One planning problem = one graph = one forward, with no cross-graph term anywhere
 (eval_gnn.py:113-116), so ranks never exchange data on the compute path.  The only collective is the
 gather of RESULTS (edge scores, or the seven per-problem planner numbers of eval_gnn.py:120-122):
-``torch.distributed`` all_gather, i.e. RCCL over xGMI with the ``nccl`` backend on GPUs and gloo in
-the CPU tests.  Payloads are small (about 45 KB of scores per 1000-node graph), so the gather is
-latency-bound; it is padded to the largest shard because all_gather needs equal sizes.
+``torch.distributed`` all_gather_into_tensor on one padded buffer, i.e. RCCL over xGMI with the ``nccl``
+backend on GPUs and gloo in the CPU tests.  Payloads are small (about 45 KB of scores per 1000-node
+graph), so the gather is latency-bound; it is padded to the largest shard because all_gather needs
+equal sizes.
 """
 import torch
 import torch.distributed as dist
@@ -34,21 +35,24 @@ def shard_range(n_items, rank, world, weights=None):
 
 
 def gather_variable(local, group=None):
-    """all_gather of 1-D tensors of different lengths; returns the list of every rank's tensor
-    (each on the local device).  Works with world_size 1 without an initialised process group."""
+    """all_gather of 1-D tensors of different lengths; returns the list of every rank's tensor (each on the local device).
+    Two collectives on flat buffers (``all_gather_into_tensor``: one RCCL launch each, no per-rank tensor lists): the
+    lengths, then ONE padded payload buffer [world, cap]; a single device-to-host read of the ``world`` lengths.  Works
+    with world_size 1 without an initialised process group."""
     if not (dist.is_available() and dist.is_initialized()):
         return [local]
     world = dist.get_world_size(group)
+    local = local.contiguous().reshape(-1)
     n = torch.tensor([local.numel()], dtype=torch.int64, device=local.device)
-    sizes = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(sizes, n, group=group)
-    sizes = [int(s.item()) for s in sizes]
+    sizes = torch.empty(world, dtype=torch.int64, device=local.device)
+    dist.all_gather_into_tensor(sizes, n, group=group)
+    sizes = sizes.tolist()                               # the one host read
     cap = max(sizes + [1])
     pad = torch.zeros(cap, dtype=local.dtype, device=local.device)
     pad[:local.numel()] = local
-    out = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(out, pad, group=group)
-    return [o[:s] for o, s in zip(out, sizes)]
+    out = torch.empty(world * cap, dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, pad, group=group)
+    return [out[r * cap:r * cap + s] for r, s in enumerate(sizes)]
 
 
 def gather_problem_results(rows, group=None):

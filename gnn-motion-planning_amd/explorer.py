@@ -422,11 +422,16 @@ class EncoderProcessDecoder(nn.Module):
         return self.forward_batch(self._single(goal, v, obstacles, edge_index, prefix_arrays=False), loop)
 
     # ------------------------------------------------------------------ reference signature
-    @torch.no_grad()
     def forward(self, goal, loop, v, obstacles, free=None, collided=None, edge_index=None, k=10, **kwargs):
         """Reference call (eval_gnn.py:194): returns the dense ``policy_output[N, N]`` with
         ``P[target, source] = score`` (model.py:148-149).  ``free``, ``collided``, ``k``, ``labels``
         and any other extra keyword are accepted and ignored exactly like the reference does
-        (model.py:115)."""
-        _, dn = self.forward_batch(self._single(goal, v, obstacles, edge_index, prefix_arrays=False), loop, dense=True)
-        return dn.view(v.shape[0], v.shape[0])
+        (model.py:115).  Like ``ModelSmoother.forward`` the call dispatches on the module's mode: under ``train()`` with
+        autograd enabled -- the reference's training loop calls ``model(...)`` and back-propagates through the result
+        (train_explorer.py:156-176) -- it is :meth:`forward_train`; under ``eval()`` or ``torch.no_grad()`` (eval_gnn.py:168)
+        the inference kernels run."""
+        if self.training and torch.is_grad_enabled() and self.mlp_dtype == 'fp32':
+            return self.forward_train(goal, loop, v, obstacles, free, collided, edge_index, k, **kwargs)
+        with torch.no_grad():
+            _, dn = self.forward_batch(self._single(goal, v, obstacles, edge_index, prefix_arrays=False), loop, dense=True)
+            return dn.view(v.shape[0], v.shape[0])

@@ -239,27 +239,30 @@ class Maze3D(Maze2D):
     def sample_n_points_stream(self, stream, n):
         raise NotImplementedError('the look-ahead sampler is 2-D only; Maze3D samples one configuration at a time')
 
+    # The orientation coordinate lives on a circle of circumference ORIENT_PERIOD = 2 * LIMITS3[2] (a numpy float64 scalar:
+    # under NEP 50 it promotes float32 operands to float64 before the result is stored back into the float32 row, which
+    # is part of the recorded behaviour).  One helper does the wrap for displacements and for configurations alike.
+    ORIENT_HALF = LIMITS3[2]
+    ORIENT_PERIOD = 2 * LIMITS3[2]
+
+    @classmethod
+    def _wrap_orientation(cls, vec):
+        """In place: bring vec[2] back into [-ORIENT_HALF, ORIENT_HALF] by one period (maze_env.py:158-170 applies this
+        rule to the displacement and to the interpolated configuration)."""
+        z = vec[2]
+        if np.abs(z) > cls.ORIENT_HALF:
+            vec[2] = z - cls.ORIENT_PERIOD if z > 0 else z + cls.ORIENT_PERIOD
+        return vec
+
     def distance(self, a, b):
-        d = np.abs(b - a)
-        if d.ndim == 1:
-            d = d.reshape(1, -1)
-        d[:, 2] = np.min((d[:, 2], np.abs(d[:, 2] - 2 * LIMITS3[2])), axis=0)
-        return np.sqrt(np.sum(d ** 2, axis=-1))
+        """Euclidean distance with the orientation gap measured the short way round (maze_env.py:138-149)."""
+        gap = np.atleast_2d(np.abs(b - a))
+        gap[:, 2] = np.minimum(gap[:, 2], np.abs(gap[:, 2] - self.ORIENT_PERIOD))
+        return np.sqrt(np.sum(gap ** 2, axis=-1))
 
     def interpolate(self, a, b, ratio):
-        diff = b - a
-        if np.abs(diff[2]) > LIMITS3[2]:
-            if diff[2] > 0:
-                diff[2] -= 2 * LIMITS3[2]
-            else:
-                diff[2] += 2 * LIMITS3[2]
-        new = a + diff * ratio
-        if np.abs(new[2]) > LIMITS3[2]:
-            if new[2] > 0:
-                new[2] -= 2 * LIMITS3[2]
-            else:
-                new[2] += 2 * LIMITS3[2]
-        return new
+        """Point at `ratio` of the way from a to b along the short orientation arc (maze_env.py:151-170)."""
+        return self._wrap_orientation(a + self._wrap_orientation(b - a) * ratio)
 
     @staticmethod
     def _ends(coord):
@@ -294,17 +297,9 @@ class Maze3D(Maze2D):
             return False
         if a.size == 2:
             return self._segment_fp(a, b)
-        disp = b - a
-        if np.abs(disp[2]) > LIMITS3[2]:
-            if disp[2] > 0:
-                disp[2] -= 2 * LIMITS3[2]
-            else:
-                disp[2] += 2 * LIMITS3[2]
-        d = self.distance(a, b)
-        K = int((d / 0.015)[0])                  # float32 array / python float: float32 division
-        for k in range(1, K):
-            c = a + k * 1. / K * disp
-            ca, cb = self._ends(c)
-            if not self._edge_fp(ca, cb):
-                return False
-        return True
+        # K - 1 interior configurations at equal fractions of the (orientation-wrapped) displacement, each checked as the 2-D
+        # edge between its stick ends (maze_env.py:330-347).  The fractions are python floats: they leave the float32 rows
+        # in float32, as the recorded runs have it.
+        step = self._wrap_orientation(b - a)
+        K = int((self.distance(a, b) / 0.015)[0])                # float32 array / python float: float32 division
+        return all(self._edge_fp(*self._ends(a + (k * 1. / K) * step)) for k in range(1, K))

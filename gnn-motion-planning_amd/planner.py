@@ -146,26 +146,32 @@ def greedy_expand_sparse(scores, edge_index, labels, v, env, state):
     return None
 
 
+def _steer_round(path, target, env):
+    """One sweep over the interior waypoints, left to right: each moves at most env.RRT_EPS towards its target and the move
+    is kept only if the edges to both neighbours stay free -- the left neighbour already at its new place, the right one
+    still at its old one.  Returns the new path and the summed distance still to go of the waypoints that moved."""
+    out = deepcopy(path)
+    remaining = 0
+    for i in range(1, len(path) - 1):
+        gap = np.linalg.norm(path[i] - target[i])
+        cand = target[i] if gap < env.RRT_EPS else env.interpolate(path[i], target[i], env.RRT_EPS / gap)
+        out[i] = cand
+        if env._edge_fp(out[i - 1], cand) and env._edge_fp(out[i + 1], cand):
+            remaining += np.linalg.norm(cand - target[i])
+        else:
+            out[i] = path[i]
+    return out, remaining
+
+
 def smooth_step(old_path, new_path, env):
-    """``proposed_path_smootherv2`` (smoother.py:194-216): steer every interior waypoint at most RRT_EPS
-    per round towards the network's proposal, keep the move only if both adjacent edges stay free
-    (the left neighbour is already updated, the right one is not)."""
-    K = int(np.ceil((np.linalg.norm(np.array(old_path) - np.array(new_path), axis=-1) / env.RRT_EPS).max()))
+    """Collision-checked steering of the smoothing stage (``proposed_path_smootherv2``, smoother.py:194-216): as many
+    sweeps as the farthest waypoint needs RRT_EPS steps, stopping early once every accepted move has arrived."""
+    far = np.linalg.norm(np.array(old_path) - np.array(new_path), axis=-1).max()
     path = deepcopy(old_path)
-    for _ in range(K):
-        diff = 0
-        nxt = deepcopy(path)
-        for i in range(1, len(path) - 1):
-            old_n, new_n = path[i], new_path[i]
-            dist = np.linalg.norm(old_n - new_n)
-            nxt[i] = new_n if dist < env.RRT_EPS else env.interpolate(old_n, new_n, env.RRT_EPS / dist)
-            if not (env._edge_fp(nxt[i - 1], nxt[i]) and env._edge_fp(nxt[i + 1], nxt[i])):
-                nxt[i] = path[i]
-            else:
-                diff += np.linalg.norm(nxt[i] - new_n)
-        path = nxt
-        if diff < 1e-5:
-            return path
+    for _ in range(int(np.ceil(far / env.RRT_EPS))):
+        path, remaining = _steer_round(path, new_path, env)
+        if remaining < 1e-5:
+            break
     return path
 
 

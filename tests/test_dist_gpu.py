@@ -72,7 +72,7 @@ dist.init_process_group('gloo')
 with np.load(%(fixture)r) as f:
     r = {k: f[k] for k in f.files}
 env = Maze2D(r['maps'], r['init_states'], r['goal_states'])
-m = gnnmp.EncoderProcessDecoder(2, 2, 32, 2); m.load_state_dict(load_weights('weights_maze'))
+m = gnnmp.EncoderProcessDecoder(2, 2, 32, 2).eval(); m.load_state_dict(load_weights('weights_maze'))
 ms = gnnmp.ModelSmoother(workspace_size=2, config_size=2, embed_size=128, obs_size=6).eval(); ms.load_state_dict(load_weights('smooth_2d_attv3'))
 rows = []
 planner.eval_gnn_device(env, range(64), m, ms, seed=int(r['seed']), batch=int(r['batch']), k=int(r['k']), device='cuda:0',

@@ -101,7 +101,10 @@ def test_dense_training_call_and_optimizer_step():
     losses = []
     for _ in range(6):
         opt.zero_grad()
-        P = m.forward_train(goal=g['goal'], loop=3, v=g['v'], obstacles=g['obstacles'], edge_index=g['edge_index'])
+        # the reference's own call: the module itself, in train() mode, extra Data fields passed through (train_explorer.py:156-160)
+        P = m(goal=g['goal'], loop=3, v=g['v'], obstacles=g['obstacles'], free=g['v'][:60], collided=g['v'][60:],
+              edge_index=g['edge_index'], labels=torch.zeros(120, 3, device=DEV), k=10)
+        assert P.grad_fn is not None and P.shape == (120, 120)
         cand = P[frontier].reshape(-1)
         loss = -cand.log_softmax(dim=0)[5]
         loss.backward()
@@ -110,3 +113,23 @@ def test_dense_training_call_and_optimizer_step():
     print('\nlosses', ['%.4f' % x for x in losses])
     assert losses[-1] < losses[0]
     assert torch.equal(frozen_before, m.edge_attentions[0].attention.key.weight.detach())
+
+
+def test_module_call_dispatches_on_mode():
+    """``model(...)`` is the training forward under train() with autograd on (train_explorer.py:156-176) and the inference
+    kernels under eval() or torch.no_grad() (eval_gnn.py:109,168) -- the same rule ModelSmoother.forward follows."""
+    from gnnmp.synth import synth_graph
+    g = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in synth_graph('maze2', 90, 5, seed=3).items()}
+    m = gnnmp.EncoderProcessDecoder(2, 2, 32, 2)
+    m.load_state_dict(load_weights('weights_maze'))
+    kw = dict(goal=g['goal'], loop=2, v=g['v'], obstacles=g['obstacles'], edge_index=g['edge_index'])
+    m.train()
+    P_train = m(**kw)
+    assert P_train.requires_grad and P_train.grad_fn is not None
+    with torch.no_grad():
+        P_ng = m(**kw)
+    assert not P_ng.requires_grad
+    m.eval()
+    P_eval = m(**kw)
+    assert not P_eval.requires_grad and torch.equal(P_eval, P_ng)
+    assert torch.allclose(P_train.detach(), P_eval, rtol=1e-5, atol=2e-5)

@@ -29,7 +29,7 @@ DEV = 'cuda:0'
 
 def make(env):
     e = ENVS[env]
-    m = gnnmp.EncoderProcessDecoder(e['workspace'], e['C'], e['d'], e['S'])
+    m = gnnmp.EncoderProcessDecoder(e['workspace'], e['C'], e['d'], e['S']).eval()
     m.load_state_dict(load_weights(e['ckpt']))
     m.mlp_dtype = 'bf16'
     return m

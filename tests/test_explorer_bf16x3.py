@@ -21,7 +21,7 @@ RTOL, ATOL = 1e-5, 2e-5
 
 def make(env, use_obstacles=True):
     e = ENVS[env]
-    m = gnnmp.EncoderProcessDecoder(e['workspace'], e['C'], e['d'], e['S'], use_obstacles=use_obstacles)
+    m = gnnmp.EncoderProcessDecoder(e['workspace'], e['C'], e['d'], e['S'], use_obstacles=use_obstacles).eval()
     m.load_state_dict(load_weights(e['ckpt']))
     m.mlp_dtype = 'bf16x3'
     return m

@@ -42,7 +42,7 @@ def check(part, w, g, loop):
 def test_random_graphs(seed):
     gen = torch.Generator().manual_seed(1000 + seed)
     w = load_weights('weights_maze')
-    m = gnnmp.EncoderProcessDecoder(2, 2, 32, 2)
+    m = gnnmp.EncoderProcessDecoder(2, 2, 32, 2).eval()
     m.load_state_dict(w)
     graphs = []
     for i in range(int(torch.randint(1, 6, (1,), generator=gen))):
@@ -70,11 +70,11 @@ def test_star_graph_hub_spans_many_tiles():
                     torch.stack((torch.zeros(n - 1, dtype=torch.long), src))), dim=1)  # node 0 -> everyone
     g = {'v': v, 'goal': v[3].clone(), 'obstacles': torch.rand(20, 2, generator=gen) - 0.5, 'edge_index': ei}
     w = load_weights('weights_maze')
-    m = gnnmp.EncoderProcessDecoder(2, 2, 32, 2)
+    m = gnnmp.EncoderProcessDecoder(2, 2, 32, 2).eval()
     m.load_state_dict(w)
     s = m.edge_scores(g['goal'].to(DEV), 4, g['v'].to(DEV), g['obstacles'].to(DEV), ei.to(DEV)).cpu()
     print(check(s, w, g, 4))
-    m2 = gnnmp.EncoderProcessDecoder(3, 7, 64, 6)                                         # d = 64 fallback kernels too
+    m2 = gnnmp.EncoderProcessDecoder(3, 7, 64, 6).eval()                                         # d = 64 fallback kernels too
     w2 = load_weights('weights_kuka')
     m2.load_state_dict(w2)
     g2 = dict(g, v=torch.rand(n, 7, generator=gen) * 2 - 1, obstacles=torch.rand(4, 6, generator=gen))
@@ -89,7 +89,7 @@ def test_per_graph_csr_build_ragged_batch():
     message kernel, both pre stages in one launch)."""
     gen = torch.Generator().manual_seed(31)
     w = load_weights('weights_maze')
-    m = gnnmp.EncoderProcessDecoder(2, 2, 32, 2)
+    m = gnnmp.EncoderProcessDecoder(2, 2, 32, 2).eval()
     m.load_state_dict(w)
     graphs = []
     for i in range(80):
@@ -113,7 +113,7 @@ def test_graph_beyond_the_lds_share_of_the_csr_build():
     (kPrepCap = 8192), the 65 small graphs next to it take the LDS path."""
     gen = torch.Generator().manual_seed(77)
     w = load_weights('weights_maze')
-    m = gnnmp.EncoderProcessDecoder(2, 2, 32, 2)
+    m = gnnmp.EncoderProcessDecoder(2, 2, 32, 2).eval()
     m.load_state_dict(w)
     graphs = [random_graph(gen, 30, 100, 7) for _ in range(30)] + [random_graph(gen, 9000, 30000, 20, hub=150)] + \
         [random_graph(gen, 50, 200, 7) for _ in range(35)]
@@ -131,7 +131,7 @@ def test_random_graphs_other_kernels(mode, seed):
     gen = torch.Generator().manual_seed(4000 + seed)
     ck, C, d, S, ws = ('weights_maze', 2, 32, 2, 2) if mode.startswith('maze') else ('weights_kuka', 7, 64, 6, 3)
     w = load_weights(ck)
-    m = gnnmp.EncoderProcessDecoder(ws, C, d, S)
+    m = gnnmp.EncoderProcessDecoder(ws, C, d, S).eval()
     m.load_state_dict(w)
     graphs = []
     for i in range(int(torch.randint(2, 5, (1,), generator=gen))):
@@ -165,7 +165,7 @@ def test_message_kernel_form_boundary(tiles):
     just below, at and above the switch give the same bits as their graphs scored one by one, and match the oracle."""
     gen = torch.Generator().manual_seed(tiles)
     w = load_weights('weights_maze')
-    m = gnnmp.EncoderProcessDecoder(2, 2, 32, 2)
+    m = gnnmp.EncoderProcessDecoder(2, 2, 32, 2).eval()
     m.load_state_dict(w)
     graphs, have = [], 0
     while have < tiles:                                   # every graph occupies a multiple of 8 tiles (256-node padding)
@@ -188,7 +188,7 @@ def test_column_split_csr_build_ragged_batch():
     the graphs scored one by one (other part counts, or the one-launch build) and the oracle on the small ones."""
     gen = torch.Generator().manual_seed(909)
     w = load_weights('weights_maze')
-    m = gnnmp.EncoderProcessDecoder(2, 2, 32, 2)
+    m = gnnmp.EncoderProcessDecoder(2, 2, 32, 2).eval()
     m.load_state_dict(w)
     graphs = [random_graph(gen, 2500, 40000, 30, hub=500), random_graph(gen, 40, 0, 5), random_graph(gen, 1, 3, 0),
               random_graph(gen, 3000, 52000, 90), random_graph(gen, 150, 600, 116, hub=90), random_graph(gen, 1800, 25000, 1)]

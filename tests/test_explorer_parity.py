@@ -24,7 +24,7 @@ DEV = 'cuda:0'
 
 def make_model(env, use_obstacles=True):
     e = ENVS[env]
-    m = gnnmp.EncoderProcessDecoder(e['workspace'], e['C'], e['d'], e['S'], use_obstacles=use_obstacles)
+    m = gnnmp.EncoderProcessDecoder(e['workspace'], e['C'], e['d'], e['S'], use_obstacles=use_obstacles).eval()
     m.load_state_dict(load_weights(e['ckpt']), strict=True)
     return m
 
@@ -116,6 +116,24 @@ def test_golden_bare_1e5(path):
     assert float((s - ref64).abs().max()) <= 1e-5, (own, float((s - ref64).abs().max()))
     if own <= 1e-5:
         assert float((s - ref32).abs().max()) <= 1e-5, (own, float((s - ref32).abs().max()))
+
+
+def test_pybullet_obstacle_layout():
+    """The PyBullet environments hand obstacles over as [O, 2, 3] (half extents, centre: environment/kuka_env.py:98) and the
+    reference views them as [-1, S] (model.py:126); the module call and the sparse entry point must accept that tensor as is."""
+    r = _load([p for p in golden_files('explorer_') if 'kuka7_N64_k4_L5.' in p][0])
+    m = make_model('kuka7')
+    obs6 = torch.from_numpy(r['obstacles']).reshape(-1, 6)
+    obs3 = obs6.reshape(-1, 2, 3).to(DEV)
+    kw = dict(goal=torch.from_numpy(r['goal']).to(DEV), loop=int(r['loop']), v=torch.from_numpy(r['v']).to(DEV),
+              edge_index=torch.from_numpy(r['edge_index']).to(DEV))
+    s3 = m.edge_scores(obstacles=obs3, **kw)
+    s6 = m.edge_scores(obstacles=obs6.to(DEV), **kw)
+    assert torch.equal(s3, s6)
+    assert_fp32_parity(s3.cpu(), torch.from_numpy(r['scores_fp32']), torch.from_numpy(r['scores_fp64']), '[O,2,3] obstacles')
+    P = m(obstacles=obs3, free=kw['v'][:30], collided=kw['v'][30:], **kw)
+    ei = kw['edge_index']
+    assert torch.equal(P[ei[1], ei[0]], s3)
 
 
 def test_dense_is_reference_layout():

@@ -27,7 +27,7 @@ DEV = 'cuda:0'
 
 def _model(env, dtype):
     e = ENVS[env]
-    m = gnnmp.EncoderProcessDecoder(e['workspace'], e['C'], e['d'], e['S'])
+    m = gnnmp.EncoderProcessDecoder(e['workspace'], e['C'], e['d'], e['S']).eval()
     m.load_state_dict(load_weights(e['ckpt']), strict=True)
     m.mlp_dtype = dtype
     return m

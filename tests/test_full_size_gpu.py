@@ -19,7 +19,7 @@ DEV = 'cuda:0'
 def test_cfg2_full_batch_properties():
     G, N, K1 = 256, 1000, 8
     graphs = synth_batch_gpu('maze2', N, K1, G, DEV)
-    m = gnnmp.EncoderProcessDecoder(2, 2, 32, 2)
+    m = gnnmp.EncoderProcessDecoder(2, 2, 32, 2).eval()
     m.load_state_dict(load_weights('weights_maze'))
     b = gnnmp.GraphBatch.from_graphs(graphs, 2, DEV)
     s1 = m.forward_batch(b, 5).clone()
@@ -63,7 +63,7 @@ def test_mixed_environment_set():
     models = {}
     for env in set(order):
         e = ENVS[env]
-        mm = gnnmp.EncoderProcessDecoder(e['workspace'], e['C'], e['d'], e['S'])
+        mm = gnnmp.EncoderProcessDecoder(e['workspace'], e['C'], e['d'], e['S']).eval()
         mm.load_state_dict(load_weights(e['ckpt']))
         models[env] = mm
     scores = run_mixed(problems, models, loop=4)

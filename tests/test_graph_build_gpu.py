@@ -87,7 +87,7 @@ def test_feeds_the_explorer():
     ptr = torch.tensor([0, 300], dtype=torch.int32, device=DEV)
     ei, _ = graph_build.build_edges_gpu(g['v'].to(DEV), ptr, [150], [6])
     assert torch.equal(ei.cpu(), g['edge_index'])
-    m = gnnmp.EncoderProcessDecoder(2, 2, 32, 2)
+    m = gnnmp.EncoderProcessDecoder(2, 2, 32, 2).eval()
     m.load_state_dict(load_weights('weights_maze'))
     s = m.edge_scores(g['goal'].to(DEV), 5, g['v'].to(DEV), g['obstacles'].to(DEV), ei).cpu()
     from parity_bar import assert_fp32_parity, explorer_oracle_pair

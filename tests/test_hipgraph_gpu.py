@@ -17,7 +17,7 @@ DEV = torch.device('cuda:0')
 
 
 def test_forward_is_graph_capturable():
-    m = gnnmp.EncoderProcessDecoder(2, 2, 32, 2)
+    m = gnnmp.EncoderProcessDecoder(2, 2, 32, 2).eval()
     m.load_state_dict(load_weights('weights_maze'))
     g1 = synth_graph('maze2', 256, 6, seed=1)
     g2 = synth_graph('maze2', 256, 6, seed=2)
@@ -61,7 +61,7 @@ def test_forward_is_graph_capturable():
 
 
 def test_capture_helper():
-    m = gnnmp.EncoderProcessDecoder(2, 2, 32, 2)
+    m = gnnmp.EncoderProcessDecoder(2, 2, 32, 2).eval()
     m.load_state_dict(load_weights('weights_maze'))
     g = synth_graph('maze2', 200, 6, seed=3)
     b = gnnmp.GraphBatch.from_graphs([g], 2, DEV)

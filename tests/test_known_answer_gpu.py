@@ -26,7 +26,7 @@ def test_published_run_1000_problems():
     with np.load(path) as f:
         r = {k: f[k] for k in f.files}
     env = Maze2D(r['maps'], r['init_states'], r['goal_states'])
-    m = gnnmp.EncoderProcessDecoder(2, 2, 32, 2)
+    m = gnnmp.EncoderProcessDecoder(2, 2, 32, 2).eval()
     m.load_state_dict(load_weights('weights_maze'))
     ms = gnnmp.ModelSmoother(workspace_size=2, config_size=2, embed_size=128, obs_size=6).eval()
     ms.load_state_dict(load_weights('smooth_2d_attv3'))
@@ -65,7 +65,7 @@ def test_sharded_evaluation_equals_sequential():
     with np.load(path) as f:
         r = {k: f[k] for k in f.files}
     env = Maze2D(r['maps'], r['init_states'], r['goal_states'])
-    m = gnnmp.EncoderProcessDecoder(2, 2, 32, 2)
+    m = gnnmp.EncoderProcessDecoder(2, 2, 32, 2).eval()
     m.load_state_dict(load_weights('weights_maze'))
     ms = gnnmp.ModelSmoother(workspace_size=2, config_size=2, embed_size=128, obs_size=6).eval()
     ms.load_state_dict(load_weights('smooth_2d_attv3'))
@@ -85,7 +85,7 @@ def test_second_setting_400_problems():
         env = Maze2D(f['maps'], f['init_states'], f['goal_states'])
     with np.load(os.path.join(GOLDEN, 'evalrows_mazehard_first400_b200_k16_s7.npz')) as f:
         ref, seed, batch, k = f['rows'], int(f['seed']), int(f['batch']), int(f['k'])
-    m = gnnmp.EncoderProcessDecoder(2, 2, 32, 2)
+    m = gnnmp.EncoderProcessDecoder(2, 2, 32, 2).eval()
     m.load_state_dict(load_weights('weights_maze'))
     ms = gnnmp.ModelSmoother(workspace_size=2, config_size=2, embed_size=128, obs_size=6).eval()
     ms.load_state_dict(load_weights('smooth_2d_attv3'))

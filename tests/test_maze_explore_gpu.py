@@ -16,7 +16,7 @@ DEV = 'cuda:0'
 
 
 def _models():
-    m = gnnmp.EncoderProcessDecoder(2, 2, 32, 2)
+    m = gnnmp.EncoderProcessDecoder(2, 2, 32, 2).eval()
     m.load_state_dict(load_weights('weights_maze'))
     return m
 

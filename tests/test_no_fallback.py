@@ -17,13 +17,13 @@ def test_constructors_raise_without_the_library(monkeypatch):
     monkeypatch.setattr(_lib, '_lib', None)
     monkeypatch.setattr(_lib, 'LIB_PATH', os.path.join(REPO, 'does', 'not', 'exist', 'libgnnmp.so'))
     with pytest.raises(RuntimeError, match='libgnnmp.so not found'):
-        gnnmp.EncoderProcessDecoder(2, 2, 32, 2)
+        gnnmp.EncoderProcessDecoder(2, 2, 32, 2).eval()
     with pytest.raises(RuntimeError, match='libgnnmp.so not found'):
         gnnmp.ModelSmoother(2, 2, 6, 128)
 
 
 def test_cpu_tensors_are_refused():
-    m = gnnmp.EncoderProcessDecoder(2, 2, 32, 2)
+    m = gnnmp.EncoderProcessDecoder(2, 2, 32, 2).eval()
     v = torch.rand(8, 2)
     ei = torch.tensor([[0, 1], [1, 0]])
     with pytest.raises(RuntimeError, match='no CPU fallback'):

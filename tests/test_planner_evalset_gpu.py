@@ -22,7 +22,7 @@ def test_eval_set_matches_reference(sparse, gpu_graph):
     with np.load(golden_files('evalset_mazehard_first12')[0]) as f:
         r = {k: f[k] for k in f.files}
     env = Maze2D(r['maps'], r['init_states'], r['goal_states'])
-    m = gnnmp.EncoderProcessDecoder(2, 2, 32, 2)
+    m = gnnmp.EncoderProcessDecoder(2, 2, 32, 2).eval()
     m.load_state_dict(load_weights('weights_maze'))
     ms = gnnmp.ModelSmoother(workspace_size=2, config_size=2, embed_size=128, obs_size=6).eval()
     ms.load_state_dict(load_weights('smooth_2d_attv3'))

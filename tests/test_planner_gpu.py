@@ -27,7 +27,7 @@ def test_gpu_planner_reproduces_reference_run(path):
     r = _load(path)
     env = Maze2D(r['map'][None], r['init_state'][None], r['goal_state'][None])
     env.init_new_problem(0)
-    m = gnnmp.EncoderProcessDecoder(2, 2, 32, 2)
+    m = gnnmp.EncoderProcessDecoder(2, 2, 32, 2).eval()
     m.load_state_dict(load_weights('weights_maze'))
     ms = gnnmp.ModelSmoother(workspace_size=2, config_size=2, embed_size=128, obs_size=6).eval()
     ms.load_state_dict(load_weights('smooth_2d_attv3'))

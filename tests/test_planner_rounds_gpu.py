@@ -38,7 +38,7 @@ def test_resample_rounds_150_problems():
     with np.load(os.path.join(GOLDEN, 'evalrows_mazehard_first150_b100_t300_k12_s5.npz')) as f:
         ref, seed, batch, t_max, k = f['rows'], int(f['seed']), int(f['batch']), int(f['t_max']), int(f['k'])
     assert t_max == 3 * batch
-    m = gnnmp.EncoderProcessDecoder(2, 2, 32, 2)
+    m = gnnmp.EncoderProcessDecoder(2, 2, 32, 2).eval()
     m.load_state_dict(load_weights('weights_maze'))
     ms = gnnmp.ModelSmoother(workspace_size=2, config_size=2, embed_size=128, obs_size=6).eval()
     ms.load_state_dict(load_weights('smooth_2d_attv3'))
@@ -61,7 +61,7 @@ def test_maze3_40_problems():
     with np.load(os.path.join(GOLDEN, 'evalset_maze3_first40_b200_k12_s9.npz')) as f:
         env = Maze3D(f['maps'], f['init_states'], f['goal_states'])
         ref, seed, batch, k = f['rows'], int(f['seed']), int(f['batch']), int(f['k'])
-    m = gnnmp.EncoderProcessDecoder(2, 3, 32, 2)
+    m = gnnmp.EncoderProcessDecoder(2, 3, 32, 2).eval()
     m.load_state_dict(load_weights('weights_maze_3'))
     rows = []
     planner.eval_gnn_device_rounds(env, range(ref.shape[0]), m, None, seed=seed, batch=batch, t_max=batch, k=k, device=DEV,
@@ -79,7 +79,7 @@ def test_maze3_host_planner_matches_device():
     with np.load(os.path.join(GOLDEN, 'evalset_maze3_first40_b200_k12_s9.npz')) as f:
         env = Maze3D(f['maps'], f['init_states'], f['goal_states'])
         ref, seed, batch, k = f['rows'], int(f['seed']), int(f['batch']), int(f['k'])
-    m = gnnmp.EncoderProcessDecoder(2, 3, 32, 2)
+    m = gnnmp.EncoderProcessDecoder(2, 3, 32, 2).eval()
     m.load_state_dict(load_weights('weights_maze_3'))
     np.random.seed(seed)
     agree = 0

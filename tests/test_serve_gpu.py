@@ -14,7 +14,7 @@ DEV = 'cuda:0'
 
 
 def test_pipeline_equals_direct_forward():
-    m = gnnmp.EncoderProcessDecoder(2, 2, 32, 2)
+    m = gnnmp.EncoderProcessDecoder(2, 2, 32, 2).eval()
     m.load_state_dict(load_weights('weights_maze'))
     graphs = [synth_graph('maze2', 150 + 10 * i, 5, seed=500 + i) for i in range(12)]
     batches = [gnnmp.GraphBatch.from_graphs(graphs[a:b], 2, DEV) for a, b in ((0, 12), (0, 5), (5, 12), (3, 4), (2, 11))]

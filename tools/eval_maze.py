@@ -42,7 +42,7 @@ def main():
     with np.load(a.problems) as f:
         env = Maze2D(f['maps'], f['init_states'], f['goal_states'])
     n = env.size if a.count <= 0 else min(a.count, env.size)
-    m = gnnmp.EncoderProcessDecoder(2, 2, 32, 2)
+    m = gnnmp.EncoderProcessDecoder(2, 2, 32, 2).eval()
     m.load_state_dict(load_weights('weights_maze'))
     ms = gnnmp.ModelSmoother(workspace_size=2, config_size=2, embed_size=128, obs_size=6).eval()
     ms.load_state_dict(load_weights('smooth_2d_attv3'))

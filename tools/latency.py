@@ -18,7 +18,7 @@ dev = torch.device('cuda:0')
 
 def model_for(env):
     e = ENVS[env]
-    m = gnnmp.EncoderProcessDecoder(e['workspace'], e['C'], e['d'], e['S'])
+    m = gnnmp.EncoderProcessDecoder(e['workspace'], e['C'], e['d'], e['S']).eval()
     m.load_state_dict(load_weights(e['ckpt']))
     return m, e
 

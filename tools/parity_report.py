@@ -33,7 +33,7 @@ for path in sorted(glob.glob(os.path.join(REPO, 'tests', 'golden', 'explorer_*.n
     env = os.path.basename(path).split('_')[1]
     e = ENVS[env]
     for mode in modes:
-        m = gnnmp.EncoderProcessDecoder(e['workspace'], e['C'], e['d'], e['S'], use_obstacles=bool(r['use_obstacles']))
+        m = gnnmp.EncoderProcessDecoder(e['workspace'], e['C'], e['d'], e['S'], use_obstacles=bool(r['use_obstacles'])).eval()
         m.load_state_dict(load_weights(e['ckpt']), strict=True)
         m.mlp_dtype = mode
         s = m.edge_scores(goal=torch.from_numpy(r['goal']).to(DEV), loop=int(r['loop']), v=torch.from_numpy(r['v']).to(DEV),

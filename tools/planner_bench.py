@@ -39,7 +39,7 @@ def main():
         maps, init, goal = f['maps'], f['init_states'], f['goal_states']
     env = Maze2D(maps, init, goal)
     dev = 'cuda:0'
-    m = gnnmp.EncoderProcessDecoder(2, 2, 32, 2)
+    m = gnnmp.EncoderProcessDecoder(2, 2, 32, 2).eval()
     m.load_state_dict(load_weights('weights_maze'))
     ms = gnnmp.ModelSmoother(workspace_size=2, config_size=2, embed_size=128, obs_size=6).eval()
     ms.load_state_dict(load_weights('smooth_2d_attv3'))
