@@ -1,0 +1,49 @@
+#!/usr/bin/env python
+"""Run ON THE GPU BOX: BASELINE configs[3] (mixed maze / snake / ur5 / kuka set, 1000-node k1 = 8, fp32) on one GPU -- graphs/s of
+the whole mixed job through gnnmp.dist.run_mixed and per family (64 problems each), kept as profiles/rNN_cfg4_mixed.txt."""
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+import gnnmp  # noqa: E402
+from gnnmp.dist import run_mixed  # noqa: E402
+from gnnmp.synth import ENVS, synth_batch_gpu  # noqa: E402
+from gnnmp.weights import load_weights  # noqa: E402
+
+DEV = 'cuda:0'
+FAMILIES = ['maze2', 'snake7', 'ur5', 'kuka7']
+PER, N, K1, LOOP = 64, 1000, 8, 5
+dtype = sys.argv[1] if len(sys.argv) > 1 else 'fp32'
+problems, models = [], {}
+for fi, env in enumerate(FAMILIES):
+    e = ENVS[env]
+    m = gnnmp.EncoderProcessDecoder(e['workspace'], e['C'], e['d'], e['S']).eval()
+    m.load_state_dict(load_weights(e['ckpt']), strict=True)
+    m.mlp_dtype = dtype
+    models[env] = m
+    problems += [dict(env=env, **g) for g in synth_batch_gpu(env, N, K1, PER, DEV, seed0=5000 + 1000 * fi)]
+
+
+def rate(ps, reps=10):
+    for _ in range(3):
+        run_mixed(ps, models, loop=LOOP)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        run_mixed(ps, models, loop=LOOP)
+    torch.cuda.synchronize()
+    return len(ps) * reps / (time.perf_counter() - t0)
+
+
+print('BASELINE configs[3] on one MI355X, %s: %d problems, %d-node k1=%d RGGs, loop %d' % (dtype, len(problems), N, K1, LOOP))
+print('%-10s %4s %4s %4s %8s %12s' % ('family', 'C', 'd', 'O', 'mean E', 'graphs/s'))
+for env in FAMILIES:
+    ps = [p for p in problems if p['env'] == env]
+    e = ENVS[env]
+    print('%-10s %4d %4d %4d %8.0f %12.1f' % (env, e['C'], e['d'], ps[0]['obstacles'].reshape(-1, e['S']).shape[0],
+                                            sum(p['edge_index'].shape[1] for p in ps) / len(ps), rate(ps)))
+print('%-10s %35s %12.1f   (run_mixed: GraphBatch assembly + one batched forward per family)' % ('mixed job', '', rate(problems)))
