@@ -43,8 +43,11 @@ def _worker(rank, world, port, n_problems, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_gather_equals_single_process():
-    world, n = 2, 7
+import pytest
+
+
+@pytest.mark.parametrize('world,n', [(2, 7), (3, 2)])       # (3, 2): one rank owns nothing -- an empty shard in the padded gather
+def test_two_rank_gather_equals_single_process(world, n):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()

@@ -100,3 +100,80 @@ def test_two_processes_shard_the_device_planner(tmp_path):
         want = f['rows']
     assert got.shape == want.shape == (64, 7)
     assert np.array_equal(got, want)          # union over ranks == the recorded single-process device run, row by row
+
+
+def test_bench_two_ranks_rccl():
+    """The driver's multi-GPU launch at N = 2 (one rank per GPU over RCCL): needs two visible GPUs and skips on the one-GPU
+    test box.  Weak scaling: both ranks own 32 problems of their own; the line's value is the whole-job rate and the gathered
+    checksum is the sum of the two ranks' plain single-process checksums (rank r's problems are seeds 1234 + r * G + i)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs two GPUs (RCCL cannot put two ranks on one device); unmeasured on hardware so far')
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), 'bench.py', '--gpus', '2'] + BENCH_ARGS
+    r = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = _json_line(r.stdout)
+    assert line['n_gpus'] == 2 and line['scaling'] == 'weak' and line['value'] > 0
+
+
+_GATHER_WORKER = r'''
+import os, sys
+import torch, torch.distributed as dist
+sys.path.insert(0, %(repo)r)
+import gnnmp
+from gnnmp.dist import gather_variable, run_mixed, shard_range
+from gnnmp.synth import ENVS, synth_graph
+from gnnmp.weights import load_weights
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+dist.init_process_group('gloo')
+dev = 'cuda:0'
+order = ['maze2', 'kuka7', 'ur5', 'snake7', 'maze2', 'kuka7', 'maze2', 'ur5', 'snake7']
+graphs = [synth_graph(env, 150 + 40 * i, 5, seed=70 + i) for i, env in enumerate(order)]          # ragged: 150 .. 470 nodes
+lo, hi = shard_range(len(graphs), rank, world, [g['edge_index'].shape[1] for g in graphs])
+models = {}
+for env in set(order):
+    e = ENVS[env]
+    models[env] = gnnmp.EncoderProcessDecoder(e['workspace'], e['C'], e['d'], e['S']).eval()
+    models[env].load_state_dict(load_weights(e['ckpt']))
+mine = [dict(env=order[i], **{k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in graphs[i].items()}) for i in range(lo, hi)]
+scores = run_mixed(mine, models, loop=3) if mine else []
+flat = torch.cat([s.cpu() for s in scores]) if scores else torch.zeros(0)
+parts = gather_variable(flat)                                   # all_gather_into_tensor over gloo, ragged lengths
+if rank == 0:
+    torch.save(dict(parts=parts, cuts=[shard_range(len(graphs), r, world, [g['edge_index'].shape[1] for g in graphs]) for r in range(world)]), %(out)r)
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_two_ranks_shard_a_ragged_mixed_set_and_gather(tmp_path):
+    """Two ranks (gloo, sharing the one GPU) split a ragged mixed-family problem set by edge count, score their shards with
+    the HIP kernels and gather the per-edge scores with gather_variable; the gathered buffers equal a single-process run."""
+    import torch
+    import gnnmp
+    from conftest import load_weights
+    from gnnmp.dist import run_mixed
+    from gnnmp.synth import ENVS, synth_graph
+    out = str(tmp_path / 'gathered.pt')
+    script = tmp_path / 'worker.py'
+    script.write_text(_GATHER_WORKER % dict(repo=REPO, out=out))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), str(script)]
+    r = subprocess.run(cmd, cwd=REPO, capture_output=True, text=True, timeout=900, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0'))
+    assert r.returncode == 0, r.stderr[-3000:]
+    got = torch.load(out)
+    order = ['maze2', 'kuka7', 'ur5', 'snake7', 'maze2', 'kuka7', 'maze2', 'ur5', 'snake7']
+    graphs = [synth_graph(env, 150 + 40 * i, 5, seed=70 + i) for i, env in enumerate(order)]
+    models = {}
+    for env in set(order):
+        e = ENVS[env]
+        models[env] = gnnmp.EncoderProcessDecoder(e['workspace'], e['C'], e['d'], e['S']).eval()
+        models[env].load_state_dict(load_weights(e['ckpt']))
+    problems = [dict(env=order[i], **{k: (v.to('cuda:0') if torch.is_tensor(v) else v) for k, v in g.items()}) for i, g in enumerate(graphs)]
+    whole = [s.cpu() for s in run_mixed(problems, models, loop=3)]
+    cuts = got['cuts']
+    assert cuts[0][0] == 0 and cuts[0][1] == cuts[1][0] and cuts[1][1] == len(graphs) and 0 < cuts[0][1] < len(graphs)
+    for (lo, hi), part in zip(cuts, got['parts']):
+        assert torch.equal(part, torch.cat(whole[lo:hi]))

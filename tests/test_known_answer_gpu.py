@@ -41,17 +41,17 @@ def test_published_run_1000_problems():
     print('reference (CPU, this container): success %d, checks %.2f (explore %.2f), smoothed cost %.4f'
           % (ref[:, 0].sum(), (ref[:, 3] + ref[:, 4]).mean(), ref[:, 3].mean(), ref[ref[:, 0] > 0, 2].mean()))
     print('published (main.ipynb:57-61):', PUBLISHED)
-    # (a) per problem against the reference's own run.  The GPU forward differs from the CPU forward by ~1e-5 on the edge
-    # scores, so a near-tie between two frontier edges may resolve differently on a handful of problems: everything
-    # else must be identical.
+    # (a) per problem against the reference's own run.  Measured (profiles/r03_planner_parity.txt): 1000 / 1000 identical in
+    # both stages.  The asserts keep a margin of 2 / 5 problems: the GPU forward differs from the CPU forward by up to 2e-5
+    # on the edge scores, so a later change of kernel rounding may resolve a near-tie between two frontier edges differently.
     same = (rows[:, 3] == ref[:, 3]) & (rows[:, 6] == ref[:, 6]) & (rows[:, 5] == ref[:, 5])
     print('explore stage identical (checks, explored nodes, path length) on %d / 1000 problems' % int(same.sum()))
     assert np.array_equal(rows[:, 0], ref[:, 0])
-    assert same.sum() >= 990
+    assert same.sum() >= 998
     assert abs(rows[:, 3].mean() - ref[:, 3].mean()) <= 0.002 * ref[:, 3].mean()
     sm_same = same & (rows[:, 4] == ref[:, 4])
     print('smoothing stage identical check counts on %d of those' % int(sm_same.sum()))
-    assert sm_same.sum() >= 0.97 * same.sum()
+    assert sm_same.sum() >= 995
     assert abs(cost - ref[ref[:, 0] > 0, 2].mean()) <= 2e-3
     # (b) the notebook
     assert n_success == PUBLISHED['success']
@@ -97,5 +97,5 @@ def test_second_setting_400_problems():
     print('\nsolved %d (reference %d) of %d; explore stage identical on %d, smoothing check counts on %d'
           % (rows[:, 0].sum(), ref[:, 0].sum(), ref.shape[0], same.sum(), sm_same.sum()))
     assert np.array_equal(rows[:, 0], ref[:, 0])
-    assert same.sum() >= 0.99 * ref.shape[0]                  # a ~1e-5 score difference may flip a near-tie
-    assert sm_same.sum() >= 0.97 * same.sum()
+    assert same.sum() >= 398                                  # measured 400 / 400 (profiles/r03_planner_parity.txt); margin 2
+    assert sm_same.sum() >= 396                               # measured 400

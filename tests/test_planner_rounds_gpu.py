@@ -51,10 +51,10 @@ def test_resample_rounds_150_problems():
     assert multi.sum() >= 30                                  # the resample path is what this test is about
     same = _compare(rows, ref, 'resample rounds')
     assert np.array_equal(rows[:, 0], ref[:, 0])
-    assert same.sum() >= 0.95 * ref.shape[0]
-    assert same[multi].sum() >= 0.9 * multi.sum()             # ... including the multi-round problems
+    assert same.sum() >= 148                                  # measured 150 / 150 (profiles/r03_planner_parity.txt); margin 2
+    assert same[multi].sum() >= multi.sum() - 2               # ... including the multi-round problems (measured 47 / 47)
     sm_same = same & (rows[:, 4] == ref[:, 4])
-    assert sm_same.sum() >= 0.95 * same.sum()
+    assert sm_same.sum() >= 147                               # measured 150
 
 
 def test_maze3_40_problems():
@@ -69,7 +69,7 @@ def test_maze3_40_problems():
     rows = np.array(rows, dtype=np.float64)
     same = _compare(rows, ref, 'maze3 (stick robot)')
     assert np.array_equal(rows[:, 0], ref[:, 0])
-    assert same.sum() >= 0.95 * ref.shape[0]
+    assert same.sum() >= 39                                   # measured 40 / 40 (profiles/r03_planner_parity.txt); margin 1
     ok = same & (ref[:, 0] > 0)
     assert np.allclose(rows[ok, 1], ref[ok, 1], rtol=0, atol=1e-6)       # same nodes -> same path cost
 
