@@ -588,10 +588,13 @@ __device__ __forceinline__ void lin64(const float* A, const f64x4 (&x)[NB], f64x
 #pragma unroll
     for (int ib = 0; ib < NB; ++ib)
 #pragma unroll
-        for (int st = 0; st < 4; ++st)
+        for (int st = 0; st < 4; ++st) {
 #pragma unroll
             for (int ob = 0; ob < NB; ++ob)
                 y[ob] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)A[((ob * NB + ib) * 4 + st) * 64 + lane], x[ib][st], y[ob], 0, 0, 0);
+            // d = 64: without a fence the scheduler hoists all 64 operand loads and conversions of a layer (128 registers)
+            if constexpr (NB > 2) __builtin_amdgcn_sched_barrier(0);
+        }
 }
 
 template <int NB>
@@ -640,10 +643,13 @@ __device__ __forceinline__ void node_f64_body(const ObsParams& p, const NodeF64P
         if (oc0 > 0 || (grp > 0 && !single_chunk)) __syncthreads();    // everybody is done with the previous chunk's operands
         if (grp == 0 || !single_chunk)
         {   // obstacle operands of this chunk: wave w owns the 32-obstacle tiles oc0/32 + w, ... (obs_body's arithmetic for b = 0)
-            const float* W = p.w[0];
             const ObsBlob Lo = p.blob;
             const int h = lane >> 5, j = lane & 31, S = p.S;
             for (int ot = (oc0 >> 5) + wave; ot < min(OT, (oc0 + OC) >> 5); ot += 4) {
+                // the weights are MFMA operands read from global memory: loop-invariant loads that the compiler would hoist out
+                // of the three enclosing loops into ~200 registers (spills at d = 64) unless the pointer is laundered here
+                const float* W = p.w[0];
+                asm volatile("" : "+s"(W));
                 const int o = ot * 32 + j;
                 const bool valid = o < O;
                 const float* orow = p.obstacles + (size_t)(o0 + (valid ? o : 0)) * S;
@@ -654,14 +660,19 @@ __device__ __forceinline__ void node_f64_body(const ObsParams& p, const NodeF64P
                 for (int t = 0; t < NT; ++t) { K[t] = splat16(0.f); V[t] = splat16(0.f); }
                 linear_acc_p<P, NT, NT>(W + Lo.blk0 + Lo.wk, code, K, lane);
                 linear_acc_p<P, NT, NT>(W + Lo.blk0 + Lo.wv, code, V, lane);
+                // scatter into the operand layouts: kd[((ob NB + f/16) 4 + (f%16)/4) 64 + o%16 + 16 (f%4)] = K'[o][f] (lane = obstacle +
+                // 16 k-slot), vd[((ob NB + f/16) 4 + o%4) 64 + f%16 + 16 ((o%16)/4)] = V[o][f] (lane = feature + 16 k-slot), ob = o/16.
+                // With f = 32 t + phi(r, h) every index is one per-lane base plus a compile-time offset (registers matter at d = 64)
                 const int oo = o - oc0;
+                float* kb = kd + (oo >> 4) * NB * 256 + (oo & 15) + 64 * h;
+                float* vb = vd + (oo >> 4) * NB * 256 + (oo & 3) * 64 + 16 * ((oo & 15) >> 2) + 4 * h;
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const int f = 32 * t + phi(r, h);
-                        kd[(((oo >> 4) * NB + (f >> 4)) * 4 + ((f & 15) >> 2)) * 64 + (oo & 15) + 16 * (f & 3)] = valid ? K[t][r] : 0.f;
-                        vd[(((oo >> 4) * NB + (f >> 4)) * 4 + (oo & 3)) * 64 + (f & 15) + 16 * ((oo & 15) >> 2)] = valid ? V[t][r] : 0.f;
+                        const int f0 = 32 * t + phi(r, 0);                       // h adds 4: same 16-block, next k-step / next lane group
+                        kb[(f0 >> 4) * 256 + ((f0 & 15) >> 2) * 64 + 16 * (f0 & 3)] = valid ? K[t][r] : 0.f;
+                        vb[(f0 >> 4) * 256 + (f0 & 15)] = valid ? V[t][r] : 0.f;
                     }
             }
         }
@@ -701,6 +712,7 @@ __device__ __forceinline__ void node_f64_body(const ObsParams& p, const NodeF64P
                     for (int ob = 0; ob < NB; ++ob) {
                         tq[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[L.wqk + ((ob * NB + ib) * 4 + st) * 64 + lane], xf[ib][st], tq[ob], 0, 0, 0);
                         mv[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[L.wv + ((ob * NB + ib) * 4 + st) * 64 + lane], xf[ib][st], mv[ob], 0, 0, 0);
+                        if constexpr (NB > 2) __builtin_amdgcn_sched_barrier(0);
                     }
             double l0 = 0.0;
 #pragma unroll
