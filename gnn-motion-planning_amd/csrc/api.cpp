@@ -793,6 +793,8 @@ int forward_impl(const gnnmp_explorer* h, const gnnmp_batch* b, int loop, int us
     HIP_TRY(launch_prep(q, c.Npad, c.Epad, at<int>(ws, c.prep_hist), st));
     // zero-fill of policy_output (model.py:148); sum_g N_g^2 is read from dense_ptr[G] on the device
     if (dense) HIP_TRY(launch_zero_dense(dense, q.dense_ptr + c.G, st));
+    // training path: CSR slots in a timing-independent order (the gradients sum over slots)
+    if (pre_only) HIP_TRY(t_sort_csr(c.Npad, q.csr, q.row_beg, q.deg, st));
     }
 
     const bool use_obs = use_obstacles != 0;
@@ -1077,6 +1079,7 @@ extern "C" int gnnmp_smoother_create(gnnmp_smoother** out, const gnnmp_smoother_
     if (prev_dev >= 0 && prev_dev != device) (void)hipSetDevice(prev_dev);
     if (e != hipSuccess) {
         if (h->w_dev) (void)hipFree(h->w_dev);
+        if (h->w_raw_dev) (void)hipFree(h->w_raw_dev);
         delete h;
         return hip_fail(e);
     }
@@ -1345,6 +1348,8 @@ struct TrainCarve {
     // offsets in floats from the start of the train region
     size_t NF, EF, NCin, NCh, NC, ECin, ECh, EC, H0, it0, it_stride, Xin, X, Zh, A, arg, H, DinCat, Dn, Pin, P1, P2, sc;
     size_t T5a, T5b, Te1, Te2, T3, dX, dH, dA, dNC, dH0, dXin, dEC, cat2, dcat2, dDn;
+    size_t obeg, ocnt, ocur, oslot;    // edges grouped by source (ints), built by the forward, read by the backward
+    size_t dwp;                        // per-block partial sums of the weight gradients (two-stage, deterministic)
     size_t total_floats;
 };
 
@@ -1367,6 +1372,12 @@ bool train_carve(const gnnmp_explorer* h, const gnnmp_batch* b, int loop, const 
     t.T5a = take(Ep * 5 * d); t.T5b = take(Ep * 5 * d); t.Te1 = take(Ep * d); t.Te2 = take(Ep * d); t.T3 = take(Ep * 3 * d);
     t.dX = take(Np * d); t.dH = take(Np * d); t.dA = take(Np * d); t.dNC = take(Np * d); t.dH0 = take(Np * d);
     t.dXin = take(Np * 4 * d); t.dEC = take(Ep * d); t.cat2 = take(Np * 2 * d); t.dcat2 = take(Np * 2 * d); t.dDn = take(Np * d);
+    t.obeg = take(Np); t.ocnt = take(Np); t.ocur = take(Np); t.oslot = take(Ep);
+    {
+        size_t m = t_linear_dw_scratch_floats((int)Ep, (int)(5 * d), (int)d);          // the widest layer over edge rows ...
+        const size_t n4 = t_linear_dw_scratch_floats((int)Np, (int)(4 * d), (int)d);  // ... and over node rows
+        t.dwp = take(m > n4 ? m : n4);
+    }
     t.total_floats = o;
     (void)b;
     return true;
@@ -1387,13 +1398,15 @@ WRef wref(const gnnmp_explorer* h, float* grad, const std::string& name, bool bi
     return r;
 }
 
-TrainGeom train_geom(const gnnmp_explorer* h, const gnnmp_batch* b, const Carve& c, void* ws) {
+TrainGeom train_geom(const gnnmp_explorer* h, const gnnmp_batch* b, const Carve& c, const TrainCarve& t, void* ws) {
     TrainGeom q;
     q.G = c.G; q.C = h->dims.config_size; q.Npad = c.Npad; q.Epad = c.Epad;
     q.v = b->v; q.goal = b->goal; q.node_ptr = b->node_ptr;
     q.node_ptr_pad = at<int>(ws, c.node_ptr_pad); q.ntile_graph = at<int>(ws, c.ntile_graph);
     q.goal_node = at<int>(ws, c.goal_node); q.row_beg = at<int>(ws, c.row_beg); q.deg = at<int>(ws, c.deg);
     q.csr = at<int4>(ws, c.csr);
+    int* TI = reinterpret_cast<int*>(static_cast<char*>(ws) + t.inf_bytes);
+    q.out_beg = TI + t.obeg; q.out_cnt = TI + t.ocnt; q.out_cur = TI + t.ocur; q.out_slot = TI + t.oslot;
     return q;
 }
 
@@ -1432,13 +1445,14 @@ extern "C" int gnnmp_explorer_train_forward(const gnnmp_explorer* h, const gnnmp
     // frozen inputs (model.py:141,142,146 detach them): node_free_code / edge_free_code after the attention stacks
     const int rc = forward_impl(h, b, loop, use_obstacles, nullptr, nullptr, ws, t.inf_bytes, hip_stream, T + t.NF, T + t.EF, true);
     if (rc != GNNMP_OK) return rc;
-    const TrainGeom q = train_geom(h, b, c, ws);
+    const TrainGeom q = train_geom(h, b, c, t, ws);
     const WRef nc0 = wref(h, nullptr, "node_code.0"), nc2 = wref(h, nullptr, "node_code.2"), ec0 = wref(h, nullptr, "edge_code.0"),
                ec2 = wref(h, nullptr, "edge_code.2"), enc = wref(h, nullptr, "encoder"), l00 = wref(h, nullptr, "process.lin_0.0"),
                l02 = wref(h, nullptr, "process.lin_0.2"), l1 = wref(h, nullptr, "process.lin_1"), dec = wref(h, nullptr, "decoder"),
                p0 = wref(h, nullptr, "policy.0"), p2 = wref(h, nullptr, "policy.2"), p4 = wref(h, nullptr, "policy.4", false);
     const float* ge = nullptr;
     for (size_t i = 0; i < h->man.size(); ++i) if (h->man[i].name == "goal_encoder") ge = h->w_raw_dev + h->man_off[i];
+    HIP_TRY(t_out_csr(q, st));                                   // edges by source: the backward's gather adjoints walk it in order
     HIP_TRY(t_node_in(q, T + t.NCin, st));
     HIP_TRY(t_linear(Np, 4 * C, d, T + t.NCin, nc0.w, nc0.b, T + t.NCh, true, st));
     HIP_TRY(t_linear(Np, d, d, T + t.NCh, nc2.w, nc2.b, T + t.NC, false, st));
@@ -1474,15 +1488,16 @@ extern "C" int gnnmp_explorer_train_backward(const gnnmp_explorer* h, const gnnm
     if (!h || !b || !ws || !grad || (b->total_edges > 0 && !d_edge_scores)) return GNNMP_ERR_NULL;
     if (!b->node_ptr || !b->edge_ptr || !b->obs_ptr) return GNNMP_ERR_NULL;
     if (loop < 1) return GNNMP_ERR_ARG;
+    if (h->dims.mlp_dtype != GNNMP_F32) return GNNMP_ERR_DIMS;           // same argument checks as train_forward
     Carve c;
     if (!carve(h, b, c)) return GNNMP_ERR_ARG;
     TrainCarve t;
     train_carve(h, b, loop, c, t);
-    if (ws_bytes < t.inf_bytes + t.total_floats * sizeof(float)) return GNNMP_ERR_WORKSPACE;
+    if (ws_bytes < t.inf_bytes + t.total_floats * sizeof(float) || (reinterpret_cast<uintptr_t>(ws) & 255)) return GNNMP_ERR_WORKSPACE;
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     float* T = reinterpret_cast<float*>(static_cast<char*>(ws) + t.inf_bytes);
     const int d = h->dims.embed_size, C = h->dims.config_size, Np = c.Npad, Ep = c.Epad;
-    const TrainGeom q = train_geom(h, b, c, ws);
+    const TrainGeom q = train_geom(h, b, c, t, ws);
     HIP_TRY(hipMemsetAsync(grad, 0, (size_t)h->n_raw * sizeof(float), st));
     const WRef nc0 = wref(h, grad, "node_code.0"), nc2 = wref(h, grad, "node_code.2"), ec0 = wref(h, grad, "edge_code.0"),
                ec2 = wref(h, grad, "edge_code.2"), enc = wref(h, grad, "encoder"), l00 = wref(h, grad, "process.lin_0.0"),
@@ -1492,18 +1507,18 @@ extern "C" int gnnmp_explorer_train_backward(const gnnmp_explorer* h, const gnnm
     for (size_t i = 0; i < h->man.size(); ++i) if (h->man[i].name == "goal_encoder") g_ge = grad + h->man_off[i];
     // ---- policy head (model.py:145-146)
     HIP_TRY(t_scores_in(q, d_edge_scores, T + t.Te1, st));                          // [Ep, 1]
-    HIP_TRY(t_linear_dw(Ep, d, 1, T + t.Te1, T + t.P2, p4.gw, nullptr, st));
+    HIP_TRY(t_linear_dw(Ep, d, 1, T + t.Te1, T + t.P2, p4.gw, nullptr, T + t.dwp, st));
     HIP_TRY(t_linear_dx(Ep, d, 1, T + t.Te1, p4.w, T + t.Te2, false, st));          // dP2
     HIP_TRY(t_relu_bwd((size_t)Ep * d, T + t.P2, T + t.Te2, st));
-    HIP_TRY(t_linear_dw(Ep, d, d, T + t.Te2, T + t.P1, p2.gw, p2.gb, st));
+    HIP_TRY(t_linear_dw(Ep, d, d, T + t.Te2, T + t.P1, p2.gw, p2.gb, T + t.dwp, st));
     HIP_TRY(t_linear_dx(Ep, d, d, T + t.Te2, p2.w, T + t.Te1, false, st));          // dP1
     HIP_TRY(t_relu_bwd((size_t)Ep * d, T + t.P1, T + t.Te1, st));
-    HIP_TRY(t_linear_dw(Ep, 3 * d, d, T + t.Te1, T + t.Pin, p0.gw, p0.gb, st));
+    HIP_TRY(t_linear_dw(Ep, 3 * d, d, T + t.Te1, T + t.Pin, p0.gw, p0.gb, T + t.dwp, st));
     HIP_TRY(t_linear_dx(Ep, 3 * d, d, T + t.Te1, p0.w, T + t.T3, false, st));       // dPin
     HIP_TRY(t_fill((size_t)Np * d, T + t.dDn, 0.f, st));
     HIP_TRY(t_pol_in_bwd(q, d, T + t.T3, T + t.dDn, st));
     // ---- decoder (model.py:143)
-    HIP_TRY(t_linear_dw(Np, 2 * d, d, T + t.dDn, T + t.DinCat, dec.gw, dec.gb, st));
+    HIP_TRY(t_linear_dw(Np, 2 * d, d, T + t.dDn, T + t.DinCat, dec.gw, dec.gb, T + t.dwp, st));
     HIP_TRY(t_linear_dx(Np, 2 * d, d, T + t.dDn, dec.w, T + t.dcat2, false, st));
     HIP_TRY(t_split(Np, d, 2, 0, T + t.dcat2, T + t.dNC, false, st));
     HIP_TRY(t_split(Np, d, 2, 1, T + t.dcat2, T + t.dH, false, st));
@@ -1513,20 +1528,20 @@ extern "C" int gnnmp_explorer_train_backward(const gnnmp_explorer* h, const gnnm
     for (int it = loop - 1; it >= 0; --it) {
         float* I = T + t.it0 + t.it_stride * (size_t)it;
         HIP_TRY(t_concat(Np, d, 2, I + t.X, I + t.A, nullptr, nullptr, T + t.cat2, st));
-        HIP_TRY(t_linear_dw(Np, 2 * d, d, T + t.dH, T + t.cat2, l1.gw, l1.gb, st));
+        HIP_TRY(t_linear_dw(Np, 2 * d, d, T + t.dH, T + t.cat2, l1.gw, l1.gb, T + t.dwp, st));
         HIP_TRY(t_linear_dx(Np, 2 * d, d, T + t.dH, l1.w, T + t.dcat2, false, st));
         HIP_TRY(t_split(Np, d, 2, 0, T + t.dcat2, T + t.dX, false, st));
         HIP_TRY(t_split(Np, d, 2, 1, T + t.dcat2, T + t.dA, false, st));
         HIP_TRY(t_fill((size_t)Ep * d, T + t.Te1, 0.f, st));                        // dM
         HIP_TRY(t_segment_max_bwd(Np, d, T + t.dA, reinterpret_cast<const int*>(I + t.arg), T + t.Te1, st));
-        HIP_TRY(t_linear_dw(Ep, d, d, T + t.Te1, I + t.Zh, l02.gw, l02.gb, st));
+        HIP_TRY(t_linear_dw(Ep, d, d, T + t.Te1, I + t.Zh, l02.gw, l02.gb, T + t.dwp, st));
         HIP_TRY(t_linear_dx(Ep, d, d, T + t.Te1, l02.w, T + t.Te2, false, st));      // dZh
         HIP_TRY(t_relu_bwd((size_t)Ep * d, I + t.Zh, T + t.Te2, st));
         HIP_TRY(t_msg_in(q, d, I + t.X, T + t.EF, T + t.EC, T + t.T5a, st));         // Zin recomputed
-        HIP_TRY(t_linear_dw(Ep, 5 * d, d, T + t.Te2, T + t.T5a, l00.gw, l00.gb, st));
+        HIP_TRY(t_linear_dw(Ep, 5 * d, d, T + t.Te2, T + t.T5a, l00.gw, l00.gb, T + t.dwp, st));
         HIP_TRY(t_linear_dx(Ep, 5 * d, d, T + t.Te2, l00.w, T + t.T5b, false, st));   // dZin
         HIP_TRY(t_msg_in_bwd(q, d, T + t.T5b, T + t.dX, T + t.dEC, st));
-        HIP_TRY(t_linear_dw(Np, 4 * d, d, T + t.dX, I + t.Xin, enc.gw, enc.gb, st));
+        HIP_TRY(t_linear_dw(Np, 4 * d, d, T + t.dX, I + t.Xin, enc.gw, enc.gb, T + t.dwp, st));
         HIP_TRY(t_linear_dx(Np, 4 * d, d, T + t.dX, enc.w, T + t.dXin, false, st));
         HIP_TRY(t_split(Np, d, 4, 0, T + t.dXin, T + t.dNC, true, st));              // node_code
         HIP_TRY(t_split(Np, d, 4, 2, T + t.dXin, T + t.dH0, true, st));              // h_0   (part 1 = node_free_code: detached)
@@ -1535,14 +1550,14 @@ extern "C" int gnnmp_explorer_train_backward(const gnnmp_explorer* h, const gnnm
     }
     HIP_TRY(t_h0_bwd(q, d, T + t.dH0, g_ge, st));
     // ---- edge_code, node_code encoders (model.py:119-120)
-    HIP_TRY(t_linear_dw(Ep, d, d, T + t.dEC, T + t.ECh, ec2.gw, ec2.gb, st));
+    HIP_TRY(t_linear_dw(Ep, d, d, T + t.dEC, T + t.ECh, ec2.gw, ec2.gb, T + t.dwp, st));
     HIP_TRY(t_linear_dx(Ep, d, d, T + t.dEC, ec2.w, T + t.Te1, false, st));
     HIP_TRY(t_relu_bwd((size_t)Ep * d, T + t.ECh, T + t.Te1, st));
-    HIP_TRY(t_linear_dw(Ep, 2 * C, d, T + t.Te1, T + t.ECin, ec0.gw, ec0.gb, st));
-    HIP_TRY(t_linear_dw(Np, d, d, T + t.dNC, T + t.NCh, nc2.gw, nc2.gb, st));
+    HIP_TRY(t_linear_dw(Ep, 2 * C, d, T + t.Te1, T + t.ECin, ec0.gw, ec0.gb, T + t.dwp, st));
+    HIP_TRY(t_linear_dw(Np, d, d, T + t.dNC, T + t.NCh, nc2.gw, nc2.gb, T + t.dwp, st));
     HIP_TRY(t_linear_dx(Np, d, d, T + t.dNC, nc2.w, T + t.dX, false, st));
     HIP_TRY(t_relu_bwd((size_t)Np * d, T + t.NCh, T + t.dX, st));
-    HIP_TRY(t_linear_dw(Np, 4 * C, d, T + t.dX, T + t.NCin, nc0.gw, nc0.gb, st));
+    HIP_TRY(t_linear_dw(Np, 4 * C, d, T + t.dX, T + t.NCin, nc0.gw, nc0.gb, T + t.dwp, st));
     return GNNMP_OK;
 }
 
@@ -1556,7 +1571,7 @@ struct SmTrainCarve {
     int Nn, K0, ecap;
     // floats from the start of the train region
     size_t states, it0, it_stride, Xin, X0, stats, X1, X, esrc, edst, ne, Zh, S, L1h, Hh;
-    size_t Zin, M, dZh, dZin, dX, dX1, dX0, dXin, dS, dL1h, dHh, prop, dprop, dpa, dpb, tmpP;
+    size_t Zin, M, dZh, dZin, dX, dX1, dX0, dXin, dS, dL1h, dHh, prop, dprop, dpa, dpb, tmpP, dwp;
     size_t total_floats;
 };
 
@@ -1580,6 +1595,12 @@ bool sm_train_carve(const gnnmp_smoother* h, const gnnmp_smooth_batch* b, int lo
     t.dX = take(Nn * d); t.dX1 = take(Nn * d); t.dX0 = take(Nn * d); t.dXin = take(Nn * K0);
     t.dS = take(P * d); t.dL1h = take(P * d); t.dHh = take(P * d); t.prop = take(P * C); t.dprop = take(P * C);
     t.dpa = take(P * C); t.dpb = take(P * C); t.tmpP = take(P * d);
+    {
+        size_t m = t_linear_dw_scratch_floats((int)Ec, (int)(3 * d), (int)d);
+        const size_t n1 = t_linear_dw_scratch_floats((int)Nn, (int)d, (int)d), n0 = t_linear_dw_scratch_floats((int)Nn, (int)K0, (int)d);
+        m = m > n1 ? m : n1;
+        t.dwp = take(m > n0 ? m : n0);
+    }
     t.total_floats = o;
     return true;
 }
@@ -1675,7 +1696,7 @@ extern "C" int gnnmp_smoother_train_forward(const gnnmp_smoother* h, const gnnmp
         HIP_TRY(t_linear(Ec, 3 * d, d, T + t.Zin, l00.w, l00.b, I + t.Zh, true, st));
         HIP_TRY(t_linear(Ec, d, d, I + t.Zh, l02.w, l02.b, T + t.M, false, st));
         HIP_TRY(t_fill((size_t)P * d, I + t.S, 0.f, st));
-        HIP_TRY(t_sm_scatter_add(ne, d, ed, T + t.M, I + t.S, Ec, st));                        // aggr = 'add' (:32)
+        HIP_TRY(t_sm_scatter_add(ne, d, ed, T + t.M, I + t.S, P, st));                        // aggr = 'add' (:32)
         HIP_TRY(t_linear(P, d, d, I + t.S, l10.w, l10.b, I + t.L1h, true, st));
         HIP_TRY(t_linear(P, d, d, I + t.L1h, l12.w, l12.b, T + t.tmpP, false, st));
         HIP_TRY(t_add_rows((size_t)P * d, I + t.X, T + t.tmpP, I + t.Hh, st));                 // x + lin_1(out) (:34), rows < P
@@ -1699,7 +1720,7 @@ extern "C" int gnnmp_smoother_train_backward(const gnnmp_smoother* h, const gnnm
     if (!sm_carve(h, b, c)) return GNNMP_ERR_ARG;
     SmTrainCarve t;
     sm_train_carve(h, b, loop, c, t);
-    if (ws_bytes < t.inf_bytes + t.total_floats * sizeof(float)) return GNNMP_ERR_WORKSPACE;
+    if (ws_bytes < t.inf_bytes + t.total_floats * sizeof(float) || (reinterpret_cast<uintptr_t>(ws) & 255)) return GNNMP_ERR_WORKSPACE;
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     float* T = reinterpret_cast<float*>(static_cast<char*>(ws) + t.inf_bytes);
     const int d = h->dims.embed_size, C = h->dims.config_size, P = b->total_path;
@@ -1717,28 +1738,28 @@ extern "C" int gnnmp_smoother_train_backward(const gnnmp_smoother* h, const gnnm
         const int* es = reinterpret_cast<const int*>(I + t.esrc);
         const int* ed = reinterpret_cast<const int*>(I + t.edst);
         HIP_TRY(t_sm_path_update_bwd(P, C, dcur, T + t.dprop, dprev, st));
-        HIP_TRY(t_linear_dw(P, d, C, T + t.dprop, I + t.Hh, sn.gw, sn.gb, st));
+        HIP_TRY(t_linear_dw(P, d, C, T + t.dprop, I + t.Hh, sn.gw, sn.gb, T + t.dwp, st));
         HIP_TRY(t_linear_dx(P, d, C, T + t.dprop, sn.w, T + t.dHh, false, st));
         HIP_TRY(t_fill((size_t)Nn * d, T + t.dX, 0.f, st));
         HIP_TRY(hipMemcpyAsync(T + t.dX, T + t.dHh, sizeof(float) * P * d, hipMemcpyDeviceToDevice, st));   // x + ...: identity branch
-        HIP_TRY(t_linear_dw(P, d, d, T + t.dHh, I + t.L1h, l12.gw, l12.gb, st));
+        HIP_TRY(t_linear_dw(P, d, d, T + t.dHh, I + t.L1h, l12.gw, l12.gb, T + t.dwp, st));
         HIP_TRY(t_linear_dx(P, d, d, T + t.dHh, l12.w, T + t.dL1h, false, st));
         HIP_TRY(t_relu_bwd((size_t)P * d, I + t.L1h, T + t.dL1h, st));
-        HIP_TRY(t_linear_dw(P, d, d, T + t.dL1h, I + t.S, l10.gw, l10.gb, st));
+        HIP_TRY(t_linear_dw(P, d, d, T + t.dL1h, I + t.S, l10.gw, l10.gb, T + t.dwp, st));
         HIP_TRY(t_linear_dx(P, d, d, T + t.dL1h, l10.w, T + t.dS, false, st));
         HIP_TRY(t_sm_scatter_add_bwd(ne, d, ed, T + t.dS, T + t.M, Ec, st));                    // dM
-        HIP_TRY(t_linear_dw(Ec, d, d, T + t.M, I + t.Zh, l02.gw, l02.gb, st));
+        HIP_TRY(t_linear_dw(Ec, d, d, T + t.M, I + t.Zh, l02.gw, l02.gb, T + t.dwp, st));
         HIP_TRY(t_linear_dx(Ec, d, d, T + t.M, l02.w, T + t.dZh, false, st));
         HIP_TRY(t_relu_bwd((size_t)Ec * d, I + t.Zh, T + t.dZh, st));
         HIP_TRY(t_sm_msg_in(ne, d, es, ed, I + t.X, T + t.Zin, Ec, st));                        // Zin recomputed
-        HIP_TRY(t_linear_dw(Ec, 3 * d, d, T + t.dZh, T + t.Zin, l00.gw, l00.gb, st));
+        HIP_TRY(t_linear_dw(Ec, 3 * d, d, T + t.dZh, T + t.Zin, l00.gw, l00.gb, T + t.dwp, st));
         HIP_TRY(t_linear_dx(Ec, 3 * d, d, T + t.dZh, l00.w, T + t.dZin, false, st));
-        HIP_TRY(t_sm_msg_in_bwd(ne, d, es, ed, T + t.dZin, T + t.dX, Ec, st));
-        HIP_TRY(t_linear_dw(Nn, d, d, T + t.dX, I + t.X1, nc3.gw, nc3.gb, st));
+        HIP_TRY(t_sm_msg_in_bwd(ne, d, es, ed, T + t.dZin, T + t.dX, Nn, st));
+        HIP_TRY(t_linear_dw(Nn, d, d, T + t.dX, I + t.X1, nc3.gw, nc3.gb, T + t.dwp, st));
         HIP_TRY(t_linear_dx(Nn, d, d, T + t.dX, nc3.w, T + t.dX1, false, st));
         HIP_TRY(t_relu_bwd((size_t)Nn * d, I + t.X1, T + t.dX1, st));
         HIP_TRY(t_bn_bwd(Nn, d, I + t.X0, T + t.dX1, bn.w, I + t.stats, T + t.dX0, bn.gw, bn.gb, st));
-        HIP_TRY(t_linear_dw(Nn, K0, d, T + t.dX0, I + t.Xin, nc0.gw, nc0.gb, st));
+        HIP_TRY(t_linear_dw(Nn, K0, d, T + t.dX0, I + t.Xin, nc0.gw, nc0.gb, T + t.dwp, st));
         HIP_TRY(t_linear_dx(Nn, K0, d, T + t.dX0, nc0.w, T + t.dXin, false, st));
         HIP_TRY(t_sm_coords_bwd(P, C, T + t.dXin, dprev, st));                                  // nodes[:P] = path (:140)
         float* sw = dcur; dcur = dprev; dprev = sw;

@@ -169,10 +169,14 @@ struct TrainGeom {
     const float *v, *goal;
     const int *node_ptr, *node_ptr_pad, *ntile_graph, *goal_node, *row_beg, *deg;
     const int4* csr;
+    int *out_beg, *out_cnt, *out_cur, *out_slot;      // edges grouped by source (t_out_csr): [Npad] x 3, [Epad] CSR slots
 };
+hipError_t t_out_csr(const TrainGeom& q, hipStream_t st);
+hipError_t t_sort_csr(int Npad, int4* csr, const int* row_beg, const int* deg, hipStream_t st);
+size_t t_linear_dw_scratch_floats(int R, int K, int O);
 hipError_t t_linear(int R, int K, int O, const float* X, const float* W, const float* b, float* Y, bool relu, hipStream_t st);
 hipError_t t_linear_dx(int R, int K, int O, const float* dY, const float* W, float* dX, bool accumulate, hipStream_t st);
-hipError_t t_linear_dw(int R, int K, int O, const float* dY, const float* X, float* dW, float* db, hipStream_t st);
+hipError_t t_linear_dw(int R, int K, int O, const float* dY, const float* X, float* dW, float* db, float* scratch, hipStream_t st);
 hipError_t t_relu_bwd(size_t n, const float* y, float* dy, hipStream_t st);
 hipError_t t_fill(size_t n, float* x, float val, hipStream_t st);
 hipError_t t_node_in(const TrainGeom& q, float* out, hipStream_t st);
@@ -197,8 +201,8 @@ hipError_t t_bn_fwd(int N, int D, const float* x, const float* gamma, const floa
 hipError_t t_bn_bwd(int N, int D, const float* x, const float* dy, const float* gamma, const float* stats, float* dx, float* dgamma,
                     float* dbeta, hipStream_t st);
 hipError_t t_sm_msg_in(const int* n_edges, int D, const int* e_src, const int* e_dst, const float* X, float* out, int cap, hipStream_t st);
-hipError_t t_sm_msg_in_bwd(const int* n_edges, int D, const int* e_src, const int* e_dst, const float* dZ, float* dX, int cap, hipStream_t st);
-hipError_t t_sm_scatter_add(const int* n_edges, int D, const int* e_dst, const float* M, float* S, int cap, hipStream_t st);
+hipError_t t_sm_msg_in_bwd(const int* n_edges, int D, const int* e_src, const int* e_dst, const float* dZ, float* dX, int n_rows, hipStream_t st);
+hipError_t t_sm_scatter_add(const int* n_edges, int D, const int* e_dst, const float* M, float* S, int n_rows, hipStream_t st);
 hipError_t t_sm_scatter_add_bwd(const int* n_edges, int D, const int* e_dst, const float* dS, float* dM, int cap, hipStream_t st);
 hipError_t t_add_rows(size_t n, const float* a, const float* b, float* out, hipStream_t st);
 hipError_t t_sm_path_update(int P, int C, const float* prev, const float* proposal, float* next, hipStream_t st);

@@ -10,7 +10,7 @@
 //
 //   rows_linear      Y = act(X W^T + b)                       W row-major [O, K] exactly as in the state_dict
 //   rows_linear_dx   dX (+)= dY W
-//   rows_linear_dw   dW += dY^T X, db += sum_rows dY          (per-block partial sums, float atomics across blocks)
+//   rows_linear_dw   dW += dY^T X, db += sum_rows dY          (per-block partial sums, then an ordered second stage)
 //   segment_max      A[n] = max over the node's CSR segment, with the arg-max slot per (node, feature); 0 if empty
 //   gather / scatter kernels for the concatenations [v, g, (v-g)^2, v-g], [v_s, v_t], [NC, NF, H0, H],
 //                    [X_s - X_t, X_s, X_t, EF, EC], [NC, H], [D_s, D_s - D_t, EF] and their adjoints
@@ -55,24 +55,33 @@ __global__ void rows_linear_dx_kernel(int R, int K, int O, const float* __restri
     dX[i] = accumulate ? dX[i] + acc : acc;
 }
 
-// dW[o, k] += sum_r dY[r, o] X[r, k];  db[o] += sum_r dY[r, o].  One block per chunk of rows.
+// dW[o, k] += sum_r dY[r, o] X[r, k];  db[o] += sum_r dY[r, o] in two DETERMINISTIC stages: one block per chunk of kDwRows
+// rows writes its partial sums (fixed row order) to part[block][O K + O]; a second kernel adds the partials block by block
+// in ascending order.  No float atomics: the same inputs give the same gradient bits on every run.
 constexpr int kDwRows = 128;
-__global__ __launch_bounds__(256) void rows_linear_dw_kernel(int R, int K, int O, const float* __restrict__ dY,
-                                                             const float* __restrict__ X, float* __restrict__ dW,
-                                                             float* __restrict__ db) {
+__global__ __launch_bounds__(256) void rows_linear_dw_partial_kernel(int R, int K, int O, const float* __restrict__ dY,
+                                                                     const float* __restrict__ X, float* __restrict__ part) {
     const int r0 = blockIdx.x * kDwRows, r1 = min(R, r0 + kDwRows);
+    float* out = part + (size_t)blockIdx.x * (O * K + O);
     for (int i = threadIdx.x; i < O * K; i += 256) {
         const int o = i / K, k = i % K;
         float acc = 0.f;
         for (int r = r0; r < r1; ++r) acc = fmaf(dY[(size_t)r * O + o], X[(size_t)r * K + k], acc);
-        atomicAdd(&dW[i], acc);
+        out[i] = acc;
     }
-    if (db)
-        for (int o = threadIdx.x; o < O; o += 256) {
-            float acc = 0.f;
-            for (int r = r0; r < r1; ++r) acc += dY[(size_t)r * O + o];
-            atomicAdd(&db[o], acc);
-        }
+    for (int o = threadIdx.x; o < O; o += 256) {
+        float acc = 0.f;
+        for (int r = r0; r < r1; ++r) acc += dY[(size_t)r * O + o];
+        out[O * K + o] = acc;
+    }
+}
+__global__ void dw_reduce_kernel(int nblk, int OK, int O, const float* __restrict__ part, float* __restrict__ dW, float* __restrict__ db) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= OK + O) return;
+    float acc = 0.f;
+    for (int b = 0; b < nblk; ++b) acc += part[(size_t)b * (OK + O) + i];
+    if (i < OK) dW[i] += acc;
+    else if (db) db[i - OK] += acc;
 }
 
 __global__ void relu_bwd_kernel(size_t n, const float* __restrict__ y, float* __restrict__ dy) {
@@ -136,10 +145,12 @@ __global__ void h0_kernel(TrainGeom q, int D, const float* __restrict__ goal_enc
     H0[i] = (g >= 0 && q.goal_node[g] == n) ? goal_encoder[f] : 0.f;
 }
 __global__ void h0_bwd_kernel(TrainGeom q, int D, const float* __restrict__ dH0, float* __restrict__ d_goal_encoder) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= q.G * D) return;
-    const int g = i / D, f = i % D;
-    if (q.goal_node[g] >= 0) atomicAdd(&d_goal_encoder[f], dH0[(size_t)q.goal_node[g] * D + f]);
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= D) return;
+    float acc = 0.f;                                        // graphs in order: deterministic
+    for (int g = 0; g < q.G; ++g)
+        if (q.goal_node[g] >= 0) acc += dH0[(size_t)q.goal_node[g] * D + f];
+    d_goal_encoder[f] += acc;
 }
 
 // out[n] = [a0[n], a1[n], a2[n], a3[n]] (row-major concat of up to four [Npad, D] arrays; nullptr parts are skipped)
@@ -176,17 +187,91 @@ __global__ void msg_in_kernel(TrainGeom q, int D, const float* __restrict__ X, c
     }
     out[i] = val;
 }
-// adjoint: dX[s] += dZ[:, 0:D] + dZ[:, D:2D];  dX[t] += -dZ[:, 0:D] + dZ[:, 2D:3D];  dEC[e] += dZ[:, 4D:5D]  (EF detached)
-__global__ void msg_in_bwd_kernel(TrainGeom q, int D, const float* __restrict__ dZ, float* __restrict__ dX, float* __restrict__ dEC) {
+// The prep stage ranks the edges of a target by ARRIVAL (LDS atomics): fine for inference (max aggregation is order-free,
+// scores go back to caller order), but the training path sums over CSR slots, so the slot order must not depend on timing.
+// One thread per node sorts its segment by caller column before anything reads the CSR.
+__global__ void csr_sort_segments_kernel(int Npad, int4* __restrict__ csr, const int* __restrict__ row_beg, const int* __restrict__ deg) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= Npad) return;
+    int4* a = csr + row_beg[n];
+    const int m = deg[n];
+    for (int i = 1; i < m; ++i) {
+        const int4 key = a[i];
+        int j = i - 1;
+        while (j >= 0 && a[j].z > key.z) { a[j + 1] = a[j]; --j; }
+        a[j + 1] = key;
+    }
+}
+
+// ---- edges grouped by SOURCE (the CSR is grouped by target): out_beg / out_cnt per padded node, out_slot = the CSR slots
+// of the node's outgoing edges in ascending slot order.  Built once per training forward (integer atomics give the counts
+// and an arbitrary fill order; every node's short list is then sorted), it lets the adjoints of the row gathers run
+// node-centric -- a fixed summation order instead of float atomics.
+__global__ void out_count_kernel(TrainGeom q) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= q.Epad) return;
+    const int4 rec = q.csr[e];
+    if (rec.x >= 0) atomicAdd(&q.out_cnt[rec.x], 1);
+}
+__global__ __launch_bounds__(1024) void out_scan_kernel(TrainGeom q) {          // one block: exclusive scan of out_cnt over Npad
+    __shared__ int sh[1024];
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < q.Npad; base += 1024) {
+        const int n = base + threadIdx.x;
+        const int c = n < q.Npad ? q.out_cnt[n] : 0;
+        sh[threadIdx.x] = c;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            const int t = threadIdx.x >= off ? sh[threadIdx.x - off] : 0;
+            __syncthreads();
+            sh[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (n < q.Npad) { q.out_beg[n] = carry + sh[threadIdx.x] - c; q.out_cur[n] = 0; }
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += sh[1023];
+        __syncthreads();
+    }
+}
+__global__ void out_fill_kernel(TrainGeom q) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= q.Epad) return;
+    const int4 rec = q.csr[e];
+    if (rec.x >= 0) q.out_slot[q.out_beg[rec.x] + atomicAdd(&q.out_cur[rec.x], 1)] = e;
+}
+__global__ void out_sort_kernel(TrainGeom q) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= q.Npad) return;
+    int* a = q.out_slot + q.out_beg[n];
+    const int m = q.out_cnt[n];
+    for (int i = 1; i < m; ++i) {                           // insertion sort: out-degrees are tens
+        const int key = a[i];
+        int j = i - 1;
+        while (j >= 0 && a[j] > key) { a[j + 1] = a[j]; --j; }
+        a[j + 1] = key;
+    }
+}
+
+// adjoint of msg_in: dX[s] += dZ[:, 0:D] + dZ[:, D:2D];  dX[t] += -dZ[:, 0:D] + dZ[:, 2D:3D];  dEC[e] += dZ[:, 4D:5D]  (EF detached)
+// node n collects its incoming slots (its CSR segment, as target) and then its outgoing slots (out list, as source)
+__global__ void msg_in_bwd_nodes_kernel(TrainGeom q, int D, const float* __restrict__ dZ, float* __restrict__ dX) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)q.Npad * D) return;
+    const int n = (int)(i / D), f = (int)(i % D);
+    float acc = 0.f;
+    const int b = q.row_beg[n], dg = q.deg[n];
+    for (int sl = b; sl < b + dg; ++sl) { const float* z = dZ + (size_t)sl * 5 * D; acc += z[2 * D + f] - z[f]; }
+    const int* os = q.out_slot + q.out_beg[n];
+    for (int k = 0; k < q.out_cnt[n]; ++k) { const float* z = dZ + (size_t)os[k] * 5 * D; acc += z[f] + z[D + f]; }
+    dX[i] += acc;
+}
+__global__ void msg_in_bwd_edges_kernel(TrainGeom q, int D, const float* __restrict__ dZ, float* __restrict__ dEC) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)q.Epad * D) return;
     const int e = (int)(i / D), f = (int)(i % D);
-    const int4 rec = q.csr[e];
-    if (rec.x < 0) return;
-    const float* z = dZ + (size_t)e * 5 * D;
-    atomicAdd(&dX[(size_t)rec.x * D + f], z[f] + z[D + f]);
-    atomicAdd(&dX[(size_t)rec.y * D + f], z[2 * D + f] - z[f]);
-    dEC[i] += z[4 * D + f];
+    if (q.csr[e].x >= 0) dEC[i] += dZ[(size_t)e * 5 * D + 4 * D + f];
 }
 
 // Pin[e] = [D_s, D_s - D_t, EF_e]  (model.py:145)
@@ -203,15 +288,17 @@ __global__ void pol_in_kernel(TrainGeom q, int D, const float* __restrict__ Dn, 
     }
     out[i] = val;
 }
+// adjoint of pol_in: dDn[s] += dP[:, 0:D] + dP[:, D:2D];  dDn[t] -= dP[:, D:2D]  -- node-centric like msg_in_bwd_nodes_kernel
 __global__ void pol_in_bwd_kernel(TrainGeom q, int D, const float* __restrict__ dP, float* __restrict__ dDn) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (size_t)q.Epad * D) return;
-    const int e = (int)(i / D), f = (int)(i % D);
-    const int4 rec = q.csr[e];
-    if (rec.x < 0) return;
-    const float* z = dP + (size_t)e * 3 * D;
-    atomicAdd(&dDn[(size_t)rec.x * D + f], z[f] + z[D + f]);
-    atomicAdd(&dDn[(size_t)rec.y * D + f], -z[D + f]);
+    if (i >= (size_t)q.Npad * D) return;
+    const int n = (int)(i / D), f = (int)(i % D);
+    float acc = 0.f;
+    const int b = q.row_beg[n], dg = q.deg[n];
+    for (int sl = b; sl < b + dg; ++sl) acc -= dP[(size_t)sl * 3 * D + D + f];
+    const int* os = q.out_slot + q.out_beg[n];
+    for (int k = 0; k < q.out_cnt[n]; ++k) { const float* z = dP + (size_t)os[k] * 3 * D; acc += z[f] + z[D + f]; }
+    dDn[i] += acc;
 }
 
 // A[n, f] = max over the node's CSR segment of M[slot, f]; arg = that slot (first maximum); 0 / -1 without incoming edges
@@ -266,9 +353,31 @@ hipError_t t_linear_dx(int R, int K, int O, const float* dY, const float* W, flo
     TRAIN_LAUNCH_CHECK();
     return hipSuccess;
 }
-hipError_t t_linear_dw(int R, int K, int O, const float* dY, const float* X, float* dW, float* db, hipStream_t st) {
+size_t t_linear_dw_scratch_floats(int R, int K, int O) { return (size_t)((R + kDwRows - 1) / kDwRows) * ((size_t)O * K + O); }
+hipError_t t_linear_dw(int R, int K, int O, const float* dY, const float* X, float* dW, float* db, float* scratch, hipStream_t st) {
     if (R <= 0) return hipSuccess;
-    hipLaunchKernelGGL(rows_linear_dw_kernel, dim3((R + kDwRows - 1) / kDwRows), dim3(256), 0, st, R, K, O, dY, X, dW, db);
+    const int nblk = (R + kDwRows - 1) / kDwRows;
+    hipLaunchKernelGGL(rows_linear_dw_partial_kernel, dim3(nblk), dim3(256), 0, st, R, K, O, dY, X, scratch);
+    TRAIN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(dw_reduce_kernel, dim3(blocks((size_t)O * K + O)), dim3(256), 0, st, nblk, O * K, O, scratch, dW, db);
+    TRAIN_LAUNCH_CHECK();
+    return hipSuccess;
+}
+hipError_t t_sort_csr(int Npad, int4* csr, const int* row_beg, const int* deg, hipStream_t st) {
+    hipLaunchKernelGGL(csr_sort_segments_kernel, dim3(blocks((size_t)Npad)), dim3(256), 0, st, Npad, csr, row_beg, deg);
+    TRAIN_LAUNCH_CHECK();
+    return hipSuccess;
+}
+hipError_t t_out_csr(const TrainGeom& q, hipStream_t st) {
+    hipError_t e = hipMemsetAsync(q.out_cnt, 0, sizeof(int) * (size_t)q.Npad, st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(out_count_kernel, dim3(blocks((size_t)q.Epad)), dim3(256), 0, st, q);
+    TRAIN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(out_scan_kernel, dim3(1), dim3(1024), 0, st, q);
+    TRAIN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(out_fill_kernel, dim3(blocks((size_t)q.Epad)), dim3(256), 0, st, q);
+    TRAIN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(out_sort_kernel, dim3(blocks((size_t)q.Npad)), dim3(256), 0, st, q);
     TRAIN_LAUNCH_CHECK();
     return hipSuccess;
 }
@@ -299,7 +408,7 @@ hipError_t t_h0(const TrainGeom& q, int D, const float* ge, float* H0, hipStream
     return hipSuccess;
 }
 hipError_t t_h0_bwd(const TrainGeom& q, int D, const float* dH0, float* dge, hipStream_t st) {
-    hipLaunchKernelGGL(h0_bwd_kernel, dim3(blocks((size_t)q.G * D)), dim3(256), 0, st, q, D, dH0, dge);
+    hipLaunchKernelGGL(h0_bwd_kernel, dim3(blocks((size_t)D)), dim3(256), 0, st, q, D, dH0, dge);
     TRAIN_LAUNCH_CHECK();
     return hipSuccess;
 }
@@ -320,7 +429,9 @@ hipError_t t_msg_in(const TrainGeom& q, int D, const float* X, const float* EF, 
     return hipSuccess;
 }
 hipError_t t_msg_in_bwd(const TrainGeom& q, int D, const float* dZ, float* dX, float* dEC, hipStream_t st) {
-    hipLaunchKernelGGL(msg_in_bwd_kernel, dim3(blocks((size_t)q.Epad * D)), dim3(256), 0, st, q, D, dZ, dX, dEC);
+    hipLaunchKernelGGL(msg_in_bwd_nodes_kernel, dim3(blocks((size_t)q.Npad * D)), dim3(256), 0, st, q, D, dZ, dX);
+    TRAIN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(msg_in_bwd_edges_kernel, dim3(blocks((size_t)q.Epad * D)), dim3(256), 0, st, q, D, dZ, dEC);
     TRAIN_LAUNCH_CHECK();
     return hipSuccess;
 }
@@ -330,7 +441,7 @@ hipError_t t_pol_in(const TrainGeom& q, int D, const float* Dn, const float* EF,
     return hipSuccess;
 }
 hipError_t t_pol_in_bwd(const TrainGeom& q, int D, const float* dP, float* dDn, hipStream_t st) {
-    hipLaunchKernelGGL(pol_in_bwd_kernel, dim3(blocks((size_t)q.Epad * D)), dim3(256), 0, st, q, D, dP, dDn);
+    hipLaunchKernelGGL(pol_in_bwd_kernel, dim3(blocks((size_t)q.Npad * D)), dim3(256), 0, st, q, D, dP, dDn);
     TRAIN_LAUNCH_CHECK();
     return hipSuccess;
 }
@@ -422,7 +533,7 @@ __global__ __launch_bounds__(256) void bn_train_bwd_kernel(int N, int D, const f
     __syncthreads();
     for (int off = 128; off > 0; off >>= 1) { if (tid < off) { r0[tid] += r0[tid + off]; r1[tid] += r1[tid + off]; } __syncthreads(); }
     const float sum_dy = r0[0], sum_dyx = r1[0];
-    if (tid == 0) { atomicAdd(&dgamma[f], sum_dyx); atomicAdd(&dbeta[f], sum_dy); }
+    if (tid == 0) { dgamma[f] += sum_dyx; dbeta[f] += sum_dy; }        // one block per feature: the only writer of slot f
     const float k = gamma[f] * invstd / N;
     for (int n = tid; n < N; n += 256) {
         const float xhat = (x[(size_t)n * D + f] - mean) * invstd;
@@ -444,23 +555,31 @@ __global__ void sm_msg_in_kernel(const int* __restrict__ n_edges, int D, const i
     }
     out[i] = val;
 }
+// adjoints / aggregation of the smoother, node-centric: a problem has a few hundred edges, so every (node, feature) thread
+// simply walks the edge list in order -- a fixed summation order, no float atomics
 __global__ void sm_msg_in_bwd_kernel(const int* __restrict__ n_edges, int D, const int* __restrict__ e_src, const int* __restrict__ e_dst,
-                                     const float* __restrict__ dZ, float* __restrict__ dX, int cap) {
+                                     const float* __restrict__ dZ, float* __restrict__ dX, int n_rows) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= cap * D) return;
-    const int e = i / D, f = i % D;
-    if (e >= *n_edges) return;
-    const float* z = dZ + (size_t)e * 3 * D;
-    atomicAdd(&dX[(size_t)e_src[e] * D + f], z[f] + z[D + f]);
-    atomicAdd(&dX[(size_t)e_dst[e] * D + f], z[2 * D + f] - z[f]);
+    if (i >= n_rows * D) return;
+    const int n = i / D, f = i % D, ne = *n_edges;
+    float acc = 0.f;
+    for (int e = 0; e < ne; ++e) {
+        const float* z = dZ + (size_t)e * 3 * D;
+        if (e_src[e] == n) acc += z[f] + z[D + f];
+        if (e_dst[e] == n) acc += z[2 * D + f] - z[f];
+    }
+    dX[i] += acc;
 }
 // S[dst] += M[e] (aggr = 'add'); adjoint dM[e] = dS[dst]
 __global__ void sm_scatter_add_kernel(const int* __restrict__ n_edges, int D, const int* __restrict__ e_dst, const float* __restrict__ M,
-                                      float* __restrict__ S, int cap) {
+                                      float* __restrict__ S, int n_rows) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= cap * D) return;
-    const int e = i / D;
-    if (e < *n_edges) atomicAdd(&S[(size_t)e_dst[e] * D + i % D], M[i]);
+    if (i >= n_rows * D) return;
+    const int n = i / D, f = i % D, ne = *n_edges;
+    float acc = 0.f;
+    for (int e = 0; e < ne; ++e)
+        if (e_dst[e] == n) acc += M[(size_t)e * D + f];
+    S[i] += acc;
 }
 __global__ void sm_scatter_add_bwd_kernel(const int* __restrict__ n_edges, int D, const int* __restrict__ e_dst, const float* __restrict__ dS,
                                           float* __restrict__ dM, int cap) {
@@ -523,13 +642,13 @@ hipError_t t_sm_msg_in(const int* n_edges, int D, const int* e_src, const int* e
     TRAIN_LAUNCH_CHECK();
     return hipSuccess;
 }
-hipError_t t_sm_msg_in_bwd(const int* n_edges, int D, const int* e_src, const int* e_dst, const float* dZ, float* dX, int cap, hipStream_t st) {
-    hipLaunchKernelGGL(sm_msg_in_bwd_kernel, dim3(blocks((size_t)cap * D)), dim3(256), 0, st, n_edges, D, e_src, e_dst, dZ, dX, cap);
+hipError_t t_sm_msg_in_bwd(const int* n_edges, int D, const int* e_src, const int* e_dst, const float* dZ, float* dX, int n_rows, hipStream_t st) {
+    hipLaunchKernelGGL(sm_msg_in_bwd_kernel, dim3(blocks((size_t)n_rows * D)), dim3(256), 0, st, n_edges, D, e_src, e_dst, dZ, dX, n_rows);
     TRAIN_LAUNCH_CHECK();
     return hipSuccess;
 }
-hipError_t t_sm_scatter_add(const int* n_edges, int D, const int* e_dst, const float* M, float* S, int cap, hipStream_t st) {
-    hipLaunchKernelGGL(sm_scatter_add_kernel, dim3(blocks((size_t)cap * D)), dim3(256), 0, st, n_edges, D, e_dst, M, S, cap);
+hipError_t t_sm_scatter_add(const int* n_edges, int D, const int* e_dst, const float* M, float* S, int n_rows, hipStream_t st) {
+    hipLaunchKernelGGL(sm_scatter_add_kernel, dim3(blocks((size_t)n_rows * D)), dim3(256), 0, st, n_edges, D, e_dst, M, S, n_rows);
     TRAIN_LAUNCH_CHECK();
     return hipSuccess;
 }

@@ -133,3 +133,36 @@ def test_module_call_dispatches_on_mode():
     P_eval = m(**kw)
     assert not P_eval.requires_grad and torch.equal(P_eval, P_ng)
     assert torch.allclose(P_train.detach(), P_eval, rtol=1e-5, atol=2e-5)
+
+
+def test_gradients_are_deterministic_and_batched_equals_accumulated():
+    """No float atomics in the training kernels: two backward passes on the same inputs give bit-identical gradients; and the
+    reference's gradient accumulation over problems (train_explorer.py:184: eight single-graph backward passes per optimizer
+    step) equals ONE batched forward / backward of the same problems up to summation order."""
+    from gnnmp.synth import synth_graph
+    graphs = [{k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in synth_graph('maze2', 150 + 30 * i, 5, seed=20 + i).items()} for i in range(4)]
+    m = gnnmp.EncoderProcessDecoder(2, 2, 32, 2)
+    m.load_state_dict(load_weights('weights_maze'))
+    m.train()
+    params = [(n, p) for n, p in m.named_parameters() if n.split('.')[0] in TRAINABLE]
+    batch = gnnmp.GraphBatch.from_graphs(graphs, 2, DEV)
+    coef = torch.linspace(-1, 1, batch.total_edges, device=DEV)
+    runs = []
+    for _ in range(2):
+        m.zero_grad()
+        (m.train_scores(batch, 3) * coef).sum().backward()
+        runs.append({n: p.grad.clone() for n, p in params if p.grad is not None})
+    assert len(runs[0]) >= 20
+    params = [(n, p) for n, p in params if n in runs[0]]
+    for n, _ in params:
+        assert torch.equal(runs[0][n], runs[1][n]), n
+    m.zero_grad()
+    off = 0
+    for g in graphs:                                                     # one problem per backward, gradients accumulate
+        b1 = m._single(g['goal'], g['v'], g['obstacles'], g['edge_index'])
+        e = g['edge_index'].shape[1]
+        (m.train_scores(b1, 3) * coef[off:off + e]).sum().backward()
+        off += e
+    for n, p in params:
+        scale = float(runs[0][n].abs().max()) + 1e-30
+        assert float((p.grad - runs[0][n]).abs().max()) <= 2e-4 * scale + 1e-6, n      # fp32 sums over thousands of rows in another order
