@@ -8,16 +8,17 @@
 // on request); this file restates the rest in the reference's own formulation (materialised concatenations), one
 // plain kernel per operator, in the padded CSR index space of explorer_kernels.hip:
 //
-//   rows_linear      Y = act(X W^T + b)                       W row-major [O, K] exactly as in the state_dict
+//   rows_linear      Y = act(X W^T + b)                       W row-major [O, K] exactly as in the state_dict; the three GEMM
+//                    shapes run on v_mfma_f32_32x32x2_f32 with the operands read at their natural strides
 //   rows_linear_dx   dX (+)= dY W
 //   rows_linear_dw   dW += dY^T X, db += sum_rows dY          (per-block partial sums, then an ordered second stage)
 //   segment_max      A[n] = max over the node's CSR segment, with the arg-max slot per (node, feature); 0 if empty
 //   gather / scatter kernels for the concatenations [v, g, (v-g)^2, v-g], [v_s, v_t], [NC, NF, H0, H],
 //                    [X_s - X_t, X_s, X_t, EF, EC], [NC, H], [D_s, D_s - D_t, EF] and their adjoints
 //
-// These are correctness-first kernels (a training step is one graph, ~10 k edges, d = 32: every launch is microseconds);
-// the MFMA chains of the inference path are not reused because their packed, pre-combined weights (W_a + W_b, ...) are
-// the wrong parameterisation for gradients.
+// The register-resident MFMA chains of the inference path are not reused: their packed, pre-combined weights (W_a + W_b,
+// ...) are the wrong parameterisation for gradients, and the weights change every optimizer step.  Everything is
+// deterministic: no float atomics, fixed summation orders (CSR segments sorted by caller column first).
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include "kernels.hpp"
@@ -82,6 +83,152 @@ __global__ void dw_reduce_kernel(int nblk, int OK, int O, const float* __restric
     for (int b = 0; b < nblk; ++b) acc += part[(size_t)b * (OK + O) + i];
     if (i < OK) dW[i] += acc;
     else if (db) db[i - OK] += acc;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The three GEMM shapes of the training path on the fp32 matrix instruction (v_mfma_f32_32x32x2_f32: an exact k-ordered fmaf
+// chain, so results do not depend on scheduling).  Weights stay in the state_dict's row-major layout -- they change every
+// optimizer step, so nothing is pre-packed: the A / B operands are read with their natural strides.
+//   D[i][j] += sum_k A[i][k] B[k][j];  A[i][k] in lane i + 32 k', B[k][j] in lane j + 32 k' (k = 2 s + k'),
+//   D[i][j] in lane j + 32 h, register r with i = phi(r, h).
+// ---------------------------------------------------------------------------------------------------------------------
+typedef float t_f32x16 __attribute__((ext_vector_type(16)));
+typedef float t_f32x4 __attribute__((ext_vector_type(4)));
+
+// Y[r, o] = act(sum_k X[r, k] W[o, k] + b[o]): one wave per (32-row tile, 32-output tile); A = W rows, B = X rows.
+__global__ __launch_bounds__(256) void rows_linear_mfma_kernel(int R, int K, int O, const float* __restrict__ X, const float* __restrict__ W,
+                                                               const float* __restrict__ b, float* __restrict__ Y, int relu) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+    const int otiles = (O + 31) >> 5;
+    const int job = blockIdx.x * 4 + wave;
+    const int rt = job / otiles, ot = job % otiles;
+    if (rt * 32 >= R) return;
+    const int row = rt * 32 + j, o = ot * 32 + j;
+    const float* xr = X + (size_t)(row < R ? row : 0) * K;
+    const float* wr = W + (size_t)(o < O ? o : 0) * K;
+    const float xm = row < R ? 1.f : 0.f, wm = o < O ? 1.f : 0.f;
+    t_f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    if ((K & 3) == 0) {
+        int k4 = 0;
+        for (; k4 + 16 <= K; k4 += 16) {                    // four float4 pairs in flight per round
+            t_f32x4 xv[4], wv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                xv[u] = *reinterpret_cast<const t_f32x4*>(xr + k4 + 4 * u);
+                wv[u] = *reinterpret_cast<const t_f32x4*>(wr + k4 + 4 * u);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[u][h] * wm, xv[u][h] * xm, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[u][2 + h] * wm, xv[u][2 + h] * xm, acc, 0, 0, 0);
+            }
+        }
+        for (; k4 < K; k4 += 4) {
+            const t_f32x4 xv = *reinterpret_cast<const t_f32x4*>(xr + k4), wv = *reinterpret_cast<const t_f32x4*>(wr + k4);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[h] * wm, xv[h] * xm, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[2 + h] * wm, xv[2 + h] * xm, acc, 0, 0, 0);
+        }
+    } else {
+        for (int k = 0; k < K; k += 2) {
+            const bool ok = k + h < K;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ok ? wr[k + h] * wm : 0.f, ok ? xr[k + h] * xm : 0.f, acc, 0, 0, 0);
+        }
+    }
+    if (row >= R) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int oo = ot * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (oo < O) {
+            const float val = acc[r] + (b ? b[oo] : 0.f);
+            Y[(size_t)row * O + oo] = (relu && val < 0.f) ? 0.f : val;
+        }
+    }
+}
+
+// dX[r, k] (+)= sum_o dY[r, o] W[o, k]: one wave per (32-row tile, 32-column tile of k); A[i = k][o] = W[o, k], B[o][j = row] = dY
+__global__ __launch_bounds__(256) void rows_linear_dx_mfma_kernel(int R, int K, int O, const float* __restrict__ dY, const float* __restrict__ W,
+                                                                  float* __restrict__ dX, int accumulate) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+    const int ktiles = (K + 31) >> 5;
+    const int job = blockIdx.x * 4 + wave;
+    const int rt = job / ktiles, kt = job % ktiles;
+    if (rt * 32 >= R) return;
+    const int row = rt * 32 + j, kc = kt * 32 + j;
+    const float* dyr = dY + (size_t)(row < R ? row : 0) * O;
+    const float ym = row < R ? 1.f : 0.f, wm = kc < K ? 1.f : 0.f;
+    const int kcc = kc < K ? kc : 0;
+    t_f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int o = 0; o < O; o += 16) {
+        float av[8], bv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const bool ok = o + 2 * u + h < O;
+            const int oo = ok ? o + 2 * u + h : 0;
+            av[u] = W[(size_t)oo * K + kcc] * (ok ? wm : 0.f);
+            bv[u] = dyr[oo] * (ok ? ym : 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
+    }
+    if (row >= R) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int kk = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (kk < K) {
+            const size_t idx = (size_t)row * K + kk;
+            dX[idx] = accumulate ? dX[idx] + acc[r] : acc[r];
+        }
+    }
+}
+
+// partial dW of one chunk of kDwRowsM rows: part[blk][o, k] = sum_{r in chunk} dY[r, o] X[r, k], part[blk][O K + o] = sum_r dY[r, o].
+// Wave w of the block owns the (o-tile, k-tile) pairs w, w + 4, ...: A[i = o][r] = dY[r, o], B[r][j = k] = X[r, k].
+constexpr int kDwRowsM = 128;
+__global__ __launch_bounds__(256) void rows_linear_dw_mfma_kernel(int R, int K, int O, const float* __restrict__ dY,
+                                                                  const float* __restrict__ X, float* __restrict__ part) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+    const int r0 = blockIdx.x * kDwRowsM, r1 = min(R, r0 + kDwRowsM);
+    float* out = part + (size_t)blockIdx.x * ((size_t)O * K + O);
+    const int otiles = (O + 31) >> 5, ktiles = (K + 31) >> 5;
+    for (int t = wave; t < otiles * ktiles; t += 4) {
+        const int ot = t / ktiles, kt = t % ktiles;
+        const int o = ot * 32 + j, kc = kt * 32 + j;
+        const float om = o < O ? 1.f : 0.f, km = kc < K ? 1.f : 0.f;
+        const int oc = o < O ? o : 0, kcc = kc < K ? kc : 0;
+        t_f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        // 16 rows (eight steps) per round: all sixteen loads are issued before the first multiply needs one
+        for (int r = r0; r < r1; r += 16) {
+            float av[8], bv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const bool ok = r + 2 * u + h < r1;
+                const size_t rr = ok ? r + 2 * u + h : r0;
+                av[u] = dY[rr * O + oc] * (ok ? om : 0.f);
+                bv[u] = X[rr * K + kcc] * (ok ? km : 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
+        }
+        if (kc < K) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int oo = ot * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (oo < O) out[(size_t)oo * K + kc] = acc[r];
+            }
+        }
+    }
+    for (int o = threadIdx.x; o < O; o += 256) {
+        float acc = 0.f;
+        for (int r = r0; r < r1; ++r) acc += dY[(size_t)r * O + o];
+        out[(size_t)O * K + o] = acc;
+    }
 }
 
 __global__ void relu_bwd_kernel(size_t n, const float* __restrict__ y, float* __restrict__ dy) {
@@ -343,12 +490,24 @@ static inline unsigned blocks(size_t n) { return (unsigned)((n + 255) / 256); }
 
 hipError_t t_linear(int R, int K, int O, const float* X, const float* W, const float* b, float* Y, bool relu, hipStream_t st) {
     if (R <= 0) return hipSuccess;
+    if (O >= 8) {       // narrow outputs (policy.4: one column) stay on the plain kernel
+        const size_t jobs = (size_t)((R + 31) / 32) * ((O + 31) / 32);
+        hipLaunchKernelGGL(rows_linear_mfma_kernel, dim3((unsigned)((jobs + 3) / 4)), dim3(256), 0, st, R, K, O, X, W, b, Y, relu ? 1 : 0);
+        TRAIN_LAUNCH_CHECK();
+        return hipSuccess;
+    }
     hipLaunchKernelGGL(rows_linear_kernel, dim3(blocks((size_t)R * O)), dim3(256), 0, st, R, K, O, X, W, b, Y, relu ? 1 : 0);
     TRAIN_LAUNCH_CHECK();
     return hipSuccess;
 }
 hipError_t t_linear_dx(int R, int K, int O, const float* dY, const float* W, float* dX, bool accumulate, hipStream_t st) {
     if (R <= 0) return hipSuccess;
+    if (O >= 8 && K >= 8) {
+        const size_t jobs = (size_t)((R + 31) / 32) * ((K + 31) / 32);
+        hipLaunchKernelGGL(rows_linear_dx_mfma_kernel, dim3((unsigned)((jobs + 3) / 4)), dim3(256), 0, st, R, K, O, dY, W, dX, accumulate ? 1 : 0);
+        TRAIN_LAUNCH_CHECK();
+        return hipSuccess;
+    }
     hipLaunchKernelGGL(rows_linear_dx_kernel, dim3(blocks((size_t)R * K)), dim3(256), 0, st, R, K, O, dY, W, dX, accumulate ? 1 : 0);
     TRAIN_LAUNCH_CHECK();
     return hipSuccess;
@@ -356,8 +515,13 @@ hipError_t t_linear_dx(int R, int K, int O, const float* dY, const float* W, flo
 size_t t_linear_dw_scratch_floats(int R, int K, int O) { return (size_t)((R + kDwRows - 1) / kDwRows) * ((size_t)O * K + O); }
 hipError_t t_linear_dw(int R, int K, int O, const float* dY, const float* X, float* dW, float* db, float* scratch, hipStream_t st) {
     if (R <= 0) return hipSuccess;
-    const int nblk = (R + kDwRows - 1) / kDwRows;
-    hipLaunchKernelGGL(rows_linear_dw_partial_kernel, dim3(nblk), dim3(256), 0, st, R, K, O, dY, X, scratch);
+    int nblk = (R + kDwRows - 1) / kDwRows;
+    if (O >= 8 && K >= 4) {
+        nblk = (R + kDwRowsM - 1) / kDwRowsM;             // fewer, larger chunks: the scratch sized for kDwRows covers them
+        hipLaunchKernelGGL(rows_linear_dw_mfma_kernel, dim3(nblk), dim3(256), 0, st, R, K, O, dY, X, scratch);
+    } else {
+        hipLaunchKernelGGL(rows_linear_dw_partial_kernel, dim3(nblk), dim3(256), 0, st, R, K, O, dY, X, scratch);
+    }
     TRAIN_LAUNCH_CHECK();
     hipLaunchKernelGGL(dw_reduce_kernel, dim3(blocks((size_t)O * K + O)), dim3(256), 0, st, nblk, O * K, O, scratch, dW, db);
     TRAIN_LAUNCH_CHECK();
