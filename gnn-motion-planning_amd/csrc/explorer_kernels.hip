@@ -1406,13 +1406,27 @@ __device__ __forceinline__ void read_stage_tile(const float* stage, int sr, int 
 
 // y[ot] += sum_it W[ot][it] . x[it] with the inputs produced one 32-feature tile at a time by `get(it, tile)`: only one
 // input tile is live, which is what lets the d = 64 instantiation keep its register count down
-template <int P, int NT, bool SWAP, class Get>
+// RELU: the input tile goes through max(x, 0) before it is multiplied.  bf16 operands: the conversion comes first and the
+// ReLU runs on the PACKED pairs as a signed 16-bit integer maximum with 0 (negative floats are negative integers, -0 is the
+// most negative one; rounding to bf16 is monotone and keeps the sign, so this equals rounding the ReLU's output bit for bit)
+// -- 8 instead of 16 VALU instructions per tile in a loop that is bound by instruction issue.
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+template <int P, int NT, bool SWAP, bool RELU = false, class Get>
 __device__ __forceinline__ void linear_acc_stream(const float* A, Get get, f32x16 (&y)[NT], int lane) {
 #pragma unroll
     for (int it = 0; it < NT; ++it) {
         f32x16 x;
         get(it, x);
-        const BOp<P> xb(x);
+        if constexpr (RELU && P != 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) x[r] = fmaxf(x[r], 0.0f);
+        }
+        BOp<P> xb(x);
+        if constexpr (RELU && P == 1) {
+            const s16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+            xb.lo = __builtin_bit_cast(bf16x8, __builtin_elementwise_max(__builtin_bit_cast(s16x8, xb.lo), zero));
+            xb.hi = __builtin_bit_cast(bf16x8, __builtin_elementwise_max(__builtin_bit_cast(s16x8, xb.hi), zero));
+        }
 #pragma unroll
         for (int ot = 0; ot < NT; ++ot) mfma_tile_p<P, SWAP>(A + (ot * NT + it) * Prec<P>::TF, xb, y[ot], lane);
     }
@@ -1436,7 +1450,7 @@ template <int D, int P, int COOP>
 // d = 64 with fp32 / bf16x3 operands: the LDS tiles leave ONE 4-wave workgroup per CU anyway, so the wave may use the whole
 // register file (no spills)
 #ifndef GNNMP_MP_WGS32
-#define GNNMP_MP_WGS32 3
+#define GNNMP_MP_WGS32 2      // the LDS tiles leave two workgroups per CU at d = 32: let the wave use the registers of two
 #endif
 #ifndef GNNMP_MP_DEEP32
 #define GNNMP_MP_DEEP32 0
@@ -1505,7 +1519,11 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
         int rec_c = 0, rec_n = 0;
         if (first + j < end) rec_c = p.rec32[first + j];
         if (first + STEP + j < end) rec_n = p.rec32[first + STEP + j];
-        KeRaw<P> ke_q[KD][PF];
+        // two K_e register sets used alternately (the chunk loop is unrolled by two): a set is refilled as soon as its chunk
+        // has expanded it -- for the chunk two ahead when KD = 2 (each set feeds every second chunk), or the OTHER set is
+        // filled for the next chunk when KD = 1.  No queue shifting and no loop-carried copies (they were 16 / 40 register
+        // moves per chunk at d = 32 fp32 / d = 64 bf16, in a loop that is bound by instruction issue).
+        KeRaw<P> qa[PF], qb[PF];
         auto ke_fetch = [&](int cc, KeRaw<P> (&dst)[PF]) {      // wave-uniform cc
             if (cc < end) {
 #pragma unroll
@@ -1515,18 +1533,15 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
         if (first < end) {
             const int mine_row = src_row(rec_c, first + j < end);
             dma_rows<D, P>(p.A, [&](int sr) { return __builtin_amdgcn_ds_bpermute(sr * 4, mine_row); }, astage, lane);
-#pragma unroll
-            for (int k = 0; k < KD; ++k) ke_fetch(first + k * STEP, ke_q[k]);
+            ke_fetch(first, qa);
+            if constexpr (KD == 2) ke_fetch(first + STEP, qb);
         }
-        for (int c0 = first; c0 < end; c0 += STEP) {
+        auto chunk = [&](const int c0, KeRaw<P> (&cur)[PF], KeRaw<P> (&fill)[PF]) {
             const int slot = c0 + j;
             const bool valid = slot < end;
             const int rec = rec_c;
             const int dloc = valid ? ((rec >> 27) & 31) : 0;
             const int eslot = valid ? slot : beg;
-            KeRaw<P> ke0[PF];
-#pragma unroll
-            for (int t = 0; t < PF; ++t) ke0[t] = ke_q[0][t];
             if (h == 0) dl[j] = dloc * D;
             // this chunk's A rows (and the job's B rows) have landed; with KD = 2 the next chunk's K_e tiles, requested
             // AFTER them, may still be in flight (vector memory returns in order)
@@ -1540,9 +1555,9 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
 #pragma unroll
             for (int ot = 0; ot < NT; ++ot) M[ot] = splat16(bias[ot]);
             // hidden = relu(A[src] + B[dst] + K_e), one 32-feature tile at a time, straight into the swapped MFMA
-            linear_acc_stream<P, NT, true>(wl + LE::w2, [&](int it, f32x16& x) {
+            linear_acc_stream<P, NT, true, true>(wl + LE::w2, [&](int it, f32x16& x) {
                 f32x16 a, b;
-                if (it < PF) expand_raw<P>(ke0[it < PF ? it : 0], x); else load_edge_slot_tile<P, NT>(p.Ke, eslot, h, it, x);
+                if (it < PF) expand_raw<P>(cur[it < PF ? it : 0], x); else load_edge_slot_tile<P, NT>(p.Ke, eslot, h, it, x);
                 read_stage_tile<D, P>(astage, j, h, it, a);
                 read_stage_tile<D, P>(btile, dloc, h, it, b);
                 if (it == NT - 1) {
@@ -1554,15 +1569,9 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
                         dma_rows<D, P>(p.A, [&](int sr) { return __builtin_amdgcn_ds_bpermute(sr * 4, mine_row); }, astage, lane);
                         if (c0 + 2 * STEP + j < end) rec_n = p.rec32[c0 + 2 * STEP + j];
                     }
-#pragma unroll
-                    for (int k = 0; k + 1 < KD; ++k)
-#pragma unroll
-                        for (int t = 0; t < PF; ++t) ke_q[k][t] = ke_q[k + 1][t];
-                    ke_fetch(c0 + KD * STEP, ke_q[KD - 1]);
+                    ke_fetch(c0 + KD * STEP, fill);
                 }
-                x += a + b;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) x[r] = fmaxf(x[r], 0.0f);
+                x += a + b;                                     // the ReLU is applied by linear_acc_stream
             }, M, lane);
             if (end - c0 < 32) {                                 // wave-uniform: the last, partial chunk -- pad edges aggregate -inf
                 const int nv = end - c0;
@@ -1589,6 +1598,12 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        };
+        for (int c0 = first; c0 < end; c0 += 2 * STEP) {
+            if constexpr (KD == 2) chunk(c0, qa, qa); else chunk(c0, qa, qb);
+            if (c0 + STEP < end) {                               // wave-uniform
+                if constexpr (KD == 2) chunk(c0 + STEP, qb, qb); else chunk(c0 + STEP, qb, qa);
+            }
         }
         if constexpr (kCoop) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's aggregation atomics have been performed

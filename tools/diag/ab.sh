@@ -8,5 +8,5 @@ for v in "$@"; do
   python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --pcie-steps 0 --dense-steps 0 --bf16x3-steps 0 --single-steps 0 --planner-problems 0 $ARGS 2>/dev/null | tail -1 | python -c "
 import json,sys
 d=json.loads(sys.stdin.read())
-print('%-12s %9.1f graphs/s  ms/step %.4f  stages %s  checksum %s' % ('$v', d['value'], d['ms_per_step'], d['config'].get('stage_ms_per_step'), d['config'].get('checksum')))"
+print('%-12s %9.1f graphs/s  ms/step %.4f  stages %s  checksum %s' % ('$v', d['value'], d['ms_per_step'], d['config'].get('stage_ms_per_step'), d['config'].get('result_checksum')))"
 done
