@@ -363,8 +363,8 @@ def main():
                     'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'launch_ms': round(mp_avg_ms, 4), 'algorithmic_bytes_per_launch': mp_bytes}
         else:
             peak = PEAK_BF16_TFLOPS if args.mlp_dtype == 'bf16' else PEAK_FP32_TFLOPS
-            roof = {'kernel': 'pre_resident_kernel<%d, %s, EDGE> (edge encoders + 3 obstacle-attention blocks)' % (e['d'], pname),
-                    'kernel_like': 'pre_resident_kernel<%d, %s, true' % (e['d'], pname),
+            roof = {'kernel': '%s<%d, %s, EDGE> (edge encoders + 3 obstacle-attention blocks)' % ('pre_resident_kernel' if (pname == '1' or (pname == '0' and e['d'] == 32)) else 'pre_kernel', e['d'], pname),
+                    'kernel_like': '%s<%d, %s, true' % ('pre_resident_kernel' if (pname == '1' or (pname == '0' and e['d'] == 32)) else 'pre_kernel', e['d'], pname),
                     'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
                     'launch_ms': round(ep_avg_ms, 4), 'algorithmic_flops_per_launch': ep_flops}
         roof['frac'] = round(roof['achieved'] / roof['peak'], 4)

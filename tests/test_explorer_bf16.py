@@ -89,3 +89,28 @@ def test_batch_equals_single_and_modes_coexist():
     s32 = m.edge_scores(g['goal'].to(DEV), 3, g['v'].to(DEV), g['obstacles'].to(DEV), g['edge_index'].to(DEV)).cpu()
     ref = ref_cpu.explorer_forward(load_weights('weights_kuka'), g['v'], g['goal'], g['obstacles'], g['edge_index'], 3)
     assert torch.allclose(s32, ref, rtol=1e-5, atol=2e-5)
+
+
+# max|gpu_bf16 - reference_fp64| per golden, recorded on the MI355X in round 3 (profiles/r03_parity.txt section G).  The emulation
+# oracle (ref_bf16.py) follows THIS implementation's rounding points, so agreement with it cannot pin the mode; this budget
+# against the unmodified reference's fp64 run does: an algebraic refold that shifts bf16 accuracy shows up here.
+BF16_BUDGET = {
+    'explorer_kuka13_N64_k4_L5': 7.621e-02, 'explorer_kuka14_N200_k8_L5': 8.443e-02, 'explorer_kuka14_N64_k4_L5': 1.018e-01,
+    'explorer_kuka7_N200_k6_L5': 5.678e-02, 'explorer_kuka7_N64_k4_L2_noobs': 4.986e-02, 'explorer_kuka7_N64_k4_L5': 4.704e-02,
+    'explorer_snake7_N64_k4_L5': 7.292e-02, 'explorer_maze3_N64_k4_L5': 1.211e-01, 'explorer_ur5_N64_k4_L5': 2.673e-01,
+    'explorer_maze2_N64_k4_L5_noobs': 3.514e-02,
+}
+
+
+@pytest.mark.parametrize('name', sorted(BF16_BUDGET))
+def test_bf16_error_budget(name):
+    path = [p for p in golden_files('explorer_') if os.path.basename(p) == name + '.npz'][0]
+    with np.load(path) as f:
+        r = {k: f[k] for k in f.files}
+    m = make(env_of(path))
+    m.use_obstacles = bool(r['use_obstacles'])
+    s = m.edge_scores(torch.from_numpy(r['goal']).to(DEV), int(r['loop']), torch.from_numpy(r['v']).to(DEV),
+                      torch.from_numpy(r['obstacles']).to(DEV), torch.from_numpy(r['edge_index']).to(DEV)).cpu().double()
+    err = float((s - torch.from_numpy(r['scores_fp64'])).abs().max())
+    print('\n%s: bf16 vs reference fp64 max %.3e (recorded %.3e)' % (name, err, BF16_BUDGET[name]))
+    assert err <= 1.3 * BF16_BUDGET[name]
