@@ -1438,7 +1438,9 @@ __device__ __forceinline__ void linear_acc_stream(const float* A, Get get, f32x1
 template <int D, int P, int COOP>
 __host__ __device__ constexpr int mp_lds_floats() {
     constexpr int stage_f = 32 * D * (P == 1 ? 2 : 4) / 4;
-    return COOP == 1 ? 4 * (32 * D + 32 + 2 * stage_f) : (32 * D + stage_f + COOP * (32 + stage_f));
+    // COOP > 1 adds four [32][D] fp32 tiles: X and R rows of the job (requested at its start), the partial H = bl + Wlx X that a
+    // wave computes while the others multiply edges, and Y for the wave that computes B'
+    return COOP == 1 ? 4 * (32 * D + 32 + 2 * stage_f) : (32 * D + stage_f + COOP * (32 + stage_f) + (D == 32 ? 4 * 32 * D : 0));
 }
 
 // COOP = 1 (large batches): one 32-node tile per WAVE, four independent waves per workgroup.
@@ -1458,6 +1460,9 @@ template <int D, int P, int COOP>
 __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 && P != 1) ? 1 : ((P == 2 || D > 32) ? 2 : GNNMP_MP_WGS32)) : 1) void mp_fused_kernel(MpFusedParams p) {
     constexpr int NT = D / 32;
     constexpr bool kCoop = COOP > 1;
+    // few tiles, d = 32: the node phase is spread over waves (below); at d = 64 the eight-wave workgroup has 256 registers per
+    // wave and the extra live tiles spill (measured: kuka7 bf16 single graph 135 -> 156 us), so it keeps the one-wave form
+    constexpr bool kSplitNode = kCoop && D == 32;
     using LE = MpEBlob<D, P>;
     using LN = MpNBlob<D, P>;
     using G = RowGeom<D, P>;
@@ -1470,6 +1475,10 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
     float* mine = kCoop ? base + 32 * D + G::STAGE_FLOATS + wave * (32 + G::STAGE_FLOATS) : agg + 32 * D;
     int* dl = reinterpret_cast<int*>(mine);                      // [32] agg row offsets (floats) of this chunk's targets
     float* astage = mine + 32;                                   // gathered A rows of the current chunk
+    float* xstage = base + 32 * D + G::STAGE_FLOATS + COOP * (32 + G::STAGE_FLOATS);     // kCoop only (see mp_lds_floats)
+    float* rstage = xstage + 32 * D;
+    float* hpart = rstage + 32 * D;
+    float* ytile = hpart + 32 * D;
     stage(wl, p.we, LE::size);
     // d = 32: the node phase's weights (MpNBlob, 20 KB) fit next to the tiles -- staged once per workgroup instead of read
     // from L1 / L2 as MFMA operands by every tile (five launches at cfg 2: 0.910 -> 0.872 ms)
@@ -1501,9 +1510,29 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
 #pragma unroll
             for (int q = 0; q < D / 8; ++q) *reinterpret_cast<f32x4*>(agg + j * D + h * (D / 2) + q * 4) = ninf;
         }
+        // Few tiles (kCoop): the node phase is a chain of five dependent layers on ONE wave behind the edge phase, i.e. pure
+        // latency.  What does not depend on the aggregation is taken out of that chain: the X and R rows are requested NOW by
+        // the two waves with the fewest chunks, and the last wave computes the partial H = bl + Wlx X right after the barrier,
+        // before its own chunks.  The accumulator goes through LDS as it is, so every layer sees the same fmaf chain as the
+        // one-wave form: results stay bit-identical to COOP = 1.
+        const float* wn = kNodeWInLds ? wnl : p.wn;
+        if constexpr (!kNodeWInLds) asm volatile("" : "+s"(wn));
+        if constexpr (kSplitNode && P != 1) {
+            if (wave == COOP - 1) dma_rows<D, 0>(p.X, [&](int sr) { return t0 + sr; }, xstage, lane);
+            if (wave == COOP - 2) dma_rows<D, 0>(p.R, [&](int sr) { return t0 + sr; }, rstage, lane);
+        }
         if constexpr (kCoop) {
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __syncthreads();
+            if (kSplitNode && wave == COOP - 1) {
+                f32x16 Hp[NT];
+                load_vec<NT>(wn + LN::bl, Hp, lane);
+                linear_acc_stream<P, NT, false>(wn + LN::wlx, [&](int it, f32x16& x) {
+                    if constexpr (P != 1) read_stage_tile<D, 0>(xstage, j, h, it, x);
+                    else load_row_tile<1, NT>(p.X, (size_t)node, h, it, x);          // bf16 mode: X rows are stored in bf16
+                }, Hp, lane);
+                store_tile<NT>(hpart, Hp, lane);
+            }
         }
         // software pipeline over 32-edge chunks: while chunk c is multiplied and aggregated, the A rows of this wave's
         // next chunk are in flight to the LDS stage (DMA, no registers), its first K_e tile to registers, and the packed
@@ -1605,16 +1634,54 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
                 if constexpr (KD == 2) chunk(c0 + STEP, qb, qb); else chunk(c0 + STEP, qb, qa);
             }
         }
-        if constexpr (kCoop) {
+        if constexpr (kCoop && !kSplitNode) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's aggregation atomics have been performed
             __syncthreads();
             if (wave != 0) continue;                             // wave 0 runs the node phase; the others wait at the next tile
         }
+        if constexpr (kSplitNode) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's aggregation atomics (and the partial H) have been performed
+            __syncthreads();
+            // ---- node phase, few tiles: wave 0 finishes H (+= Wla agg), Y = R + M1 H; then waves 0 and 1 compute A' and B' side
+            // by side.  Critical path behind the edge phase: three layers instead of five, no global read.
+            f32x16 y[NT];
+            if (wave == 0) {
+                f32x16 H[NT];
+                load_tile<NT>(hpart, H, lane);
+                linear_acc_stream<P, NT, false>(wn + LN::wla, [&](int it, f32x16& x) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 a = *reinterpret_cast<const f32x4*>(agg + j * D + it * 32 + q * 8 + h * 4);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) x[q * 4 + c] = dg == 0 ? 0.f : a[c];      // torch_scatter: no incoming edge -> 0
+                    }
+                }, H, lane);
+                if (p.store_h) store_row<NT>(p.Hout + (size_t)node * D, H, h);
+                if constexpr (P != 1) {
+#pragma unroll
+                    for (int tt = 0; tt < NT; ++tt) read_stage_tile<D, 0>(rstage, j, h, tt, y[tt]);
+                } else {
+                    load_row<NT>(p.R + (size_t)node * D, y, h);
+                }
+                linear_acc_p<P, NT, NT>(wn + LN::m1, H, y, lane);
+                store_row_p<P == 1 ? 1 : 0, NT>(p.Xout, (size_t)node, y, h);
+                store_tile<NT>(ytile, y, lane);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (wave < 2) {
+                if (wave == 1) load_tile<NT>(ytile, y, lane);
+                f32x16 z[NT];
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt) z[tt] = splat16(0.f);
+                linear_acc_p<P, NT, NT>(wn + (wave == 0 ? LN::m2 : LN::m3), y, z, lane);
+                store_row_p<P, NT>(wave == 0 ? p.Aout : p.Bout, (size_t)node, z, h);
+            }
+            continue;                                            // the next job's first barrier collects the workgroup
+        }
         // ---- node phase.  X and R rows of the tile (contiguous, fp32) come through the two stages as well; the weights
         // (MpNBlob) are read from global memory as MFMA operands (at d = 64 the pointer is laundered per job so that the
         // compiler does not hoist those loop-invariant loads out of the job loop into ~70 registers)
-        const float* wn = kNodeWInLds ? wnl : p.wn;
-        if constexpr (!kNodeWInLds) asm volatile("" : "+s"(wn));
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if constexpr (P != 1) {                                  // fp32 rows fill a whole stage each
             dma_rows<D, 0>(p.X, [&](int sr) { return t0 + sr; }, astage, lane);
