@@ -437,6 +437,14 @@ __device__ __forceinline__ void obs_body(const ObsParams& p, const int vblock) {
         const int side = vblock & 1;
         const float* W = p.w[side];
         const ObsBlob L = p.blob;
+        // d = 32: the side's whole blob (55 KB fp32) goes to LDS in one DMA burst first -- the stage is a chain of ~14 dependent
+        // layers, and every layer used to start with an L2 round trip for its operands (single-graph forward: 15 -> ~10 us)
+        if constexpr (D == 32 && P != 2) {
+            extern __shared__ __attribute__((aligned(16))) float obs_lds[];
+            stage(obs_lds, W, L.size);
+            __syncthreads();
+            W = obs_lds;
+        }
         float* kv_side = p.kv[side];
         for (int ot = wave; ot < OT; ot += 4) {
             const int o = ot * 32 + j;
@@ -1905,7 +1913,9 @@ hipError_t launch_prep(const PrepParams& q, int Npad, int Epad, int* hist, hipSt
 template <int D, int P>
 static hipError_t launch_obs_t(const ObsParams& p, const NodeF64Params& q, int G, hipStream_t st) {
     const int f64_blocks = P == 1 ? 0 : q.n_wg;
-    const size_t lds = f64_blocks ? (size_t)(((q.blob.size + 3) & ~3) + 2 * f64_obs_chunk(D) * D) * sizeof(float) : 0;
+    size_t lds = f64_blocks ? (size_t)(((q.blob.size + 3) & ~3) + 2 * f64_obs_chunk(D) * D) * sizeof(float) : 0;
+    const size_t obs_lds = (D == 32 && P != 2) ? (size_t)((p.blob.size + 3) & ~3) * sizeof(float) : 0;     // obstacle role: its blob
+    if (obs_lds > lds) lds = obs_lds;
     if (lds) {
         const hipError_t e = set_lds(obs_kernel<D, P>, lds);
         if (e != hipSuccess) return e;
