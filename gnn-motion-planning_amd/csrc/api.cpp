@@ -894,6 +894,8 @@ int forward_impl(const gnnmp_explorer* h, const gnnmp_batch* b, int loop, int us
         f.we = W + h->off.mpe; f.wn = W + (last ? h->off.mpn_last : h->off.mpn);
         f.Hout = at<float>(ws, c.H); f.Xout = at<float>(ws, c.X); f.Aout = Abuf[cur ^ 1]; f.Bout = at<float>(ws, c.B);
         f.n_tiles = c.Npad / 32;
+        f.tpw = 1;
+        f.est_tiles = (int)((long long)c.G * (((b->total_nodes + c.G - 1) / c.G + kPad - 1) / kPad * kPad) / 32);     // equal graphs assumed
         f.store_h = last ? 1 : 0;
         StageScope sc(prof, GNNMP_STAGE_MP, st);
         HIP_TRY(launch_mp_fused(D, P, f, st));

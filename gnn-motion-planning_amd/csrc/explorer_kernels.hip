@@ -1498,7 +1498,21 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
     float bias[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) bias[t] = wl[LE::b2 + (t * 2 + ((j >> 2) & 1)) * 16 + (j & 3) + 4 * (j >> 3)];
-    for (XcdWalk wk(kCoop ? p.n_tiles : (p.n_tiles + 3) / 4); wk.valid(); wk.next()) {
+    XcdWalk wk(kCoop ? p.n_tiles : (p.n_tiles + 3) / 4);
+    if constexpr (!kCoop) {
+        // every workgroup takes p.tpw ADJACENT four-tile groups, one after the other (the launcher picks tpw so that the
+        // workgroups fill whole rounds of the resident slots: launch_mp_fused_t)
+        // XCD-aware like XcdWalk -- workgroup b runs on XCD b % 8, which works through a contiguous eighth of the group space --
+        // but the eighths are cut from the groups IN USE (p.real_wgs workgroups, the host's estimate): the padded tile space
+        // has up to 255 spare rows per graph behind the last graph (22 % at 1000 nodes), and eighths of the padded space left
+        // XCD 7 and half of XCD 6 without work (round 2's mapping).  Workgroups beyond the estimate take what is left in order.
+        const int per = (p.real_wgs + 7) >> 3, q8 = blockIdx.x >> 3, x8 = blockIdx.x & 7;
+        const int wg = q8 < per ? x8 * per + q8 : 8 * per + (q8 - per) * 8 + x8;
+        wk.cur = wg * p.tpw;
+        wk.end = min((p.n_tiles + 3) / 4, wk.cur + p.tpw);
+        wk.step = 1;
+    }
+    for (; wk.valid(); wk.next()) {
         // static strided split: at any moment the resident workgroups of an XCD work on ADJACENT tiles, so the K_e stream
         // is one dense front in HBM and neighbouring tiles share gathered A rows (tiles pulled one by one from a per-XCD
         // counter, or one contiguous run of tiles per workgroup, both measured 13-18 % slower)
@@ -2039,10 +2053,33 @@ static hipError_t launch_mp_fused_t(const MpFusedParams& p, hipStream_t st) {
         // group to whichever CU frees up first, which balances the uneven tiles better than a static share per resident
         // workgroup did (five launches: cfg 2 0.952 -> 0.910 ms, kuka7 bf16 0.72 -> 0.70, kuka14 bf16 0.633 -> 0.592;
         // a grid of 1.5x the resident workgroups is the worst case: 1.087 ms at cfg 2)
-        static const int forced = getenv("GNNMP_WGS_PER_CU") ? atoi(getenv("GNNMP_WGS_PER_CU")) : 0;      // experiments
-        int grid = ((p.n_tiles + 3) / 4 + 7) & ~7;
-        if (forced > 0) grid = grid_for(mp_fused_kernel<D, P, COOP>, lds, p.n_tiles, forced);
-        hipLaunchKernelGGL((mp_fused_kernel<D, P, COOP>), dim3(grid < 8 ? 8 : grid), dim3(256), lds, st, p);
+        // How many adjacent groups a workgroup takes (tpw): the hardware hands workgroups to whichever CU frees up first, and
+        // what counts is how many ROUNDS of the resident slots the grid makes -- the last round is only partly filled.
+        // Measured, five launches: cfg 2 (2048 groups, 512 slots) 0.861 / 0.806 / 0.79 ms at t = 1 / 2 / 4; kuka7 bf16 (1024 groups,
+        // 512 slots) 0.690 / 0.60 / 0.78; kuka14 bf16 (1256 groups, 768 slots) 0.587 / 0.68 / 0.86
+        // p.n_tiles is the padded upper bound (G x 255 spare rows); the estimate wants the tiles actually in use: equal graphs assumed
+        const int groups_cap = (p.n_tiles + 3) / 4;
+        const int groups = p.est_tiles > 0 && p.est_tiles < p.n_tiles ? (p.est_tiles + 3) / 4 : groups_cap;
+        const Residency r = resident_workgroups(reinterpret_cast<const void*>(mp_fused_kernel<D, P, COOP>), lds);
+        const int slots = r.cus * r.per_cu > 0 ? r.cus * r.per_cu : 512;
+        static const int forced_tpw = getenv("GNNMP_MP_TPW") ? atoi(getenv("GNNMP_MP_TPW")) : 0;      // experiments
+        // estimate in units of one group's time: all workgroups resident at once -> t groups in a row plus ~15 % for the
+        // uneven tiles nothing can balance any more; otherwise the dispatcher keeps the slots busy (rounds + a partial last
+        // one); every workgroup start-up (weights staged into LDS) costs ~0.15 of a group
+        int tpw = 1;
+        double best = 0.0;
+        for (int t = 1; t <= 4; t *= 2) {
+            const double wgs = (double)((groups + t - 1) / t);
+            const double est = (wgs <= slots ? t * 1.15 : t * (wgs / slots + 0.35)) * (1.0 + 0.15 / t);
+            if (t == 1 || est < best) { best = est; tpw = t; }
+        }
+        if (getenv("GNNMP_DEBUG_GRID")) fprintf(stderr, "[gnnmp] mp_fused groups %d slots %d (cus %d x %d) -> tpw %d\n", groups, slots, r.cus, r.per_cu, tpw);
+        if (forced_tpw > 0) tpw = forced_tpw;
+        MpFusedParams q = p;
+        q.tpw = tpw;
+        q.real_wgs = (groups + tpw - 1) / tpw;
+        int grid = ((groups_cap + tpw - 1) / tpw + 7) & ~7;
+        hipLaunchKernelGGL((mp_fused_kernel<D, P, COOP>), dim3(grid < 8 ? 8 : grid), dim3(256), lds, st, q);
     } else {
         const int grid = ((p.n_tiles + 7) & ~7) < 8 ? 8 : ((p.n_tiles + 7) & ~7);          // one workgroup per tile
         hipLaunchKernelGGL((mp_fused_kernel<D, P, COOP>), dim3(grid), dim3(COOP * 64), lds, st, p);

@@ -84,6 +84,9 @@ struct MpFusedParams {
     float *Hout, *Xout, *Aout, *Bout;
     int n_tiles;                 // 32-node tiles of the padded node space
     int store_h;
+    int tpw;                     // adjacent four-tile groups per workgroup (set by launch_mp_fused)
+    int real_wgs;                // workgroups expected to hold tiles in use (set by launch_mp_fused from est_tiles)
+    int est_tiles;               // host estimate of the tiles actually in use (n_tiles is an upper bound); 0 = unknown
 };
 
 struct PolicyParams {

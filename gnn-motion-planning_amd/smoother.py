@@ -123,7 +123,7 @@ class _TrainSmooth(torch.autograd.Function):
     def forward(ctx, model, sb, loop, *params):
         dev = sb.path.device
         _check_limits(sb)
-        h = model._native(dev)
+        h = model._native(dev, for_training=True)
         cb = _cbatch(sb)
         need = ctypes.c_size_t()
         _lib.check(_lib.lib().gnnmp_smoother_train_workspace_bytes(h, ctypes.byref(cb), int(loop), ctypes.byref(need)),
@@ -225,17 +225,26 @@ class ModelSmoother(nn.Module):
         """Drop the packed device copy of the weights (see EncoderProcessDecoder.refresh_weights)."""
         self._drop_handle()
 
-    def _native(self, device):
+    def _native(self, device, for_training=False):
+        """The native handle for ``device``, rebuilt when a weight changed.  ``for_training``: the BatchNorm running statistics
+        are left out of the staleness check -- the training forward normalises with batch statistics and never reads them,
+        but updates them after every call, which would otherwise re-pack and re-upload all weights per training step.  The
+        stored key stays the full one, so the next inference call (which folds those statistics into node_code.0) rebuilds."""
         if self._manifest is None:
             self._manifest = _lib.manifest('smoother', self._dims())
+            self._bn_slots = frozenset(i for i, (n, _) in enumerate(self._manifest)
+                                       if n.endswith(('running_mean', 'running_var', 'num_batches_tracked')))
         sd = self.state_dict(keep_vars=True)
         wt = [sd[n] for n, _ in self._manifest]
         dev = torch.device(device)
         idx = dev.index if dev.index is not None else torch.cuda.current_device()
         key = (idx, float(self.scale), self.mlp_dtype, list(map(_VERSION, wt)), wt)
         hk = self._handle_key
-        if self._handle is not None and hk[:4] == key[:4] and len(hk[4]) == len(wt) and all(map(operator.is_, hk[4], wt)):
-            return self._handle
+        if self._handle is not None and hk[:3] == key[:3] and len(hk[4]) == len(wt) and all(map(operator.is_, hk[4], wt)):
+            if hk[3] == key[3]:
+                return self._handle
+            if for_training and all(a == b for i, (a, b) in enumerate(zip(hk[3], key[3])) if i not in self._bn_slots):
+                return self._handle
         self._drop_handle()
         blob = torch.cat([t.detach().to('cpu', torch.float32).reshape(-1) for t in wt]).contiguous()
         h = ctypes.c_void_p()
@@ -281,16 +290,17 @@ class ModelSmoother(nn.Module):
         if path.device.type != 'cuda':
             raise RuntimeError('gnnmp runs on the GPU only (got %s tensors); there is no CPU fallback' % path.device)
         sb = SmoothBatch([path], [free], [collided], [edge_index], path.device)
-        self._native(path.device)
+        self._native(path.device, for_training=True)
         sd = self.state_dict(keep_vars=True)
         out, stats = _TrainSmooth.apply(self, sb, loop, *[sd[n] for n, _ in self._manifest])
         bn = self.node_code[1]
         with torch.no_grad():
             for it in range(int(loop)):
-                m = 0.1 if bn.momentum is None else bn.momentum
+                # torch.nn.BatchNorm1d: the counter goes up first; momentum None means a cumulative moving average
+                bn.num_batches_tracked += 1
+                m = 1.0 / float(bn.num_batches_tracked) if bn.momentum is None else bn.momentum
                 bn.running_mean.mul_(1 - m).add_(stats[it, 0].to(bn.running_mean.device), alpha=m)
                 bn.running_var.mul_(1 - m).add_(stats[it, 1].to(bn.running_var.device), alpha=m)
-                bn.num_batches_tracked += 1
         return out
 
     def forward(self, path, free, collided, obstacles=None, edge_index=None, loop=10, **kwargs):

@@ -140,3 +140,40 @@ def test_sgd_step_moves_the_loss_down():
     m.refresh_weights()
     after = total()
     assert after.item() < before.item(), (before.item(), after.item())
+
+
+def test_training_steps_keep_the_native_handle_and_momentum_none():
+    """BatchNorm's running statistics change after every training forward; the training path never reads them, so the native
+    handle (packed + raw weights on the device) must survive across training forwards as long as no trained weight changed,
+    and be rebuilt by the next inference call (which folds the statistics).  momentum=None follows torch: cumulative average."""
+    gen = torch.Generator().manual_seed(3)
+    path, free, coll = (torch.rand(n, 2, generator=gen).to(DEV) * 2 - 1 for n in (10, 50, 40))
+    from gnnmp.planner import chain_edge_index
+    ei = chain_edge_index(10).to(DEV)
+    m = gnnmp.ModelSmoother(workspace_size=2, config_size=2, embed_size=128, obs_size=6)
+    m.load_state_dict(load_weights('smooth_2d_attv3'))
+    m.train()
+    m(path=path, free=free, collided=coll, edge_index=ei, loop=2)
+    h1 = m._handle
+    m(path=path, free=free, collided=coll, edge_index=ei, loop=2)          # running stats were bumped in between
+    assert m._handle is h1
+    m.eval()
+    with torch.no_grad():
+        m(path=path, free=free, collided=coll, edge_index=ei, loop=1)      # inference folds the new statistics: rebuild
+    assert m._handle is not h1
+    # momentum None: cumulative moving average, like nn.BatchNorm1d
+    ref = torch.nn.BatchNorm1d(128, momentum=None).to(DEV).train()
+    m2 = gnnmp.ModelSmoother(workspace_size=2, config_size=2, embed_size=128, obs_size=6)
+    m2.load_state_dict(load_weights('smooth_2d_attv3'))
+    m2.node_code[1].momentum = None
+    m2.node_code[1].reset_running_stats()
+    m2.train()
+    nodes = torch.cat((path, free, coll))
+    info = torch.zeros(100, 3, device=DEV); info[:10, 0] = 1; info[10:60, 1] = 1; info[60:, 2] = 1
+    with torch.no_grad():
+        x0 = torch.nn.functional.linear(torch.cat((nodes, info), -1), m2.node_code[0].weight, m2.node_code[0].bias)
+    ref(x0)
+    m2(path=path, free=free, collided=coll, edge_index=ei, loop=1)
+    assert int(m2.node_code[1].num_batches_tracked) == 1
+    assert torch.allclose(m2.node_code[1].running_mean, ref.running_mean, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(m2.node_code[1].running_var, ref.running_var, rtol=1e-4, atol=1e-6)
