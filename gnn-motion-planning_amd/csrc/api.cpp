@@ -895,7 +895,7 @@ int forward_impl(const gnnmp_explorer* h, const gnnmp_batch* b, int loop, int us
         f.Hout = at<float>(ws, c.H); f.Xout = at<float>(ws, c.X); f.Aout = Abuf[cur ^ 1]; f.Bout = at<float>(ws, c.B);
         f.n_tiles = c.Npad / 32;
         f.tpw = 1;
-        f.est_tiles = (int)((long long)c.G * (((b->total_nodes + c.G - 1) / c.G + kPad - 1) / kPad * kPad) / 32);     // equal graphs assumed
+        f.G = c.G;
         f.store_h = last ? 1 : 0;
         StageScope sc(prof, GNNMP_STAGE_MP, st);
         HIP_TRY(launch_mp_fused(D, P, f, st));

@@ -962,9 +962,12 @@ __global__ __launch_bounds__(WAVES * 64) void pre_kernel(PreParams p) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
     // XCD-aware order (see XcdWalk): XCD b % 8 works on a contiguous eighth of the workgroup tiles, so a
     // graph's K/V slabs and weights are staged from ONE XCD's L2
-    const int per = (p.n_wg + 7) >> 3;
+    // The eighths are cut from the workgroup tiles IN USE (the prep stage's padded total), not from the launch's upper bound:
+    // up to 255 spare rows per graph sit behind the last graph and would leave the last XCDs without work
+    const int n_wg = min(p.n_wg, p.ptr_pad_total[p.G] / (32 * WAVES));
+    const int per = (n_wg + 7) >> 3;
     const int wg = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-    if ((int)(blockIdx.x >> 3) >= per || wg >= p.n_wg) return;
+    if ((int)(blockIdx.x >> 3) >= per || wg >= n_wg) return;
     const int tile = wg * WAVES + wave;
     const int g = p.tile_graph[wg * WAVES];               // kPad is a multiple of 32*WAVES: uniform per WG
     if (g < 0) return;
@@ -1503,10 +1506,11 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
         // every workgroup takes p.tpw ADJACENT four-tile groups, one after the other (the launcher picks tpw so that the
         // workgroups fill whole rounds of the resident slots: launch_mp_fused_t)
         // XCD-aware like XcdWalk -- workgroup b runs on XCD b % 8, which works through a contiguous eighth of the group space --
-        // but the eighths are cut from the groups IN USE (p.real_wgs workgroups, the host's estimate): the padded tile space
+        // but the eighths are cut from the groups IN USE (node_ptr_pad[G], written by the prep stage): the padded tile space
         // has up to 255 spare rows per graph behind the last graph (22 % at 1000 nodes), and eighths of the padded space left
-        // XCD 7 and half of XCD 6 without work (round 2's mapping).  Workgroups beyond the estimate take what is left in order.
-        const int per = (p.real_wgs + 7) >> 3, q8 = blockIdx.x >> 3, x8 = blockIdx.x & 7;
+        // XCD 7 and half of XCD 6 without work (round 2's mapping).  Workgroups beyond that take the unused tail in order.
+        const int real_wgs = ((p.node_ptr_pad[p.G] >> 7) + p.tpw - 1) / p.tpw;      // exact: the prep stage's padded total / 128 rows per group
+        const int per = (real_wgs + 7) >> 3, q8 = blockIdx.x >> 3, x8 = blockIdx.x & 7;
         const int wg = q8 < per ? x8 * per + q8 : 8 * per + (q8 - per) * 8 + x8;
         wk.cur = wg * p.tpw;
         wk.end = min((p.n_tiles + 3) / 4, wk.cur + p.tpw);
@@ -2053,31 +2057,16 @@ static hipError_t launch_mp_fused_t(const MpFusedParams& p, hipStream_t st) {
         // group to whichever CU frees up first, which balances the uneven tiles better than a static share per resident
         // workgroup did (five launches: cfg 2 0.952 -> 0.910 ms, kuka7 bf16 0.72 -> 0.70, kuka14 bf16 0.633 -> 0.592;
         // a grid of 1.5x the resident workgroups is the worst case: 1.087 ms at cfg 2)
-        // How many adjacent groups a workgroup takes (tpw): the hardware hands workgroups to whichever CU frees up first, and
-        // what counts is how many ROUNDS of the resident slots the grid makes -- the last round is only partly filled.
-        // Measured, five launches: cfg 2 (2048 groups, 512 slots) 0.861 / 0.806 / 0.79 ms at t = 1 / 2 / 4; kuka7 bf16 (1024 groups,
-        // 512 slots) 0.690 / 0.60 / 0.78; kuka14 bf16 (1256 groups, 768 slots) 0.587 / 0.68 / 0.86
-        // p.n_tiles is the padded upper bound (G x 255 spare rows); the estimate wants the tiles actually in use: equal graphs assumed
+        // p.n_tiles is the padded upper bound (up to 255 spare rows per graph); the kernel cuts its XCD eighths from the tiles
+        // actually in use.  A workgroup may take several ADJACENT groups (GNNMP_MP_TPW, experiments only): with the eighths cut
+        // right, one group per workgroup is the fastest everywhere -- five launches at t = 1 / 2 / 4: cfg 2 0.740 / 0.779 / 0.780 ms,
+        // kuka7 bf16 0.582 / 0.589 / 0.779, kuka14 bf16 0.562 / 0.597 / 0.865
         const int groups_cap = (p.n_tiles + 3) / 4;
-        const int groups = p.est_tiles > 0 && p.est_tiles < p.n_tiles ? (p.est_tiles + 3) / 4 : groups_cap;
-        const Residency r = resident_workgroups(reinterpret_cast<const void*>(mp_fused_kernel<D, P, COOP>), lds);
-        const int slots = r.cus * r.per_cu > 0 ? r.cus * r.per_cu : 512;
         static const int forced_tpw = getenv("GNNMP_MP_TPW") ? atoi(getenv("GNNMP_MP_TPW")) : 0;      // experiments
-        // estimate in units of one group's time: all workgroups resident at once -> t groups in a row plus ~15 % for the
-        // uneven tiles nothing can balance any more; otherwise the dispatcher keeps the slots busy (rounds + a partial last
-        // one); every workgroup start-up (weights staged into LDS) costs ~0.15 of a group
         int tpw = 1;
-        double best = 0.0;
-        for (int t = 1; t <= 4; t *= 2) {
-            const double wgs = (double)((groups + t - 1) / t);
-            const double est = (wgs <= slots ? t * 1.15 : t * (wgs / slots + 0.35)) * (1.0 + 0.15 / t);
-            if (t == 1 || est < best) { best = est; tpw = t; }
-        }
-        if (getenv("GNNMP_DEBUG_GRID")) fprintf(stderr, "[gnnmp] mp_fused groups %d slots %d (cus %d x %d) -> tpw %d\n", groups, slots, r.cus, r.per_cu, tpw);
         if (forced_tpw > 0) tpw = forced_tpw;
         MpFusedParams q = p;
         q.tpw = tpw;
-        q.real_wgs = (groups + tpw - 1) / tpw;
         int grid = ((groups_cap + tpw - 1) / tpw + 7) & ~7;
         hipLaunchKernelGGL((mp_fused_kernel<D, P, COOP>), dim3(grid < 8 ? 8 : grid), dim3(256), lds, st, q);
     } else {

@@ -85,8 +85,7 @@ struct MpFusedParams {
     int n_tiles;                 // 32-node tiles of the padded node space
     int store_h;
     int tpw;                     // adjacent four-tile groups per workgroup (set by launch_mp_fused)
-    int real_wgs;                // workgroups expected to hold tiles in use (set by launch_mp_fused from est_tiles)
-    int est_tiles;               // host estimate of the tiles actually in use (n_tiles is an upper bound); 0 = unknown
+    int G;                       // graphs: node_ptr_pad[G] / 32 = tiles actually in use (n_tiles is an upper bound)
 };
 
 struct PolicyParams {
