@@ -1490,6 +1490,11 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
     float* rstage = xstage + 32 * D;
     float* hpart = rstage + 32 * D;
     float* ytile = hpart + 32 * D;
+    if constexpr (!kCoop) {
+        // workgroups of the unused tail of the padded tile space (up to 22 % of the grid) leave before they stage anything
+        const int q8 = blockIdx.x >> 3, per = ((((p.node_ptr_pad[p.G] >> 7) + p.tpw - 1) / p.tpw) + 7) >> 3;
+        if (q8 >= per) return;
+    }
     stage(wl, p.we, LE::size);
     // d = 32: the node phase's weights (MpNBlob, 20 KB) fit next to the tiles -- staged once per workgroup instead of read
     // from L1 / L2 as MFMA operands by every tile (five launches at cfg 2: 0.910 -> 0.872 ms)
@@ -1501,7 +1506,9 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
     float bias[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) bias[t] = wl[LE::b2 + (t * 2 + ((j >> 2) & 1)) * 16 + (j & 3) + 4 * (j >> 3)];
-    XcdWalk wk(kCoop ? p.n_tiles : (p.n_tiles + 3) / 4);
+    // tiles actually in use (the prep stage's padded total): the XCD eighths are cut from those, not from the launch's upper bound
+    const int real_tiles = min(p.n_tiles, p.node_ptr_pad[p.G] >> 5);
+    XcdWalk wk(kCoop ? real_tiles : (real_tiles + 3) / 4);
     if constexpr (!kCoop) {
         // every workgroup takes p.tpw ADJACENT four-tile groups, one after the other (the launcher picks tpw so that the
         // workgroups fill whole rounds of the resident slots: launch_mp_fused_t)
