@@ -196,8 +196,8 @@ __device__ __forceinline__ void prep_graph_body(const PrepParams& q, int g, int 
 // goal node of graph g: argmin_i |v_i - goal|^2, lowest index on ties (model.py:132); any power-of-two workgroup
 __device__ __forceinline__ void goal_body(int C, const float* __restrict__ v, const float* __restrict__ goal,
                                           const int* __restrict__ node_ptr, int g, int n0_pad, int* __restrict__ goal_node) {
-    __shared__ float s_d[1024];
-    __shared__ int s_i[1024];
+    __shared__ float s_d[16];
+    __shared__ int s_i[16];
     const int tid = threadIdx.x, nt = blockDim.x;
     const int n0 = node_ptr[g], n = node_ptr[g + 1] - n0;
     float best = INFINITY;
@@ -210,16 +210,29 @@ __device__ __forceinline__ void goal_body(int C, const float* __restrict__ v, co
         }
         if (d < best) { best = d; bi = i; }
     }
-    s_d[tid] = best; s_i[tid] = bi;
-    __syncthreads();
-    for (int off = nt >> 1; off > 0; off >>= 1) {
-        if (tid < off) {
-            const float od = s_d[tid + off];
-            const int oi = s_i[tid + off];
-            if (od < s_d[tid] || (od == s_d[tid] && oi < s_i[tid])) { s_d[tid] = od; s_i[tid] = oi; }
-        }
-        __syncthreads();
+    // (distance, index) minimum, lowest index on ties: inside a wave by shuffles, then the wave results through LDS -- two
+    // barriers instead of one per halving step (this runs in the one-workgroup prep stage of a single-graph forward)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float od = __shfl_down(best, off);
+        const int oi = __shfl_down(bi, off);
+        if (od < best || (od == best && oi < bi)) { best = od; bi = oi; }
     }
+    if ((tid & 63) == 0) { s_d[tid >> 6] = best; s_i[tid >> 6] = bi; }
+    __syncthreads();
+    if (tid < 64) {
+        const int nw = nt >> 6;
+        best = tid < nw ? s_d[tid] : INFINITY;
+        bi = tid < nw ? s_i[tid] : 0x7fffffff;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float od = __shfl_down(best, off);
+            const int oi = __shfl_down(bi, off);
+            if (od < best || (od == best && oi < bi)) { best = od; bi = oi; }
+        }
+        if (tid == 0) { s_d[0] = best; s_i[0] = bi; }
+    }
+    __syncthreads();
     if (tid == 0) goal_node[g] = (n > 0) ? n0_pad + s_i[0] : -1;
 }
 
@@ -2088,7 +2101,10 @@ template <int D, int P>
 static hipError_t launch_mp_fused_dp(const MpFusedParams& p, hipStream_t st) {
     static const int forced = getenv("GNNMP_MP_COOP") ? atoi(getenv("GNNMP_MP_COOP")) : -1;
     const bool coop = forced >= 0 ? forced != 0 : p.n_tiles <= (D > 32 ? kCoopMaxTiles64 : kCoopMaxTiles32);
-    return coop ? launch_mp_fused_t<D, P, 8>(p, st) : launch_mp_fused_t<D, P, 1>(p, st);
+    // d = 64 with fp32 / bf16x3 operands: four waves per tile instead of eight -- at eight waves a wave has 256 registers and the
+    // kernel spilled 116 of them (single 2000-node kuka7 graph: 42 us per launch)
+    if constexpr (D > 32 && P != 1) return coop ? launch_mp_fused_t<D, P, 4>(p, st) : launch_mp_fused_t<D, P, 1>(p, st);
+    else return coop ? launch_mp_fused_t<D, P, 8>(p, st) : launch_mp_fused_t<D, P, 1>(p, st);
 }
 hipError_t launch_mp_fused(int D, int P, const MpFusedParams& p_in, hipStream_t st) {
     const MpFusedParams& p = p_in;
