@@ -11,8 +11,10 @@ n, k = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (1000, 8)
 e = ENVS[env]
 m = gnnmp.EncoderProcessDecoder(e['workspace'], e['C'], e['d'], e['S']).eval()
 m.load_state_dict(load_weights(e['ckpt']))
-if len(sys.argv) > 4:
+if len(sys.argv) > 4 and sys.argv[4] != '-':
     m.mlp_dtype = sys.argv[4]
+if len(sys.argv) > 5 and sys.argv[5] == 'noobs':
+    m.use_obstacles = False
 g = {kk: (v.to(dev) if torch.is_tensor(v) else v) for kk, v in synth_graph(env, n, k).items()}
 b = m._single(g['goal'], g['v'], g['obstacles'], g['edge_index'])
 for _ in range(20):
