@@ -171,9 +171,9 @@ def test_training_steps_keep_the_native_handle_and_momentum_none():
     nodes = torch.cat((path, free, coll))
     info = torch.zeros(100, 3, device=DEV); info[:10, 0] = 1; info[10:60, 1] = 1; info[60:, 2] = 1
     with torch.no_grad():
-        x0 = torch.nn.functional.linear(torch.cat((nodes, info), -1), m2.node_code[0].weight, m2.node_code[0].bias)
+        x0 = torch.nn.functional.linear(torch.cat((nodes, info), -1), m2.node_code[0].weight.to(DEV), m2.node_code[0].bias.to(DEV))
     ref(x0)
     m2(path=path, free=free, collided=coll, edge_index=ei, loop=1)
     assert int(m2.node_code[1].num_batches_tracked) == 1
-    assert torch.allclose(m2.node_code[1].running_mean, ref.running_mean, rtol=1e-5, atol=1e-6)
-    assert torch.allclose(m2.node_code[1].running_var, ref.running_var, rtol=1e-4, atol=1e-6)
+    assert torch.allclose(m2.node_code[1].running_mean.cpu(), ref.running_mean.cpu(), rtol=1e-5, atol=1e-6)
+    assert torch.allclose(m2.node_code[1].running_var.cpu(), ref.running_var.cpu(), rtol=1e-4, atol=1e-6)
