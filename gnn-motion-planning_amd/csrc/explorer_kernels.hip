@@ -1479,7 +1479,7 @@ template <int D, int P, int COOP>
 #define GNNMP_MP_WGS32 2      // the LDS tiles leave two workgroups per CU at d = 32: let the wave use the registers of two
 #endif
 #ifndef GNNMP_MP_DEEP32
-#define GNNMP_MP_DEEP32 0
+#define GNNMP_MP_DEEP32 0     // experiment switch: K_e two chunks ahead at d = 32 fp32 (measured slower: 0.906 vs 0.875 ms)
 #endif
 __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 && P != 1) ? 1 : ((P == 2 || D > 32) ? 2 : GNNMP_MP_WGS32)) : 1) void mp_fused_kernel(MpFusedParams p) {
     constexpr int NT = D / 32;
@@ -1505,8 +1505,10 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
     float* ytile = hpart + 32 * D;
     if constexpr (!kCoop) {
         // workgroups of the unused tail of the padded tile space (up to 22 % of the grid) leave before they stage anything
-        const int q8 = blockIdx.x >> 3, per = ((((p.node_ptr_pad[p.G] >> 7) + p.tpw - 1) / p.tpw) + 7) >> 3;
-        if (q8 >= per) return;
+        if (p.tpw > 0) {
+            const int q8 = blockIdx.x >> 3, per = ((((p.node_ptr_pad[p.G] >> 7) + p.tpw - 1) / p.tpw) + 7) >> 3;
+            if (q8 >= per) return;
+        }
     }
     stage(wl, p.we, LE::size);
     // d = 32: the node phase's weights (MpNBlob, 20 KB) fit next to the tiles -- staged once per workgroup instead of read
@@ -1522,7 +1524,7 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
     // tiles actually in use (the prep stage's padded total): the XCD eighths are cut from those, not from the launch's upper bound
     const int real_tiles = min(p.n_tiles, p.node_ptr_pad[p.G] >> 5);
     XcdWalk wk(kCoop ? real_tiles : (real_tiles + 3) / 4);
-    if constexpr (!kCoop) {
+    if (!kCoop && p.tpw > 0) {                 // tpw == 0 (experiment): persistent workgroups, strided walk of the XCD's eighth
         // every workgroup takes p.tpw ADJACENT four-tile groups, one after the other (the launcher picks tpw so that the
         // workgroups fill whole rounds of the resident slots: launch_mp_fused_t)
         // XCD-aware like XcdWalk -- workgroup b runs on XCD b % 8, which works through a contiguous eighth of the group space --
@@ -2088,6 +2090,10 @@ static hipError_t launch_mp_fused_t(const MpFusedParams& p, hipStream_t st) {
         MpFusedParams q = p;
         q.tpw = tpw;
         int grid = ((groups_cap + tpw - 1) / tpw + 7) & ~7;
+        if (forced_tpw < 0) {                  // experiment: persistent workgroups, -forced_tpw per CU
+            q.tpw = 0;
+            grid = 256 * (-forced_tpw);
+        }
         hipLaunchKernelGGL((mp_fused_kernel<D, P, COOP>), dim3(grid < 8 ? 8 : grid), dim3(256), lds, st, q);
     } else {
         const int grid = ((p.n_tiles + 7) & ~7) < 8 ? 8 : ((p.n_tiles + 7) & ~7);          // one workgroup per tile
