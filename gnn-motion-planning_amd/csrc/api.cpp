@@ -811,6 +811,12 @@ int forward_impl(const gnnmp_explorer* h, const gnnmp_batch* b, int loop, int us
         nq.w = W + h->off.f64; nq.blob = F64Blob::make(D, C);
         nq.m0 = at<float>(ws, c.M0);
         nq.groups = c.Npad / 64 > 2 * h->n_cu ? 4 : 1;                          // kPad = 256 rows = 4 groups
+        {
+            static const char* ord = std::getenv("GNNMP_F64_FIRST");
+            // measured: cfg 2 (d = 32, 1024 double-precision workgroups = two rounds) 0.145 -> 0.139 ms with them first;
+            // kuka7 fp32 (d = 64, 512 = one round) 0.153 -> 0.162 ms, so d = 64 keeps the obstacle workgroups in front
+            nq.f64_first = ord ? (ord[0] != '0') : (nq.groups > 1 && D == 32);
+        }
         nq.n_wg = (P != GNNMP_BF16 && h->node_f64) ? c.Npad / (64 * nq.groups) : 0;
         use_m0 = nq.n_wg > 0;
         StageScope sc(prof, GNNMP_STAGE_OBS, st);

@@ -832,13 +832,18 @@ __device__ __forceinline__ void node_f64_body(const ObsParams& p, const NodeF64P
 // the obstacle launch: workgroups [0, f64_blocks) run node_f64_body (fp32-class modes only), the rest obs_body
 template <int D, int P>
 __global__ __launch_bounds__(256) void obs_kernel(ObsParams p, NodeF64Params q, int f64_blocks) {
-    // the (few, short) obstacle workgroups first: the edge side's K/V is what the next launch waits for
+    // q.f64_first: the double-precision workgroups (long: 256 node rows each) come first and the short obstacle workgroups fill
+    // the slots that free up in their last round; otherwise the obstacle workgroups lead (few graphs: both fit at once anyway)
     const int obs_blocks = (int)gridDim.x - f64_blocks;
     if constexpr (P != 1) {
-        if ((int)blockIdx.x >= obs_blocks) {
-            node_f64_body<D, P>(p, q, (int)blockIdx.x - obs_blocks);
+        const int b = (int)blockIdx.x;
+        const bool is_f64 = q.f64_first ? b < f64_blocks : b >= obs_blocks;
+        if (is_f64) {
+            node_f64_body<D, P>(p, q, q.f64_first ? b : b - obs_blocks);
             return;
         }
+        obs_body<D, P>(p, q.f64_first ? b - f64_blocks : b);
+        return;
     }
     obs_body<D, P>(p, (int)blockIdx.x);
 }

@@ -42,6 +42,7 @@ struct NodeF64Params {
     F64Blob blob;
     float* m0;               // out [Npad, d]: node_free_code after the attention sub-block of block 0 (input of its map_feed)
     int n_wg;                // workgroups of this role (64 * groups padded node rows each); 0 = role not used
+    int f64_first;           // dispatch order inside the obstacle launch: 1 = these workgroups before the obstacle ones
     int groups;              // 64-row groups per workgroup: 1 (few graphs: shortest chains) or 4 (obstacle operands built once per 256 rows)
 };
 
