@@ -174,3 +174,13 @@ def test_f64_chain_layout(D, C):
         for ob in range(NB):
             for r in range(4):                                         # both land in the f64 layout: feature 16 ob + 4 r + g
                 assert np.allclose(y[ob, r], ref[j, 16 * ob + 4 * r + g], rtol=1e-12, atol=1e-9)
+
+
+def test_f64_pack_rejects_bad_arguments():
+    w = np.zeros((16, 4), dtype=np.float32)
+    dst = np.zeros(16 * 64, dtype=np.float32)
+    L = _lib.lib()
+    assert L.gnnmp_pack_f64_ops(w.ctypes.data, 15, 4, 0, 4, 0, dst.ctypes.data) < 0        # rows not a multiple of 16
+    assert L.gnnmp_pack_f64_ops(w.ctypes.data, 16, 4, 0, 0, 0, dst.ctypes.data) < 0        # no input columns
+    assert L.gnnmp_pack_f64_ops(None, 16, 4, 0, 4, 0, dst.ctypes.data) < 0
+    assert L.gnnmp_pack_f64_ops(w.ctypes.data, 16, 4, 0, 4, 0, dst.ctypes.data) == 64      # one 16-row block, one k-step
