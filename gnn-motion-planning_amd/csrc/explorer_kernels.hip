@@ -1859,10 +1859,9 @@ __global__ __launch_bounds__(256) void policy_kernel(PolicyParams p) {
         const int s = rec.x, t = rec.y;
 #pragma unroll
         for (int tt = 0; tt < NT; ++tt) hid[tt] += a[tt] - b[tt];
-        relu_<NT>(hid);
         f32x16 y[NT], w3[NT];
         load_vec<NT>(wl + L::b2, y, lane);
-        linear_acc_p<P, NT, NT>(wl + L::w2, hid, y, lane);
+        linear_acc_relu_p<P, NT, NT>(wl + L::w2, hid, y, lane);
         relu_<NT>(y);
         load_vec<NT>(wl + L::w3, w3, lane);
         float sc = 0.f;
