@@ -1518,7 +1518,10 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
     stage(wl, p.we, LE::size);
     // d = 32: the node phase's weights (MpNBlob, 20 KB) fit next to the tiles -- staged once per workgroup instead of read
     // from L1 / L2 as MFMA operands by every tile (five launches at cfg 2: 0.910 -> 0.872 ms)
-    constexpr bool kNodeWInLds = D == 32 && P != 2;          // bf16x3: 31 KB, would leave one workgroup per CU
+#ifndef GNNMP_MP_NODEW_LDS
+#define GNNMP_MP_NODEW_LDS 1
+#endif
+    constexpr bool kNodeWInLds = GNNMP_MP_NODEW_LDS && D == 32 && P != 2;          // bf16x3: 31 KB, would leave one workgroup per CU
     float* wnl = lds + ((LE::size + 3) & ~3) + mp_lds_floats<D, P, COOP>();
     if constexpr (kNodeWInLds) stage(wnl, p.wn, LN::size);
     __syncthreads();
@@ -2075,7 +2078,7 @@ static int grid_for(K kernel, size_t lds_bytes, int n_tiles, int max_per_cu) {
 
 template <int D, int P, int COOP>
 static hipError_t launch_mp_fused_t(const MpFusedParams& p, hipStream_t st) {
-    const size_t lds = (size_t)(((MpEBlob<D, P>::size + 3) & ~3) + mp_lds_floats<D, P, COOP>() + (D == 32 && P != 2 ? ((MpNBlob<D, P>::size + 3) & ~3) : 0)) * sizeof(float);
+    const size_t lds = (size_t)(((MpEBlob<D, P>::size + 3) & ~3) + mp_lds_floats<D, P, COOP>() + (GNNMP_MP_NODEW_LDS && D == 32 && P != 2 ? ((MpNBlob<D, P>::size + 3) & ~3) : 0)) * sizeof(float);
     hipError_t e = set_lds(mp_fused_kernel<D, P, COOP>, lds);
     if (e != hipSuccess) return e;
     if (COOP == 1) {
