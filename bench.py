@@ -55,6 +55,21 @@ def mp_fused_bytes(N, E, d, bf16):
     return E * (d * se + 4) + N * d * (3 * se + 4) + N * d * 3 * se
 
 
+def node_side_flops(N, O, C, d, S):
+    """Reference-formulation FLOPs of the node side (obs + node_pre stages): node encoders (model.py:119,122), the obstacle
+    encoders and the K / V projections of the obstacle codes for all six blocks (model.py:125-130), three node attention
+    blocks."""
+    return 2 * N * (4 * C * d + d * d) + 2 * N * (C * d + d * d) + 2 * 2 * O * (S * d + d * d) + 3 * 16 * O * d * d \
+        + 3 * N * (10 * d * d + 4 * d * (O + 1))
+
+
+def policy_bytes(N, E, d, bf16):
+    """HBM bytes of the policy launch for one graph: the per-edge first-layer constant PE_e and the CSR record (16 B) in, one
+    score out; the PS / PT rows gathered by source / target are served by L2 after their first touch."""
+    se = 2 if bf16 else 4
+    return E * (d * se + 16 + 4) + 2 * N * d * se
+
+
 def algorithmic_bytes(N, E, O, C, S):
     """SURVEY.md section 8(d) B_sparse: v, goal, obstacles, int32 edge pairs, scores out."""
     return 4 * N * C + 4 * C + 4 * O * S + 8 * E + 4 * E
@@ -368,6 +383,27 @@ def main():
                     'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
                     'launch_ms': round(ep_avg_ms, 4), 'algorithmic_flops_per_launch': ep_flops}
         roof['frac'] = round(roof['achieved'] / roof['peak'], 4)
+        # every stage against the roof that bounds it (the `roofline` block above is the dominant one of these)
+        is_bf16 = args.mlp_dtype == 'bf16'
+        mfma_peak = PEAK_BF16_TFLOPS if is_bf16 else PEAK_FP32_TFLOPS
+        def per_launch(stage):
+            ms, n = prof.get(stage, (0.0, 0))
+            return ms / max(n, 1)
+        stage_roof = {}
+        ns_ms = per_launch('obs') + per_launch('node_pre')
+        ns_flops = sum(node_side_flops(n, o, e['C'], e['d'], e['S']) for n, o in zip(Ns, Os))
+        for name, ms, work, bound in (
+                ('edge_pre', ep_avg_ms, ep_flops, 'mfma'), ('obs+node_pre', ns_ms, ns_flops, 'mfma'),
+                ('mp (per launch)', per_launch('mp'), sum(mp_fused_bytes(n, m, e['d'], is_bf16) for n, m in zip(Ns, Es)), 'hbm'),
+                ('policy', per_launch('policy'), sum(policy_bytes(n, m, e['d'], is_bf16) for n, m in zip(Ns, Es)), 'hbm')):
+            if ms <= 0:
+                continue
+            if bound == 'mfma':
+                ach = work / (ms * 1e-3) / 1e12
+                stage_roof[name] = {'bound': 'mfma', 'ms': round(ms, 4), 'TFLOPs': round(ach, 1), 'frac': round(ach / mfma_peak, 3)}
+            else:
+                ach = work / (ms * 1e-3) / 1e9
+                stage_roof[name] = {'bound': 'hbm', 'ms': round(ms, 4), 'GBs': round(ach, 0), 'frac': round(ach / PEAK_HBM_GBS, 3)}
         # HBM bytes per launch of that kernel come from separate rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE cannot be
         # read inside this process; tools/traffic_json.py writes profiles/kernel_traffic.json): every entry carries the
         # workload it was measured on, the date of the pass and a hash of the kernel sources; the number is reported only
@@ -408,7 +444,7 @@ def main():
                                          'algorithmic_GBs': round(bytes_batch * args.steps / elapsed / 1e9, 3),
                                          'frac_fp32_peak': round(flops_batch * args.steps / elapsed / 1e12 / PEAK_FP32_TFLOPS, 4),
                                          'frac_hbm_peak': round(bytes_batch * args.steps / elapsed / 1e9 / PEAK_HBM_GBS, 6)},
-                       'stage_ms_per_step': stages, 'result_checksum': checksum,
+                       'stage_ms_per_step': stages, 'stage_roofline': stage_roof, 'result_checksum': checksum,
                        'pcie_inclusive_graphs_per_s_per_gpu': None if e2e is None else round(e2e, 1),
                        'pcie_inclusive_one_batch_at_a_time': None if e2e_serial is None else round(e2e_serial, 1),
                        'dense_output_graphs_per_s_per_gpu': None if dense_rate is None else round(dense_rate, 1),
