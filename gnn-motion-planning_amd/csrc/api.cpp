@@ -1178,6 +1178,7 @@ extern "C" int gnnmp_smoother_forward(const gnnmp_smoother* h, const gnnmp_smoot
     p.msg = at<float>(ws, c.msg);
     p.cand_cap = b->max_edges + kSmK * b->max_path;
     if (p.cand_cap < 1) p.cand_cap = 1;
+    p.samp_cap = b->max_samples > 0 ? b->max_samples : 0; p.path_cap = b->max_path > 0 ? b->max_path : 0;
     if ((size_t)2 * p.cand_cap * sizeof(int) > 60000) return GNNMP_ERR_DIMS;
     p.n_etiles = c.ecap / 32; p.n_ptiles = c.pcap / 32;
     p.one_free = b->total_free; p.one_coll = b->total_collided;
@@ -1641,6 +1642,7 @@ void sm_fill_params(const gnnmp_smoother* h, const gnnmp_smooth_batch* b, const 
     p.msg = at<float>(ws, c.msg);
     p.cand_cap = b->max_edges + kSmK * b->max_path;
     if (p.cand_cap < 1) p.cand_cap = 1;
+    p.samp_cap = b->max_samples > 0 ? b->max_samples : 0; p.path_cap = b->max_path > 0 ? b->max_path : 0;
     p.n_etiles = c.ecap / 32; p.n_ptiles = c.pcap / 32;
     p.one_free = b->total_free; p.one_coll = b->total_collided; p.init_from_path = 0; p.out = nullptr;
 }

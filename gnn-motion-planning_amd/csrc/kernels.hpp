@@ -113,6 +113,7 @@ struct SmParams {
     int *etile_prob, *ptile_prob;     // tile -> problem (-1 unused)
     float* msg;                       // [edge capacity, d]
     int cand_cap, n_etiles, n_ptiles;
+    int samp_cap, path_cap;           // caller's upper bounds max_b (F_b + Co_b), max_b P_b (sm_graph_kernel's LDS carve-up)
     int one_free, one_coll;           // path_ptr == nullptr: ONE problem, its sample counts (waypoints / edges: total_path / total_edges)
     int init_from_path;               // first iteration: the knn kernel also writes cur = path / scale
     float* out;                       // last iteration: the node kernel also writes out = cur * scale (else nullptr)

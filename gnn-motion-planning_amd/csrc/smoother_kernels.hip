@@ -17,6 +17,8 @@
 // Weights (d = 128: 0.46 MB) are read as MFMA A operands straight from global memory / L2.
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <mutex>
+#include <stdlib.h>
 #include "chain.hpp"
 #include "layout.hpp"
 #include "kernels.hpp"
@@ -191,6 +193,289 @@ __global__ __launch_bounds__(256) void sm_edges_kernel(SmParams p) {
     const int pt_end = b + 1 < p.B ? sm_poff(p, b + 1) / 32 : p.n_ptiles;
     for (int t = eoff / 32 + tid; t < et_end; t += 256) p.etile_prob[t] = t < et_used ? b : -1;
     for (int t = poff / 32 + tid; t < pt_end; t += 256) p.ptile_prob[t] = t < pt_used ? b : -1;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// kNN + edge list in ONE launch, one 1024-thread workgroup per problem (the form used whenever a problem's samples fit
+// the LDS; sm_knn_kernel + sm_edges_kernel above remain for larger ones).  The two-launch form spent 44 + 26 us of a
+// 115 us single call (the reference's pattern: five calls with loop = 1 per planning problem, smoother.py:243) on this:
+// every path node's wave re-read and re-divided all samples from global memory with one dependent round trip per
+// coordinate, and the edge list ran its compaction scan through 32 barriers.  Here the scaled samples are staged in LDS
+// once per problem (row stride made odd: lane = sample reads are conflict-free), a wave handles a path node with all
+// its sample slots in flight per coordinate, the neighbour ids never leave LDS, the rank sort uses four lanes per
+// candidate (inside the candidate's target bucket) and the compaction is one wave-shuffle scan per 1024 candidates: 24 us
+// for the 20-waypoint, 1000-sample call (stage 4, kNN 14 -- twenty path nodes' distance and selection loops share the four
+// SIMDs of one CU --, sort 4, compaction 2).
+// Same arithmetic as the two kernels: x / scale and path / scale as IEEE divisions, squared distance accumulated over the
+// coordinates in order with fmaf, (distance, sample index) minimum with infinite / NaN distances never selected, keys
+// target * M + source sorted ascending, duplicates dropped -- identical neighbour sets and edge lists.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int sm_scan_1024(int v, int* wsum, int& total) {     // inclusive prefix over the workgroup
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int x = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int y = __shfl_up(x, off);
+        if (lane >= off) x += y;
+    }
+    __syncthreads();                                   // wsum of the previous call has been read
+    if (lane == 63) wsum[wave] = x;
+    __syncthreads();
+    int before = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        const int t = wsum[w];
+        before += w < wave ? t : 0;
+        all += t;
+    }
+    total = all;
+    return x + before;
+}
+
+// (distance, index) minimum over the 64 lanes, lowest index on ties, result in every lane: first the minimum distance, then
+// the lowest index among the lanes that hold it.  Inside a row of 16 lanes the partner values come through the VALU's DPP
+// path (quad permutes, then the half-row and row mirrors: any pairing that crosses the halves works for a reduction),
+// across rows through v_permlane16_swap / v_permlane32_swap -- no LDS round trips (ds_bpermute shuffles made the ten
+// selection rounds the longest part of a path node's kNN).
+template <int CTRL> __device__ __forceinline__ float sm_dpp_f(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL> __device__ __forceinline__ int sm_dpp_i(int x) { return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xf, 0xf, false); }
+__device__ __forceinline__ float sm_wave_min(float x) {
+    x = fminf(x, sm_dpp_f<0xB1>(x));           // quad_perm [1,0,3,2]
+    x = fminf(x, sm_dpp_f<0x4E>(x));           // quad_perm [2,3,0,1]
+    x = fminf(x, sm_dpp_f<0x141>(x));          // row_half_mirror
+    x = fminf(x, sm_dpp_f<0x140>(x));          // row_mirror
+    const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    x = fminf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    const auto c = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fminf(__uint_as_float(c[0]), __uint_as_float(c[1]));
+}
+__device__ __forceinline__ int sm_wave_min(int x) {
+    x = min(x, sm_dpp_i<0xB1>(x));
+    x = min(x, sm_dpp_i<0x4E>(x));
+    x = min(x, sm_dpp_i<0x141>(x));
+    x = min(x, sm_dpp_i<0x140>(x));
+    const auto a = __builtin_amdgcn_permlane16_swap((unsigned)x, (unsigned)x, false, false);
+    x = min((int)a[0], (int)a[1]);
+    const auto c = __builtin_amdgcn_permlane32_swap((unsigned)x, (unsigned)x, false, false);
+    return min((int)c[0], (int)c[1]);
+}
+
+template <int kSlots>          // 64-sample slots per lane: 16 (up to 1024 samples per problem) or 32 (up to 2048)
+__global__ __launch_bounds__(1024) void sm_graph_kernel(SmParams p) {
+    extern __shared__ int sm_lds[];
+    __shared__ int s_wsum[16];
+    const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int C = p.C, cs = C | 1;
+    const int p0 = sm_pp(p, b), P = sm_pp(p, b + 1) - p0;
+    const int f0 = sm_fp(p, b), F = sm_fp(p, b + 1) - f0;
+    const int c0 = sm_cp(p, b), Co = sm_cp(p, b + 1) - c0;
+    const int ns = F + Co, M = P + ns;
+    const int e0 = sm_ep(p, b), ne = sm_ep(p, b + 1) - e0;
+    const int ncand = ne + kSmK * P;
+    float* xs = reinterpret_cast<float*>(sm_lds);                    // [samp_cap][cs] scaled samples
+    float* qs = xs + (size_t)p.samp_cap * cs;                        // [path_cap][cs] scaled path rows
+    int* knn_l = reinterpret_cast<int*>(qs + (size_t)p.path_cap * cs);   // [path_cap][kSmK]
+    int* key = knn_l + p.path_cap * kSmK;                            // [cand_cap]
+    int* sorted = key + p.cand_cap;                                  // [cand_cap]
+    int* cnt_l = sorted + p.cand_cap;                                // [path_cap]
+    int* beg_l = cnt_l + p.path_cap;                                 // [path_cap]
+    const int eoff = sm_eoff(p, b), poff = sm_poff(p, b);
+    // the caps are the caller's upper bounds (gnnmp_smooth_batch.max_*): a problem beyond them gets no edges instead of
+    // running over the LDS carve-up
+    const bool fits = P <= p.path_cap && ns <= p.samp_cap && ncand <= p.cand_cap;
+    const bool first = p.init_from_path != 0;
+    // the first 1024 candidates' caller edges are requested now and consumed after the kNN
+    int pre_src = 0, pre_dst = 0;
+    if (fits && tid < ne) {
+        pre_src = (int)p.edge_index[e0 + tid];
+        pre_dst = (int)p.edge_index[(size_t)p.total_edges + e0 + tid];
+    }
+    if (fits) {
+        // the free rows and the collided rows of a problem are two contiguous runs: element i of the staged block is element i
+        // of the first run or element i - F C of the second; sixteen independent loads per thread and trip
+        constexpr int U = 16;
+        const int nfe = F * C, nel = ns * C;
+        const float* fr = p.free_pts + (size_t)f0 * C;
+        const float* co = p.collided + (size_t)c0 * C - nfe;
+        for (int base = tid; base < nel; base += U * 1024) {
+            float v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = base + u * 1024;
+                v[u] = i < nel ? (i < nfe ? fr[i] : co[i]) : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = base + u * 1024;
+                if (i < nel) {
+                    const int sidx = i / C, c = i - sidx * C;
+                    xs[sidx * cs + c] = v[u] / p.scale;
+                }
+            }
+        }
+    }
+    // first iteration: the scaled working copy of the path (model_smoother.py:118) is written here
+    for (int i = tid; i < P * C; i += 1024) {
+        const int n = i / C, c = i - n * C;
+        const size_t at = (size_t)(p0 + n) * C + c;
+        const float q = first ? p.path[at] / p.scale : p.cur[at];
+        if (first) p.cur[at] = q;
+        if (fits) qs[n * cs + c] = q;
+    }
+    for (int i = tid; i < P && i < p.path_cap; i += 1024) { cnt_l[i] = 0; beg_l[i] = 0; }
+    __syncthreads();
+    if (fits) {
+        // ---- kNN: wave w takes path nodes w, w + 16, ...; lane l holds samples l, l + 64, ...
+        const int k = ns < kSmK ? ns : kSmK;
+        for (int n = wave; n < P; n += 16) {
+            float dist[kSlots];
+#pragma unroll
+            for (int t = 0; t < kSlots; ++t) dist[t] = 0.f;
+            for (int c = 0; c < C; ++c) {                   // coordinates in order, all slots of the lane in flight
+                const float q = qs[n * cs + c];
+                // branch-free over the slots (a guard per slot puts every LDS read into a basic block of its own and the reads
+                // are then waited for one by one: 34 us instead of 16 for the kNN of a 20-waypoint problem); slots beyond the
+                // problem's samples read row 0 and are set to infinity below
+#pragma unroll
+                for (int t = 0; t < kSlots; ++t) {
+                    const int s = t * 64 + lane;
+                    const float df = xs[(s < ns ? s : 0) * cs + c] - q;
+                    dist[t] = fmaf(df, df, dist[t]);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < kSlots; ++t)
+                if (!(t * 64 + lane < ns)) dist[t] = INFINITY;
+            for (int r = 0; r < kSmK; ++r) {
+                int res = -1;
+                if (r < k) {
+                    float bd = INFINITY;
+                    int bi = 0x7fffffff;
+#pragma unroll
+                    for (int t = 0; t < kSlots; ++t)
+                        if (dist[t] < bd) { bd = dist[t]; bi = t * 64 + lane; }
+                    // lowest index among the samples at the minimum distance; no finite distance left: every lane still holds
+                    // (inf, 0x7fffffff) and that comes out (dropped by the candidate check below)
+                    const float gm = sm_wave_min(bd);
+                    bi = sm_wave_min(bd == gm ? bi : 0x7fffffff);
+                    res = bi;
+#pragma unroll
+                    for (int t = 0; t < kSlots; ++t)
+                        if (t * 64 + lane == bi) dist[t] = INFINITY;
+                }
+                if (lane == 0) knn_l[n * kSmK + r] = res;
+            }
+        }
+    }
+    __syncthreads();
+    const int nc = fits ? ncand : 0;
+    // ---- candidates: caller edges with a path-node target, then the kNN edges (sample -> path node)
+    for (int c = tid; c < nc; c += 1024) {
+        int src, dst;
+        if (c < ne) {
+            src = c < 1024 ? pre_src : (int)p.edge_index[e0 + c];
+            dst = c < 1024 ? pre_dst : (int)p.edge_index[(size_t)p.total_edges + e0 + c];
+        } else {
+            const int pn = (c - ne) / kSmK, r = (c - ne) - pn * kSmK;
+            const int s = knn_l[pn * kSmK + r];
+            src = (s >= 0 && s < ns) ? P + s : -1;
+            dst = pn;
+        }
+        const bool ok = src >= 0 && src < M && dst >= 0 && dst < P;   // only rows < P of h are consumed
+        key[c] = ok ? dst * M + src : 0x7fffffff;
+    }
+    __syncthreads();
+    // ---- stable rank sort.  Keys are target * M + source: a candidate's rank is the number of valid candidates with a smaller
+    // target (histogram over the targets + prefix) plus its rank among the candidates of ITS target -- and those are the
+    // caller edges (scanned, four lanes per candidate) and the ten kNN candidates of that target, not all ne + 10 P.
+    // Invalid candidates write nothing: the sorted array is pre-filled with the invalid key.
+    for (int c = tid; c < nc; c += 1024) sorted[c] = 0x7fffffff;
+    for (int c = tid; c < nc; c += 1024) {
+        const int kc = key[c];
+        if (kc != 0x7fffffff) atomicAdd(&cnt_l[kc / M], 1);
+    }
+    __syncthreads();
+    if (tid < 64) {                                       // exclusive prefix over the targets (beg_l), one wave
+        int run = 0;
+        const int Pl = fits ? P : 0;
+        for (int base = 0; base < Pl; base += 64) {
+            const int i = base + tid;
+            const int v = i < Pl ? cnt_l[i] : 0;
+            int x = v;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int y = __shfl_up(x, off);
+                if (tid >= off) x += y;
+            }
+            if (i < Pl) beg_l[i] = run + x - v;
+            run += __shfl(x, 63);
+        }
+    }
+    __syncthreads();
+    for (int base = 0; base < nc; base += 256) {
+        const int c = base + (tid >> 2), part = tid & 3;
+        int rank = 0;
+        int kc = 0x7fffffff;
+        if (c < nc) {
+            kc = key[c];
+            if (kc != 0x7fffffff) {
+                const int dst = kc / M;
+                const int lo = dst * M, hi = lo + M;        // keys of this target
+                const int x0 = (int)((long long)ne * part / 4), x1 = (int)((long long)ne * (part + 1) / 4);
+#pragma unroll 4
+                for (int x = x0; x < x1; ++x) {
+                    const int kx = key[x];
+                    rank += (kx >= lo && kx < hi) && ((kx < kc) || (kx == kc && x < c));
+                }
+                for (int r = part; r < kSmK; r += 4) {      // kNN candidates of this target
+                    const int x = ne + dst * kSmK + r;
+                    const int kx = key[x];
+                    rank += (kx != 0x7fffffff) && ((kx < kc) || (kx == kc && x < c));
+                }
+            }
+        }
+        rank += __shfl_xor(rank, 1, 64);
+        rank += __shfl_xor(rank, 2, 64);
+        if (kc != 0x7fffffff && part == 0) sorted[beg_l[kc / M] + rank] = kc;
+    }
+    __syncthreads();
+    for (int i = tid; i < P && i < p.path_cap; i += 1024) { cnt_l[i] = 0; beg_l[i] = 0; }    // reused as the segment counters below
+    __syncthreads();
+    // ---- unique + compaction
+    int carry = 0;
+    for (int base = 0; base < nc; base += 1024) {
+        const int c = base + tid;
+        const int kc = (c < nc) ? sorted[c] : 0x7fffffff;
+        const int keep = (c < nc) && kc != 0x7fffffff && (c == 0 || sorted[c - 1] != kc);
+        int chunk_total;
+        const int incl = sm_scan_1024(keep, s_wsum, chunk_total);
+        if (keep) {
+            const int pos = carry + incl - 1;
+            const int dst = kc / M, src = kc - dst * M;
+            p.e_src[eoff + pos] = src;
+            p.e_dst[eoff + pos] = dst;
+            atomicAdd(&cnt_l[dst], 1);
+            if (c == 0 || sorted[c - 1] / M != dst) beg_l[dst] = eoff + pos;     // first edge of a target's run
+        }
+        carry += chunk_total;
+    }
+    __syncthreads();
+    for (int i = tid; i < sm_round32(P); i += 1024) {
+        const bool in = i < P && i < p.path_cap;
+        p.seg_beg[poff + i] = in ? beg_l[i] : 0;
+        p.seg_cnt[poff + i] = in ? cnt_l[i] : 0;
+    }
+    const int n = carry;
+    if (tid == 0) p.e_count[b] = n;
+    // tile -> problem maps of this problem's whole capacity range (-1 = unused tile; no separate fill launch): the range
+    // ends where the next problem's begins, the last problem's at the end of the tile space
+    const int et_used = (eoff + sm_round32(n)) / 32, pt_used = (poff + sm_round32(P)) / 32;
+    const int et_end = b + 1 < p.B ? sm_eoff(p, b + 1) / 32 : p.n_etiles;
+    const int pt_end = b + 1 < p.B ? sm_poff(p, b + 1) / 32 : p.n_ptiles;
+    for (int t = eoff / 32 + tid; t < et_end; t += 1024) p.etile_prob[t] = t < et_used ? b : -1;
+    for (int t = poff / 32 + tid; t < pt_end; t += 1024) p.ptile_prob[t] = t < pt_used ? b : -1;
 }
 
 // node features [coords / scale (path rows are already scaled), one-hot(kind)]   model_smoother.py:130-135
@@ -480,13 +765,46 @@ hipError_t launch_sm_final(int n, float scale, const float* cur, float* out, hip
 
 constexpr int kSmSplitMaxTilesBf16 = 2048;   // bf16 operands: the split kernels up to this many 32-edge tiles
 
-template <int D, int P>
-static hipError_t launch_sm_iter_t(const SmParams& p, hipStream_t st) {
+// graph stage of one iteration: the one-launch form when a problem's staged samples, path rows, neighbour ids, sort
+// buffers and segment counters fit the LDS of a workgroup, else kNN and edge list as two launches
+static size_t sm_graph_lds_bytes(const SmParams& p) {
+    const size_t cs = (size_t)(p.C | 1);
+    return sizeof(float) * cs * ((size_t)p.samp_cap + p.path_cap) + sizeof(int) * ((size_t)p.path_cap * (kSmK + 2) + 2 * (size_t)p.cand_cap);
+}
+static hipError_t launch_sm_graph(const SmParams& p, hipStream_t st) {
+    static const int fused_env = getenv("GNNMP_SM_FUSED_GRAPH") ? atoi(getenv("GNNMP_SM_FUSED_GRAPH")) : 1;
+    const size_t lds = sm_graph_lds_bytes(p);
+    if (fused_env != 0 && lds <= 150 * 1024) {
+        static std::mutex mu;
+        static size_t granted = 0;
+        {
+            std::lock_guard<std::mutex> lock(mu);
+            if (lds > granted) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sm_graph_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+                if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(sm_graph_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+                if (e != hipSuccess) return e;
+                granted = 150 * 1024;
+            }
+        }
+        if (p.samp_cap <= 1024) hipLaunchKernelGGL(sm_graph_kernel<16>, dim3(p.B), dim3(1024), lds, st, p);
+        else hipLaunchKernelGGL(sm_graph_kernel<32>, dim3(p.B), dim3(1024), lds, st, p);
+        LAUNCH_CHECK();
+        return hipSuccess;
+    }
     hipLaunchKernelGGL(sm_knn_kernel, dim3((p.total_path + 3) / 4), dim3(256), 0, st, p);
     LAUNCH_CHECK();
-    const size_t lds = (size_t)2 * p.cand_cap * sizeof(int);
-    hipLaunchKernelGGL(sm_edges_kernel, dim3(p.B), dim3(256), lds, st, p);
+    const size_t lds2 = (size_t)2 * p.cand_cap * sizeof(int);
+    hipLaunchKernelGGL(sm_edges_kernel, dim3(p.B), dim3(256), lds2, st, p);
     LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+template <int D, int P>
+static hipError_t launch_sm_iter_t(const SmParams& p, hipStream_t st) {
+    {
+        hipError_t e = launch_sm_graph(p, st);
+        if (e != hipSuccess) return e;
+    }
     // one tile per workgroup, its layers split over D / 32 waves (bit-identical, a quarter of the chain depth): measured
     // faster at EVERY batch size with exact-fp32 MFMAs (1 problem 143 -> 88 us, 256 problems 313 -> 238 us, 2048 problems
     // 1.67 -> 1.43 ms) and up to ~250 problems with bf16 operands (beyond that the tile-per-wave kernels win by 5-10 %)
@@ -506,14 +824,7 @@ static hipError_t launch_sm_iter_t(const SmParams& p, hipStream_t st) {
     return hipSuccess;
 }
 
-hipError_t launch_sm_knn_edges(const SmParams& p, hipStream_t st) {
-    hipLaunchKernelGGL(sm_knn_kernel, dim3((p.total_path + 3) / 4), dim3(256), 0, st, p);
-    LAUNCH_CHECK();
-    const size_t lds = (size_t)2 * p.cand_cap * sizeof(int);
-    hipLaunchKernelGGL(sm_edges_kernel, dim3(p.B), dim3(256), lds, st, p);
-    LAUNCH_CHECK();
-    return hipSuccess;
-}
+hipError_t launch_sm_knn_edges(const SmParams& p, hipStream_t st) { return launch_sm_graph(p, st); }
 
 hipError_t launch_sm_iter(int D, int P, const SmParams& p, hipStream_t st) {
     switch (D) {

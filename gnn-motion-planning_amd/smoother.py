@@ -29,12 +29,15 @@ class SmoothBatch:
             p = torch.zeros(len(counts) + 1, dtype=torch.int64)
             p[1:] = torch.tensor(counts, dtype=torch.int64).cumsum(0)
             return p.to(torch.int32).to(device)
-        f32 = lambda ts: torch.cat([t.float().reshape(t.shape[0], -1) for t in ts]).contiguous().to(device)  # noqa: E731
+        # rows of C coordinates; a problem may have no free or no collided samples ([0, C] or an empty tensor)
+        C = int(paths[0].reshape(paths[0].shape[0], -1).shape[1]) if paths[0].shape[0] > 0 else int(paths[0].shape[-1])
+        rows = lambda t: t.float().reshape(t.shape[0], C) if t.numel() > 0 else t.float().new_zeros(0, C)  # noqa: E731
+        f32 = lambda ts: torch.cat([rows(t) for t in ts]).contiguous().to(device)  # noqa: E731
         self.n = len(paths)
         if self.n == 1:
             # the reference's call (one problem, smoother.py:243): no concatenations, and the four prefix arrays travel
             # as ONE small host-to-device copy instead of four
-            one = lambda t: t.float().reshape(t.shape[0], -1).contiguous().to(device)  # noqa: E731
+            one = lambda t: rows(t).contiguous().to(device)  # noqa: E731
             self.path, self.free, self.collided = one(paths[0]), one(frees[0]), one(collideds[0])
             self.edge_index = edge_indexes[0].long().contiguous().to(device)
             if prefix_arrays:
