@@ -83,6 +83,11 @@ __device__ __forceinline__ int block_scan_1024(int v, int* wsum, int& total) {
     return x + before;
 }
 
+// caller prefix arrays as the prep stage reads them: for ONE graph given by its totals (single_out) the entries are kernel
+// arguments -- the arrays in the workspace are written for the later stages, and nothing in this launch waits for them
+__device__ __forceinline__ int prep_np(const PrepParams& q, int i) { return q.single_out ? (i > 0 ? q.single_n : 0) : q.node_ptr[i]; }
+__device__ __forceinline__ int prep_ep(const PrepParams& q, int i) { return q.single_out ? (i > 0 ? q.single_e : 0) : q.edge_ptr[i]; }
+
 // Workgroup `part` of `parts` builds the CSR rows of the target nodes [lo, hi) of graph g (a slice of its padded node
 // range): it walks ALL edge columns of the graph, counts the ones whose target lies below its slice (that count is where
 // its slice starts in the slot space -- no communication between the parts) and ranks / scatters the ones inside.
@@ -91,7 +96,7 @@ __device__ __forceinline__ void prep_graph_body(const PrepParams& q, int g, int 
     __shared__ int carry;                              // prep_lds: cnt[kPrepCap], rb[kPrepCap], scan[1024]
     __shared__ int below_w[16];
     const int tid = threadIdx.x;
-    const int c0 = q.edge_ptr[g], Eg = q.edge_ptr[g + 1] - c0;            // caller columns of this graph
+    const int c0 = prep_ep(q, g), Eg = prep_ep(q, g + 1) - c0;            // caller columns of this graph
     const int span = ((Np + parts - 1) / parts + 31) & ~31;
     const int lo = min(part * span, Np), hi = min(lo + span, Np), Nown = hi - lo;
     const bool in_lds = Nown <= kPrepCap;
@@ -108,7 +113,8 @@ __device__ __forceinline__ void prep_graph_body(const PrepParams& q, int g, int 
     constexpr int U = 16;                               // independent columns per thread and trip: the loop is latency-bound
     // graphs of up to U * 1024 columns built by one workgroup: every thread keeps its columns (source, target, arrival
     // rank) in registers between the ranking and the scatter -- edge_index is read once and the rank never goes to memory
-    const bool in_regs = parts == 1 && Eg <= U * 1024;
+    // (with several slices per graph every workgroup reads all columns and keeps the ones whose target lies in its slice)
+    const bool in_regs = Eg <= U * 1024;
     int sv_r[U], tv_r[U], rk_r[U];
     if (in_regs) {
 #pragma unroll
@@ -119,7 +125,13 @@ __device__ __forceinline__ void prep_graph_body(const PrepParams& q, int g, int 
             sv_r[u] = ok ? (int)srcs[cc] : 0;
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) rk_r[u] = tv_r[u] >= 0 ? atomicAdd(&cnt[tv_r[u]], 1) : 0;
+        for (int u = 0; u < U; ++u) {
+            const int t = tv_r[u];
+            below += (t >= 0 && t < lo) ? 1 : 0;
+            const bool mine = t >= lo && t < hi;
+            rk_r[u] = mine ? atomicAdd(&cnt[t - lo], 1) : 0;
+            if (!mine) tv_r[u] = -1;
+        }
     } else {
         for (int c = tid; c < Eg; c += U * 1024) {
             int d[U];
@@ -161,7 +173,7 @@ __device__ __forceinline__ void prep_graph_body(const PrepParams& q, int g, int 
 #pragma unroll
         for (int u = 0; u < U; ++u)
             if (tv_r[u] >= 0)                                            // {source, target, caller column}
-                q.csr[rb[tv_r[u]] + rk_r[u]] = make_int4(n0 + sv_r[u], n0 + tv_r[u], c0 + tid + u * 1024, 0);
+                q.csr[rb[tv_r[u] - lo] + rk_r[u]] = make_int4(n0 + sv_r[u], n0 + tv_r[u], c0 + tid + u * 1024, 0);
     } else {
         for (int c = tid; c < Eg; c += U * 1024) {
             int sv[U], tv[U], rk[U];
@@ -195,11 +207,10 @@ __device__ __forceinline__ void prep_graph_body(const PrepParams& q, int g, int 
 
 // goal node of graph g: argmin_i |v_i - goal|^2, lowest index on ties (model.py:132); any power-of-two workgroup
 __device__ __forceinline__ void goal_body(int C, const float* __restrict__ v, const float* __restrict__ goal,
-                                          const int* __restrict__ node_ptr, int g, int n0_pad, int* __restrict__ goal_node) {
+                                          int n0, int n, int g, int n0_pad, int* __restrict__ goal_node) {
     __shared__ float s_d[16];
     __shared__ int s_i[16];
     const int tid = threadIdx.x, nt = blockDim.x;
-    const int n0 = node_ptr[g], n = node_ptr[g + 1] - n0;
     float best = INFINITY;
     int bi = 0x7fffffff;
     for (int i = tid; i < n; i += nt) {
@@ -246,19 +257,24 @@ __device__ __forceinline__ void goal_body(int C, const float* __restrict__ v, co
 // -----------------------------------------------------------------------------------------------------
 // padded prefix sums over the graphs before graph g (every workgroup reduces them itself -- G loads spread over 1024
 // threads -- instead of waiting for a separate scan launch); part 0 publishes the entries of its graph
+template <bool FENCE>
 __device__ __forceinline__ void prep_prefix(const PrepParams& q, int g, int part, int& n0, int& n1, int& e0, int& e1) {
     __shared__ long long red[3][16];
     const int tid = threadIdx.x;
     if (q.single_out) {                                // one graph given by its totals: its prefix arrays come first
         if (tid < 6) q.single_out[tid] = (tid & 1) ? (tid == 1 ? q.single_n : (tid == 3 ? q.single_e : q.single_o)) : 0;
-        __threadfence();
-        __syncthreads();
+        // FENCE: the caller goes on to read the arrays through q.node_ptr / q.edge_ptr; the one-launch form reads the kernel
+        // arguments instead (prep_np / prep_ep) and does not pay the ~1.5 us of the device-scope fence
+        if constexpr (FENCE) {
+            __threadfence();
+            __syncthreads();
+        }
     }
     long long an = 0, ae = 0, ad = 0;
     for (int t = tid; t < g; t += 1024) {
-        const int ng = q.node_ptr[t + 1] - q.node_ptr[t];
+        const int ng = prep_np(q, t + 1) - prep_np(q, t);
         an += round_up(ng, kPad);
-        ae += round_up(q.edge_ptr[t + 1] - q.edge_ptr[t], kPad);
+        ae += round_up(prep_ep(q, t + 1) - prep_ep(q, t), kPad);
         ad += (long long)ng * ng;
     }
 #pragma unroll
@@ -268,9 +284,9 @@ __device__ __forceinline__ void prep_prefix(const PrepParams& q, int g, int part
     an = 0; ae = 0; ad = 0;
 #pragma unroll
     for (int w = 0; w < 16; ++w) { an += red[0][w]; ae += red[1][w]; ad += red[2][w]; }
-    const int ng_own = q.node_ptr[g + 1] - q.node_ptr[g];
+    const int ng_own = prep_np(q, g + 1) - prep_np(q, g);
     n0 = (int)an; e0 = (int)ae;
-    n1 = n0 + round_up(ng_own, kPad); e1 = e0 + round_up(q.edge_ptr[g + 1] - q.edge_ptr[g], kPad);
+    n1 = n0 + round_up(ng_own, kPad); e1 = e0 + round_up(prep_ep(q, g + 1) - prep_ep(q, g), kPad);
     if (tid == 0 && part == 0) {
         if (g == 0) { q.node_ptr_pad[0] = 0; q.edge_ptr_pad[0] = 0; q.dense_ptr[0] = 0; }
         q.node_ptr_pad[g + 1] = n1; q.edge_ptr_pad[g + 1] = e1; q.dense_ptr[g + 1] = ad + (long long)ng_own * ng_own;
@@ -290,9 +306,9 @@ __global__ __launch_bounds__(1024) void prep_small_kernel(PrepParams q, int Npad
     extern __shared__ int prep_lds[];
     const int g = blockIdx.x / parts, part = blockIdx.x - g * parts;
     int n0, n1, e0, e1;
-    prep_prefix(q, g, part, n0, n1, e0, e1);
+    prep_prefix<false>(q, g, part, n0, n1, e0, e1);
     prep_graph_body(q, g, part, parts, n0, n1 - n0, e0, e1, prep_lds);
-    if (part == 0) goal_body(q.C, q.v, q.goal, q.node_ptr, g, n0, q.goal_node);
+    if (part == 0) goal_body(q.C, q.v, q.goal, prep_np(q, g), prep_np(q, g + 1) - prep_np(q, g), g, n0, q.goal_node);
     if (g == q.G - 1 && part == parts - 1) prep_trailing(q, n1, e1, Npad, Epad);
 }
 
@@ -313,7 +329,7 @@ __global__ __launch_bounds__(1024) void prep_hist_kernel(PrepParams q, int Npad,
     const int idx = blockIdx.x >> 3, g = (idx / parts) * 8 + (blockIdx.x & 7), part = idx % parts, tid = threadIdx.x;
     if (g >= q.G) return;
     int n0, n1, e0, e1;
-    prep_prefix(q, g, part, n0, n1, e0, e1);
+    prep_prefix<true>(q, g, part, n0, n1, e0, e1);
     const int Np = n1 - n0;
     const int c0 = q.edge_ptr[g], Eg = q.edge_ptr[g + 1] - c0;
     const int cs = (int)((long long)Eg * part / parts), ce = (int)((long long)Eg * (part + 1) / parts);
@@ -342,7 +358,7 @@ __global__ __launch_bounds__(1024) void prep_hist_kernel(PrepParams q, int Npad,
         q.etile_graph[t] = g;
         q.tile_meta[t] = t * 32 < e0 + Eg ? 4 : 0;
     }
-    if (part == parts - 1) goal_body(q.C, q.v, q.goal, q.node_ptr, g, n0, q.goal_node);
+    if (part == parts - 1) goal_body(q.C, q.v, q.goal, q.node_ptr[g], q.node_ptr[g + 1] - q.node_ptr[g], g, n0, q.goal_node);
     if (g == q.G - 1 && part == 0) prep_trailing(q, n1, e1, Npad, Epad);
 }
 
@@ -1515,6 +1531,17 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
             if (q8 >= per) return;
         }
     }
+    // few tiles: a workgroup has ONE tile; its row range (and graph) are requested before the weights are staged, so that
+    // round trip runs under the staging instead of behind it (a launch here is a handful of dependent round trips)
+    int pre_rb = 0, pre_dg = 0, pre_g = -1;
+    if constexpr (kCoop) {
+        XcdWalk wk0(min(p.n_tiles, p.node_ptr_pad[p.G] >> 5));
+        if (wk0.valid() && wk0.cur < p.n_tiles) {
+            pre_g = p.ntile_graph[wk0.cur];
+            pre_rb = p.row_beg[wk0.cur * 32 + j];
+            pre_dg = p.deg[wk0.cur * 32 + j];
+        }
+    }
     stage(wl, p.we, LE::size);
     // d = 32: the node phase's weights (MpNBlob, 20 KB) fit next to the tiles -- staged once per workgroup instead of read
     // from L1 / L2 as MFMA operands by every tile (five launches at cfg 2: 0.910 -> 0.872 ms)
@@ -1551,13 +1578,15 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
         // is one dense front in HBM and neighbouring tiles share gathered A rows (tiles pulled one by one from a per-XCD
         // counter, or one contiguous run of tiles per workgroup, both measured 13-18 % slower)
         const int tile = kCoop ? wk.cur : wk.cur * 4 + wave;
-        if (tile >= p.n_tiles || p.ntile_graph[tile] < 0) continue;           // workgroup-uniform when kCoop
+        if (tile >= p.n_tiles) continue;
+        const int tg = kCoop ? pre_g : p.ntile_graph[tile];                    // kCoop: the workgroup's only tile, requested above
+        if (tg < 0) continue;                                                  // workgroup-uniform when kCoop
         const int t0 = tile * 32;
         const int node = t0 + j;
-        const int rb = p.row_beg[node], dg = p.deg[node];
+        const int rb = kCoop ? pre_rb : p.row_beg[node], dg = kCoop ? pre_dg : p.deg[node];
         const int beg = __builtin_amdgcn_readfirstlane(rb);
         const int end = __builtin_amdgcn_readlane(rb + dg, 31);
-        const int n0 = p.node_ptr_pad[p.ntile_graph[tile]];
+        const int n0 = p.node_ptr_pad[tg];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the previous job's LDS reads are done
         if constexpr (kCoop) __syncthreads();                    // ... by every wave of the workgroup
         if (!kCoop || wave == 0) {
@@ -1940,7 +1969,18 @@ hipError_t launch_prep(const PrepParams& q, int Npad, int Epad, int* hist, hipSt
     if (parts == 1) {
         const hipError_t attr = set_lds(prep_small_kernel, glds);
         if (attr != hipSuccess) return attr;
-        hipLaunchKernelGGL(prep_small_kernel, dim3(q.G), dim3(1024), glds, st, q, Npad, Epad, 1);
+        // Few graphs (the reference's call is ONE): a graph's target nodes are cut into slices, one workgroup each.  A
+        // workgroup's scatter of the int4 records is bound by its CU's request rate to L2 (one 16-byte store per clock: 7 of the
+        // 14 us a single 1000-node graph's CSR build took); every slice's workgroup reads all columns (L2 hits) and ranks /
+        // scatters its own.  One slice per 128 target nodes at most, and no more workgroups than a third of the CUs.
+        static const int slices_env = getenv("GNNMP_PREP_SLICES") ? atoi(getenv("GNNMP_PREP_SLICES")) : 0;    // experiments
+        int slices = q.G > 0 ? 84 / q.G : 1;
+        const int by_nodes = q.G > 0 ? (Npad / q.G) / 128 : 1;
+        if (slices > by_nodes) slices = by_nodes;
+        if (slices > 8) slices = 8;
+        if (slices_env > 0) slices = slices_env;
+        if (slices < 1) slices = 1;
+        hipLaunchKernelGGL(prep_small_kernel, dim3(q.G * slices), dim3(1024), glds, st, q, Npad, Epad, slices);
         LAUNCH_CHECK();
         return hipSuccess;
     }
