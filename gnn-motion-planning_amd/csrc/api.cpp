@@ -1106,7 +1106,7 @@ extern "C" int gnnmp_smoother_destroy(gnnmp_smoother* h) {
 namespace {
 struct SmCarve {
     int ecap, pcap;
-    size_t cur, knn, e_src, e_dst, e_count, seg_beg, seg_cnt, ff_beg, etile, ptile, ff_end, msg, total;
+    size_t cur, knn, e_src, e_dst, e_count, seg_beg, seg_cnt, ff_beg, etile, ptile, ff_end, msg, tgt, tflag, total;
 };
 
 bool sm_carve(const gnnmp_smoother* h, const gnnmp_smooth_batch* b, SmCarve& c) {
@@ -1132,6 +1132,8 @@ bool sm_carve(const gnnmp_smoother* h, const gnnmp_smooth_batch* b, SmCarve& c) 
     c.ptile = take(sizeof(int) * (c.pcap / 32));
     c.ff_end = o;
     c.msg = take(sizeof(float) * (size_t)c.ecap * D);
+    c.tgt = take(sizeof(float) * (size_t)c.pcap * D);
+    c.tflag = take(sizeof(int) * (c.pcap / 32));
     c.total = o;
     return true;
 }
@@ -1176,6 +1178,8 @@ extern "C" int gnnmp_smoother_forward(const gnnmp_smoother* h, const gnnmp_smoot
     p.seg_beg = at<int>(ws, c.seg_beg); p.seg_cnt = at<int>(ws, c.seg_cnt);
     p.etile_prob = at<int>(ws, c.etile); p.ptile_prob = at<int>(ws, c.ptile);
     p.msg = at<float>(ws, c.msg);
+    p.tgt = at<float>(ws, c.tgt); p.tgt_flag = at<int>(ws, c.tflag);
+    { static const int no_tgt = getenv("GNNMP_SM_NO_TARGET_ROLE") ? atoi(getenv("GNNMP_SM_NO_TARGET_ROLE")) : 0; if (no_tgt) p.tgt_flag = nullptr; }      // experiments
     p.cand_cap = b->max_edges + kSmK * b->max_path;
     if (p.cand_cap < 1) p.cand_cap = 1;
     p.samp_cap = b->max_samples > 0 ? b->max_samples : 0; p.path_cap = b->max_path > 0 ? b->max_path : 0;
@@ -1640,6 +1644,8 @@ void sm_fill_params(const gnnmp_smoother* h, const gnnmp_smooth_batch* b, const 
     p.seg_beg = at<int>(ws, c.seg_beg); p.seg_cnt = at<int>(ws, c.seg_cnt);
     p.etile_prob = at<int>(ws, c.etile); p.ptile_prob = at<int>(ws, c.ptile);
     p.msg = at<float>(ws, c.msg);
+    p.tgt = at<float>(ws, c.tgt); p.tgt_flag = at<int>(ws, c.tflag);
+    { static const int no_tgt = getenv("GNNMP_SM_NO_TARGET_ROLE") ? atoi(getenv("GNNMP_SM_NO_TARGET_ROLE")) : 0; if (no_tgt) p.tgt_flag = nullptr; }      // experiments
     p.cand_cap = b->max_edges + kSmK * b->max_path;
     if (p.cand_cap < 1) p.cand_cap = 1;
     p.samp_cap = b->max_samples > 0 ? b->max_samples : 0; p.path_cap = b->max_path > 0 ? b->max_path : 0;

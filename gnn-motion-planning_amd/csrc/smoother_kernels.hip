@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void sm_edges_kernel(SmParams p) {
     const int et_end = b + 1 < p.B ? sm_eoff(p, b + 1) / 32 : p.n_etiles;
     const int pt_end = b + 1 < p.B ? sm_poff(p, b + 1) / 32 : p.n_ptiles;
     for (int t = eoff / 32 + tid; t < et_end; t += 256) p.etile_prob[t] = t < et_used ? b : -1;
-    for (int t = poff / 32 + tid; t < pt_end; t += 256) p.ptile_prob[t] = t < pt_used ? b : -1;
+    for (int t = poff / 32 + tid; t < pt_end; t += 256) { p.ptile_prob[t] = t < pt_used ? b : -1; if (p.tgt_flag) p.tgt_flag[t] = 0; }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -475,7 +475,7 @@ __global__ __launch_bounds__(1024) void sm_graph_kernel(SmParams p) {
     const int et_end = b + 1 < p.B ? sm_eoff(p, b + 1) / 32 : p.n_etiles;
     const int pt_end = b + 1 < p.B ? sm_poff(p, b + 1) / 32 : p.n_ptiles;
     for (int t = eoff / 32 + tid; t < et_end; t += 1024) p.etile_prob[t] = t < et_used ? b : -1;
-    for (int t = poff / 32 + tid; t < pt_end; t += 1024) p.ptile_prob[t] = t < pt_used ? b : -1;
+    for (int t = poff / 32 + tid; t < pt_end; t += 1024) { p.ptile_prob[t] = t < pt_used ? b : -1; if (p.tgt_flag) p.tgt_flag[t] = 0; }
 }
 
 // node features [coords / scale (path rows are already scaled), one-hot(kind)]   model_smoother.py:130-135
@@ -619,14 +619,21 @@ __global__ __launch_bounds__(256) void sm_node_kernel(SmParams p) {
 // the results are bit-identical.
 // ---------------------------------------------------------------------------------------------------
 template <int NT>
-__device__ __forceinline__ void sm_exchange(float* buf, int wave, const f32x16& mine, f32x16 (&all)[NT], int lane) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) buf[(wave * 16 + r) * 64 + lane] = mine[r];
-    __syncthreads();
+__device__ __forceinline__ void sm_exchange_get(const float* buf, f32x16 (&all)[NT], int lane) {
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) all[t][r] = buf[(t * 16 + r) * 64 + lane];
+}
+__device__ __forceinline__ void sm_exchange_put(float* buf, int wave, const f32x16& mine, int lane) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) buf[(wave * 16 + r) * 64 + lane] = mine[r];
+    __syncthreads();
+}
+template <int NT>
+__device__ __forceinline__ void sm_exchange(float* buf, int wave, const f32x16& mine, f32x16 (&all)[NT], int lane) {
+    sm_exchange_put(buf, wave, mine, lane);
+    sm_exchange_get<NT>(buf, all, lane);
 }
 
 // tile `wave` of x = node_code(in): layer 0 (a few MFMAs from the raw inputs) is computed whole by every wave
@@ -643,33 +650,91 @@ __device__ __forceinline__ void sm_node_code_tile(const SmParams& p, const SmNod
     x = y[0];
 }
 
+// Target role.  The first-layer term of a message that belongs to the TARGET, b00 + (W_c - W_a) x_i, is the same for every
+// incoming edge of a path node (~13 of them), and it is 40 % of an edge tile's MFMAs (node_code of the target + one d x d
+// layer).  The first n_ptiles workgroups of the launch compute it once per path node (one 32-node tile each, same chain,
+// same accumulation order) and publish the rows; an edge tile computes its source half first, then takes its rows from
+// there -- the accumulator it continues with is bit for bit the one it would have computed itself.  Target workgroups have
+// the lowest block indices, i.e. they are resident before any edge workgroup; should a flag nevertheless not show up within
+// the polling budget, the edge tile computes the target half itself (same bits), so the wait can never hang a launch.
+// Registers: without a bound the compiler spreads the chain's operand prefetch over 94 VGPRs + 80 AGPRs (two workgroups per
+// CU); asked for four workgroups per CU it fits 124 without spilling.
 template <int D, int P>
-__global__ __launch_bounds__(D * 2) void sm_msg_split_kernel(SmParams p) {
+__global__ __launch_bounds__(D * 2, D == 128 ? 4 : 1) void sm_msg_split_kernel(SmParams p) {
     constexpr int NT = D / 32;
     __shared__ float xbuf[2][NT * 16 * 64];
+    __shared__ int s_ready;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
-    const int tile = blockIdx.x;
-    const int b = p.etile_prob[tile];
-    if (b < 0) return;                                   // workgroup-uniform
-    const int eoff = sm_eoff(p, b);
-    const int e = tile * 32 + j;
-    const bool valid = (e - eoff) < p.e_count[b];
-    const int src = valid ? p.e_src[e] : 0, dst = valid ? p.e_dst[e] : 0;
     const float* W = p.w;
     constexpr size_t TF = Prec<P>::TF;
+    const int n_troles = p.tgt_flag ? p.n_ptiles : 0;
+    const bool trole = (int)blockIdx.x < n_troles;       // workgroup-uniform
+    int b, src = 0, dst = 0, e = 0, trow = 0;
+    if (trole) {
+        const int tile = blockIdx.x;
+        b = p.ptile_prob[tile];
+        if (b < 0) return;
+        const int PN = sm_pp(p, b + 1) - sm_pp(p, b);
+        const int n = tile * 32 + j - sm_poff(p, b);     // local path index
+        dst = n < PN ? n : 0;
+        trow = tile * 32 + j;
+    } else {
+        const int tile = blockIdx.x - n_troles;
+        b = p.etile_prob[tile];
+        if (b < 0) return;
+        e = tile * 32 + j;
+        const bool valid = (e - sm_eoff(p, b)) < p.e_count[b];
+        src = valid ? p.e_src[e] : 0;
+        dst = valid ? p.e_dst[e] : 0;
+        trow = sm_poff(p, b) + dst;                      // the target's row in the padded path space
+    }
+    bool target_half = trole;                            // does this workgroup compute b00 + (W_c - W_a) x_i itself?
+    if (!trole) {
+        // source half first: it does not depend on the target rows.  The tile stays in xbuf[1] until it is needed
+        f32x16 mine;
+        sm_node_code_tile<NT, P>(p, sm_node_in(p, b, src), wave, mine, lane);      // x_j (source)
+        sm_exchange_put(xbuf[1], wave, mine, lane);
+        if (n_troles > 0) {
+            if (wave == 0) {                             // the flags of the path tiles this edge tile's targets live in
+                bool ready = false;
+                for (int spin = 0; spin < 256 && !ready; ++spin) {
+                    // relaxed: an acquire here would invalidate the CU's L1 (every wave's weight operands) on every poll; the
+                    // one acquire fence below, after the flags are up, is what orders the row loads
+                    const int f = __hip_atomic_load(&p.tgt_flag[trow >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ready = __all(f != 0);
+                    if (!ready) __builtin_amdgcn_s_sleep(8);
+                }
+                if (lane == 0) s_ready = ready ? 1 : 0;
+            }
+            __syncthreads();
+            target_half = s_ready == 0;                  // the rare path: a flag did not show up in time
+        } else {
+            target_half = true;
+        }
+    }
     f32x16 z[1];
-    load_vec<1>(W + p.L.b00 + wave * 32, z, lane);
-    {
+    if (target_half) {                                   // workgroup-uniform; ONE copy of this code for both roles
         f32x16 mine, x[NT];
+        load_vec<1>(W + p.L.b00 + wave * 32, z, lane);
         sm_node_code_tile<NT, P>(p, sm_node_in(p, b, dst), wave, mine, lane);      // x_i (target)
         sm_exchange<NT>(xbuf[0], wave, mine, x, lane);
         linear_acc_p<P, 1, NT>(W + p.L.wdst + (size_t)wave * NT * TF, x, z, lane);   // (W_c - W_a) x_i
+        if (trole) {
+            store_row<1>(p.tgt + (size_t)trow * D + wave * 32, z, h);
+            __threadfence();                             // the rows are visible device-wide before the flag is
+            __syncthreads();
+            if (threadIdx.x == 0) __hip_atomic_store(&p.tgt_flag[blockIdx.x], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        __syncthreads();                                 // every wave has read xbuf[0] before the z exchange below reuses it
+    } else {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        load_row<1>(p.tgt + (size_t)trow * D + wave * 32, z, h);
     }
     {
-        f32x16 mine, x[NT];
-        sm_node_code_tile<NT, P>(p, sm_node_in(p, b, src), wave, mine, lane);      // x_j (source)
-        sm_exchange<NT>(xbuf[1], wave, mine, x, lane);
-        linear_acc_p<P, 1, NT>(W + p.L.wsrc + (size_t)wave * NT * TF, x, z, lane);   // (W_a + W_b) x_j
+        f32x16 xs[NT];
+        sm_exchange_get<NT>(xbuf[1], xs, lane);
+        linear_acc_p<P, 1, NT>(W + p.L.wsrc + (size_t)wave * NT * TF, xs, z, lane);  // (W_a + W_b) x_j
     }
     relu_<1>(z);
     f32x16 zall[NT], m[1];
@@ -811,7 +876,7 @@ static hipError_t launch_sm_iter_t(const SmParams& p, hipStream_t st) {
     static const int split_env = getenv("GNNMP_SM_SPLIT") ? atoi(getenv("GNNMP_SM_SPLIT")) : -1;
     const bool split = D >= 64 && (split_env >= 0 ? split_env != 0 : (P == 0 || p.n_etiles <= kSmSplitMaxTilesBf16));
     if (split) {
-        hipLaunchKernelGGL((sm_msg_split_kernel<D, P>), dim3(p.n_etiles), dim3(D * 2), 0, st, p);
+        hipLaunchKernelGGL((sm_msg_split_kernel<D, P>), dim3(p.n_etiles + (p.tgt_flag ? p.n_ptiles : 0)), dim3(D * 2), 0, st, p);
         LAUNCH_CHECK();
         hipLaunchKernelGGL((sm_node_split_kernel<D, P>), dim3(p.n_ptiles), dim3(D * 2), 0, st, p);
         LAUNCH_CHECK();
