@@ -1206,7 +1206,7 @@ extern "C" int gnnmp_smoother_forward(const gnnmp_smoother* h, const gnnmp_smoot
 // device-side graph construction (create_data counterpart, eval_gnn.py:159-164)
 // =============================================================================================
 namespace {
-struct GbCarve { size_t nb_all, nb_free, zero_beg, cnt, cur, zero_end, off, ucnt, uoff, gtotal, bucket, total; };
+struct GbCarve { size_t nb_all, nb_free, zero_beg, cnt, cur, large_cnt, zero_end, off, ucnt, uoff, gtotal, bucket, total; };
 bool gb_carve(const gnnmp_graph_batch* b, GbCarve& c) {
     if (b->n_graphs < 1 || b->total_nodes < 0 || b->k1_max < 1 || b->config_size < 1) return false;
     if ((long long)4 * b->k1_max * b->total_nodes > 0x3fffffffLL) return false;
@@ -1218,6 +1218,7 @@ bool gb_carve(const gnnmp_graph_batch* b, GbCarve& c) {
     c.zero_beg = o;
     c.cnt = take(sizeof(int) * n);
     c.cur = take(sizeof(int) * n);
+    c.large_cnt = take(sizeof(int));
     c.zero_end = o;
     c.off = take(sizeof(int) * n);
     c.ucnt = take(sizeof(int) * n);
@@ -1254,6 +1255,7 @@ extern "C" int gnnmp_graph_build(const gnnmp_graph_batch* b, int64_t* edge_index
     p.cnt = at<int>(ws, c.cnt); p.cur = at<int>(ws, c.cur); p.off = at<int>(ws, c.off);
     p.ucnt = at<int>(ws, c.ucnt); p.uoff = at<int>(ws, c.uoff); p.gtotal = at<int>(ws, c.gtotal);
     p.bucket = at<int>(ws, c.bucket);
+    p.large_cnt = at<int>(ws, c.large_cnt); p.large = p.uoff;      // (uoff is first written after the kNN launches)
     p.edge_ptr = edge_ptr_out;
     p.edge_index = reinterpret_cast<long long*>(edge_index_out);
     p.out_cap = out_cap;

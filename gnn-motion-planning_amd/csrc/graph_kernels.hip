@@ -31,28 +31,68 @@ __device__ __forceinline__ int gb_find(const int* __restrict__ ptr, int G, int x
     return lo;
 }
 
-// Selection with the candidate distances held in registers (T per lane, graphs up to 64 T nodes): distances are
-// computed once per pass, then each of the k rounds is a register scan + a wave argmin over (distance, index),
-// and the winner is retired.  Same order as the general path: ascending distance, ties by the lower index.
-template <int T>
-__device__ __forceinline__ void gb_knn_cached(const GbParams& p, const float* __restrict__ xi, int n0, int M, int k,
-                                              int* __restrict__ out, int lane) {
-    const int C = p.C;
-    double dist[T];
-#pragma unroll
-    for (int t = 0; t < T; ++t) {
-        const int c = t * 64 + lane;
-        double d = INFINITY;
-        if (c < M) {
-            const float* xc = p.v + (size_t)(n0 + c) * C;
-            d = 0.0;
-            for (int q = 0; q < C; ++q) {
-                const double df = (double)xi[q] - (double)xc[q];
-                d = fma(df, df, d);
-            }
-        }
-        dist[t] = d;
+// Wave-wide minima without LDS round trips: inside a row of 16 lanes the partner values come through the VALU's DPP path
+// (quad permutes, then the half-row and row mirrors -- any pairing that crosses the halves works for a reduction), across
+// rows through v_permlane16_swap / v_permlane32_swap.  The result is in every lane.
+template <int CTRL> __device__ __forceinline__ int gb_dpp(int x) { return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xf, 0xf, false); }
+template <int CTRL> __device__ __forceinline__ double gb_dpp(double x) {
+    return __hiloint2double(gb_dpp<CTRL>(__double2hiint(x)), gb_dpp<CTRL>(__double2loint(x)));
+}
+__device__ __forceinline__ double gb_wave_min(double x) {
+    x = fmin(x, gb_dpp<0xB1>(x));              // quad_perm [1,0,3,2]
+    x = fmin(x, gb_dpp<0x4E>(x));              // quad_perm [2,3,0,1]
+    x = fmin(x, gb_dpp<0x141>(x));             // row_half_mirror
+    x = fmin(x, gb_dpp<0x140>(x));             // row_mirror
+    {
+        const unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
+        const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+        const auto c = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        x = fmin(__hiloint2double((int)c[0], (int)a[0]), __hiloint2double((int)c[1], (int)a[1]));
     }
+    {
+        const unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
+        const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+        const auto c = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        x = fmin(__hiloint2double((int)c[0], (int)a[0]), __hiloint2double((int)c[1], (int)a[1]));
+    }
+    return x;
+}
+__device__ __forceinline__ int gb_wave_min(int x) {
+    x = min(x, gb_dpp<0xB1>(x));
+    x = min(x, gb_dpp<0x4E>(x));
+    x = min(x, gb_dpp<0x141>(x));
+    x = min(x, gb_dpp<0x140>(x));
+    const auto a = __builtin_amdgcn_permlane16_swap((unsigned)x, (unsigned)x, false, false);
+    x = min((int)a[0], (int)a[1]);
+    const auto c = __builtin_amdgcn_permlane32_swap((unsigned)x, (unsigned)x, false, false);
+    return min((int)c[0], (int)c[1]);
+}
+
+// squared distances (float64 from the fp32 coordinates, accumulated over the coordinates in order with fma -- what the oracle's
+// cdist does) from centre xi to the candidates lane, lane + 64, ... of its graph: coordinate by coordinate with all T slots of
+// the lane in flight (a guard and an inner coordinate loop per slot left the loads waiting on each other one by one)
+template <int T>
+__device__ __forceinline__ void gb_distances(const GbParams& p, const float* __restrict__ xi, int n0, int M, double (&dist)[T], int lane) {
+    const int C = p.C;
+#pragma unroll
+    for (int t = 0; t < T; ++t) dist[t] = 0.0;
+    for (int q = 0; q < C; ++q) {
+        const double xq = (double)xi[q];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const int c = t * 64 + lane;
+            const double df = xq - (double)p.v[(size_t)(n0 + (c < M ? c : 0)) * C + q];
+            dist[t] = fma(df, df, dist[t]);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+        if (t * 64 + lane >= M) dist[t] = INFINITY;
+}
+
+// k rounds of "smallest (distance, index), lowest index on ties" over the distances in registers; the winner is retired
+template <int T>
+__device__ __forceinline__ void gb_select(const GbParams& p, double (&dist)[T], int k, int* __restrict__ out, int lane) {
     for (int r = 0; r < p.kmax; ++r) {
         int pick = -1;
         if (r < k) {
@@ -61,12 +101,8 @@ __device__ __forceinline__ void gb_knn_cached(const GbParams& p, const float* __
 #pragma unroll
             for (int t = 0; t < T; ++t)
                 if (dist[t] < bd) { bd = dist[t]; bi = t * 64 + lane; }      // ascending t = ascending index per lane
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const double od = __shfl_xor(bd, off, 64);
-                const int oi = __shfl_xor(bi, off, 64);
-                if (od < bd || (od == bd && oi < bi)) { bd = od; bi = oi; }
-            }
+            const double gm = gb_wave_min(bd);
+            bi = gb_wave_min(bd == gm ? bi : 0x7fffffff);                    // lowest index among the candidates at the minimum
             pick = bi;
 #pragma unroll
             for (int t = 0; t < T; ++t)
@@ -76,17 +112,44 @@ __device__ __forceinline__ void gb_knn_cached(const GbParams& p, const float* __
     }
 }
 
-// pass 0 = neighbours among all nodes, pass 1 = among the free nodes only (centres < n_free)
-__global__ __launch_bounds__(256) void gb_knn_kernel(GbParams p) {
+// pass 0 = neighbours among all nodes, pass 1 = among the free nodes only (centres < n_free).
+// Two instantiations, launched one after the other: SMALL takes the nodes of graphs up to 1024 nodes (16 candidate
+// distances per lane in registers, both passes from ONE set of distances: the free nodes come first in a graph, so the
+// second pass's candidates are a prefix of the first pass's) and lists the nodes of larger graphs for the other one (32 per
+// lane up to 2048 nodes, beyond that every round recomputes the distances).  One kernel for all sizes is allocated the registers of
+// its largest path (226: two waves per SIMD for selection rounds that are dependent chains).
+template <bool SMALL>
+__global__ __launch_bounds__(256, SMALL ? 4 : 1) void gb_knn_kernel(GbParams p) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int node = blockIdx.x * 4 + wave;                // global node row
+    int node = blockIdx.x * 4 + wave;                      // global node row (SMALL) / slot of the large-node list
+    if constexpr (!SMALL) {
+        if (node >= *p.large_cnt) return;                  // (one scalar load: usually there is no such node)
+        node = p.large[node];
+    }
     if (node >= p.total_nodes) return;
     const int g = gb_find(p.node_ptr, p.G, node);
     const int n0 = p.node_ptr[g], N = p.node_ptr[g + 1] - n0;
+    if constexpr (SMALL) {
+        if (N > 1024) {                                    // listed for the second launch
+            if (lane == 0) p.large[atomicAdd(p.large_cnt, 1)] = node;
+            return;
+        }
+    }
     const int F = min(p.n_free[g], N);
     const int i = node - n0;
     const int C = p.C;
     const float* xi = p.v + (size_t)node * C;
+    if constexpr (SMALL) {
+        double dist[16], keep[16];
+        gb_distances<16>(p, xi, n0, N, dist, lane);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) keep[t] = t * 64 + lane < F ? dist[t] : (double)INFINITY;
+        gb_select<16>(p, dist, min(p.k1[g], N), p.nb_all + (size_t)node * p.kmax, lane);
+        int* of = p.nb_free + (size_t)node * p.kmax;
+        if (i < F) gb_select<16>(p, keep, min(p.k1[g], F), of, lane);
+        else for (int r = lane; r < p.kmax; r += 64) of[r] = -1;
+        return;
+    }
     for (int pass = 0; pass < 2; ++pass) {
         const int M = pass == 0 ? N : F;                   // candidate set size
         int* out = (pass == 0 ? p.nb_all : p.nb_free) + (size_t)node * p.kmax;
@@ -95,8 +158,12 @@ __global__ __launch_bounds__(256) void gb_knn_kernel(GbParams p) {
             for (int r = lane; r < p.kmax; r += 64) out[r] = -1;
             continue;
         }
-        if (M <= 1024) { gb_knn_cached<16>(p, xi, n0, M, k, out, lane); continue; }
-        if (M <= 2048) { gb_knn_cached<32>(p, xi, n0, M, k, out, lane); continue; }
+        if (M <= 2048) {
+            double dist[32];
+            gb_distances<32>(p, xi, n0, M, dist, lane);
+            gb_select<32>(p, dist, k, out, lane);
+            continue;
+        }
         // general path (any graph size): every round recomputes the distances and takes the smallest
         // (distance, index) strictly after the previous pick
         double last_d = -1.0;
@@ -295,8 +362,12 @@ __global__ void gb_write_kernel(GbParams p) {
 
 hipError_t launch_graph_build(const GbParams& p, hipStream_t st) {
     const int nb = (p.total_nodes + 255) / 256;
-    hipLaunchKernelGGL(gb_knn_kernel, dim3((p.total_nodes + 3) / 4), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(gb_knn_kernel<true>, dim3((p.total_nodes + 3) / 4), dim3(256), 0, st, p);
     LAUNCH_CHECK();
+    if (p.total_nodes > 1024) {                            // (a graph of more than 1024 nodes needs more than 1024 nodes in all)
+        hipLaunchKernelGGL(gb_knn_kernel<false>, dim3((p.total_nodes + 3) / 4), dim3(256), 0, st, p);
+        LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL(gb_count_kernel, dim3(nb), dim3(256), 0, st, p);
     LAUNCH_CHECK();
     hipLaunchKernelGGL(gb_scan_kernel, dim3(p.G), dim3(256), 0, st, p, (const int*)p.cnt, p.off, (int*)nullptr,

@@ -131,6 +131,7 @@ struct GbParams {
     const int *node_ptr, *n_free, *k1;
     int *nb_all, *nb_free;            // [total_nodes, kmax] neighbour ids (graph-local) or -1
     int *cnt, *cur, *off, *ucnt, *uoff, *gtotal;
+    int *large_cnt, *large;           // nodes of graphs beyond 1024 nodes, listed by the first kNN launch for the second (large aliases uoff)
     int* bucket;                      // [4 * kmax * total_nodes] targets grouped by source
     int* edge_ptr;                    // out [G+1]
     long long* edge_index;            // out [2, out_cap]

@@ -106,6 +106,9 @@ def test_hub_bucket_beyond_lds_share_and_large_graphs():
     _check([x, torch.rand(50, 7, generator=gen)], [400, 20], [2, 3])
     _check([torch.rand(1500, 2, generator=gen) * 2 - 1], [700], [5])
     _check([torch.rand(2500, 3, generator=gen) * 2 - 1], [1200], [4])
+    # small and large graphs in one batch: the first kNN launch handles the small ones and lists the others' nodes for the second
+    _check([torch.rand(300, 2, generator=gen), torch.rand(1500, 2, generator=gen), torch.rand(40, 2, generator=gen),
+            torch.rand(2100, 2, generator=gen), torch.rand(1024, 2, generator=gen)], [100, 800, 40, 1000, 500], [4, 5, 3, 4, 6])
 
 
 def test_small_capacity_is_retried(monkeypatch):
