@@ -35,16 +35,21 @@ __device__ __forceinline__ float f_div(float x, float y) { return x / y; }      
 __device__ __forceinline__ float f_sqrt(float x) { return __builtin_sqrtf(x); }   // correctly rounded (hipcc default)
 
 constexpr int kMazeLdsCells = 4096;      // maps up to 64 x 64 are staged into LDS as bytes
+constexpr int kMazeLdsNodes = 1024;      // problems up to this many nodes keep their per-node explore state in LDS
 
 struct MazeCtx {
     const double* map;          // [w, w] occupancy (1 = obstacle), row-major map[x][y]
     const unsigned char* occ;   // LDS copy (1 = obstacle) or nullptr for maps beyond kMazeLdsCells
     int w;
     long long checks;
+    double* stack;              // LDS, 4 x 48 doubles: the bisection's explicit stack (ONE lane of the wave walks a segment at a time;
+                                // as private arrays indexed at run time it lived in scratch memory, a global round trip per push / pop)
 };
 
 // all lanes of the wave: stage the problem's map into LDS
 __device__ __forceinline__ void maze_ctx_init(MazeCtx& m, const double* map, int w, unsigned char* lds, int lane) {
+    __shared__ double s_stack[4 * 48];
+    m.stack = s_stack;
     m.map = map;
     m.w = w;
     m.checks = 0;
@@ -74,7 +79,7 @@ __device__ __forceinline__ bool maze_state_fp(MazeCtx& m, float x, float y) {
 
 // iterative form of the recursive bisection (left half first, stop at the first blocked midpoint)
 __device__ bool maze_segment_fp(MazeCtx& m, float ax, float ay, float bx, float by) {
-    float sx0[48], sy0[48], sx1[48], sy1[48];
+    float* sx0 = reinterpret_cast<float*>(m.stack), *sy0 = sx0 + 48, *sx1 = sx0 + 96, *sy1 = sx0 + 144;
     int sp = 0;
     sx0[0] = ax; sy0[0] = ay; sx1[0] = bx; sy1[0] = by; sp = 1;
     while (sp > 0) {
@@ -116,7 +121,7 @@ __device__ __forceinline__ bool maze_point_fp64(MazeCtx& m, double x, double y) 
     return m.occ ? m.occ[idx] == 0 : m.map[idx] == 0.0;
 }
 __device__ bool maze_segment_fp64(MazeCtx& m, double ax, double ay, double bx, double by) {
-    double sx0[48], sy0[48], sx1[48], sy1[48];
+    double* sx0 = m.stack, *sy0 = sx0 + 48, *sx1 = sx0 + 96, *sy1 = sx0 + 144;
     int sp = 1;
     sx0[0] = ax; sy0[0] = ay; sx1[0] = bx; sy1[0] = by;
     while (sp > 0) {
@@ -190,12 +195,20 @@ __global__ __launch_bounds__(64) void maze_explore_kernel(MazeParams p) {
     const long long* dst = p.edge_index + (size_t)p.total_edges + e0;
     const float* sc = p.scores + e0;
     const float* v = p.v + (size_t)n0 * DIM;
-    int* in_ptr = p.in_ptr + n0 + b;              // [N + 1] per problem
+    // Per-node state of problems up to kMazeLdsNodes nodes lives in LDS: every step of the greedy loop reads the cached row
+    // maxima of the whole frontier, the explored list, row ranges and explored positions -- from the workspace in global
+    // memory each of them was a dependent round trip of ~1 us inside a loop of ~2 000 steps.  (Generic pointers: the same
+    // code addresses LDS or, for larger problems, the workspace.)
+    __shared__ int s_in_ptr[kMazeLdsNodes + 1], s_pos[kMazeLdsNodes], s_explored[kMazeLdsNodes];
+    __shared__ int s_rb_src[kMazeLdsNodes], s_rb_eid[kMazeLdsNodes];
+    __shared__ float s_rb_val[kMazeLdsNodes];
+    const bool in_lds = N <= kMazeLdsNodes;
+    int* in_ptr = in_lds ? s_in_ptr : p.in_ptr + n0 + b;              // [N + 1] per problem
     int* cnt = p.cnt + n0;
     int* in_eid = p.in_eid + e0;
     unsigned char* alive = p.alive + e0;
-    int* pos = p.pos + n0;                        // position in the explored list or -1
-    int* explored = p.explored + n0;
+    int* pos = in_lds ? s_pos : p.pos + n0;                            // position in the explored list or -1
+    int* explored = in_lds ? s_explored : p.explored + n0;            // (copied to p.explored at the end)
     int* prev = p.prev + n0;
     int* ee = p.explored_edges + 2 * ((size_t)2 * e0 + b);      // [2E + 1] (a, b) pairs per problem
 
@@ -269,9 +282,9 @@ __global__ __launch_bounds__(64) void maze_explore_kernel(MazeParams p) {
     // Cached best live cell of every explored row i: (value, column, edge id), first maximum in column order.
     // A row's best only changes when that very cell dies -- its column gets explored, or the edge is found
     // blocked -- so a step rescans one to three rows instead of the whole frontier.
-    float* rb_val = p.rb_val + n0;
-    int* rb_src = p.rb_src + n0;
-    int* rb_eid = p.rb_eid + n0;
+    float* rb_val = in_lds ? s_rb_val : p.rb_val + n0;
+    int* rb_src = in_lds ? s_rb_src : p.rb_src + n0;
+    int* rb_eid = in_lds ? s_rb_eid : p.rb_eid + n0;
     auto rescan = [&](int i) {
         const int a = explored[i];
         float bv = -INFINITY;
@@ -340,13 +353,19 @@ __global__ __launch_bounds__(64) void maze_explore_kernel(MazeParams p) {
                 }
             } else {
                 alive[be] = 0;                                             // cell (a, nb)
-                for (int q = in_ptr[nb]; q < in_ptr[nb + 1]; ++q)          // cell (nb, a): edge a -> nb
-                    if ((int)src[in_eid[q]] == a) alive[in_eid[q]] = 0;
             }
         }
         n_pairs += 2;
         free_edge = __shfl(free_edge, 0, 64);
         goal_hit = __shfl(goal_hit, 0, 64);
+        if (!free_edge) {
+            // cell (nb, a): edge a -> nb, looked up among nb's incoming edges by the whole wave (one lane walking the ~50
+            // dependent loads of that list was most of a blocked step, and most steps are blocked edges)
+            for (int q = in_ptr[nb] + lane; q < in_ptr[nb + 1]; q += 64) {
+                const int e = in_eid[q];
+                if ((int)src[e] == a) alive[e] = 0;
+            }
+        }
         sync();
         if (free_edge) {
             ++n_expl;
@@ -381,6 +400,8 @@ __global__ __launch_bounds__(64) void maze_explore_kernel(MazeParams p) {
         p.path_len[b] = path_len;
         p.checks[b] = m.checks;
     }
+    if (in_lds)
+        for (int i = lane; i < n_expl; i += 64) p.explored[n0 + i] = explored[i];
 }
 
 // ---------------------------------------------------------------------------------------------------------
