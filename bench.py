@@ -49,10 +49,11 @@ def edge_pre_flops(E, O, C, d):
 def mp_fused_bytes(N, E, d, bf16):
     """HBM bytes one mp_fused launch (one message-passing iteration, model.py:139-143) has to move for one graph: the
     per-edge first-layer constant K_e and the packed edge record stream in once; every node row of A (gathered by source:
-    the gather itself is served by L2, its first touch is HBM), B, X and R is read once and X', A', B' are written once.
-    bf16 mode stores K_e, A, B and X in bf16."""
+    the gather itself is served by L2, its first touch is HBM), X and R is read once and X', A' are written once.  (Until
+    late in round 3 a tile's B' rows were also written and read back, N d se each way; they are now recomputed from the
+    tile's X rows -- the count below is the smaller, current one.)  bf16 mode stores K_e, A and X in bf16."""
     se = 2 if bf16 else 4
-    return E * (d * se + 4) + N * d * (3 * se + 4) + N * d * 3 * se
+    return E * (d * se + 4) + N * d * (2 * se + 4) + N * d * 2 * se
 
 
 def node_side_flops(N, O, C, d, S):

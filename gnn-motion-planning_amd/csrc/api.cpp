@@ -898,6 +898,7 @@ int forward_impl(const gnnmp_explorer* h, const gnnmp_batch* b, int loop, int us
         f.A = Abuf[cur]; f.B = at<float>(ws, c.B); f.Ke = at<float>(ws, c.Ke);
         f.X = at<float>(ws, c.X); f.R = at<float>(ws, last ? c.DN : c.XI);
         f.we = W + h->off.mpe; f.wn = W + (last ? h->off.mpn_last : h->off.mpn);
+        f.wn_std = W + h->off.mpn; f.last = last ? 1 : 0;
         f.Hout = at<float>(ws, c.H); f.Xout = at<float>(ws, c.X); f.Aout = Abuf[cur ^ 1]; f.Bout = at<float>(ws, c.B);
         f.n_tiles = c.Npad / 32;
         f.tpw = 1;

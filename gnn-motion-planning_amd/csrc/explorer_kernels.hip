@@ -1313,7 +1313,10 @@ struct XcdWalk {
 //                transpose, no segment walk, no partial maxima across tile boundaries, no agg round trip to HBM.
 //   node phase   agg tile (0 for nodes without incoming edges: torch_scatter) -> H = Wlx X + Wla agg + bl,
 //                Y = R + M1 H, A' = M2 Y, B' = M3 Y  (weights read as MFMA operands from L1/L2).
-// A' goes to the OTHER A buffer: other jobs still gather this iteration's A rows.
+// A' goes to the OTHER A buffer: other jobs still gather this iteration's A rows.  B' belongs to the tile itself (the
+// target's term of ITS incoming edges), so the one-tile-per-wave form does not store it: the next iteration's job
+// recomputes it from the X = Y rows it reads anyway (same 16 NT^2 MFMAs, moved from the end of one launch to the start
+// of the next; the last iteration stores PT for the policy head there instead).
 // =====================================================================================================
 // one 32-feature tile `t` of edge slot `slot` (per-edge tiles are stored tile-native, [slot / 32][NT][...][64 lanes][...],
 // chain.hpp store_tile_p; a chunk need not start on a tile boundary, so every lane addresses its own slot)
@@ -1447,6 +1450,23 @@ __device__ __forceinline__ void read_stage_tile(const float* stage, int sr, int 
             for (int c = 0; c < 4; ++c) x[q * 4 + c] = a[c];
         }
     }
+}
+
+// the inverse of read_stage_tile for a whole row: the lane's NT tiles of stage row sr (its half h) in the row format of
+// precision P (fp32 / bf16x3: fp32 rows; bf16: rows rounded to bf16 like store_row_p)
+template <int D, int P, int NT>
+__device__ __forceinline__ void write_stage_tiles(float* stage, int sr, int h, const f32x16 (&x)[NT]) {
+    using G = RowGeom<D, P>;
+    char* row = reinterpret_cast<char*>(stage) + sr * G::RB;
+    const int sw = G::swz(sr);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 a = {x[t][q * 4 + 0], x[t][q * 4 + 1], x[t][q * 4 + 2], x[t][q * 4 + 3]};
+            if constexpr (P != 1) *reinterpret_cast<f32x4*>(row + (((t * 8 + q * 2 + h) ^ sw) * 16)) = a;
+            else *reinterpret_cast<bf16x4*>(row + (((t * 4 + q) ^ sw) * 16) + h * 8) = __builtin_convertvector(a, bf16x4);
+        }
 }
 
 // y[ot] += sum_it W[ot][it] . x[it] with the inputs produced one 32-feature tile at a time by `get(it, tile)`: only one
@@ -1590,10 +1610,33 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the previous job's LDS reads are done
         if constexpr (kCoop) __syncthreads();                    // ... by every wave of the workgroup
         if (!kCoop || wave == 0) {
-            dma_rows<D, P>(p.B, [&](int sr) { return t0 + sr; }, btile, lane);
+            // large batches (one tile per wave): the tile's B' rows are NOT read back -- they are W_dst times the tile's own X
+            // rows, which the previous iteration wrote anyway: X rows -> stage, 16 NT^2 MFMAs (the ones the node phase no
+            // longer spends on B'), result into the stage in the row format the chunks read.  Same chain on the same values:
+            // the bits of the stored B'.  Saves a write and a read of [N, d] per iteration (10 % of the launch's HBM bytes).
+            constexpr int XP = P == 1 ? 1 : 0;                              // X rows are stored in bf16 in the bf16 mode
+            if constexpr (kCoop) dma_rows<D, P>(p.B, [&](int sr) { return t0 + sr; }, btile, lane);
+            else dma_rows<D, XP>(p.X, [&](int sr) { return t0 + sr; }, btile, lane);
             const f32x4 ninf = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};      // agg tile <- -inf
 #pragma unroll
             for (int q = 0; q < D / 8; ++q) *reinterpret_cast<f32x4*>(agg + j * D + h * (D / 2) + q * 4) = ninf;
+            if constexpr (!kCoop) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                f32x16 z[NT];
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt) z[tt] = splat16(0.f);
+                auto xrows = [&](int it, f32x16& x) { read_stage_tile<D, XP>(btile, j, h, it, x); };
+                if (kNodeWInLds && !p.last) {                               // W_dst is in the staged blob (not in the last iteration's)
+                    linear_acc_stream<P, NT, false>(wnl + LN::m3, xrows, z, lane);
+                } else {
+                    const float* wb = p.wn_std + LN::m3;
+                    asm volatile("" : "+s"(wb));                            // (no hoisting of these loads out of the job loop)
+                    linear_acc_stream<P, NT, false>(wb, xrows, z, lane);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();                            // both halves of every row have been read
+                write_stage_tiles<D, P, NT>(btile, j, h, z);
+            }
         }
         // Few tiles (kCoop): the node phase is a chain of five dependent layers on ONE wave behind the edge phase, i.e. pure
         // latency.  What does not depend on the aggregation is taken out of that chain: the X and R rows are requested NOW by
@@ -1808,7 +1851,7 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
             linear_acc_ops<P, NT, NT>(wn + LN::m2, yop, z, lane);
             store_row_p<P, NT>(p.Aout, (size_t)node, z, h);
         }
-        {
+        if (kCoop || p.last) {                                   // one tile per wave: only PT for the policy head -- B' is recomputed by the next iteration
             f32x16 z[NT];
 #pragma unroll
             for (int tt = 0; tt < NT; ++tt) z[tt] = splat16(0.f);

@@ -82,6 +82,8 @@ struct MpFusedParams {
     const int *row_beg, *deg, *ntile_graph, *node_ptr_pad;
     const float *A, *B, *Ke, *X, *R;
     const float *we, *wn;        // MpEBlob (staged into LDS), MpNBlob (read from global)
+    const float* wn_std;         // the MpNBlob of the non-last iterations (its m3 = W_dst: B' of a tile is recomputed from its X rows)
+    int last;                    // last iteration: wn holds the decoder / policy matrices and the node phase writes PT where B' went
     float *Hout, *Xout, *Aout, *Bout;
     int n_tiles;                 // 32-node tiles of the padded node space
     int store_h;
