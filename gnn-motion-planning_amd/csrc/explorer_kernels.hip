@@ -1609,6 +1609,7 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
         const int n0 = p.node_ptr_pad[tg];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the previous job's LDS reads are done
         if constexpr (kCoop) __syncthreads();                    // ... by every wave of the workgroup
+        int pre_rec_c = 0, pre_rec_n = 0;
         if (!kCoop || wave == 0) {
             // large batches (one tile per wave): the tile's B' rows are NOT read back -- they are W_dst times the tile's own X
             // rows, which the previous iteration wrote anyway: X rows -> stage, 16 NT^2 MFMAs (the ones the node phase no
@@ -1621,7 +1622,15 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
 #pragma unroll
             for (int q = 0; q < D / 8; ++q) *reinterpret_cast<f32x4*>(agg + j * D + h * (D / 2) + q * 4) = ninf;
             if constexpr (!kCoop) {
+                // the first two chunks' edge records travel with the X rows, and the first chunk's A rows are requested before
+                // the MFMAs below: one dependent round trip at the start of a tile instead of three
+                if (beg + j < end) pre_rec_c = p.rec32[beg + j];
+                if (beg + 32 + j < end) pre_rec_n = p.rec32[beg + 32 + j];
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (beg < end) {
+                    const int mine_row = (beg + j < end) ? n0 + (pre_rec_c & 0x7ffffff) : t0;
+                    dma_rows<D, P>(p.A, [&](int sr) { return __builtin_amdgcn_ds_bpermute(sr * 4, mine_row); }, astage, lane);
+                }
                 f32x16 z[NT];
 #pragma unroll
                 for (int tt = 0; tt < NT; ++tt) z[tt] = splat16(0.f);
@@ -1673,9 +1682,11 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
         constexpr int PF = kDeep ? NT : 1;                       // prefetched tiles per chunk (the rest is loaded in place)
         constexpr int KD = kDeep ? 2 : 1;                        // chunks ahead
         constexpr int LPT = P == 1 ? 2 : 4;                      // load instructions per tile
-        int rec_c = 0, rec_n = 0;
-        if (first + j < end) rec_c = p.rec32[first + j];
-        if (first + STEP + j < end) rec_n = p.rec32[first + STEP + j];
+        int rec_c = pre_rec_c, rec_n = pre_rec_n;
+        if constexpr (kCoop) {
+            if (first + j < end) rec_c = p.rec32[first + j];
+            if (first + STEP + j < end) rec_n = p.rec32[first + STEP + j];
+        }
         // two K_e register sets used alternately (the chunk loop is unrolled by two): a set is refilled as soon as its chunk
         // has expanded it -- for the chunk two ahead when KD = 2 (each set feeds every second chunk), or the OTHER set is
         // filled for the next chunk when KD = 1.  No queue shifting and no loop-carried copies (they were 16 / 40 register
@@ -1688,8 +1699,10 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
             }
         };
         if (first < end) {
-            const int mine_row = src_row(rec_c, first + j < end);
-            dma_rows<D, P>(p.A, [&](int sr) { return __builtin_amdgcn_ds_bpermute(sr * 4, mine_row); }, astage, lane);
+            if constexpr (kCoop) {                               // (one tile per wave: requested at the start of the tile)
+                const int mine_row = src_row(rec_c, first + j < end);
+                dma_rows<D, P>(p.A, [&](int sr) { return __builtin_amdgcn_ds_bpermute(sr * 4, mine_row); }, astage, lane);
+            }
             ke_fetch(first, qa);
             if constexpr (KD == 2) ke_fetch(first + STEP, qb);
         }
