@@ -1610,6 +1610,11 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the previous job's LDS reads are done
         if constexpr (kCoop) __syncthreads();                    // ... by every wave of the workgroup
         int pre_rec_c = 0, pre_rec_n = 0;
+        // d = 32, one tile per wave: the part of H that depends on the tile's X rows, bl + Wlx X, is taken while those rows
+        // are in the stage for B' (16 registers through the chunk loop) -- the node phase then neither reads X again (by then
+        // the rows had left the L2: a second HBM read of [N, d] per iteration) nor waits for them
+        constexpr bool kHpEarly = !kCoop && D == 32 && P != 2;
+        f32x16 Hp[kHpEarly ? NT : 1];
         if (!kCoop || wave == 0) {
             // large batches (one tile per wave): the tile's B' rows are NOT read back -- they are W_dst times the tile's own X
             // rows, which the previous iteration wrote anyway: X rows -> stage, 16 NT^2 MFMAs (the ones the node phase no
@@ -1635,6 +1640,10 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
 #pragma unroll
                 for (int tt = 0; tt < NT; ++tt) z[tt] = splat16(0.f);
                 auto xrows = [&](int it, f32x16& x) { read_stage_tile<D, XP>(btile, j, h, it, x); };
+                if constexpr (kHpEarly) {                                   // (kNodeWInLds holds for these instantiations)
+                    load_vec<NT>(wnl + LN::bl, Hp, lane);
+                    linear_acc_stream<P, NT, false>(wnl + LN::wlx, xrows, Hp, lane);
+                }
                 if (kNodeWInLds && !p.last) {                               // W_dst is in the staged blob (not in the last iteration's)
                     linear_acc_stream<P, NT, false>(wnl + LN::m3, xrows, z, lane);
                 } else {
@@ -1825,16 +1834,22 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
         // compiler does not hoist those loop-invariant loads out of the job loop into ~70 registers)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if constexpr (P != 1) {                                  // fp32 rows fill a whole stage each
-            dma_rows<D, 0>(p.X, [&](int sr) { return t0 + sr; }, astage, lane);
+            if constexpr (!kHpEarly) dma_rows<D, 0>(p.X, [&](int sr) { return t0 + sr; }, astage, lane);
             dma_rows<D, 0>(p.R, [&](int sr) { return t0 + sr; }, btile, lane);
         }
         f32x16 H[NT];
-        load_vec<NT>(wn + LN::bl, H, lane);
-        if constexpr (P != 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        linear_acc_stream<P, NT, false>(wn + LN::wlx, [&](int it, f32x16& x) {
-            if constexpr (P != 1) read_stage_tile<D, 0>(astage, j, h, it, x);
-            else load_row_tile<1, NT>(p.X, (size_t)node, h, it, x);          // bf16 mode: X rows are stored in bf16
-        }, H, lane);
+        if constexpr (kHpEarly) {
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt) H[tt] = Hp[tt];
+            if constexpr (P != 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            load_vec<NT>(wn + LN::bl, H, lane);
+            if constexpr (P != 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            linear_acc_stream<P, NT, false>(wn + LN::wlx, [&](int it, f32x16& x) {
+                if constexpr (P != 1) read_stage_tile<D, 0>(astage, j, h, it, x);
+                else load_row_tile<1, NT>(p.X, (size_t)node, h, it, x);          // bf16 mode: X rows are stored in bf16
+            }, H, lane);
+        }
         linear_acc_stream<P, NT, false>(wn + LN::wla, [&](int it, f32x16& x) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
