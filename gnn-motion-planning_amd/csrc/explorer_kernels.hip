@@ -1609,12 +1609,31 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
         const int n0 = p.node_ptr_pad[tg];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the previous job's LDS reads are done
         if constexpr (kCoop) __syncthreads();                    // ... by every wave of the workgroup
+        // K_e streams from HBM: PF tiles of a chunk are requested KD chunks ahead and wait in registers
+        constexpr bool kDeep = P == 1 || (GNNMP_MP_DEEP32 && P == 0 && D == 32 && COOP == 1);   // packed bf16 tiles are cheap to hold (fp32, d = 32: measured 0.95 -> 0.99 ms)
+        constexpr int PF = kDeep ? NT : 1;                       // prefetched tiles per chunk (the rest is loaded in place)
+        constexpr int KD = kDeep ? 2 : 1;                        // chunks ahead
+        constexpr int LPT = P == 1 ? 2 : 4;                      // load instructions per tile
+        // two K_e register sets used alternately (the chunk loop is unrolled by two): a set is refilled as soon as its chunk
+        // has expanded it -- for the chunk two ahead when KD = 2 (each set feeds every second chunk), or the OTHER set is
+        // filled for the next chunk when KD = 1.  No queue shifting and no loop-carried copies (they were 16 / 40 register
+        // moves per chunk at d = 32 fp32 / d = 64 bf16, in a loop that is bound by instruction issue).
+        KeRaw<P> qa[PF], qb[PF];
+        auto ke_fetch = [&](int cc, KeRaw<P> (&dst)[PF]) {      // wave-uniform cc
+            if (cc < end) {
+#pragma unroll
+                for (int t = 0; t < PF; ++t) load_edge_slot_raw<P, NT>(p.Ke, cc + j < end ? cc + j : beg, h, t, dst[t]);
+            }
+        };
         int pre_rec_c = 0, pre_rec_n = 0;
         // d = 32, one tile per wave: the part of H that depends on the tile's X rows, bl + Wlx X, is taken while those rows
         // are in the stage for B' (16 registers through the chunk loop) -- the node phase then neither reads X again (by then
         // the rows had left the L2: a second HBM read of [N, d] per iteration) nor waits for them
         constexpr bool kHpEarly = !kCoop && D == 32 && P != 2;
         f32x16 Hp[kHpEarly ? NT : 1];
+        constexpr bool kREarly = kHpEarly && P == 0;             // ... and then the A stage is free for the R rows (fp32 rows)
+        constexpr bool kKeEarly = kHpEarly;                      // registers to spare at d = 32: the first chunk's K_e is requested with its A rows
+        bool r_requested = false;
         if (!kCoop || wave == 0) {
             // large batches (one tile per wave): the tile's B' rows are NOT read back -- they are W_dst times the tile's own X
             // rows, which the previous iteration wrote anyway: X rows -> stage, 16 NT^2 MFMAs (the ones the node phase no
@@ -1635,6 +1654,10 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
                 if (beg < end) {
                     const int mine_row = (beg + j < end) ? n0 + (pre_rec_c & 0x7ffffff) : t0;
                     dma_rows<D, P>(p.A, [&](int sr) { return __builtin_amdgcn_ds_bpermute(sr * 4, mine_row); }, astage, lane);
+                    if constexpr (kKeEarly) {                               // ... and its K_e tiles: their HBM latency runs under the MFMAs
+                        ke_fetch(beg, qa);
+                        if constexpr (KD == 2) ke_fetch(beg + 32, qb);
+                    }
                 }
                 f32x16 z[NT];
 #pragma unroll
@@ -1686,34 +1709,20 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
         constexpr int STEP = 32 * COOP;
         const int first = beg + (kCoop ? 32 * wave : 0);
         auto src_row = [&](int rec, bool valid) { return valid ? n0 + (rec & 0x7ffffff) : t0; };
-        // K_e streams from HBM: PF tiles of a chunk are requested KD chunks ahead and wait in registers
-        constexpr bool kDeep = P == 1 || (GNNMP_MP_DEEP32 && P == 0 && D == 32 && COOP == 1);   // packed bf16 tiles are cheap to hold (fp32, d = 32: measured 0.95 -> 0.99 ms)
-        constexpr int PF = kDeep ? NT : 1;                       // prefetched tiles per chunk (the rest is loaded in place)
-        constexpr int KD = kDeep ? 2 : 1;                        // chunks ahead
-        constexpr int LPT = P == 1 ? 2 : 4;                      // load instructions per tile
         int rec_c = pre_rec_c, rec_n = pre_rec_n;
         if constexpr (kCoop) {
             if (first + j < end) rec_c = p.rec32[first + j];
             if (first + STEP + j < end) rec_n = p.rec32[first + STEP + j];
         }
-        // two K_e register sets used alternately (the chunk loop is unrolled by two): a set is refilled as soon as its chunk
-        // has expanded it -- for the chunk two ahead when KD = 2 (each set feeds every second chunk), or the OTHER set is
-        // filled for the next chunk when KD = 1.  No queue shifting and no loop-carried copies (they were 16 / 40 register
-        // moves per chunk at d = 32 fp32 / d = 64 bf16, in a loop that is bound by instruction issue).
-        KeRaw<P> qa[PF], qb[PF];
-        auto ke_fetch = [&](int cc, KeRaw<P> (&dst)[PF]) {      // wave-uniform cc
-            if (cc < end) {
-#pragma unroll
-                for (int t = 0; t < PF; ++t) load_edge_slot_raw<P, NT>(p.Ke, cc + j < end ? cc + j : beg, h, t, dst[t]);
-            }
-        };
         if (first < end) {
             if constexpr (kCoop) {                               // (one tile per wave: requested at the start of the tile)
                 const int mine_row = src_row(rec_c, first + j < end);
                 dma_rows<D, P>(p.A, [&](int sr) { return __builtin_amdgcn_ds_bpermute(sr * 4, mine_row); }, astage, lane);
             }
-            ke_fetch(first, qa);
-            if constexpr (KD == 2) ke_fetch(first + STEP, qb);
+            if constexpr (!kKeEarly) {
+                ke_fetch(first, qa);
+                if constexpr (KD == 2) ke_fetch(first + STEP, qb);
+            }
         }
         auto chunk = [&](const int c0, KeRaw<P> (&cur)[PF], KeRaw<P> (&fill)[PF]) {
             const int slot = c0 + j;
@@ -1747,6 +1756,10 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
                         const int mine_row = src_row(rec_c, c0 + STEP + j < end);
                         dma_rows<D, P>(p.A, [&](int sr) { return __builtin_amdgcn_ds_bpermute(sr * 4, mine_row); }, astage, lane);
                         if (c0 + 2 * STEP + j < end) rec_n = p.rec32[c0 + 2 * STEP + j];
+                    } else if constexpr (kREarly) {
+                        // last chunk: the A stage is free from here on -- the node phase's R rows travel under this chunk's MFMAs
+                        dma_rows<D, 0>(p.R, [&](int sr) { return t0 + sr; }, astage, lane);
+                        r_requested = true;
                     }
                     ke_fetch(c0 + KD * STEP, fill);
                 }
@@ -1833,9 +1846,10 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
         // (MpNBlob) are read from global memory as MFMA operands (at d = 64 the pointer is laundered per job so that the
         // compiler does not hoist those loop-invariant loads out of the job loop into ~70 registers)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        float* rrows = kREarly ? astage : btile;
         if constexpr (P != 1) {                                  // fp32 rows fill a whole stage each
             if constexpr (!kHpEarly) dma_rows<D, 0>(p.X, [&](int sr) { return t0 + sr; }, astage, lane);
-            dma_rows<D, 0>(p.R, [&](int sr) { return t0 + sr; }, btile, lane);
+            if (!(kREarly && r_requested)) dma_rows<D, 0>(p.R, [&](int sr) { return t0 + sr; }, rrows, lane);
         }
         f32x16 H[NT];
         if constexpr (kHpEarly) {
@@ -1864,7 +1878,7 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
             f32x16 y[NT];
             if constexpr (P != 1) {
 #pragma unroll
-                for (int tt = 0; tt < NT; ++tt) read_stage_tile<D, 0>(btile, j, h, tt, y[tt]);
+                for (int tt = 0; tt < NT; ++tt) read_stage_tile<D, 0>(rrows, j, h, tt, y[tt]);
             } else {
                 load_row<NT>(p.R + (size_t)node * D, y, h);
             }
