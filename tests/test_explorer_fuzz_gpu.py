@@ -123,6 +123,33 @@ def test_graph_beyond_the_lds_share_of_the_csr_build():
         print(check(parts[i].cpu(), w, graphs[i], 2))
 
 
+def test_sliced_csr_build_small_batches():
+    """Few small graphs: the CSR build cuts a graph's target nodes into slices, one workgroup each (one to eight by batch size).
+    (a) batches of 1, 3, 40 and 300 graphs, bit-equal to the same graphs scored one by one; (b) three graphs of which one has
+    more than 16 k edges: its slices take the form that keeps the ranks in the workspace instead of registers."""
+    w = load_weights('weights_maze')
+    m = gnnmp.EncoderProcessDecoder(2, 2, 32, 2).eval()
+    m.load_state_dict(w)
+    gen = torch.Generator().manual_seed(5)
+    for count in (1, 3, 40, 300):
+        graphs = [random_graph(gen, int(torch.randint(130, 700, (1,), generator=gen)), int(torch.randint(200, 3000, (1,), generator=gen)),
+                               int(torch.randint(0, 30, (1,), generator=gen))) for _ in range(count)]
+        b = gnnmp.GraphBatch.from_graphs(graphs, 2, DEV)
+        parts = b.split_edges(m.forward_batch(b, 2))
+        for i in range(0, count, max(1, count // 6)):
+            g = graphs[i]
+            one = m.edge_scores(g['goal'].to(DEV), 2, g['v'].to(DEV), g['obstacles'].to(DEV), g['edge_index'].to(DEV))
+            assert torch.equal(parts[i], one), (count, i)
+        print(check(parts[0].cpu(), w, graphs[0], 2))
+    graphs = [random_graph(gen, 1000, 17500, 12), random_graph(gen, 150, 400, 5), random_graph(gen, 300, 900, 9)]
+    b = gnnmp.GraphBatch.from_graphs(graphs, 2, DEV)
+    parts = b.split_edges(m.forward_batch(b, 2))
+    for i, g in enumerate(graphs):
+        one = m.edge_scores(g['goal'].to(DEV), 2, g['v'].to(DEV), g['obstacles'].to(DEV), g['edge_index'].to(DEV))
+        assert torch.equal(parts[i], one), i
+    print(check(parts[1].cpu(), w, graphs[1], 2))
+
+
 @pytest.mark.parametrize('seed', range(4))
 @pytest.mark.parametrize('mode', ['kuka7_fp32', 'maze_bf16x3', 'kuka7_bf16'])
 def test_random_graphs_other_kernels(mode, seed):
