@@ -1192,7 +1192,8 @@ extern "C" int gnnmp_smoother_forward(const gnnmp_smoother* h, const gnnmp_smoot
         HIP_TRY(launch_sm_final(b->total_path * C, p.scale, p.cur, out_path, st));
         return GNNMP_OK;
     }
-    // four launches per iteration (kNN, edge list, messages, path update): the scaled working copy is written by the
+    // three launches per iteration (graph stage = kNN + edge list, messages, path update; four when a problem's buffers exceed
+    // the LDS share of the one-launch graph stage): the scaled working copy is written by the
     // first kNN launch, the tile maps by the edge-list kernel, the result by the last path-update launch
     for (int it = 0; it < loop; ++it) {
         p.init_from_path = it == 0 ? 1 : 0;

@@ -2,6 +2,8 @@
 // ModelSmoother.forward of the reference (model_smoother.py:104-142), batched over independent
 // smoothing problems.  Per `loop` iteration:
 //
+//   sm_graph   sm_knn + sm_edges in ONE launch, a workgroup per problem, samples staged in LDS (the usual form; the two
+//              kernels below remain for problems whose buffers exceed a workgroup's LDS share)
 //   sm_knn     10 nearest samples (free + collided) of every path node     (model_smoother.py:125)
 //   sm_edges   caller edges + kNN edges -> sorted by (target, source), duplicates dropped
 //                                                                            (model_smoother.py:126-128)
