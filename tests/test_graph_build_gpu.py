@@ -105,7 +105,8 @@ def test_hub_bucket_beyond_lds_share_and_large_graphs():
     x[5] = 0.0
     _check([x, torch.rand(50, 7, generator=gen)], [400, 20], [2, 3])
     _check([torch.rand(1500, 2, generator=gen) * 2 - 1], [700], [5])
-    _check([torch.rand(2500, 3, generator=gen) * 2 - 1], [1200], [4])
+    _check([torch.rand(2500, 3, generator=gen) * 2 - 1], [1200], [4])          # beyond 2048 nodes, k <= 16: streamed per-lane top-16
+    _check([torch.rand(2300, 2, generator=gen) * 2 - 1], [1100], [19])         # ... k > 16: the form that recomputes the distances per round
     # small and large graphs in one batch: the first kNN launch handles the small ones and lists the others' nodes for the second
     _check([torch.rand(300, 2, generator=gen), torch.rand(1500, 2, generator=gen), torch.rand(40, 2, generator=gen),
             torch.rand(2100, 2, generator=gen), torch.rand(1024, 2, generator=gen)], [100, 800, 40, 1000, 500], [4, 5, 3, 4, 6])
