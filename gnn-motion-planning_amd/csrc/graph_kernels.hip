@@ -185,14 +185,23 @@ __global__ __launch_bounds__(256, SMALL ? 4 : 1) void gb_knn_kernel(GbParams p) 
         if (node >= *p.large_cnt) return;                  // (one scalar load: usually there is no such node)
         node = p.large[node];
     }
-    if (node >= p.total_nodes) return;
-    const int g = gb_find(p.node_ptr, p.G, node);
+    const bool in_range = node < p.total_nodes;
+    if (!SMALL && !in_range) return;
+    const int g = in_range ? gb_find(p.node_ptr, p.G, node) : 0;
     const int n0 = p.node_ptr[g], N = p.node_ptr[g + 1] - n0;
     if constexpr (SMALL) {
-        if (N > 1024) {                                    // listed for the second launch
-            if (lane == 0) p.large[atomicAdd(p.large_cnt, 1)] = node;
-            return;
-        }
+        // nodes of larger graphs are listed for the second launch: one slot request per WORKGROUP (a request per wave on the one
+        // counter was 1.8 ms when all 160 k nodes of a batch belong to large graphs)
+        __shared__ int s_n, s_base, s_nodes[4];
+        const bool large = in_range && N > 1024;
+        if (threadIdx.x == 0) s_n = 0;
+        __syncthreads();
+        if (large && lane == 0) s_nodes[atomicAdd(&s_n, 1)] = node;
+        __syncthreads();
+        if (threadIdx.x == 0 && s_n > 0) s_base = atomicAdd(p.large_cnt, s_n);
+        __syncthreads();
+        if ((int)threadIdx.x < s_n) p.large[s_base + threadIdx.x] = s_nodes[threadIdx.x];
+        if (large || !in_range) return;
     }
     const int F = min(p.n_free[g], N);
     const int i = node - n0;
