@@ -67,3 +67,18 @@ def test_one_launch_graph_stage_equals_two_launch_form_bitwise(case, tmp_path):
     for k in outs[0]:
         assert bool(torch.isfinite(outs[0][k]).all())
         assert torch.equal(outs[0][k], outs[1][k]), k
+
+
+@pytest.mark.parametrize('case', ['c7', 'c14'])
+def test_message_kernel_without_target_role_same_bits(case, tmp_path):
+    """The split message kernel's edge tiles normally continue from the target rows its first workgroups publish; the path
+    that computes the target half inside the edge tile (taken when a flag does not show up within the polling budget, and
+    with GNNMP_SM_NO_TARGET_ROLE=1) must give the same bits."""
+    outs = []
+    for no_target in ('0', '1'):
+        out = str(tmp_path / ('out_%s.pt' % no_target))
+        env = dict(os.environ, GNNMP_SM_NO_TARGET_ROLE=no_target)
+        subprocess.run([sys.executable, '-c', SCRIPT % (REPO, REPO), case, out], check=True, env=env, timeout=300)
+        outs.append(torch.load(out))
+    for k in outs[0]:
+        assert torch.equal(outs[0][k], outs[1][k]), k
