@@ -162,13 +162,18 @@ def planner_leg(n_host, n_device, dev):
         r = planner.explore(env, m, ms, True, batch=500, t_max=500, k=30, device=dev)
         fwd += r['forward']; tot += r['total']; checks += r['c_explore'] + r['c_smooth']
     wall_host = time.perf_counter() - t0
-    np.random.seed(1234)
-    planner.eval_gnn_device(env, range(min(n_device, 64)), m, ms, device=dev)                     # warm-up
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    out = planner.eval_gnn_device(env, range(n_device), m, ms, device=dev)
-    torch.cuda.synchronize(dev)
-    wall_dev = time.perf_counter() - t0
+    # the device planner is quoted at ONE size everywhere (README, DESIGN, this line): n_device problems (the evaluation set
+    # cycled), median of three timed passes after a warm-up pass at the same size (allocator, kernel variants)
+    idx = [i % len(env.maps) for i in range(n_device)]
+    planner.eval_gnn_device(env, idx, m, ms, device=dev)                                          # warm-up
+    walls = []
+    for _ in range(3):
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        out = planner.eval_gnn_device(env, idx, m, ms, device=dev)
+        torch.cuda.synchronize(dev)
+        walls.append(time.perf_counter() - t0)
+    wall_dev = sorted(walls)[1]
     return {'problems': 'mazes_hard.npz (2-D maze), batch = t_max = 500, k = 30, smoothing on',
             'host_loop': {'problems': n_host, 'problems_per_s': round(n_host / wall_host, 2), 'host_cores': 1,
                           'gnn_forward_ms_per_problem': round(1e3 * fwd / n_host, 2),
@@ -176,6 +181,8 @@ def planner_leg(n_host, n_device, dev):
                           'collision_checks_per_problem': round(checks / n_host, 1),
                           'what': 'dense drop-in forward on the GPU; sampling, greedy loop, collision checks, steering on one host core'},
             'device_planner': {'problems': n_device, 'problems_per_s': round(n_device / wall_dev, 1), 'host_cores': 1,
+                               'timing': 'median of 3 passes over the same %d problems: %s problems/s' % (
+                                   n_device, ' / '.join('%.0f' % (n_device / w) for w in walls)),
                                'success': int(out[0]), 'collision_checks_per_problem': round(out[1], 2),
                                'what': 'sampling on one host core; graphs, forwards, greedy loop, collision checks, steering on the GPU'}}
 
@@ -186,6 +193,10 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--graphs', type=int, default=256, help='graphs per GPU per step')
+    ap.add_argument('--strong', type=int, default=0, metavar='N_TOTAL',
+                    help='strong scaling: a FIXED set of N_TOTAL problems (seeds 1234 .. 1234 + N_TOTAL - 1) split over the '
+                         'ranks by gnnmp.dist.shard_range; --graphs is ignored.  Default (0): weak scaling, --graphs per GPU')
+    ap.add_argument('--gather-reps', type=int, default=5, help='timed repetitions of the final result gather (median reported)')
     ap.add_argument('--env', default='maze2')
     ap.add_argument('--nodes', type=int, default=1000)
     ap.add_argument('--k1', type=int, default=8)
@@ -225,11 +236,20 @@ def main():
     from gnnmp.weights import load_weights
     from gnnmp.synth import ENVS, synth_batch_gpu
     e = ENVS[args.env]
-    G = args.graphs
+    if args.strong > 0:
+        # strong scaling: the job is the fixed problem set 0 .. N_TOTAL - 1 (problem i = seed 1234 + i whatever the rank count);
+        # rank r scores the contiguous block shard_range gives it (equal-size graphs: no weights needed)
+        from gnnmp.dist import shard_range
+        lo, hi = shard_range(args.strong, rank, world)
+        G, seed0 = hi - lo, 1234 + lo
+        if G < 1:
+            raise SystemExit('bench.py: --strong %d leaves rank %d of %d without a problem' % (args.strong, rank, world))
+    else:
+        G, seed0 = args.graphs, 1234 + rank * args.graphs
     uniq = G if args.unique <= 0 else min(G, args.unique)
-    # same node / obstacle draws as synth_graph(seed = 1234 + rank * G + i); the kNN edge lists are built by the
+    # same node / obstacle draws as synth_graph(seed = seed0 + i); the kNN edge lists are built by the
     # device graph builder (bit-identical to the host builder) so start-up takes seconds instead of half a minute
-    base = synth_batch_gpu(args.env, args.nodes, args.k1, uniq, dev, seed0=1234 + rank * G)
+    base = synth_batch_gpu(args.env, args.nodes, args.k1, uniq, dev, seed0=seed0)
     graphs = [base[i % uniq] for i in range(G)]
     batch = gnnmp.GraphBatch.from_graphs(graphs, e['S'], dev)
     model = gnnmp.EncoderProcessDecoder(e['workspace'], e['C'], e['d'], e['S']).eval()
@@ -254,10 +274,21 @@ def main():
     elapsed = time.perf_counter() - t0
     prof = model.profile_read(dev)
     model.profile(dev, False)
+    # multi-GPU self-checks (they also run with one rank under GNNMP_BENCH_FORCE_DIST=1): how many ranks the collective
+    # library really connected (an all_reduce of ones), every rank's own step time (min / max show imbalance; `value` uses
+    # the MAX), the job's total graph count
+    ranks_seen, rank_ms, total_graphs = 1, [elapsed / args.steps * 1e3], G
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        ones = torch.ones(1, dtype=torch.float64, device=dev)
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        ranks_seen = int(round(float(ones.item())))
+        mine = torch.tensor([elapsed, float(G)], dtype=torch.float64, device=dev)
+        allr = torch.empty(2 * world, dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(allr, mine)
+        allr = allr.view(world, 2).cpu()
+        rank_ms = [float(x) / args.steps * 1e3 for x in allr[:, 0]]
+        total_graphs = int(round(float(allr[:, 1].sum())))
+        elapsed = float(allr[:, 0].max())
 
     # PCIe-inclusive variant (reported next to, never instead of, `value`): the reference's own forward
     # timer spans H2D + compute + D2H (eval_gnn.py:193-196); here inputs start in pinned host memory and
@@ -346,11 +377,25 @@ def main():
                                                              edge_index=g0['edge_index']))}
 
     # final result gather (the only collective of the job): per-rank edge scores -> every rank
+    # It is timed on its own (barrier + sync on both sides, median of --gather-reps, max over ranks) and NEVER enters `value`:
+    # no rank needs another rank's scores to make progress.
     checksum = float(scores.double().sum().item())
+    gather_ms = None
     if use_dist:
         from gnnmp.dist import gather_variable
-        parts = gather_variable(scores)                    # one padded buffer, all_gather_into_tensor (RCCL)
+        parts = gather_variable(scores)                    # one padded buffer, all_gather_into_tensor (RCCL); also the warm-up
         checksum = float(torch.stack([p_.double().sum() for p_ in parts]).sum().item())
+        ts = []
+        for _ in range(max(args.gather_reps, 1)):
+            sync()
+            t1 = time.perf_counter()
+            parts = gather_variable(scores)
+            torch.cuda.synchronize(dev)
+            ts.append(time.perf_counter() - t1)
+        tg = torch.tensor([sorted(ts)[len(ts) // 2]], dtype=torch.float64, device=dev)
+        dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+        gather_ms = round(float(tg.item()) * 1e3, 4)
+        del parts
 
     if rank == 0:
         Ns = [int(g['v'].shape[0]) for g in graphs]
@@ -424,26 +469,58 @@ def main():
                                                   'gfx950 corrections of MI355X_MICROARCH.md'}
             except Exception:
                 pass
-        cfg_name = 'BASELINE configs[1]' if (args.env, args.nodes, args.k1, G, args.mlp_dtype) == ('maze2', 1000, 8, 256, 'fp32') \
-            else ('BASELINE configs[2] shape' if (args.env, args.nodes, args.k1, args.mlp_dtype) == ('kuka7', 2000, 10, 'bf16')
-                  else 'custom workload')
+        shape = (args.env, args.nodes, args.k1, args.mlp_dtype)
+        cfg_name = 'BASELINE configs[1]' if shape == ('maze2', 1000, 8, 'fp32') and G == 256 \
+            else ('BASELINE configs[2] shape' if shape == ('kuka7', 2000, 10, 'bf16')
+                  else ('BASELINE configs[4] shape (explorer half)' if shape == ('kuka14', 5000, 16, 'bf16')
+                        else ('BASELINE configs[0] shape, batched' if shape == ('maze2', 200, 6, 'fp32') else 'custom workload')))
         ms_step = elapsed / args.steps * 1e3
-        value = world * G * args.steps / elapsed
+        value = total_graphs * args.steps / elapsed          # whole job: the graphs ALL ranks scored per step / the slowest rank's time
+        # launch time of the roofline kernel as the committed rocprofv3 --kernel-trace run saw it (timed launches only, warm-ups
+        # dropped: tools/rocprof_summary.py --warmup / --steps -> profiles/kernel_launch_ms.json), next to the in-process HIP-event
+        # figure `launch_ms`; the profiler's own overhead sits in the gap between the two
+        lpath = os.path.join(REPO, 'profiles', 'kernel_launch_ms.json')
+        if os.path.exists(lpath):
+            try:
+                for lj in json.load(open(lpath)):
+                    if lj.get('kernel_like') == roof['kernel_like'] and lj.get('workload') == wkey:
+                        roof['launch_ms_rocprof'] = lj.get('avg_ms_timed_launches')
+                        work = roof.get('algorithmic_flops_per_launch', roof.get('algorithmic_bytes_per_launch'))
+                        unit = 1e12 if roof['bound'] == 'mfma' else 1e9
+                        roof['frac_rocprof'] = round(work / (lj['avg_ms_timed_launches'] * 1e-3) / unit / roof['peak'], 4)
+                        roof['launch_ms_rocprof_source'] = {'file': 'profiles/kernel_launch_ms.json', 'measured': lj.get('measured'),
+                                                            'launches': lj.get('launches'), 'stale': lj.get('kernel_source_sha256') != kernel_source_hash()}
+            except Exception:
+                pass
         stages = {k: round(v[0] / max(args.steps, 1), 4) for k, v in prof.items()}
         res = {
-            'metric': 'RGG graphs/sec (GNN explorer forward), 1000-node k=8',
+            'metric': 'RGG graphs/sec (GNN explorer forward), %d-node k=%d' % (args.nodes, args.k1),
             'value': round(value, 2), 'unit': 'graphs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': round(ms_step, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'ms_per_step': round(ms_step, 4), 'higher_is_better': True, 'scaling': 'strong' if args.strong > 0 else 'weak',
+            'vs_baseline': None,
             'dtype': {'fp32': 'f32', 'bf16': 'bf16', 'bf16x3': 'f32 (3 x bf16 split MFMA operands, fp32 accumulate)'}[args.mlp_dtype],
             'data': 'synthetic',
             'config': {'workload': '%s: %s, batch of %d problems per GPU, %d-node k1=%d RGGs '
                                    '(mean E=%.0f, O=%d), loop=%d, use_obstacles, real %s checkpoint, %s, sparse '
                                    'per-edge scores' % (cfg_name, args.env, G, args.nodes, args.k1, sum(Es) / len(Es), Os[0],
                                                         args.loop, e['ckpt'], args.mlp_dtype),
-                       'graphs_per_gpu': G, 'parallelism': 'problem-sharded x%d' % world,
+                       'graphs_per_gpu': G, 'graphs_total': total_graphs,
+                       'parallelism': 'problem-sharded x%d (%s)' % (world, 'fixed set of %d problems split by shard_range' % args.strong
+                                                                  if args.strong > 0 else '%d problems per GPU' % G),
+                       # multi-GPU self-checks: ranks the collective library connected, every rank's own ms per step, the result
+                       # gather timed on its own (not part of `value`)
+                       'ranks_seen': ranks_seen,
+                       'rank_ms_per_step': {'min': round(min(rank_ms), 4), 'max': round(max(rank_ms), 4),
+                                            'all': [round(x, 4) for x in rank_ms]},
+                       'gather_ms': gather_ms,
+                       'gather': None if gather_ms is None else 'per-edge scores of every rank -> every rank: two all_gather_into_tensor '
+                                 'calls (lengths, one padded payload of %d floats per rank), median of %d, max over ranks; outside the '
+                                 'timed region' % (int(scores.numel()), max(args.gather_reps, 1)),
+                       # rank 0's share of the job against the peaks of ONE GPU (rank 0's FLOPs / bytes over the job's step time)
                        'whole_forward': {'algorithmic_TFLOPs': round(flops_batch * args.steps / elapsed / 1e12, 2),
                                          'algorithmic_GBs': round(bytes_batch * args.steps / elapsed / 1e9, 3),
-                                         'frac_fp32_peak': round(flops_batch * args.steps / elapsed / 1e12 / PEAK_FP32_TFLOPS, 4),
+                                         ('frac_bf16_mfma_peak' if is_bf16 else 'frac_fp32_peak'):
+                                             round(flops_batch * args.steps / elapsed / 1e12 / mfma_peak, 4),
                                          'frac_hbm_peak': round(bytes_batch * args.steps / elapsed / 1e9 / PEAK_HBM_GBS, 6)},
                        'stage_ms_per_step': stages, 'stage_roofline': stage_roof, 'result_checksum': checksum,
                        'pcie_inclusive_graphs_per_s_per_gpu': None if e2e is None else round(e2e, 1),
@@ -454,7 +531,7 @@ def main():
             'roofline': roof,
         }
         if world == 1 and args.planner_problems > 0 and (args.env, args.mlp_dtype) == ('maze2', 'fp32'):
-            res['config']['planner'] = planner_leg(args.planner_problems, 512, dev)
+            res['config']['planner'] = planner_leg(args.planner_problems, 1024, dev)
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(args.env, args.nodes, args.k1, args.cpu_seconds, 1234)
         print(json.dumps(res), flush=True)

@@ -6,6 +6,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('GNNMP_LIB') or os.path.join(_HERE, 'libgnnmp.so')      # GNNMP_LIB: an experiment build (tools/diag/build_variant.sh)
 
+ABI_VERSION = 2                        # include/gnnmp.h gnnmp_abi_version(): what this binding was written against
+
 c_float_p = ctypes.POINTER(ctypes.c_float)
 c_int32_p = ctypes.POINTER(ctypes.c_int32)
 c_int64_p = ctypes.POINTER(ctypes.c_int64)
@@ -75,7 +77,20 @@ def lib():
     L.gnnmp_status_string.restype = ctypes.c_char_p
     L.gnnmp_status_string.argtypes = [ctypes.c_int]
     L.gnnmp_last_hip_error.restype = ctypes.c_char_p
+    # the ABI number is checked before anything else is bound: a stale build (an experiment library left in GNNMP_LIB, an
+    # in-tree .so older than this binding) would otherwise change results or crash with no indication
+    if not hasattr(L, 'gnnmp_abi_version'):
+        raise RuntimeError('%s exports no gnnmp_abi_version: not a libgnnmp build this binding can use' % LIB_PATH)
     L.gnnmp_abi_version.restype = ctypes.c_int
+    abi = L.gnnmp_abi_version()
+    if abi != ABI_VERSION:
+        raise RuntimeError('%s has ABI version %d, this binding expects %d -- rebuild it (`python -c "import __graft_entry__ '
+                           'as g; g.build(force=True)"`)%s' % (LIB_PATH, abi, ABI_VERSION,
+                                                               ' or unset GNNMP_LIB' if os.environ.get('GNNMP_LIB') else ''))
+    if os.environ.get('GNNMP_LIB'):
+        import sys
+        print('[gnnmp] GNNMP_LIB is set: using the experiment build %s (ABI %d) instead of the in-tree libgnnmp.so'
+              % (LIB_PATH, abi), file=sys.stderr, flush=True)
     L.gnnmp_explorer_manifest.argtypes = [ctypes.POINTER(ExplorerDims), ctypes.c_int, ctypes.c_char_p, sz, c_int64_p]
     L.gnnmp_explorer_create.argtypes = [ctypes.POINTER(vp), ctypes.POINTER(ExplorerDims), vp, sz, ctypes.c_int]
     L.gnnmp_explorer_destroy.argtypes = [vp]

@@ -1497,6 +1497,23 @@ __device__ __forceinline__ void linear_acc_stream(const float* A, Get get, f32x1
     }
 }
 
+// ablation switches of mp_fused for attribution runs (tools/diag/build_variant.sh abl_x -DGNNMP_ABL_X=1): WRONG results, timing only
+#ifndef GNNMP_ABL_NO_KE
+#define GNNMP_ABL_NO_KE 0            // no K_e stream (zeros instead)
+#endif
+#ifndef GNNMP_ABL_NO_GATHER
+#define GNNMP_ABL_NO_GATHER 0        // the chunk's A rows are the tile's own contiguous rows instead of the gathered sources
+#endif
+#ifndef GNNMP_ABL_NO_NODE
+#define GNNMP_ABL_NO_NODE 0          // no node phase
+#endif
+#ifndef GNNMP_ABL_NO_ATOMICS
+#define GNNMP_ABL_NO_ATOMICS 0       // no LDS max atomics
+#endif
+#ifndef GNNMP_ABL_NO_EDGE
+#define GNNMP_ABL_NO_EDGE 0          // no edge phase at all (tile start + node phase only)
+#endif
+
 // LDS floats of mp_fused besides the staged MpEBlob.  COOP = 1: every wave owns a max-aggregation tile [32][D], 32 row
 // offsets and two 32-row gather stages; COOP > 1: the workgroup's COOP waves share the aggregation tile and the B-row
 // stage, every wave keeps its own row offsets and A-row stage
@@ -1522,7 +1539,7 @@ template <int D, int P, int COOP>
 #ifndef GNNMP_MP_DEEP32
 #define GNNMP_MP_DEEP32 0     // experiment switch: K_e two chunks ahead at d = 32 fp32 (measured slower: 0.906 vs 0.875 ms)
 #endif
-__global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 && P != 1) ? 1 : ((P == 2 || D > 32) ? 2 : GNNMP_MP_WGS32)) : 1) void mp_fused_kernel(MpFusedParams p) {
+__global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 && P != 1) ? 1 : ((P == 2 || D > 32) ? 2 : GNNMP_MP_WGS32)) : ((COOP == 2 || (COOP == 4 && P == 1)) ? (D == 32 ? 3 : 2) : 1)) void mp_fused_kernel(MpFusedParams p) {
     constexpr int NT = D / 32;
     constexpr bool kCoop = COOP > 1;
     // few tiles, d = 32: the node phase is spread over waves (below); at d = 64 the eight-wave workgroup has 256 registers per
@@ -1588,7 +1605,13 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
         // XCD 7 and half of XCD 6 without work (round 2's mapping).  Workgroups beyond that take the unused tail in order.
         const int real_wgs = ((p.node_ptr_pad[p.G] >> 7) + p.tpw - 1) / p.tpw;      // exact: the prep stage's padded total / 128 rows per group
         const int per = (real_wgs + 7) >> 3, q8 = blockIdx.x >> 3, x8 = blockIdx.x & 7;
-        const int wg = q8 < per ? x8 * per + q8 : 8 * per + (q8 - per) * 8 + x8;
+        int qq = q8;
+        if (p.gpg > 1 && per % p.gpg == 0 && q8 < per) {          // EXPERIMENT: heavy (first-half) groups of every graph first, then the light ones
+            const int half = p.gpg >> 1, hp = per >> 1;
+            const int q2 = q8 < hp ? q8 : q8 - hp;
+            qq = (q2 / half) * p.gpg + (q8 < hp ? 0 : half) + q2 % half;
+        }
+        const int wg = q8 < per ? x8 * per + qq : 8 * per + (q8 - per) * 8 + x8;
         wk.cur = wg * p.tpw;
         wk.end = min((p.n_tiles + 3) / 4, wk.cur + p.tpw);
         wk.step = 1;
@@ -1620,6 +1643,7 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
         // moves per chunk at d = 32 fp32 / d = 64 bf16, in a loop that is bound by instruction issue).
         KeRaw<P> qa[PF], qb[PF];
         auto ke_fetch = [&](int cc, KeRaw<P> (&dst)[PF]) {      // wave-uniform cc
+            if (GNNMP_ABL_NO_KE) return;
             if (cc < end) {
 #pragma unroll
                 for (int t = 0; t < PF; ++t) load_edge_slot_raw<P, NT>(p.Ke, cc + j < end ? cc + j : beg, h, t, dst[t]);
@@ -1652,7 +1676,7 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
                 if (beg + 32 + j < end) pre_rec_n = p.rec32[beg + 32 + j];
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if (beg < end) {
-                    const int mine_row = (beg + j < end) ? n0 + (pre_rec_c & 0x7ffffff) : t0;
+                    const int mine_row = (beg + j < end && !GNNMP_ABL_NO_GATHER) ? n0 + (pre_rec_c & 0x7ffffff) : t0 + j;
                     dma_rows<D, P>(p.A, [&](int sr) { return __builtin_amdgcn_ds_bpermute(sr * 4, mine_row); }, astage, lane);
                     if constexpr (kKeEarly) {                               // ... and its K_e tiles: their HBM latency runs under the MFMAs
                         ke_fetch(beg, qa);
@@ -1708,7 +1732,7 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
         // record (source id local to the graph | target's row in this tile << 27) of the one after is requested
         constexpr int STEP = 32 * COOP;
         const int first = beg + (kCoop ? 32 * wave : 0);
-        auto src_row = [&](int rec, bool valid) { return valid ? n0 + (rec & 0x7ffffff) : t0; };
+        auto src_row = [&](int rec, bool valid) { return (valid && !GNNMP_ABL_NO_GATHER) ? n0 + (rec & 0x7ffffff) : t0 + j; };
         int rec_c = pre_rec_c, rec_n = pre_rec_n;
         if constexpr (kCoop) {
             if (first + j < end) rec_c = p.rec32[first + j];
@@ -1782,16 +1806,25 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
                 const int4 o = *reinterpret_cast<const int4*>(dl + 8 * g4 + 4 * h);
                 off[g4 * 4 + 0] = o.x; off[g4 * 4 + 1] = o.y; off[g4 * 4 + 2] = o.z; off[g4 * 4 + 3] = o.w;
             }
+            if (!GNNMP_ABL_NO_ATOMICS) {
 #pragma unroll
             for (int ot = 0; ot < NT; ++ot)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     __builtin_amdgcn_ds_fmaxf((lds_float*)(agg + off[r] + ot * 32 + j), M[ot][r], 0, 0, false);
+            } else {
+                float keep = 0.f;
+#pragma unroll
+                for (int ot = 0; ot < NT; ++ot)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) keep += M[ot][r];
+                if (keep == 123.456f) agg[j] = keep;
+            }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         };
-        for (int c0 = first; c0 < end; c0 += 2 * STEP) {
+        for (int c0 = first; c0 < (GNNMP_ABL_NO_EDGE ? first : end); c0 += 2 * STEP) {
             if constexpr (KD == 2) chunk(c0, qa, qa); else chunk(c0, qa, qb);
             if (c0 + STEP < end) {                               // wave-uniform
                 if constexpr (KD == 2) chunk(c0 + STEP, qb, qb); else chunk(c0 + STEP, qb, qa);
@@ -1842,6 +1875,7 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
             }
             continue;                                            // the next job's first barrier collects the workgroup
         }
+        if (GNNMP_ABL_NO_NODE) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); continue; }
         // ---- node phase.  X and R rows of the tile (contiguous, fp32) come through the two stages as well; the weights
         // (MpNBlob) are read from global memory as MFMA operands (at d = 64 the pointer is laundered per job so that the
         // compiler does not hoist those loop-invariant loads out of the job loop into ~70 registers)
@@ -2231,6 +2265,8 @@ static hipError_t launch_mp_fused_t(const MpFusedParams& p, hipStream_t st) {
         if (forced_tpw > 0) tpw = forced_tpw;
         MpFusedParams q = p;
         q.tpw = tpw;
+        static const int gpg_env = getenv("GNNMP_MP_GPG") ? atoi(getenv("GNNMP_MP_GPG")) : 0;      // experiment
+        q.gpg = gpg_env;
         int grid = ((groups_cap + tpw - 1) / tpw + 7) & ~7;
         if (forced_tpw < 0) {                  // experiment: persistent workgroups, -forced_tpw per CU
             q.tpw = 0;
@@ -2252,7 +2288,13 @@ static hipError_t launch_mp_fused_dp(const MpFusedParams& p, hipStream_t st) {
     // d = 64 with fp32 / bf16x3 operands: four waves per tile instead of eight -- at eight waves a wave has 256 registers and the
     // kernel spilled 116 of them (single 2000-node kuka7 graph: 42 us per launch)
     if constexpr (D > 32 && P != 1) return coop ? launch_mp_fused_t<D, P, 4>(p, st) : launch_mp_fused_t<D, P, 1>(p, st);
-    else return coop ? launch_mp_fused_t<D, P, 8>(p, st) : launch_mp_fused_t<D, P, 1>(p, st);
+    else {
+        if constexpr (P == 1) {                                  // experiments: GNNMP_MP_COOP = 2 / 4 waves per tile at any batch size
+            if (forced == 2) return launch_mp_fused_t<D, P, 2>(p, st);
+            if (forced == 4) return launch_mp_fused_t<D, P, 4>(p, st);
+        }
+        return coop ? launch_mp_fused_t<D, P, 8>(p, st) : launch_mp_fused_t<D, P, 1>(p, st);
+    }
 }
 hipError_t launch_mp_fused(int D, int P, const MpFusedParams& p_in, hipStream_t st) {
     const MpFusedParams& p = p_in;

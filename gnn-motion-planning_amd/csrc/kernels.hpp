@@ -89,6 +89,7 @@ struct MpFusedParams {
     int store_h;
     int tpw;                     // adjacent four-tile groups per workgroup (set by launch_mp_fused)
     int G;                       // graphs: node_ptr_pad[G] / 32 = tiles actually in use (n_tiles is an upper bound)
+    int gpg;                     // experiment
 };
 
 struct PolicyParams {

@@ -842,21 +842,17 @@ static hipError_t launch_sm_graph(const SmParams& p, hipStream_t st) {
     static const int fused_env = getenv("GNNMP_SM_FUSED_GRAPH") ? atoi(getenv("GNNMP_SM_FUSED_GRAPH")) : 1;
     const size_t lds = sm_graph_lds_bytes(p);
     if (fused_env != 0 && lds <= 150 * 1024) {
-        static std::mutex mu;
-        static size_t granted = 0;
-        {
-            std::lock_guard<std::mutex> lock(mu);
-            if (lds > granted) {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sm_graph_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-                if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(sm_graph_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-                if (e != hipSuccess) return e;
-                granted = 150 * 1024;
-            }
+        // the raised dynamic-LDS limit is a property of (kernel, CURRENT device): set on every launch like the explorer's
+        // set_lds (a process that drives a second GPU would otherwise launch there with the default 64 KB limit and fail as
+        // soon as a problem needs more).  If the attribute cannot be set the two-launch form below runs instead.
+        const void* fn = p.samp_cap <= 1024 ? reinterpret_cast<const void*>(sm_graph_kernel<16>) : reinterpret_cast<const void*>(sm_graph_kernel<32>);
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess) {
+            if (p.samp_cap <= 1024) hipLaunchKernelGGL(sm_graph_kernel<16>, dim3(p.B), dim3(1024), lds, st, p);
+            else hipLaunchKernelGGL(sm_graph_kernel<32>, dim3(p.B), dim3(1024), lds, st, p);
+            LAUNCH_CHECK();
+            return hipSuccess;
         }
-        if (p.samp_cap <= 1024) hipLaunchKernelGGL(sm_graph_kernel<16>, dim3(p.B), dim3(1024), lds, st, p);
-        else hipLaunchKernelGGL(sm_graph_kernel<32>, dim3(p.B), dim3(1024), lds, st, p);
-        LAUNCH_CHECK();
-        return hipSuccess;
+        (void)hipGetLastError();
     }
     hipLaunchKernelGGL(sm_knn_kernel, dim3((p.total_path + 3) / 4), dim3(256), 0, st, p);
     LAUNCH_CHECK();

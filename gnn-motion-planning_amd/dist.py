@@ -80,3 +80,138 @@ def run_mixed(problems, models, loop=5):
         for i, sc in zip(idxs, b.split_edges(m.forward_batch(b, loop))):
             out[i] = sc
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE configs[3]: a MIXED set of planning problems (maze / snake / ur5 / kuka -- every family has its own (C, d, S),
+# weights and kernel instantiation: constructor sites str2name.py:14,22,38,46 of the reference) sharded over the GPUs of a node.
+# "mixed-env batches are first bucketed by env family so each rank runs one kernel instantiation per
+# bucket".  shard_range() cuts the CALLER'S order into contiguous blocks, which on 8 ranks turns a 256-problem job into four
+# tiny batches per rank; mixed_plan() buckets first and cuts the family-major order at cost quantiles, so a rank gets at most
+# two families (one while no family is smaller than a rank's share and the cuts snap to a family boundary).
+# ---------------------------------------------------------------------------------------------------------------------
+# device time per reference-formulation FLOP relative to the d = 32 fp32 kernels, measured on one MI355X at 64 problems per
+# family (profiles/r04_cfg4_mixed.txt): d = 64 in fp32 runs the non-resident pre kernel and one message workgroup per CU
+_REL_TIME_PER_FLOP = {(32, 'fp32'): 1.0, (64, 'fp32'): 0.82, (32, 'bf16'): 0.45, (64, 'bf16'): 0.25,
+                      (32, 'bf16x3'): 0.95, (64, 'bf16x3'): 0.9}
+
+
+def forward_cost(n_nodes, n_edges, n_obs, C, d, S, loop=5, mlp_dtype='fp32'):
+    """Predicted device time of ONE problem's explorer forward, in arbitrary units (only ratios matter): the FLOPs of the
+    reference formulation (model.py:115-150) times the measured relative time per FLOP of the kernels
+    that run this (d, operand mode).  E d^2 alone ignores that the obstacle attention of a 116-cell maze costs as much as the
+    whole message passing, and that a d = 64 graph costs 2.4 x a d = 32 one at equal E."""
+    N, E, O = float(n_nodes), float(n_edges), float(n_obs)
+    f_enc = 2 * N * (4 * C * d + d * d) + 4 * E * (2 * C * d + d * d) + 2 * N * (C * d + d * d) + 4 * O * (S * d + d * d)
+    f_att = 3 * ((N + E) * (10 * d * d + 4 * d * (O + 1)) + 16 * O * d * d)
+    f_loop = loop * (8 * N * d * d + 12 * E * d * d + E * d + 4 * N * d * d) + 4 * N * d * d
+    f_pol = E * (8 * d * d + 2 * d)
+    return (f_enc + f_att + f_loop + f_pol) * _REL_TIME_PER_FLOP.get((d, mlp_dtype), 1.0)
+
+
+def problem_costs(problems, models, loop=5):
+    """forward_cost of every problem of a mixed set (``problems[i]['env']`` keys ``models``)."""
+    out = []
+    for p in problems:
+        m = models[p['env']]
+        out.append(forward_cost(p['v'].shape[0], p['edge_index'].shape[1], p['obstacles'].reshape(-1, m.obs_size).shape[0],
+                                m.config_size, m.embed_size, m.obs_size, loop, getattr(m, 'mlp_dtype', 'fp32')))
+    return out
+
+
+def mixed_plan(families, costs, world, snap=0.08):
+    """Family-aware split of a mixed problem set over ``world`` ranks.  ``families[i]`` is problem i's family key, ``costs[i]``
+    its predicted time.  Problems are put in family-major order (families by decreasing total cost, caller order inside a
+    family) and that sequence is cut at the cost quantiles; a cut closer than ``snap`` x (a rank's share) to a family boundary
+    moves onto it, so no rank is left with a sliver of a second family.  Returns ``plan[rank]`` = list of problem indices
+    (caller numbering).  Every rank computes the same plan from the same metadata: nothing is communicated."""
+    n = len(families)
+    assert len(costs) == n
+    by_fam = {}
+    for i, f in enumerate(families):
+        by_fam.setdefault(f, []).append(i)
+    fam_order = sorted(by_fam, key=lambda f: (-sum(costs[i] for i in by_fam[f]), str(f)))
+    order = [i for f in fam_order for i in by_fam[f]]
+    cum = [0.0]
+    for i in order:
+        cum.append(cum[-1] + float(costs[i]))
+    total = cum[-1]
+    bounds, pos = [], 0
+    for f in fam_order[:-1]:
+        pos += len(by_fam[f])
+        bounds.append(pos)
+    share = total / world if world else 0.0
+    cuts = [0]
+    for r in range(1, world):
+        target = total * r / world
+        # first position whose prefix cost reaches the target (bisect on the monotone prefix sums)
+        lo, hi = 0, n
+        while lo < hi:
+            mid = (lo + hi) // 2
+            if cum[mid] < target:
+                lo = mid + 1
+            else:
+                hi = mid
+        cut = lo
+        if cut > 0 and target - cum[cut - 1] < cum[cut] - target:
+            cut -= 1                                   # the nearer of the two neighbouring positions
+        for bnd in bounds:
+            if abs(cum[bnd] - target) <= snap * share:
+                cut = bnd
+                break
+        cuts.append(max(cut, cuts[-1]))
+    cuts.append(n)
+    return [order[cuts[r]:cuts[r + 1]] for r in range(world)]
+
+
+def shard_mixed(problems, rank, world, models, loop=5):
+    """Indices (caller numbering) of the problems of a mixed set that ``rank`` of ``world`` scores: mixed_plan over
+    problem_costs.  ``[problems[i] for i in shard_mixed(...)]`` goes to :class:`MixedJob` / :func:`run_mixed`."""
+    return mixed_plan([p['env'] for p in problems], problem_costs(problems, models, loop), world)[rank]
+
+
+class MixedJob:
+    """A mixed problem set resident on one GPU, scored with every family's batched forward on its OWN stream.
+
+    run_mixed() assembles the per-family batches on every call and runs the family forwards back to back on one stream: at
+    64 problems per family each forward under-fills the device (launch tails, the serial prep -> obstacle -> pre chain), and
+    the job costs the SUM of four under-filled forwards.  Here the batches, workspaces and score buffers are built once
+    (inputs resident, like bench.py's headline batch) and run() forks one stream per family from the caller's stream, most
+    expensive family first, and joins them: the tails of one family's launches overlap the other families' kernels.  Same
+    kernels on the same inputs: scores are byte-identical to run_mixed (tests/test_full_size_mixed_gpu.py)."""
+
+    def __init__(self, problems, models, loop=5, concurrent=True):
+        from .batch import GraphBatch
+        self.loop, self.models, self.n = int(loop), models, len(problems)
+        buckets = {}
+        for i, p in enumerate(problems):
+            buckets.setdefault(p['env'], []).append(i)
+        costs = problem_costs(problems, models, loop)
+        self.parts = []                                  # (env, caller indices, batch, workspace, scores, stream)
+        for env in sorted(buckets, key=lambda e: -sum(costs[i] for i in buckets[e])):
+            idxs = buckets[env]
+            m = models[env]
+            dev = problems[idxs[0]]['v'].device
+            b = GraphBatch.from_graphs([problems[i] for i in idxs], m.obs_size, dev)
+            ws = torch.empty(m.workspace_bytes(b), dtype=torch.uint8, device=dev)
+            out = torch.empty(max(b.total_edges, 1), dtype=torch.float32, device=dev)
+            self.parts.append((env, idxs, b, ws, out, torch.cuda.Stream(dev) if concurrent else None))
+
+    def run(self):
+        """One forward per family; returns the per-problem score tensors in the caller's order (views into the job's own
+        buffers: valid until the next run())."""
+        res = [None] * self.n
+        cur = torch.cuda.current_stream()
+        for env, idxs, b, ws, out, st in self.parts:
+            if st is None:
+                sc = self.models[env].forward_batch(b, self.loop, ws=ws, out=out)
+            else:
+                st.wait_stream(cur)
+                with torch.cuda.stream(st):
+                    sc = self.models[env].forward_batch(b, self.loop, ws=ws, out=out)
+            for i, s in zip(idxs, b.split_edges(sc)):
+                res[i] = s
+        for part in self.parts:
+            if part[5] is not None:
+                cur.wait_stream(part[5])
+        return res

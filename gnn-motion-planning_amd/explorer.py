@@ -174,6 +174,8 @@ class EncoderProcessDecoder(nn.Module):
         self._wt = None
         self.register_load_state_dict_post_hook(lambda m, _k: m._drop_handle())
 
+    _warned_train_dispatch = False          # one warning per process when forward() takes the training path implicitly
+
     # ------------------------------------------------------------------ native handle
     def _drop_handle(self):
         self._handle = None                # _lib.NativeHandle: destroyed with its last reference
@@ -430,7 +432,20 @@ class EncoderProcessDecoder(nn.Module):
         autograd enabled -- the reference's training loop calls ``model(...)`` and back-propagates through the result
         (train_explorer.py:156-176) -- it is :meth:`forward_train`; under ``eval()`` or ``torch.no_grad()`` (eval_gnn.py:168)
         the inference kernels run."""
-        if self.training and torch.is_grad_enabled() and self.mlp_dtype == 'fp32':
+        if self.training and torch.is_grad_enabled():
+            if self.mlp_dtype != 'fp32':
+                # the inference kernels under no_grad would return a tensor that "does not require grad" and the caller's
+                # backward() would fail far from the cause
+                raise RuntimeError("EncoderProcessDecoder is in training mode with autograd enabled but mlp_dtype = %r: the "
+                                   "training path runs in fp32 only.  Call .eval() (or wrap the call in torch.no_grad()) for "
+                                   "inference with %s operands, or set mlp_dtype = 'fp32' to train." % (self.mlp_dtype, self.mlp_dtype))
+            if not EncoderProcessDecoder._warned_train_dispatch:
+                EncoderProcessDecoder._warned_train_dispatch = True
+                import warnings
+                warnings.warn('gnnmp.EncoderProcessDecoder: the module is in training mode (the default of a freshly constructed '
+                              'torch module) and autograd is enabled, so model(...) runs the differentiable training path '
+                              '(train_explorer.py:156-176).  Call .eval() or use torch.no_grad() for the inference kernels.',
+                              stacklevel=2)
             return self.forward_train(goal, loop, v, obstacles, free, collided, edge_index, k, **kwargs)
         with torch.no_grad():
             _, dn = self.forward_batch(self._single(goal, v, obstacles, edge_index, prefix_arrays=False), loop, dense=True)

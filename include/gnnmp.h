@@ -203,6 +203,11 @@ int gnnmp_smoother_destroy(gnnmp_smoother* h);
 typedef struct {
     int32_t n_problems;
     int32_t total_path, total_free, total_collided, total_edges;
+    /* The three max_* fields are caller PROMISES that size the kernels' LDS carve-up; the prefix arrays live on the device
+     * and forward() never reads them back (no hidden synchronisation), so they are not checked against the arrays.  A
+     * problem that exceeds any of them gets NO kNN / chain edges in that iteration (its interior waypoints then follow
+     * smooth_node of the plain node codes) -- a wrong path, not an error code.  Compute them from the same host-side counts
+     * the prefix arrays are built from (the Python wrapper does). */
     int32_t max_path;            /* >= max_b P_b                                              */
     int32_t max_samples;         /* >= max_b (F_b + Co_b)                                     */
     int32_t max_edges;           /* >= max_b E_b                                              */

@@ -129,3 +129,129 @@ def test_shard_ranges_cover_and_balance():
 def test_gather_without_process_group():
     x = torch.arange(5.)
     assert torch.equal(gather_variable(x)[0], x)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE configs[3]: family-aware sharding of a mixed problem set (gnnmp.dist.mixed_plan / shard_mixed)
+# ---------------------------------------------------------------------------------------------------------------------
+_FAM = {'maze2': (2, 32, 2, 116, 11270), 'snake7': (7, 32, 2, 116, 12321), 'ur5': (6, 32, 6, 5, 12101), 'kuka7': (7, 64, 6, 5, 12291)}
+
+
+def _mixed_job(n=256, jitter=True):
+    """families interleaved the way a mixed evaluation set arrives; per-problem edge counts jittered around the measured means"""
+    from gnnmp.dist import forward_cost
+    names = list(_FAM)
+    fams = [names[i % 4] for i in range(n)]
+    g = torch.Generator().manual_seed(7)
+    costs = []
+    for f in fams:
+        C, d, S, O, E = _FAM[f]
+        e = int(E * (1 + (0.1 * (torch.rand(1, generator=g).item() - 0.5) if jitter else 0)))
+        costs.append(forward_cost(1000, e, O, C, d, S))
+    return fams, costs
+
+
+def test_mixed_plan_is_a_partition_with_few_families_per_rank():
+    from gnnmp.dist import mixed_plan
+    fams, costs = _mixed_job()
+    for world in (1, 2, 3, 4, 8):
+        plan = mixed_plan(fams, costs, world)
+        assert sorted(i for r in plan for i in r) == list(range(len(fams)))               # a partition of the job
+        loads = [sum(costs[i] for i in r) for r in plan]
+        assert max(loads) <= 1.10 * sum(loads) / world, (world, loads)                   # predicted-time imbalance <= 10 %
+        if world >= 4:
+            assert max(len({fams[i] for i in r}) for r in plan) <= 2, world               # <= 2 kernel instantiations per rank
+        for r in plan:                                                                    # caller order is kept inside a family
+            for f in set(fams[i] for i in r):
+                mine = [i for i in r if fams[i] == f]
+                assert mine == sorted(mine)
+    # cost share, not edge share: at equal edge counts a d = 64 kuka7 problem costs ~2.4 x a d = 32 one, so the ranks that
+    # hold kuka7 hold FEWER problems
+    plan = mixed_plan(fams, costs, 8)
+    kuka_only = [r for r in plan if {fams[i] for i in r} == {'kuka7'}]
+    d32_only = [r for r in plan if 'kuka7' not in {fams[i] for i in r}]
+    assert kuka_only and d32_only and max(map(len, kuka_only)) < min(map(len, d32_only))
+
+
+def _mixed_worker(rank, world, port, q):
+    from gnnmp.dist import mixed_plan
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    fams, costs = _mixed_job(256)
+    plan = mixed_plan(fams, costs, world)                  # every rank derives the same plan from the same metadata
+    mine = plan[rank]
+    local = torch.cat([_fake_scores(i, i + 1) for i in mine]) if mine else torch.zeros(0)
+    parts = gather_variable(local)
+    # reassemble in CALLER order from the plan alone (no index exchange)
+    out = [None] * len(fams)
+    for r, part in enumerate(parts):
+        off = 0
+        for i in plan[r]:
+            n = 5 + i % 3
+            out[i] = part[off:off + n]
+            off += n
+    q.put((rank, [fams[i] for i in mine], sum(costs[i] for i in mine), torch.cat(out).numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_ranks_family_aware_shards_and_gather():
+    """world size 8 over gloo: every rank scores the problems mixed_plan gives it (stand-in scores), the padded gather returns
+    every rank's block, and the job's scores come back in the caller's problem order; <= 2 families per rank, predicted
+    time within 10 % of the mean."""
+    world = 8
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_mixed_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    whole = _fake_scores(0, 256)
+    loads = {}
+    for rank, fam_list, load, flat in got:
+        assert torch.equal(torch.from_numpy(flat), whole)
+        assert len(set(fam_list)) <= 2
+        loads[rank] = load
+    mean = sum(loads.values()) / world
+    assert max(loads.values()) <= 1.10 * mean, loads
+
+
+def _strong_worker(rank, world, port, n_total, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    lo, hi = shard_range(n_total, rank, world)             # bench.py --strong N_TOTAL: problem i = seed 1234 + i on whatever rank
+    local = _fake_scores(1234 + lo, 1234 + hi)
+    parts = gather_variable(local)
+    ones = torch.ones(1, dtype=torch.float64)
+    dist.all_reduce(ones)                                  # bench.py's `ranks_seen`
+    q.put((rank, hi - lo, int(ones.item()), torch.cat(parts).numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_strong_split_scores_the_same_fixed_set(world):
+    """bench.py --strong: the job is a FIXED problem set whatever the rank count -- the gathered scores of a 2- or 3-rank run are
+    the bytes of the one-rank run, every rank holds its contiguous block, and the all_reduce of ones counts the ranks."""
+    n_total = 10
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_strong_worker, args=(r, world, port, n_total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    whole = _fake_scores(1234, 1234 + n_total)
+    assert sum(g[1] for g in got) == n_total
+    for rank, n_local, seen, flat in got:
+        assert seen == world
+        assert torch.equal(torch.from_numpy(flat), whole)

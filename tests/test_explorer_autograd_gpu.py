@@ -133,6 +133,14 @@ def test_module_call_dispatches_on_mode():
     P_eval = m(**kw)
     assert not P_eval.requires_grad and torch.equal(P_eval, P_ng)
     assert torch.allclose(P_train.detach(), P_eval, rtol=1e-5, atol=2e-5)
+    # reduced-precision operands have no training path: under train() with autograd on, the call says so instead of
+    # returning an inference result whose backward() fails far from the cause
+    m.train()
+    m.mlp_dtype = 'bf16'
+    with pytest.raises(RuntimeError, match='training path runs in fp32 only'):
+        m(**kw)
+    with torch.no_grad():
+        assert not m(**kw).requires_grad                 # inference under no_grad is fine in any mode
 
 
 def test_gradients_are_deterministic_and_batched_equals_accumulated():

@@ -3,14 +3,15 @@ str2name.py:14,22,38,46 of the reference) -- 256 problems, 64 per family, 1000-n
 ``gnnmp.dist.run_mixed`` (one batched forward per family, results in the caller's order).  Size-independent properties:
 (a) two runs give identical bytes; (b) a graph scored inside the mixed job equals the same graph scored alone, bit for bit,
 for every family; (c) one sampled graph per family agrees with the CPU oracle within the absolute fp32 bar of
-tests/parity_bar.py; (d) the per-rank shard of the job (gnnmp.dist.shard_range weighted by edge counts) scores its problems
-to the same bytes as the whole job does.  kuka7 (d = 64) runs the fp32 d = 64 kernels here -- a BASELINE config member."""
+tests/parity_bar.py; (d) the resident, stream-per-family form (gnnmp.dist.MixedJob) gives the bytes of run_mixed; (e) the family-aware shards of the job
+(gnnmp.dist.shard_mixed: bucketed by family, cut at cost quantiles) partition it, hold at most two families per rank, balance the
+predicted time within 10 % and score their problems to the same bytes as the whole job does.  kuka7 (d = 64) runs the fp32 d = 64 kernels here -- a BASELINE config member."""
 import pytest
 import torch
 
 from conftest import load_weights
 import gnnmp
-from gnnmp.dist import run_mixed, shard_range
+from gnnmp.dist import MixedJob, problem_costs, run_mixed, shard_mixed, shard_range
 from gnnmp.synth import ENVS, synth_batch_gpu
 from parity_bar import assert_fp32_parity, explorer_oracle_pair
 
@@ -54,14 +55,34 @@ def test_cfg4_mixed_set_full_size():
         c = assert_fp32_parity(s1[idx].cpu(), ref32, ref64, env)                        # (c)
         print('%s N=%d E=%d: |gpu-ref64| %.2e  |gpu-ref32| %.2e  oracle fp32-vs-fp64 %.2e  bar %.2e' % (
             env, N, g['edge_index'].shape[1], c['err64'], c['err32'], c['own'], c['atol']))
-    # (d) an edge-weighted 2-way split of the job: every rank's shard gives the bytes the whole job gave
-    weights = [int(p['edge_index'].shape[1]) for p in problems]
-    covered = 0
-    for rank in range(2):
-        lo, hi = shard_range(len(problems), rank, 2, weights)
-        part = run_mixed(problems[lo:hi], models, loop=LOOP)
-        assert all(torch.equal(a, b) for a, b in zip(part, s1[lo:hi]))
-        covered += hi - lo
-        share = sum(weights[lo:hi]) / sum(weights)
-        assert 0.45 < share < 0.55, share
-    assert covered == len(problems)
+    # (d) the resident form of the job -- batches built once, every family's forward on its own stream (gnnmp.dist.MixedJob) --
+    # gives the bytes of run_mixed, with and without the concurrent streams, run after run
+    for concurrent in (True, False):
+        job = MixedJob(problems, models, loop=LOOP, concurrent=concurrent)
+        for _ in range(2):
+            got = job.run()
+            torch.cuda.synchronize()
+            assert all(torch.equal(a, b) for a, b in zip(got, s1)), concurrent
+    # (e) family-aware shards (gnnmp.dist.shard_mixed: bucket by family, cut the family-major order at COST quantiles -- a
+    # d = 64 kuka7 problem costs ~2.4 x a d = 32 one at equal edge count, so edge shares would be the wrong thing to balance):
+    # every rank's shard gives the bytes the whole job gave, the shards partition the job, a rank holds at most two families
+    # once there are as many ranks as families, and the predicted time of the slowest rank is within 10 % of the mean
+    costs = problem_costs(problems, models, LOOP)
+    for world in (2, 4, 8):
+        seen = []
+        loads = []
+        for rank in range(world):
+            idx = shard_mixed(problems, rank, world, models, LOOP)
+            seen += idx
+            loads.append(sum(costs[i] for i in idx))
+            if world >= 4:
+                assert len({problems[i]['env'] for i in idx}) <= 2, (world, rank)
+            if world == 4 or rank in (0, world - 1):                                    # scoring every shard of every split would only repeat (b)
+                part = MixedJob([problems[i] for i in idx], models, loop=LOOP).run()
+                torch.cuda.synchronize()
+                assert all(torch.equal(a, s1[i]) for a, i in zip(part, idx)), (world, rank)
+        assert sorted(seen) == list(range(len(problems)))
+        assert max(loads) <= 1.10 * sum(loads) / world, (world, loads)
+    # the contiguous edge-weighted split of the caller's order still works for single-family sets (tests/test_dist_gloo.py)
+    lo, hi = shard_range(len(problems), 0, 2, [int(p['edge_index'].shape[1]) for p in problems])
+    assert 0 < hi < len(problems)

@@ -46,4 +46,49 @@ for env in FAMILIES:
     e = ENVS[env]
     print('%-10s %4d %4d %4d %8.0f %12.1f' % (env, e['C'], e['d'], ps[0]['obstacles'].reshape(-1, e['S']).shape[0],
                                             sum(p['edge_index'].shape[1] for p in ps) / len(ps), rate(ps)))
-print('%-10s %35s %12.1f   (run_mixed: GraphBatch assembly + one batched forward per family)' % ('mixed job', '', rate(problems)))
+print('%-10s %35s %12.1f   (run_mixed: GraphBatch assembly + one batched forward per family, one stream)' % ('mixed job', '', rate(problems)))
+
+
+def job_rate(job, reps=20):
+    for _ in range(3):
+        job.run()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            job.run()
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    return len(problems) * reps / sorted(ts)[1]
+
+
+from gnnmp.dist import MixedJob, mixed_plan, problem_costs  # noqa: E402
+ref = run_mixed(problems, models, loop=LOOP)
+for conc in (False, True):
+    job = MixedJob(problems, models, loop=LOOP, concurrent=conc)
+    same = all(torch.equal(a, b) for a, b in zip(job.run(), ref))
+    print('%-10s %35s %12.1f   (MixedJob: batches resident, %s; bytes equal run_mixed: %s)' % (
+        'mixed job', '', job_rate(job), 'one stream per family, most expensive first' if conc else 'families back to back on one stream', same))
+costs = problem_costs(problems, models, LOOP)
+fam_cost = {env: sum(c for c, p in zip(costs, problems) if p['env'] == env) / PER for env in FAMILIES}
+print('cost model (gnnmp.dist.forward_cost, relative to maze2): ' + ', '.join('%s %.2f' % (e, fam_cost[e] / fam_cost['maze2']) for e in FAMILIES))
+for world in (2, 4, 8):
+    plan = mixed_plan([p['env'] for p in problems], costs, world)
+    loads = [sum(costs[i] for i in r) for r in plan]
+    print('shard_mixed over %d ranks: problems per rank %s, families per rank %s, predicted slowest / mean %.3f' % (
+        world, [len(r) for r in plan], [len({problems[i]['env'] for i in r}) for r in plan], max(loads) / (sum(loads) / world)))
+    if world == 8:
+        # what ONE rank of the 8-rank job runs, measured on this GPU: the slowest shard bounds the job
+        rates = []
+        for r in plan:
+            j = MixedJob([problems[i] for i in r], models, loop=LOOP)
+            for _ in range(3):
+                j.run()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                j.run()
+            torch.cuda.synchronize()
+            rates.append((time.perf_counter() - t0) / 10 * 1e3)
+        print('   measured ms per shard on this GPU: %s -> slowest / mean %.3f' % (['%.2f' % x for x in rates], max(rates) / (sum(rates) / len(rates))))

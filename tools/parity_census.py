@@ -1,0 +1,103 @@
+#!/usr/bin/env python
+"""Run ON THE GPU BOX: full-size parity census of the explorer forward (fp32 mode) against the fp64 oracle.
+
+The golden fixtures pin 16 small graphs; the full-size tests used to compare 3 of 256 (cfg 2), 2 of 64 (cfg 3 shape) and 4 of
+256 (cfg 4) graphs with the oracle.  This runs the oracle (oracle/ref_cpu.py, the reference's formulation of model.py:115-150,
+in fp32 AND fp64) on EVERY graph of
+
+    cfg 2        256 x maze2  1000-node k1 = 8      (BASELINE configs[1])
+    cfg 3 shape   64 x kuka7  2000-node k1 = 10     (configs[2] shape, fp32 operands)
+    cfg 5 shape    8 x kuka14 5000-node k1 = 16     (configs[4] shape, fp32 operands)
+    cfg 4         16 per family of maze2 / snake7 / ur5 / kuka7, 1000-node k1 = 8   (configs[3])
+
+and prints, per workload, the histogram over graphs of max|gpu - ref64| (the distance to the exact result), of the reference's
+own fp32-vs-fp64 distance `own`, and of max|gpu - ref32|; the worst graphs; and how many graphs exceed 1e-5 against fp64.
+tests/test_parity_census_gpu.py asserts <= 1e-5 against fp64 on every graph through the same functions.
+
+    python tools/parity_census.py [--quick] > profiles/r04_parity_census.txt
+"""
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, 'tests'))
+import gnnmp  # noqa: E402
+from gnnmp.synth import ENVS, synth_batch_gpu  # noqa: E402
+from gnnmp.weights import load_weights  # noqa: E402
+
+DEV = 'cuda:0'
+WORKLOADS = [                                   # (name, env, nodes, k1, graphs, seed0)
+    ('cfg2  maze2  N=1000 k1=8', 'maze2', 1000, 8, 256, 1234),
+    ('cfg3  kuka7  N=2000 k1=10', 'kuka7', 2000, 10, 64, 1234),
+    ('cfg5  kuka14 N=5000 k1=16', 'kuka14', 5000, 16, 8, 1234),
+    ('cfg4  maze2  N=1000 k1=8', 'maze2', 1000, 8, 16, 5000),
+    ('cfg4  snake7 N=1000 k1=8', 'snake7', 1000, 8, 16, 6000),
+    ('cfg4  ur5    N=1000 k1=8', 'ur5', 1000, 8, 16, 7000),
+    ('cfg4  kuka7  N=1000 k1=8', 'kuka7', 1000, 8, 16, 8000),
+]
+EDGES = [0.0, 1e-6, 2e-6, 4e-6, 6e-6, 8e-6, 1e-5, 1.5e-5, 2e-5, 3e-5, 1.0]
+
+
+def census(env, nodes, k1, n_graphs, seed0, loop=5, mlp_dtype='fp32', device=DEV):
+    """Per graph: (err64 = max|gpu - ref64|, err32 = max|gpu - ref32|, own = max|ref32 - ref64|, #elements > 1e-5 vs ref64, E).
+    The GPU scores come from ONE batched forward over all graphs (the measured configuration)."""
+    from oracle import ref_cpu
+    e = ENVS[env]
+    w = load_weights(e['ckpt'])
+    w64 = {k: (t.double() if t.is_floating_point() else t) for k, t in w.items()}
+    graphs = synth_batch_gpu(env, nodes, k1, n_graphs, device, seed0=seed0)
+    m = gnnmp.EncoderProcessDecoder(e['workspace'], e['C'], e['d'], e['S']).eval()
+    m.load_state_dict(w, strict=True)
+    m.mlp_dtype = mlp_dtype
+    b = gnnmp.GraphBatch.from_graphs(graphs, e['S'], device)
+    parts = [p.cpu().double() for p in b.split_edges(m.forward_batch(b, loop))]
+    rows = []
+    for g, s in zip(graphs, parts):
+        v, goal, obs, ei = (g[k].cpu() for k in ('v', 'goal', 'obstacles', 'edge_index'))
+        r32 = ref_cpu.explorer_forward(w, v, goal, obs, ei, loop).double()
+        r64 = ref_cpu.explorer_forward(w64, v.double(), goal.double(), obs.double(), ei, loop)
+        d64 = (s - r64).abs()
+        rows.append((d64.max().item(), (s - r32).abs().max().item(), (r32 - r64).abs().max().item(), int((d64 > 1e-5).sum()), int(ei.shape[1])))
+    return rows
+
+
+def hist(vals):
+    out = []
+    for lo, hi in zip(EDGES[:-1], EDGES[1:]):
+        n = sum(1 for x in vals if lo <= x < hi)
+        out.append(n)
+    return out
+
+
+def report(name, rows):
+    n = len(rows)
+    print('%s: %d graphs, %d edge scores' % (name, n, sum(r[4] for r in rows)))
+    print('    %-28s' % 'bin (upper edge)' + ''.join('%9s' % ('<%.1e' % hi if hi < 1 else '>=3e-5') for hi in EDGES[1:]))
+    for label, col in (('max|gpu - ref64| per graph', 0), ('own = max|ref32 - ref64|', 2), ('max|gpu - ref32| per graph', 1)):
+        print('    %-28s' % label + ''.join('%9d' % c for c in hist([r[col] for r in rows])))
+    worst = sorted(range(n), key=lambda i: -rows[i][0])[:3]
+    print('    worst graphs vs fp64: ' + '; '.join('#%d %.2e (own %.2e, vs ref32 %.2e)' % (i, rows[i][0], rows[i][2], rows[i][1]) for i in worst))
+    over = [i for i in range(n) if rows[i][0] > 1e-5]
+    print('    max over graphs: |gpu - ref64| %.3e   own %.3e   |gpu - ref32| %.3e;  graphs over 1e-5 vs fp64: %d of %d (%d elements)' % (
+        max(r[0] for r in rows), max(r[2] for r in rows), max(r[1] for r in rows), len(over), n, sum(r[3] for r in rows)))
+    return len(over)
+
+
+def main():
+    quick = '--quick' in sys.argv
+    print('explorer forward, fp32 mode, every graph of each workload against the fp64 oracle (oracle/ref_cpu.py); north_star bar 1e-5')
+    bad = 0
+    t0 = time.time()
+    for name, env, nodes, k1, ng, seed0 in WORKLOADS:
+        rows = census(env, nodes, k1, max(2, ng // 8) if quick else ng, seed0)
+        bad += report(name, rows)
+    print('census done in %.0f s; graphs over 1e-5 against fp64: %d' % (time.time() - t0, bad))
+    return bad
+
+
+if __name__ == '__main__':
+    sys.exit(1 if main() else 0)
