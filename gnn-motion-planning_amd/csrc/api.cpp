@@ -903,6 +903,8 @@ int forward_impl(const gnnmp_explorer* h, const gnnmp_batch* b, int loop, int us
         f.n_tiles = c.Npad / 32;
         f.tpw = 1;
         f.gpg = 0;
+        f.pair = 0;
+        f.trace = nullptr;
         f.G = c.G;
         f.store_h = last ? 1 : 0;
         StageScope sc(prof, GNNMP_STAGE_MP, st);

@@ -1391,6 +1391,25 @@ __device__ __forceinline__ void load_row_tile(const float* array_f32_units, size
 }
 
 typedef __attribute__((address_space(3))) float lds_float;
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+// s_waitcnt vmcnt(N) as the BUILTIN, not as inline asm: the compiler's own wait-count bookkeeping reads S_WAITCNT instructions
+// that are already there, so after this one it knows that everything but the last N vector-memory operations has completed and
+// inserts no (coarser) wait of its own for registers or LDS-DMA destinations filled by the older ones.  An inline-asm wait is
+// invisible to it: it then guarded the first use of every prefetched register with s_waitcnt vmcnt(0), which also drained
+// the requests issued a moment earlier.  (gfx9 encoding: vmcnt[3:0] | expcnt << 4 | lgkmcnt << 8 | vmcnt[5:4] << 14.)
+__device__ __forceinline__ void wait_all() {            // s_waitcnt vmcnt(0) lgkmcnt(0)
+    __builtin_amdgcn_s_waitcnt(7 << 4);
+    asm volatile("" ::: "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));
+    asm volatile("" ::: "memory");
+}
+// byte address of an LDS location as the DS instructions take it
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
+}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Row gathers through LDS.  A wave-wide global load in the chain layout (lane = row, 16 bytes per lane per instruction)
@@ -1452,6 +1471,32 @@ __device__ __forceinline__ void read_stage_tile(const float* stage, int sr, int 
     }
 }
 
+// the same 32-feature tile kept as read (bf16 rows stay packed: 8 registers instead of 16) -- the message kernel empties the A
+// stage into registers at the top of a chunk so that the NEXT chunk's rows can be requested a whole chunk ahead
+template <int P> struct StageRaw { f32x4 q[4]; };
+template <> struct StageRaw<1> { bf16x4 q[4]; };
+template <int D, int P>
+__device__ __forceinline__ void read_stage_raw(const float* stage, int sr, int h, int t, StageRaw<P>& r) {
+    using G = RowGeom<D, P>;
+    const char* row = reinterpret_cast<const char*>(stage) + sr * G::RB;
+    const int sw = G::swz(sr);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if constexpr (P != 1) r.q[q] = *reinterpret_cast<const f32x4*>(row + (((t * 8 + q * 2 + h) ^ sw) * 16));
+        else r.q[q] = *reinterpret_cast<const bf16x4*>(row + (((t * 4 + q) ^ sw) * 16) + h * 8);
+    }
+}
+template <int P>
+__device__ __forceinline__ void expand_stage_raw(const StageRaw<P>& r, f32x16& x) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        f32x4 a;
+        if constexpr (P != 1) a = r.q[q]; else a = __builtin_convertvector(r.q[q], f32x4);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) x[q * 4 + c] = a[c];
+    }
+}
+
 // the inverse of read_stage_tile for a whole row: the lane's NT tiles of stage row sr (its half h) in the row format of
 // precision P (fp32 / bf16x3: fp32 rows; bf16: rows rounded to bf16 like store_row_p)
 template <int D, int P, int NT>
@@ -1510,6 +1555,22 @@ __device__ __forceinline__ void linear_acc_stream(const float* A, Get get, f32x1
 #ifndef GNNMP_ABL_NO_ATOMICS
 #define GNNMP_ABL_NO_ATOMICS 0       // no LDS max atomics
 #endif
+#ifndef GNNMP_ABL_KE_L2
+#define GNNMP_ABL_KE_L2 0            // every chunk reads the K_e tiles of the first 4096 edge slots (L2 hits): same instructions, no HBM stream
+#endif
+// the chunk loop's request / wait structure, per operand precision (experiments: -DGNNMP_MP_FLOW_BF16=0 / -DGNNMP_MP_FLOW_F32=1).
+// "New flow" = (a) the A stage is emptied into registers at the top of a chunk and the next chunk's rows are requested there, a whole
+// chunk ahead; (b) requests inside the loop are unconditional; (c) the prefetched registers' first uses are pinned behind the
+// explicit wait; (d) the target offsets and the aggregation atomics are issued by hand.  It is what lets the prefetch run more than
+// one request deep (see the chunk body); measured: bf16 d = 64 five launches 0.556 -> 0.545 ms, bf16 d = 32 0.548 -> 0.512, but
+// fp32 d = 32 0.704 -> 0.752 (its sixteen 64-cycle MFMAs per chunk cover the latency anyway and the extra registers cost), so
+// the exact-fp32 kernels keep the round-3 flow.
+#ifndef GNNMP_MP_FLOW_BF16
+#define GNNMP_MP_FLOW_BF16 1
+#endif
+#ifndef GNNMP_MP_FLOW_F32
+#define GNNMP_MP_FLOW_F32 0
+#endif
 #ifndef GNNMP_ABL_NO_EDGE
 #define GNNMP_ABL_NO_EDGE 0          // no edge phase at all (tile start + node phase only)
 #endif
@@ -1536,21 +1597,36 @@ template <int D, int P, int COOP>
 #ifndef GNNMP_MP_WGS32
 #define GNNMP_MP_WGS32 2      // the LDS tiles leave two workgroups per CU at d = 32: let the wave use the registers of two
 #endif
+#ifndef GNNMP_MP_WGS32B
+#define GNNMP_MP_WGS32B 2     // d = 32, bf16 operands: three workgroups per CU fit the LDS, but at 168 registers the kernel spills (0.54 vs 0.51 ms at the configs[4] shape)
+#endif
 #ifndef GNNMP_MP_DEEP32
 #define GNNMP_MP_DEEP32 0     // experiment switch: K_e two chunks ahead at d = 32 fp32 (measured slower: 0.906 vs 0.875 ms)
 #endif
-__global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 && P != 1) ? 1 : ((P == 2 || D > 32) ? 2 : GNNMP_MP_WGS32)) : ((COOP == 2 || (COOP == 4 && P == 1)) ? (D == 32 ? 3 : 2) : 1)) void mp_fused_kernel(MpFusedParams p) {
+__global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 && P != 1) ? 1 : ((P == 2 || D > 32) ? 2 : (P == 1 ? GNNMP_MP_WGS32B : GNNMP_MP_WGS32))) : ((COOP == 2 || (COOP == 4 && P == 1)) ? (D == 32 ? 3 : 2) : 1)) void mp_fused_kernel(MpFusedParams p) {
     constexpr int NT = D / 32;
     constexpr bool kCoop = COOP > 1;
     // few tiles, d = 32: the node phase is spread over waves (below); at d = 64 the eight-wave workgroup has 256 registers per
     // wave and the extra live tiles spill (measured: kuka7 bf16 single graph 135 -> 156 us), so it keeps the one-wave form
     constexpr bool kSplitNode = kCoop && D == 32;
+    constexpr bool kNewFlow = P == 1 ? (GNNMP_MP_FLOW_BF16 != 0) : (GNNMP_MP_FLOW_F32 != 0);
+    constexpr bool kAsmTail = kNewFlow, kAEarly = kNewFlow, kUncond = kNewFlow, kLaunder = kNewFlow;
     using LE = MpEBlob<D, P>;
     using LN = MpNBlob<D, P>;
     using G = RowGeom<D, P>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* wl = lds;                                             // MpEBlob
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
+#ifdef GNNMP_MP_TRACE
+    // diagnostics build: [0] wave start, then per tile: start, end of the edge phase, end of the node phase (100 MHz clock)
+    long long* trc = p.trace ? p.trace + ((size_t)blockIdx.x * (blockDim.x >> 6) + wave) * 8 : nullptr;
+    int trc_n = 0;
+#define GNNMP_TRC() do { if (trc && lane == 0 && trc_n < 8) trc[trc_n] = wall_clock64(); ++trc_n; } while (0)
+    if (trc && lane == 0) { for (int i = 0; i < 8; ++i) trc[i] = 0; }
+    GNNMP_TRC();
+#else
+#define GNNMP_TRC() do {} while (0)
+#endif
     float* base = lds + ((LE::size + 3) & ~3);
     float* agg = kCoop ? base : base + wave * (32 * D + 32 + 2 * G::STAGE_FLOATS);                   // [32][D]
     float* btile = kCoop ? base + 32 * D : agg + 32 * D + 32 + G::STAGE_FLOATS;                      // B rows of the tile
@@ -1615,6 +1691,26 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
         wk.cur = wg * p.tpw;
         wk.end = min((p.n_tiles + 3) / 4, wk.cur + p.tpw);
         wk.step = 1;
+        if (p.pair) {
+            // MIRRORED PAIRS (tpw == 2): workgroup `wg` stands for the 256-row block `wg` of the padded node space (every graph
+            // is a whole number of them: kPad); it takes the group that far from the START of its graph and then the group that
+            // far from its END.  The reference's graphs list the free samples first, and those have ~1.5 x the incoming edges
+            // of the collided ones (kNN over all samples + kNN over the free ones: eval_gnn.py:160-164), so the first half of a
+            // graph's tiles is heavy and the second light: a (first, last) pair costs the same for every workgroup, where
+            // four adjacent tiles did not (first-half groups 2350 edges, second-half 1580 at the configs[2] shape) -- with two
+            // workgroups per slot and launch the hardware dispatcher could not level that out (29 % of the wave slots idle).
+            const int blk_tile = wg * 8;
+            const int bg = blk_tile < p.n_tiles ? p.ntile_graph[blk_tile] : -1;
+            if (bg >= 0) {
+                const int g0 = p.node_ptr_pad[bg] >> 7, g1 = p.node_ptr_pad[bg + 1] >> 7;       // the graph's groups [g0, g1), an even count
+                const int i = wg - (g0 >> 1);
+                wk.cur = g0 + i;
+                wk.step = (g1 - 1 - i) - wk.cur;                  // >= 1
+                wk.end = g1 - i;
+            } else {
+                wk.end = wk.cur;                                   // block behind the last graph
+            }
+        }
     }
     for (; wk.valid(); wk.next()) {
         // static strided split: at any moment the resident workgroups of an XCD work on ADJACENT tiles, so the K_e stream
@@ -1630,6 +1726,7 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
         const int beg = __builtin_amdgcn_readfirstlane(rb);
         const int end = __builtin_amdgcn_readlane(rb + dg, 31);
         const int n0 = p.node_ptr_pad[tg];
+        GNNMP_TRC();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the previous job's LDS reads are done
         if constexpr (kCoop) __syncthreads();                    // ... by every wave of the workgroup
         // K_e streams from HBM: PF tiles of a chunk are requested KD chunks ahead and wait in registers
@@ -1642,11 +1739,17 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
         // filled for the next chunk when KD = 1.  No queue shifting and no loop-carried copies (they were 16 / 40 register
         // moves per chunk at d = 32 fp32 / d = 64 bf16, in a loop that is bound by instruction issue).
         KeRaw<P> qa[PF], qb[PF];
+        // Requests inside the chunk loop are UNCONDITIONAL (a chunk beyond the tile's range re-reads slot `beg`: one cache line):
+        // the compiler counts the outstanding vector-memory operations per control-flow path and, where paths differ, waits
+        // for all of them (s_waitcnt vmcnt(0)) the first time a loaded register is used -- with the requests behind wave-uniform
+        // branches that drained the K_e tiles of the chunk after next in the middle of every chunk.
         auto ke_fetch = [&](int cc, KeRaw<P> (&dst)[PF]) {      // wave-uniform cc
             if (GNNMP_ABL_NO_KE) return;
-            if (cc < end) {
+            if (!kUncond && cc >= end) return;
 #pragma unroll
-                for (int t = 0; t < PF; ++t) load_edge_slot_raw<P, NT>(p.Ke, cc + j < end ? cc + j : beg, h, t, dst[t]);
+            for (int t = 0; t < PF; ++t) {
+                const int sl = cc + j < end ? cc + j : beg;
+                load_edge_slot_raw<P, NT>(p.Ke, GNNMP_ABL_KE_L2 ? (sl & 4095) : sl, h, t, dst[t]);
             }
         };
         int pre_rec_c = 0, pre_rec_n = 0;
@@ -1674,9 +1777,9 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
                 // the MFMAs below: one dependent round trip at the start of a tile instead of three
                 if (beg + j < end) pre_rec_c = p.rec32[beg + j];
                 if (beg + 32 + j < end) pre_rec_n = p.rec32[beg + 32 + j];
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                wait_vmcnt<0>();
                 if (beg < end) {
-                    const int mine_row = (beg + j < end && !GNNMP_ABL_NO_GATHER) ? n0 + (pre_rec_c & 0x7ffffff) : t0 + j;
+                    const int mine_row = (beg + j < end) ? (GNNMP_ABL_NO_GATHER ? t0 + j : n0 + (pre_rec_c & 0x7ffffff)) : t0;
                     dma_rows<D, P>(p.A, [&](int sr) { return __builtin_amdgcn_ds_bpermute(sr * 4, mine_row); }, astage, lane);
                     if constexpr (kKeEarly) {                               // ... and its K_e tiles: their HBM latency runs under the MFMAs
                         ke_fetch(beg, qa);
@@ -1715,7 +1818,7 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
             if (wave == COOP - 2) dma_rows<D, 0>(p.R, [&](int sr) { return t0 + sr; }, rstage, lane);
         }
         if constexpr (kCoop) {
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            wait_all();
             __syncthreads();
             if (kSplitNode && wave == COOP - 1) {
                 f32x16 Hp[NT];
@@ -1732,7 +1835,7 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
         // record (source id local to the graph | target's row in this tile << 27) of the one after is requested
         constexpr int STEP = 32 * COOP;
         const int first = beg + (kCoop ? 32 * wave : 0);
-        auto src_row = [&](int rec, bool valid) { return (valid && !GNNMP_ABL_NO_GATHER) ? n0 + (rec & 0x7ffffff) : t0 + j; };
+        auto src_row = [&](int rec, bool valid) { return valid ? (GNNMP_ABL_NO_GATHER ? t0 + j : n0 + (rec & 0x7ffffff)) : t0; };
         int rec_c = pre_rec_c, rec_n = pre_rec_n;
         if constexpr (kCoop) {
             if (first + j < end) rec_c = p.rec32[first + j];
@@ -1749,43 +1852,89 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
             }
         }
         auto chunk = [&](const int c0, KeRaw<P> (&cur)[PF], KeRaw<P> (&fill)[PF]) {
+            // this chunk's A rows (and the job's B rows) have landed; with KD = 2 the next chunk's K_e tiles, requested
+            // AFTER them, may still be in flight (vector memory returns in order)
+            if constexpr (KD == 2) {
+                if (kUncond || c0 + STEP < end) wait_vmcnt<LPT * PF>();     // (requests are unconditional)
+                else wait_vmcnt<0>();
+            } else {
+                wait_vmcnt<0>();
+            }
+            // Nothing the compiler generates may touch a prefetched register or LDS BEFORE that wait: an LDS-DMA in flight counts
+            // as a "flat" access for its bookkeeping, and any vector-memory dependency it has to guard while one is pending becomes
+            // s_waitcnt vmcnt(0) -- draining the K_e tiles of the chunk after next.  The empty asm statements pin the first use of
+            // the next record and of this chunk's K_e registers behind the wait (the scheduler had hoisted the record's address
+            // arithmetic above it); after the wait the bookkeeping knows they have arrived and adds nothing.
+            if constexpr (kLaunder) {
+            asm volatile("" : "+v"(rec_n), "+v"(rec_c));
+#pragma unroll
+            for (int t = 0; t < PF; ++t) {
+                if constexpr (P == 1) asm volatile("" : "+v"(cur[t].lo), "+v"(cur[t].hi));
+                else asm volatile("" : "+v"(cur[t].v[0]), "+v"(cur[t].v[4]), "+v"(cur[t].v[8]), "+v"(cur[t].v[12]));
+            }
+            }
             const int slot = c0 + j;
             const bool valid = slot < end;
             const int rec = rec_c;
             const int dloc = valid ? ((rec >> 27) & 31) : 0;
             const int eslot = valid ? slot : beg;
             if (h == 0) dl[j] = dloc * D;
-            // this chunk's A rows (and the job's B rows) have landed; with KD = 2 the next chunk's K_e tiles, requested
-            // AFTER them, may still be in flight (vector memory returns in order)
-            if constexpr (KD == 2) {
-                if (c0 + STEP < end) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT * PF) : "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
             f32x16 M[NT];
 #pragma unroll
             for (int ot = 0; ot < NT; ++ot) M[ot] = splat16(bias[ot]);
+            // the next chunk's A rows (and the record of the one after) are requested by `request_rows`: with AEARLY right here,
+            // after this chunk's rows have been taken out of the stage as they are (packed bf16 rows: 8 registers per tile) -- a
+            // whole chunk ahead instead of the second half of one; the gather is an L2 hit, but under load its round trip was
+            // longer than the half chunk it had (attribution runs: the chunk loop spent a quarter of its time waiting for it)
+            auto request_rows = [&]() {
+                    rec_c = rec_n;
+                    if ((kUncond && !kREarly) || c0 + STEP < end) {    // wave-uniform
+                        const int mine_row = src_row(rec_c, c0 + STEP + j < end);       // beyond the range: the tile's first row, 32 times
+                        dma_rows<D, P>(p.A, [&](int sr) { return __builtin_amdgcn_ds_bpermute(sr * 4, mine_row); }, astage, lane);
+                    } else if (kREarly) {
+                        // last chunk: the A stage is free from here on -- the node phase's R rows travel under this chunk's MFMAs
+                        // (the same number of DMA instructions as the A rows they replace)
+                        dma_rows<D, 0>(p.R, [&](int sr) { return t0 + sr; }, astage, lane);
+                        r_requested = true;
+                    }
+                    {
+                        const int ri = c0 + 2 * STEP + j;
+                        if (kUncond) rec_n = p.rec32[ri < end ? ri : end - 1];
+                        else if (ri < end) rec_n = p.rec32[ri];
+                    }
+            };
+            // (the target rows B[dst] are taken out of LDS here as well: any LDS read the compiler generates while a DMA is in
+            // flight is guarded by a wait for that DMA -- it cannot tell the stages apart)
+            StageRaw<P> araw[kAEarly ? NT : 1], braw[kAEarly ? NT : 1];
+            if constexpr (kAEarly) {
+#pragma unroll
+                for (int it = 0; it < NT; ++it) {
+                    read_stage_raw<D, P>(astage, j, h, it, araw[it]);
+                    read_stage_raw<D, P>(btile, dloc, h, it, braw[it]);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                request_rows();
+            }
             // hidden = relu(A[src] + B[dst] + K_e), one 32-feature tile at a time, straight into the swapped MFMA
             linear_acc_stream<P, NT, true, true>(wl + LE::w2, [&](int it, f32x16& x) {
                 f32x16 a, b;
                 if (it < PF) expand_raw<P>(cur[it < PF ? it : 0], x); else load_edge_slot_tile<P, NT>(p.Ke, eslot, h, it, x);
-                read_stage_tile<D, P>(astage, j, h, it, a);
-                read_stage_tile<D, P>(btile, dloc, h, it, b);
+                if constexpr (kAEarly) {
+                    expand_stage_raw<P>(araw[it], a);
+                    expand_stage_raw<P>(braw[it], b);
+                } else {
+                    read_stage_tile<D, P>(astage, j, h, it, a);
+                    read_stage_tile<D, P>(btile, dloc, h, it, b);
+                }
                 if (it == NT - 1) {
+                  if constexpr (kAEarly) {
+                    ke_fetch(c0 + KD * STEP, fill);
+                  } else {
                     // the stage has been read: request the next chunk's rows, K_e and the record after that
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    rec_c = rec_n;
-                    if (c0 + STEP < end) {                                     // wave-uniform
-                        const int mine_row = src_row(rec_c, c0 + STEP + j < end);
-                        dma_rows<D, P>(p.A, [&](int sr) { return __builtin_amdgcn_ds_bpermute(sr * 4, mine_row); }, astage, lane);
-                        if (c0 + 2 * STEP + j < end) rec_n = p.rec32[c0 + 2 * STEP + j];
-                    } else if constexpr (kREarly) {
-                        // last chunk: the A stage is free from here on -- the node phase's R rows travel under this chunk's MFMAs
-                        dma_rows<D, 0>(p.R, [&](int sr) { return t0 + sr; }, astage, lane);
-                        r_requested = true;
-                    }
+                    request_rows();
                     ke_fetch(c0 + KD * STEP, fill);
+                  }
                 }
                 x += a + b;                                     // the ReLU is applied by linear_acc_stream
             }, M, lane);
@@ -1796,40 +1945,72 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
 #pragma unroll
                     for (int r = 0; r < 16; ++r) M[ot][r] = phi(r, h) < nv ? M[ot][r] : -INFINITY;
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // The offsets and the aggregation atomics are issued BY HAND (inline asm).  The next chunk's A rows (LDS-DMA) and the K_e
+            // tiles of the chunk after it have just been requested; the compiler cannot tell that the DMA's LDS destination
+            // (the A stage) and these LDS locations never alias, and guards any LDS access it generates behind an in-flight
+            // DMA with s_waitcnt vmcnt(0) -- which drained EVERY outstanding request (the HBM K_e stream included) at this
+            // point of every chunk, i.e. the whole prefetch pipeline ran one request deep (rounds 1-3: 47 % of the wave time in
+            // s_waitcnt at d = 64 bf16).  Instructions inside asm statements get no such guard; what they need is stated here:
+            // LDS instructions of a wave execute in order, so the offset reads see this chunk's dl[] writes, and the no-return
+            // atomics need nothing after them (the node phase waits for lgkmcnt(0) before it reads the tile).
             // register r of this lane is edge phi(r, h) = 8 (r >> 2) + 4 h + (r & 3) of the chunk
-            int off[16];
+            __builtin_amdgcn_wave_barrier();
+            i32x4 o4[4];
+            if constexpr (!kAsmTail) {
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const int4 o = *reinterpret_cast<const int4*>(dl + 8 * g4 + 4 * h);
-                off[g4 * 4 + 0] = o.x; off[g4 * 4 + 1] = o.y; off[g4 * 4 + 2] = o.z; off[g4 * 4 + 3] = o.w;
-            }
+                for (int g4 = 0; g4 < 4; ++g4) o4[g4] = *reinterpret_cast<const i32x4*>(dl + 8 * g4 + 4 * h);
+#pragma unroll
+                for (int ot = 0; ot < NT; ++ot)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        __builtin_amdgcn_ds_fmaxf((lds_float*)(agg + o4[r >> 2][r & 3] + ot * 32 + j), M[ot][r], 0, 0, false);
+            } else {
+            // The MFMA results are INPUTS of this block although it does not read them: nothing interlocks an MFMA's result
+            // register against a DS instruction the compiler cannot see into (its hazard recognizer pads only what it generates),
+            // and the scheduler would sink the chunk's last MFMAs below this block, right in front of the atomics that send
+            // their accumulators to LDS (seen as run-to-run differences with the 16-pass fp32 MFMAs).  With the dependency the
+            // MFMAs are issued first; s_nop 15 + s_nop 7 are the 19 wait states a 16-pass MFMA needs before a DS read of its
+            // result, and the LDS round trip of the offsets lies on top.
+            // (one element per accumulator is enough: an MFMA writes all sixteen registers; a 512-bit asm operand also breaks the host pass)
+            asm volatile("s_nop 15\n\ts_nop 7\n\tds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:32\n\tds_read_b128 %2, %4 offset:64\n\t"
+                         "ds_read_b128 %3, %4 offset:96\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(o4[0]), "=&v"(o4[1]), "=&v"(o4[2]), "=&v"(o4[3])
+                         : "v"(lds_addr(dl) + 16u * h), "v"(M[0][0]), "v"(M[NT - 1][15]) : "memory");
             if (!GNNMP_ABL_NO_ATOMICS) {
+                const unsigned agg0 = lds_addr(agg) + 4u * j;
 #pragma unroll
-            for (int ot = 0; ot < NT; ++ot)
+                for (int r = 0; r < 16; ++r) {
+                    const unsigned a = agg0 + 4u * (unsigned)o4[r >> 2][r & 3];
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    __builtin_amdgcn_ds_fmaxf((lds_float*)(agg + off[r] + ot * 32 + j), M[ot][r], 0, 0, false);
+                    for (int ot = 0; ot < NT; ++ot)
+                        asm volatile("ds_max_f32 %0, %1 offset:%2" ::"v"(a), "v"(M[ot][r]), "n"(ot * 128) : "memory");
+                }
             } else {
                 float keep = 0.f;
 #pragma unroll
                 for (int ot = 0; ot < NT; ++ot)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) keep += M[ot][r];
+                    for (int r = 0; r < 16; ++r) keep += M[ot][r] + (float)o4[r >> 2][r & 3];
                 if (keep == 123.456f) agg[j] = keep;
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            }
             __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         };
-        for (int c0 = first; c0 < (GNNMP_ABL_NO_EDGE ? first : end); c0 += 2 * STEP) {
-            if constexpr (KD == 2) chunk(c0, qa, qa); else chunk(c0, qa, qb);
-            if (c0 + STEP < end) {                               // wave-uniform
-                if constexpr (KD == 2) chunk(c0 + STEP, qb, qb); else chunk(c0 + STEP, qb, qa);
+        // two chunks per trip in ONE basic block (exit test at the bottom), an odd last chunk behind the loop: with the exit between
+        // the two bodies the register allocator copied half of the in-flight K_e registers on the back edge -- and a copy of a
+        // register that a load is still filling needs s_waitcnt vmcnt(0)
+        {
+            const int stop = GNNMP_ABL_NO_EDGE ? first : end;
+            int c0 = first;
+            for (; c0 + STEP < stop; c0 += 2 * STEP) {
+                if constexpr (KD == 2) { chunk(c0, qa, qa); chunk(c0 + STEP, qb, qb); }
+                else { chunk(c0, qa, qb); chunk(c0 + STEP, qb, qa); }
+            }
+            if (c0 < stop) {
+                if constexpr (KD == 2) chunk(c0, qa, qa); else chunk(c0, qa, qb);
             }
         }
+        GNNMP_TRC();
         if constexpr (kCoop && !kSplitNode) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's aggregation atomics have been performed
             __syncthreads();
@@ -1875,7 +2056,7 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
             }
             continue;                                            // the next job's first barrier collects the workgroup
         }
-        if (GNNMP_ABL_NO_NODE) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); continue; }
+        if (GNNMP_ABL_NO_NODE) { wait_all(); continue; }
         // ---- node phase.  X and R rows of the tile (contiguous, fp32) come through the two stages as well; the weights
         // (MpNBlob) are read from global memory as MFMA operands (at d = 64 the pointer is laundered per job so that the
         // compiler does not hoist those loop-invariant loads out of the job loop into ~70 registers)
@@ -1889,10 +2070,10 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
         if constexpr (kHpEarly) {
 #pragma unroll
             for (int tt = 0; tt < NT; ++tt) H[tt] = Hp[tt];
-            if constexpr (P != 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if constexpr (P != 1) wait_vmcnt<0>();
         } else {
             load_vec<NT>(wn + LN::bl, H, lane);
-            if constexpr (P != 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if constexpr (P != 1) wait_vmcnt<0>();
             linear_acc_stream<P, NT, false>(wn + LN::wlx, [&](int it, f32x16& x) {
                 if constexpr (P != 1) read_stage_tile<D, 0>(astage, j, h, it, x);
                 else load_row_tile<1, NT>(p.X, (size_t)node, h, it, x);          // bf16 mode: X rows are stored in bf16
@@ -1934,6 +2115,7 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
             linear_acc_ops<P, NT, NT>(wn + LN::m3, yop, z, lane);
             store_row_p<P, NT>(p.Bout, (size_t)node, z, h);
         }
+        GNNMP_TRC();
     }
 }
 
@@ -1968,18 +2150,22 @@ __global__ __launch_bounds__(256) void policy_kernel(PolicyParams p) {
             rec = p.csr[tile * 32 + j];
         }
     };
-    f32x16 hid_n[NT];
+    // the prefetched PE tile stays AS LOADED (bf16 tiles packed) until its tile is multiplied: converting it where it is
+    // requested made the conversion wait for the load it had just issued (s_waitcnt vmcnt(0) right behind the request: the
+    // bf16 policy kernel ran without any prefetch)
+    KeRaw<P> hid_n[NT];
     auto issue = [&](const int4& rec, int g, int tile) {      // rows + PE tile of a fetched tile (g wave-uniform after the wait)
         if (g < 0) return;
         const int srow = rec.x >= 0 ? rec.x : 0, trow = rec.y >= 0 ? rec.y : 0;
         dma_rows<D, P>(p.PS, [&](int sr) { return __builtin_amdgcn_ds_bpermute(sr * 4, srow); }, sstage, lane);
         dma_rows<D, P>(p.PT, [&](int sr) { return __builtin_amdgcn_ds_bpermute(sr * 4, trow); }, tstage, lane);
-        load_tile_nt_p<P, NT>(p.PE + (size_t)tile * NT * kETile, hid_n, lane);
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) load_edge_slot_raw<P, NT>(p.PE, tile * 32 + j, h, tt, hid_n[tt]);
     };
     if (wk.valid()) {
         fetch(wk.cur, rec_c, g_c, tile_c);
         wk.next();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wait_vmcnt<0>();
         g_c = __builtin_amdgcn_readfirstlane(g_c);
         issue(rec_c, g_c, tile_c);
         if (wk.valid()) fetch(wk.cur, rec_n, g_n, tile_n);
@@ -1988,11 +2174,11 @@ __global__ __launch_bounds__(256) void policy_kernel(PolicyParams p) {
         const int4 rec = rec_c;
         const int g = g_c;
         f32x16 hid[NT], a[NT], b[NT];
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this tile's rows and PE tile (and the next records) have landed
+        wait_vmcnt<0>();      // this tile's rows and PE tile (and the next records) have landed
         if (g >= 0) {
 #pragma unroll
             for (int tt = 0; tt < NT; ++tt) {
-                hid[tt] = hid_n[tt];
+                expand_raw<P>(hid_n[tt], hid[tt]);
                 read_stage_tile<D, P>(sstage, j, h, tt, a[tt]);
                 read_stage_tile<D, P>(tstage, j, h, tt, b[tt]);
             }
@@ -2245,6 +2431,18 @@ static int grid_for(K kernel, size_t lds_bytes, int n_tiles, int max_per_cu) {
     return groups < cap ? groups : (cap < 8 ? 8 : cap);
 }
 
+#ifdef GNNMP_MP_TRACE
+static long long* g_mp_trace = nullptr;
+static size_t g_mp_trace_n = 0;
+// diagnostics build: copy the per-wave timestamps of the LAST message-passing launch to the host (tools/diag/mp_trace.py)
+extern "C" long long gnnmp_debug_mp_trace(long long* dst, long long cap) {
+    if (!g_mp_trace) return 0;
+    const size_t n = g_mp_trace_n < (size_t)cap ? g_mp_trace_n : (size_t)cap;
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpy(dst, g_mp_trace, n * sizeof(long long), hipMemcpyDeviceToHost);
+    return (long long)n;
+}
+#endif
 template <int D, int P, int COOP>
 static hipError_t launch_mp_fused_t(const MpFusedParams& p, hipStream_t st) {
     const size_t lds = (size_t)(((MpEBlob<D, P>::size + 3) & ~3) + mp_lds_floats<D, P, COOP>() + (GNNMP_MP_NODEW_LDS && D == 32 && P != 2 ? ((MpNBlob<D, P>::size + 3) & ~3) : 0)) * sizeof(float);
@@ -2267,6 +2465,19 @@ static hipError_t launch_mp_fused_t(const MpFusedParams& p, hipStream_t st) {
         q.tpw = tpw;
         static const int gpg_env = getenv("GNNMP_MP_GPG") ? atoi(getenv("GNNMP_MP_GPG")) : 0;      // experiment
         q.gpg = gpg_env;
+#ifdef GNNMP_MP_TRACE
+        {
+            static long long* tbuf = nullptr;
+            static size_t tcap = 0;
+            const size_t need = (size_t)(groups_cap + 16) * 4 * 8;
+            if (tcap < need) { if (tbuf) (void)hipFree(tbuf); (void)hipMalloc(&tbuf, need * sizeof(long long)); tcap = need; }
+            q.trace = tbuf;
+            g_mp_trace = tbuf; g_mp_trace_n = need;
+        }
+#endif
+        static const int pair_env = getenv("GNNMP_MP_PAIR") ? atoi(getenv("GNNMP_MP_PAIR")) : 0;   // experiment
+        q.pair = 0;
+        if (pair_env > 0 && forced_tpw == 0) { q.pair = 1; q.tpw = tpw = 2; }
         int grid = ((groups_cap + tpw - 1) / tpw + 7) & ~7;
         if (forced_tpw < 0) {                  // experiment: persistent workgroups, -forced_tpw per CU
             q.tpw = 0;

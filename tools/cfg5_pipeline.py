@@ -58,7 +58,7 @@ class Cfg5Job:
         take = torch.zeros(n_problems, P_MAX, dtype=torch.bool)
         for b, c in enumerate(self.counts):
             take[b, :c] = True
-        self.take = take.to(device)
+        self.take_idx = take.reshape(-1).nonzero().reshape(-1).to(device)      # host-side: no boolean-mask sync in the job
         n_free = [g['n_free'] for g in self.graphs]
         nfree_s = [min(500, nf) for nf in n_free]
         ncoll_s = [min(500, int(g['v'].shape[0]) - nf) for g, nf in zip(self.graphs, n_free)]
@@ -75,18 +75,27 @@ class Cfg5Job:
         return self.model.forward_batch(self.batch, self.loop)
 
     def paths(self, scores):
-        """[sum P_b, C] waypoint rows: the chain of best-scored incoming edges from the goal node (see the module docstring)."""
-        n = self.batch.total_nodes
-        best = torch.full((n,), float('-inf'), device=self.dev).scatter_reduce_(0, self.tgt, scores, 'amax', include_self=True)
-        cand = torch.where(scores == best[self.tgt], self.col, torch.full_like(self.col, self.col.numel()))
-        first = torch.full((n,), self.col.numel(), dtype=torch.int64, device=self.dev).scatter_reduce_(0, self.tgt, cand, 'amin', include_self=True)
-        best_src = self.src[first.clamp(max=self.col.numel() - 1)]          # every node has its self loop, so `first` is a real column
-        cur = self.goal_nodes
-        chain = [cur]
-        for _ in range(P_MAX - 1):
-            cur = best_src[cur]
-            chain.append(cur)
-        nodes = torch.stack(chain, dim=1)[self.take]                        # row-major: problem after problem, waypoint after waypoint
+        """[sum P_b, C] waypoint rows: the chain of best-scored incoming edges from the goal node (see the module docstring).
+        All torch ops on the current stream, no host synchronisation: one 64-bit scatter-max picks every node's best incoming
+        edge (key = order-preserving integer image of the score, then the LOWEST column), and the chain is followed with jump
+        tables (J_2s = J_s o J_s): 11 small launches instead of one gather per waypoint."""
+        n, ncol = self.batch.total_nodes, self.col.numel()
+        bits = scores.view(torch.int32)
+        ordered = (bits ^ ((bits >> 31) & 0x7fffffff)).to(torch.int64)      # monotone in the float value
+        key = (ordered << 32) | (0xffffffff - self.col)                    # ties: the lowest column wins
+        best = torch.full((n,), torch.iinfo(torch.int64).min, dtype=torch.int64, device=self.dev)
+        best.scatter_reduce_(0, self.tgt, key, 'amax', include_self=True)
+        first = (0xffffffff - (best & 0xffffffff)).clamp_(max=ncol - 1)   # every node has its self loop, so this is a real column
+        jump = self.src[first]                                             # J_1: node -> source of its best incoming edge
+        pos = torch.empty(self.B, 64, dtype=torch.int64, device=self.dev)
+        pos[:, 0] = self.goal_nodes
+        s = 1
+        while s < P_MAX:
+            pos[:, s:2 * s] = jump[pos[:, 0:s]]                            # waypoints s .. 2 s - 1 are s steps behind waypoints 0 .. s - 1
+            s *= 2
+            if s < P_MAX:
+                jump = jump[jump]
+        nodes = pos[:, :P_MAX].reshape(-1)[self.take_idx]                  # problem after problem, waypoint after waypoint
         return self.batch.v[nodes].contiguous()
 
     def smooth(self, path, iters=5):

@@ -11,8 +11,9 @@ in fp32 AND fp64) on EVERY graph of
     cfg 4         16 per family of maze2 / snake7 / ur5 / kuka7, 1000-node k1 = 8   (configs[3])
 
 and prints, per workload, the histogram over graphs of max|gpu - ref64| (the distance to the exact result), of the reference's
-own fp32-vs-fp64 distance `own`, and of max|gpu - ref32|; the worst graphs; and how many graphs exceed 1e-5 against fp64.
-tests/test_parity_census_gpu.py asserts <= 1e-5 against fp64 on every graph through the same functions.
+own fp32-vs-fp64 distance `own`, and of max|gpu - ref32|; the worst graphs; how many graphs exceed 1e-5 against fp64; and on
+how many graphs the GPU is further from the exact result than the reference's own fp32 run.
+tests/test_parity_census_gpu.py asserts the per-workload bar through the same functions.
 
     python tools/parity_census.py [--quick] > profiles/r04_parity_census.txt
 """
@@ -82,9 +83,26 @@ def report(name, rows):
     worst = sorted(range(n), key=lambda i: -rows[i][0])[:3]
     print('    worst graphs vs fp64: ' + '; '.join('#%d %.2e (own %.2e, vs ref32 %.2e)' % (i, rows[i][0], rows[i][2], rows[i][1]) for i in worst))
     over = [i for i in range(n) if rows[i][0] > 1e-5]
-    print('    max over graphs: |gpu - ref64| %.3e   own %.3e   |gpu - ref32| %.3e;  graphs over 1e-5 vs fp64: %d of %d (%d elements)' % (
-        max(r[0] for r in rows), max(r[2] for r in rows), max(r[1] for r in rows), len(over), n, sum(r[3] for r in rows)))
+    print('    max over graphs: |gpu - ref64| %.3e   own %.3e   |gpu - ref32| %.3e;  graphs over 1e-5 vs fp64: %d of %d (%d of %d elements)' % (
+        max(r[0] for r in rows), max(r[2] for r in rows), max(r[1] for r in rows), len(over), n, sum(r[3] for r in rows), sum(r[4] for r in rows)))
+    st = stats(rows)
+    print('    medians: |gpu - ref64| %.3e   own %.3e;  graphs on which the GPU is FURTHER from fp64 than the reference\'s own fp32 run: %d of %d;  '
+          'workload bar max(1e-5, 1.25 x median own) = %.3e: %s' % (st['med_err64'], st['med_own'], st['n_worse_than_ref'], n, st['bar'],
+                                                                    'held by every graph' if st['ok'] else 'EXCEEDED by %d graphs' % st['n_over_bar']))
     return len(over)
+
+
+def stats(rows):
+    """Population-level figures of one workload: the reference's own fp32-vs-fp64 distance `own` is a property of the WORKLOAD (graph
+    size, obstacle count); its per-graph maximum over ~11 k scores fluctuates by 4 x between graphs of one workload, so the bar of
+    tests/parity_bar.py, max(1e-5, 1.25 own), is taken with the workload's MEDIAN own."""
+    e = sorted(r[0] for r in rows)
+    o = sorted(r[2] for r in rows)
+    med = lambda x: x[len(x) // 2]  # noqa: E731
+    bar = max(1e-5, 1.25 * med(o))
+    return {'med_err64': med(e), 'med_own': med(o), 'max_err64': e[-1], 'max_own': o[-1], 'bar': bar,
+            'n_worse_than_ref': sum(1 for r in rows if r[0] > r[2]), 'n_over_bar': sum(1 for r in rows if r[0] > bar),
+            'ok': e[-1] <= bar}
 
 
 def main():
