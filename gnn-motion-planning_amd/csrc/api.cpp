@@ -902,8 +902,7 @@ int forward_impl(const gnnmp_explorer* h, const gnnmp_batch* b, int loop, int us
         f.Hout = at<float>(ws, c.H); f.Xout = at<float>(ws, c.X); f.Aout = Abuf[cur ^ 1]; f.Bout = at<float>(ws, c.B);
         f.n_tiles = c.Npad / 32;
         f.tpw = 1;
-        f.gpg = 0;
-        f.pair = 0;
+        f.order = 0;
         f.trace = nullptr;
         f.G = c.G;
         f.store_h = last ? 1 : 0;

@@ -1571,6 +1571,12 @@ __device__ __forceinline__ void linear_acc_stream(const float* A, Get get, f32x1
 #ifndef GNNMP_MP_FLOW_F32
 #define GNNMP_MP_FLOW_F32 0
 #endif
+#ifndef GNNMP_MP_F32_NEWLOOP
+#define GNNMP_MP_F32_NEWLOOP 0       // experiment: the straight-line two-chunk loop for the round-3 flow as well
+#endif
+#ifndef GNNMP_MP_ASM_WAITS
+#define GNNMP_MP_ASM_WAITS 0         // experiment: round 3's inline-asm waits in the round-3 flow
+#endif
 #ifndef GNNMP_ABL_NO_EDGE
 #define GNNMP_ABL_NO_EDGE 0          // no edge phase at all (tile start + node phase only)
 #endif
@@ -1603,7 +1609,7 @@ template <int D, int P, int COOP>
 #ifndef GNNMP_MP_DEEP32
 #define GNNMP_MP_DEEP32 0     // experiment switch: K_e two chunks ahead at d = 32 fp32 (measured slower: 0.906 vs 0.875 ms)
 #endif
-__global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 && P != 1) ? 1 : ((P == 2 || D > 32) ? 2 : (P == 1 ? GNNMP_MP_WGS32B : GNNMP_MP_WGS32))) : ((COOP == 2 || (COOP == 4 && P == 1)) ? (D == 32 ? 3 : 2) : 1)) void mp_fused_kernel(MpFusedParams p) {
+__global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 && P != 1) ? 1 : ((P == 2 || D > 32) ? 2 : (P == 1 ? GNNMP_MP_WGS32B : GNNMP_MP_WGS32))) : 1) void mp_fused_kernel(MpFusedParams p) {
     constexpr int NT = D / 32;
     constexpr bool kCoop = COOP > 1;
     // few tiles, d = 32: the node phase is spread over waves (below); at d = 64 the eight-wave workgroup has 256 registers per
@@ -1681,24 +1687,20 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
         // XCD 7 and half of XCD 6 without work (round 2's mapping).  Workgroups beyond that take the unused tail in order.
         const int real_wgs = ((p.node_ptr_pad[p.G] >> 7) + p.tpw - 1) / p.tpw;      // exact: the prep stage's padded total / 128 rows per group
         const int per = (real_wgs + 7) >> 3, q8 = blockIdx.x >> 3, x8 = blockIdx.x & 7;
-        int qq = q8;
-        if (p.gpg > 1 && per % p.gpg == 0 && q8 < per) {          // EXPERIMENT: heavy (first-half) groups of every graph first, then the light ones
-            const int half = p.gpg >> 1, hp = per >> 1;
-            const int q2 = q8 < hp ? q8 : q8 - hp;
-            qq = (q2 / half) * p.gpg + (q8 < hp ? 0 : half) + q2 % half;
-        }
-        const int wg = q8 < per ? x8 * per + qq : 8 * per + (q8 - per) * 8 + x8;
+        const int wg = q8 < per ? x8 * per + q8 : 8 * per + (q8 - per) * 8 + x8;
         wk.cur = wg * p.tpw;
         wk.end = min((p.n_tiles + 3) / 4, wk.cur + p.tpw);
         wk.step = 1;
-        if (p.pair) {
-            // MIRRORED PAIRS (tpw == 2): workgroup `wg` stands for the 256-row block `wg` of the padded node space (every graph
-            // is a whole number of them: kPad); it takes the group that far from the START of its graph and then the group that
-            // far from its END.  The reference's graphs list the free samples first, and those have ~1.5 x the incoming edges
-            // of the collided ones (kNN over all samples + kNN over the free ones: eval_gnn.py:160-164), so the first half of a
-            // graph's tiles is heavy and the second light: a (first, last) pair costs the same for every workgroup, where
-            // four adjacent tiles did not (first-half groups 2350 edges, second-half 1580 at the configs[2] shape) -- with two
-            // workgroups per slot and launch the hardware dispatcher could not level that out (29 % of the wave slots idle).
+        if (p.order == 1) {
+            // MIRRORED PAIRS (tpw == 2).  The reference's graphs list the free samples first, and those have ~1.5 x the incoming
+            // edges of the collided ones (kNN over all samples + kNN over the free ones: eval_gnn.py:160-164), so the first half of
+            // a graph's tiles is heavy and the second light (first-half groups 2350 edges, second-half 1580 at the configs[2]
+            // shape).  With only 2-4 groups per resident workgroup slot and launch the hardware dispatcher cannot level that out:
+            // a quarter of the wave slots sat idle (tools/diag/mp_trace.py).  Every graph is a whole number of 256-row blocks
+            // (kPad) = pairs of groups; workgroup `wg` stands for block `wg` and takes the group that far from the START of its
+            // graph and then the group that far from its END: every workgroup costs about the same, and the launch has half as
+            // many workgroups (chosen when that does not add a round of workgroups: launch_mp_fused_t).  Measured: five launches
+            // 0.555 -> 0.534 ms at the configs[2] shape; "start groups first" with one group per workgroup measured no gain.
             const int blk_tile = wg * 8;
             const int bg = blk_tile < p.n_tiles ? p.ntile_graph[blk_tile] : -1;
             if (bg >= 0) {
@@ -1999,7 +2001,14 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
         // two chunks per trip in ONE basic block (exit test at the bottom), an odd last chunk behind the loop: with the exit between
         // the two bodies the register allocator copied half of the in-flight K_e registers on the back edge -- and a copy of a
         // register that a load is still filling needs s_waitcnt vmcnt(0)
-        {
+        if constexpr (!kNewFlow && !GNNMP_MP_F32_NEWLOOP) {
+            for (int c0 = first; c0 < (GNNMP_ABL_NO_EDGE ? first : end); c0 += 2 * STEP) {      // round-3 form (exact-fp32 kernels)
+                if constexpr (KD == 2) chunk(c0, qa, qa); else chunk(c0, qa, qb);
+                if (c0 + STEP < end) {                           // wave-uniform
+                    if constexpr (KD == 2) chunk(c0 + STEP, qb, qb); else chunk(c0 + STEP, qb, qa);
+                }
+            }
+        } else {
             const int stop = GNNMP_ABL_NO_EDGE ? first : end;
             int c0 = first;
             for (; c0 + STEP < stop; c0 += 2 * STEP) {
@@ -2087,6 +2096,7 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
                 for (int c = 0; c < 4; ++c) x[q * 4 + c] = dg == 0 ? 0.f : a[c];      // torch_scatter: no incoming edge -> 0
             }
         }, H, lane);
+        GNNMP_TRC();                                             // (diagnostics build) H done
         if (p.store_h) store_row<NT>(p.Hout + (size_t)node * D, H, h);
         BOp<P> yop[NT];
         {
@@ -2098,6 +2108,7 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
                 load_row<NT>(p.R + (size_t)node * D, y, h);
             }
             linear_acc_p<P, NT, NT>(wn + LN::m1, H, y, lane);
+            GNNMP_TRC();                                         // (diagnostics build) Y done
             store_row_p<P == 1 ? 1 : 0, NT>(p.Xout, (size_t)node, y, h);        // X is only ever read as an MFMA operand: bf16 rows lose nothing
             make_ops<P, NT>(y, yop);
         }
@@ -2463,8 +2474,6 @@ static hipError_t launch_mp_fused_t(const MpFusedParams& p, hipStream_t st) {
         if (forced_tpw > 0) tpw = forced_tpw;
         MpFusedParams q = p;
         q.tpw = tpw;
-        static const int gpg_env = getenv("GNNMP_MP_GPG") ? atoi(getenv("GNNMP_MP_GPG")) : 0;      // experiment
-        q.gpg = gpg_env;
 #ifdef GNNMP_MP_TRACE
         {
             static long long* tbuf = nullptr;
@@ -2475,9 +2484,18 @@ static hipError_t launch_mp_fused_t(const MpFusedParams& p, hipStream_t st) {
             g_mp_trace = tbuf; g_mp_trace_n = need;
         }
 #endif
-        static const int pair_env = getenv("GNNMP_MP_PAIR") ? atoi(getenv("GNNMP_MP_PAIR")) : 0;   // experiment
-        q.pair = 0;
-        if (pair_env > 0 && forced_tpw == 0) { q.pair = 1; q.tpw = tpw = 2; }
+        // dispatch order (see the kernel): mirrored pairs when two groups per workgroup do not cost a round of workgroups
+        // (rounds = what the slowest resident slot runs one after the other); GNNMP_MP_ORDER = 0 / 1 forces it (experiments)
+        static const int order_env = getenv("GNNMP_MP_ORDER") ? atoi(getenv("GNNMP_MP_ORDER")) : -1;
+        q.order = 0;
+        if (forced_tpw == 0) {
+            const Residency r = resident_workgroups(reinterpret_cast<const void*>(mp_fused_kernel<D, P, COOP>), lds);
+            const long long slots = (long long)r.cus * (r.per_cu > 0 ? r.per_cu : 1);
+            const long long rounds1 = (groups_cap + slots - 1) / slots, rounds2 = 2 * ((groups_cap / 2 + slots - 1) / slots);
+            q.order = rounds2 <= rounds1 ? 1 : 0;
+            if (order_env >= 0) q.order = order_env == 1 ? 1 : 0;
+            if (q.order == 1) q.tpw = tpw = 2;
+        }
         int grid = ((groups_cap + tpw - 1) / tpw + 7) & ~7;
         if (forced_tpw < 0) {                  // experiment: persistent workgroups, -forced_tpw per CU
             q.tpw = 0;
@@ -2499,13 +2517,7 @@ static hipError_t launch_mp_fused_dp(const MpFusedParams& p, hipStream_t st) {
     // d = 64 with fp32 / bf16x3 operands: four waves per tile instead of eight -- at eight waves a wave has 256 registers and the
     // kernel spilled 116 of them (single 2000-node kuka7 graph: 42 us per launch)
     if constexpr (D > 32 && P != 1) return coop ? launch_mp_fused_t<D, P, 4>(p, st) : launch_mp_fused_t<D, P, 1>(p, st);
-    else {
-        if constexpr (P == 1) {                                  // experiments: GNNMP_MP_COOP = 2 / 4 waves per tile at any batch size
-            if (forced == 2) return launch_mp_fused_t<D, P, 2>(p, st);
-            if (forced == 4) return launch_mp_fused_t<D, P, 4>(p, st);
-        }
-        return coop ? launch_mp_fused_t<D, P, 8>(p, st) : launch_mp_fused_t<D, P, 1>(p, st);
-    }
+    else return coop ? launch_mp_fused_t<D, P, 8>(p, st) : launch_mp_fused_t<D, P, 1>(p, st);
 }
 hipError_t launch_mp_fused(int D, int P, const MpFusedParams& p_in, hipStream_t st) {
     const MpFusedParams& p = p_in;

@@ -89,8 +89,7 @@ struct MpFusedParams {
     int store_h;
     int tpw;                     // adjacent four-tile groups per workgroup (set by launch_mp_fused)
     int G;                       // graphs: node_ptr_pad[G] / 32 = tiles actually in use (n_tiles is an upper bound)
-    int gpg;                     // experiment
-    int pair;                    // mirrored pairs of groups per workgroup (tpw == 2), see mp_fused_kernel
+    int order;                   // dispatch order of the four-tile groups: 0 plain, 1 mirrored pairs (tpw == 2) (mp_fused_kernel)
     long long* trace;            // diagnostics builds only (-DGNNMP_MP_TRACE): per-wave timestamps, else nullptr
 };
 

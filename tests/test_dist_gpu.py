@@ -50,6 +50,38 @@ def test_bench_rccl_path_one_rank_equals_plain_run():
     # the gathered (all_gather over RCCL) scores are the same bytes as the local ones
     assert a['config']['result_checksum'] == b['config']['result_checksum']
     assert b['value'] > 0.5 * a['value']
+    # the multi-GPU self-checks of the line (the driver's 8-GPU run reads these): ranks the collective library connected, every
+    # rank's own step time, the result gather timed on its own and outside `value`
+    ca, cb = a['config'], b['config']
+    assert ca['ranks_seen'] == 1 and ca['gather_ms'] is None                    # plain run: no process group, nothing gathered
+    assert cb['ranks_seen'] == 1 and cb['gather_ms'] is not None and 0 < cb['gather_ms'] < 50
+    assert cb['rank_ms_per_step']['min'] == cb['rank_ms_per_step']['max'] == cb['rank_ms_per_step']['all'][0]
+    assert abs(cb['rank_ms_per_step']['max'] - b['ms_per_step']) < 1e-3
+    assert cb['graphs_total'] == cb['graphs_per_gpu'] == 32 and b['scaling'] == 'weak'
+
+
+def test_bench_strong_mode_is_the_same_fixed_problem_set():
+    """--strong N_TOTAL: the job is problems 0 .. N_TOTAL - 1 (seed 1234 + i) whatever the rank count; with one rank it is
+    exactly the weak run of N_TOTAL graphs (same checksum), labelled `strong`; under the forced RCCL path the gathered
+    checksum is the same again.  (The 2- and 3-rank split of the set is covered on CPU: tests/test_dist_gloo.py.)"""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    weak = subprocess.run([sys.executable, 'bench.py', '--gpus', '1'] + BENCH_ARGS, cwd=REPO, env=env, capture_output=True, text=True, timeout=600)
+    assert weak.returncode == 0, weak.stderr[-2000:]
+    args = [x for x in BENCH_ARGS]
+    gi = args.index('--graphs')
+    del args[gi:gi + 2]
+    strong = subprocess.run([sys.executable, 'bench.py', '--gpus', '1', '--strong', '32'] + args, cwd=REPO, env=env, capture_output=True,
+                            text=True, timeout=600)
+    assert strong.returncode == 0, strong.stderr[-2000:]
+    a, b = _json_line(weak.stdout), _json_line(strong.stdout)
+    assert b['scaling'] == 'strong' and a['scaling'] == 'weak'
+    assert b['config']['graphs_total'] == 32 and b['config']['result_checksum'] == a['config']['result_checksum']
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), 'bench.py', '--gpus', '1', '--strong', '32'] + args
+    forced = subprocess.run(cmd, cwd=REPO, env=dict(env, GNNMP_BENCH_FORCE_DIST='1'), capture_output=True, text=True, timeout=600)
+    assert forced.returncode == 0, forced.stderr[-2000:]
+    c = _json_line(forced.stdout)
+    assert c['scaling'] == 'strong' and c['config']['result_checksum'] == a['config']['result_checksum'] and c['config']['gather_ms'] > 0
 
 
 def test_bench_refuses_world_size_mismatch():
@@ -116,6 +148,7 @@ def test_bench_two_ranks_rccl():
     assert r.returncode == 0, r.stderr[-3000:]
     line = _json_line(r.stdout)
     assert line['n_gpus'] == 2 and line['scaling'] == 'weak' and line['value'] > 0
+    assert line['config']['ranks_seen'] == 2 and len(line['config']['rank_ms_per_step']['all']) == 2 and line['config']['gather_ms'] > 0
 
 
 _GATHER_WORKER = r'''

@@ -72,3 +72,51 @@ def test_mixed_environment_set():
         g = {k: p[k].cpu() for k in ('v', 'goal', 'obstacles', 'edge_index')}
         ref32, ref64 = explorer_oracle_pair(load_weights(ENVS[p['env']]['ckpt']), g, 4)
         assert_fp32_parity(s.cpu(), ref32, ref64, p['env'])
+
+
+_RAGGED_SNIPPET = r'''
+import hashlib, sys, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from conftest import load_weights
+import gnnmp
+from gnnmp.synth import synth_graph
+sizes = [300 + 37 * (i %% 29) + 5 * i for i in range(72)]            # 300 .. 1700 nodes: every graph another number of 256-row blocks
+graphs = [{k: (v.to('cuda:0') if torch.is_tensor(v) else v) for k, v in synth_graph('maze2', n, 6, seed=900 + i).items()} for i, n in enumerate(sizes)]
+m = gnnmp.EncoderProcessDecoder(2, 2, 32, 2).eval(); m.load_state_dict(load_weights('weights_maze')); m.mlp_dtype = %r
+b = gnnmp.GraphBatch.from_graphs(graphs, 2, 'cuda:0')
+s = m.forward_batch(b, 5)
+torch.cuda.synchronize()
+print('HASH', hashlib.sha256(s.cpu().numpy().tobytes()).hexdigest(), int(b.total_nodes))
+'''
+
+
+@pytest.mark.parametrize('mode', ['fp32', 'bf16'])
+def test_ragged_large_batch_dispatch_orders(mode):
+    """The message-passing launch walks the four-tile groups of a large batch in one of two orders (plain, or mirrored pairs per
+    workgroup: csrc/explorer_kernels.hip mp_fused_kernel): on a RAGGED batch -- 72 graphs of 300 ... 1700 nodes, every graph
+    another number of 256-row blocks -- both give the bytes of the per-graph calls (which run the
+    tile-per-workgroup form), i.e. every group is visited exactly once whatever the order."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = _RAGGED_SNIPPET % (os.path.dirname(here), here, mode)
+    hashes = {}
+    for order in ('0', '1', ''):
+        env = dict(os.environ)
+        env.pop('GNNMP_MP_ORDER', None)
+        if order:
+            env['GNNMP_MP_ORDER'] = order
+        out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        hashes[order or 'auto'] = [ln for ln in out.stdout.splitlines() if ln.startswith('HASH')][0].split()[1]
+    assert len(set(hashes.values())) == 1, hashes
+    # and against per-graph calls in this process
+    import hashlib
+    sizes = [300 + 37 * (i % 29) + 5 * i for i in range(72)]
+    graphs = [{k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in synth_graph('maze2', n, 6, seed=900 + i).items()} for i, n in enumerate(sizes)]
+    m = gnnmp.EncoderProcessDecoder(2, 2, 32, 2).eval()
+    m.load_state_dict(load_weights('weights_maze'))
+    m.mlp_dtype = mode
+    alone = torch.cat([m.edge_scores(g['goal'], 5, g['v'], g['obstacles'], g['edge_index']) for g in graphs])
+    assert hashlib.sha256(alone.cpu().numpy().tobytes()).hexdigest() == hashes['auto']

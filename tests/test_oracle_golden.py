@@ -18,6 +18,16 @@ def _load(path):
         return {k: f[k] for k in f.files}
 
 
+# max|oracle (default form) - golden fp32| measured per fixture in the authoring container (tools: see DESIGN.md section 2)
+_PLAIN_GAP = {
+    'explorer_kuka13_N64_k4_L5.npz': 5.13e-06, 'explorer_kuka14_N200_k8_L5.npz': 4.05e-06, 'explorer_kuka14_N64_k4_L5.npz': 4.29e-06,
+    'explorer_kuka7_N200_k6_L5.npz': 2.86e-06, 'explorer_kuka7_N64_k4_L2_noobs.npz': 0.0, 'explorer_kuka7_N64_k4_L5.npz': 2.86e-06,
+    'explorer_maze2_N1000_k8_L5.npz': 1.14e-05, 'explorer_maze2_N200_k6_L5.npz': 2.77e-05, 'explorer_maze2_N64_k4_L1.npz': 7.63e-06,
+    'explorer_maze2_N64_k4_L3.npz': 7.63e-06, 'explorer_maze2_N64_k4_L5.npz': 7.63e-06, 'explorer_maze2_N64_k4_L5_noobs.npz': 0.0,
+    'explorer_maze3_N64_k4_L5.npz': 5.72e-06, 'explorer_snake7_N64_k4_L5.npz': 5.72e-06, 'explorer_ur5_N64_k4_L5.npz': 5.72e-06,
+}
+
+
 @pytest.mark.parametrize('path', golden_files('explorer_'), ids=os.path.basename)
 def test_explorer_oracle_matches_reference(path):
     r = _load(path)
@@ -30,16 +40,22 @@ def test_explorer_oracle_matches_reference(path):
     taps = {}
     s = ref_cpu.explorer_forward(w, taps=taps, **args)
     ref32 = torch.from_numpy(r['scores_fp32'])
-    # same formulation, same dtype: only BLAS blocking / the contracted value-mix may differ
-    assert torch.allclose(s, ref32, rtol=2e-5, atol=2e-5), (s - ref32).abs().max()
+    # the oracle's default (contracted value-mix) form rounds differently from the reference's materialising form: held to the
+    # distance MEASURED per fixture (round 4, identical at 1 and 8 torch threads) + 25 % + 1e-6 for BLAS blocking on other hosts
+    # -- never looser than the bar the GPU is held to against the same golden (tests/parity_bar.py)
+    gap = _PLAIN_GAP[os.path.basename(path)]
+    assert (s - ref32).abs().max().item() <= 1.25 * gap + 1e-6, ((s - ref32).abs().max().item(), gap)
     # fp64 run of the oracle reproduces the fp64 run of the reference to fp64 roundoff
     w64 = {k: v.double() for k, v in w.items()}
     a64 = {k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in args.items()}
     s64 = ref_cpu.explorer_forward(w64, **a64)
     assert torch.allclose(s64, torch.from_numpy(r['scores_fp64']), rtol=1e-10, atol=1e-10)
     # the materialising attention form (the reference's literal one) agrees too
+    # the materialising attention form (the reference's literal one, model.py:178-179) is the PIN: it reproduces the reference's
+    # fp32 run bit for bit at the thread count the goldens were recorded with (8) and to <= 3.8e-6 at one thread (BLAS blocking);
+    # bar = that worst case + 25 %
     sm = ref_cpu.explorer_forward(w, materialize=True, **args)
-    assert torch.allclose(sm, ref32, rtol=2e-5, atol=2e-5)
+    assert (sm - ref32).abs().max().item() <= 4.8e-6, (sm - ref32).abs().max().item()
     if 'tap_node_code' in r:
         for key, mine in (('tap_node_code', taps['node_code']), ('tap_edge_code', taps['edge_code']),
                           ('tap_node_free_code', taps['node_free_code']),

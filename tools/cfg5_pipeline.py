@@ -69,6 +69,10 @@ class Cfg5Job:
         self.chain = torch.cat(eis, dim=1).to(device)
         self.chain_counts = [int(x.shape[1]) for x in eis]
         self.free_counts, self.coll_counts = nfree_s, ncoll_s
+        # the smoothing batch descriptor (prefix arrays on the device) is the same for all five iterations: built once, only
+        # its path rows change (building it per iteration cost four small blocking host-to-device copies each time)
+        self.sb = SmoothBatch.from_device(torch.zeros(sum(self.counts), e['C'], device=device), self.free, self.coll, self.chain,
+                                          self.counts, self.free_counts, self.coll_counts, self.chain_counts)
 
     # ---- the three stages; each only enqueues work on the current stream
     def explore(self):
@@ -100,9 +104,8 @@ class Cfg5Job:
 
     def smooth(self, path, iters=5):
         for _ in range(iters):                                              # smoother.py:233-246 with every proposal accepted
-            sb = SmoothBatch.from_device(path, self.free, self.coll, self.chain, self.counts, self.free_counts, self.coll_counts,
-                                         self.chain_counts)
-            path = self.smoother.forward_batch(sb, 1)
+            self.sb.path = path
+            path = self.smoother.forward_batch(self.sb, 1)
         return path
 
     def run(self):

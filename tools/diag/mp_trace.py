@@ -30,12 +30,18 @@ us = lambda x: (x - t0) / 100.0           # 100 MHz
 start = us(t[:, 0])
 last = np.array([row[row > 0].max() for row in t])
 end = us(last)
-ntile = ((t > 0).sum(1) - 1) // 3
+ntile = ((t > 0).sum(1) - 1) // 5
 print('%s N=%s k1=%s x%s %s: %d waves recorded, launch span %.1f us' % (env, nodes, k1, G, dt, len(t), end.max()))
 print('wave start  (us): min %.1f  p50 %.1f  p90 %.1f  max %.1f' % (start.min(), np.percentile(start, 50), np.percentile(start, 90), start.max()))
 print('wave end    (us): min %.1f  p10 %.1f  p50 %.1f  p90 %.1f  max %.1f' % (end.min(), np.percentile(end, 10), np.percentile(end, 50), np.percentile(end, 90), end.max()))
 dur = end - start
 print('wave length (us): min %.1f  p50 %.1f  p90 %.1f  max %.1f ; tiles per wave: %s' % (dur.min(), np.percentile(dur, 50), np.percentile(dur, 90), dur.max(), np.bincount(ntile.astype(int)).tolist()))
+full = t[:, 5] > 0
+if full.any():                       # builds with the two extra marks inside the node phase: [3] H done, [4] Y done, [5] end
+    tt = t[full]
+    print('node phase of the first tile (us): X rows + Wlx + Wla -> H  p50 %.1f | R rows + M1 -> Y  p50 %.1f | stores + M2 (+ M3)  p50 %.1f' % (
+        np.percentile((tt[:, 3] - tt[:, 2]) / 100.0, 50), np.percentile((tt[:, 4] - tt[:, 3]) / 100.0, 50), np.percentile((tt[:, 5] - tt[:, 4]) / 100.0, 50)))
+    t = np.concatenate((t[:, :3], t[:, 5:6], t[:, 6:], np.zeros((len(t), 2))), axis=1)[:, :8]     # back to [start, tile start, edge end, node end, ...]
 has = t[:, 3] > 0
 if has.any():
     tt = t[has]
