@@ -637,7 +637,7 @@ struct Carve {
     // offsets in bytes
     size_t node_ptr_pad, edge_ptr_pad, goal_node, dense_ptr, in_ptrs, prep_hist;
     size_t zero_beg, deg, cursor, zero_end;
-    size_t ff_beg, ntile_graph, etile_graph, csr, ff_end, tile_meta, rec32;
+    size_t ff_beg, ntile_graph, etile_graph, csr, ff_end, tile_meta, rec32, blk_span;
     size_t row_beg;
     size_t XI, X, A, A2, B, DN, H, Ke, PE, kv_e, kv_n, M0;
     size_t total;
@@ -677,6 +677,7 @@ bool carve(const gnnmp_explorer* h, const gnnmp_batch* b, Carve& c) {
     c.csr = take(sizeof(int) * 4 * (size_t)c.Epad);
     c.ff_end = o;
     c.rec32 = take(sizeof(int) * (size_t)c.Epad);
+    c.blk_span = take(sizeof(int) * 2 * (size_t)(c.Npad / kPad));
     c.row_beg = take(sizeof(int) * c.Npad);
     {   // per-part target histograms + first slots of the prep stage's two-launch form (large graphs only)
         const int parts = prep_parts(c.G, b->total_edges);
@@ -790,6 +791,7 @@ int forward_impl(const gnnmp_explorer* h, const gnnmp_batch* b, int loop, int us
     q.csr = at<int4>(ws, c.csr);
     q.goal_node = at<int>(ws, c.goal_node);
     q.tile_meta = at<int>(ws, c.tile_meta); q.n_etiles = c.Epad / 32;
+    q.blk_span = at<int2>(ws, c.blk_span);
     HIP_TRY(launch_prep(q, c.Npad, c.Epad, at<int>(ws, c.prep_hist), st));
     // zero-fill of policy_output (model.py:148); sum_g N_g^2 is read from dense_ptr[G] on the device
     if (dense) HIP_TRY(launch_zero_dense(dense, q.dense_ptr + c.G, st));
@@ -903,6 +905,7 @@ int forward_impl(const gnnmp_explorer* h, const gnnmp_batch* b, int loop, int us
         f.n_tiles = c.Npad / 32;
         f.tpw = 1;
         f.order = 0;
+        f.blk_span = q.blk_span;
         f.trace = nullptr;
         f.G = c.G;
         f.store_h = last ? 1 : 0;

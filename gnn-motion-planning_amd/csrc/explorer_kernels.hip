@@ -197,6 +197,8 @@ __device__ __forceinline__ void prep_graph_body(const PrepParams& q, int g, int 
         }
     }
     // pad slots and the per-tile maps of the graph, shared out over its parts
+    if (part == 0)
+        for (int b = (n0 >> 8) + tid; b < ((n0 + Np) >> 8); b += 1024) q.blk_span[b] = make_int2(n0 >> 7, (n0 + Np) >> 7);
     for (int sl = e0 + Eg + part * 1024 + tid; sl < e1; sl += parts * 1024) q.csr[sl] = make_int4(-1, -1, -1, -1);
     for (int t = (n0 + lo) / 32 + tid; t < (n0 + hi) / 32; t += 1024) q.ntile_graph[t] = g;
     for (int t = e0 / 32 + part * 1024 + tid; t < e1 / 32; t += parts * 1024) {
@@ -354,6 +356,8 @@ __global__ __launch_bounds__(1024) void prep_hist_kernel(PrepParams q, int Npad,
     // pad slots and the per-tile maps of the graph, shared out over its parts
     for (int sl = e0 + Eg + part * 1024 + tid; sl < e1; sl += parts * 1024) q.csr[sl] = make_int4(-1, -1, -1, -1);
     for (int t = n0 / 32 + part * 1024 + tid; t < n1 / 32; t += parts * 1024) q.ntile_graph[t] = g;
+    if (part == 0)
+        for (int b = (n0 >> 8) + tid; b < (n1 >> 8); b += 1024) q.blk_span[b] = make_int2(n0 >> 7, n1 >> 7);
     for (int t = e0 / 32 + part * 1024 + tid; t < e1 / 32; t += parts * 1024) {
         q.etile_graph[t] = g;
         q.tile_meta[t] = t * 32 < e0 + Eg ? 4 : 0;
@@ -1288,6 +1292,29 @@ __global__ __launch_bounds__(WAVES * 64) void pre_resident_both_kernel(PreParams
 // holds the node rows of "its" graphs instead of every XCD caching every graph.
 struct XcdWalk {
     int cur, end, step;
+    // order 2 (mp_fused, persistent workgroups): the XCD's 256-row blocks [blk0, blk0 + B) stand for 2 B four-tile groups -- the
+    // i-th group from the START of its graph (heavy: the free samples come first) for positions 0 .. B-1, the i-th group from
+    // its END (light) for positions B .. 2B-1 in reverse block order.  Workgroup u of U walks the positions on a snake (u,
+    // 2U-1-u, 2U+u, 4U-1-u, ...): longest jobs first, every resident workgroup gets a near-equal share of heavy and light groups.
+    int snake = 0, k = 0, U = 1, u = 0, blk0 = 0, B = 0, ns = 0;
+    const int2* span = nullptr;
+    int2 nspan;
+    __device__ __forceinline__ int pos(int kk) const { return (kk & 1) ? (kk + 1) * U - 1 - u : kk * U + u; }
+    __device__ __forceinline__ int blk_of(int s) const { return blk0 + (s < B ? s : 2 * B - 1 - s); }
+    __device__ __forceinline__ void snake_prefetch() {            // the NEXT position's block span, requested a whole group ahead
+        ++k;
+        ns = pos(k);
+        if (ns < 2 * B) nspan = span[blk_of(ns)];
+    }
+    __device__ __forceinline__ void snake_set(int s, int2 sp) {
+        if (s < 2 * B) {
+            const int i = blk_of(s) - (sp.x >> 1);
+            cur = s < B ? sp.x + i : sp.y - 1 - i;
+            end = cur + 1;
+        } else {
+            end = cur;
+        }
+    }
     __device__ __forceinline__ XcdWalk(int n_groups) {
         const int nb = gridDim.x >> 3;                    // blocks per XCD (gridDim.x is a multiple of 8)
         const int per = (n_groups + 7) >> 3;
@@ -1297,7 +1324,10 @@ struct XcdWalk {
         step = nb;
     }
     __device__ __forceinline__ bool valid() const { return cur < end; }
-    __device__ __forceinline__ void next() { cur += step; }
+    __device__ __forceinline__ void next() {
+        if (snake) snake_set(ns, nspan);
+        else cur += step;
+    }
 };
 
 
@@ -1514,6 +1544,22 @@ __device__ __forceinline__ void write_stage_tiles(float* stage, int sr, int h, c
         }
 }
 
+// 32 staged rows -> 32 CONSECUTIVE rows of a [rows, D] array, the inverse of dma_rows for a contiguous block: lane l stores LDS piece
+// (l % PP) of stage row (l / PP) of its instruction, i.e. PP lanes write one whole row (64 .. 256 contiguous bytes) instead of every
+// lane writing 8 / 16 bytes of a different row (a store in the chain layout is one L2 write request per lane)
+template <int D, int P>
+__device__ __forceinline__ void store_rows_coalesced(float* array_f32_units, size_t row0, const float* stage, int lane) {
+    using G = RowGeom<D, P>;
+    char* base = reinterpret_cast<char*>(array_f32_units) + row0 * G::RB;
+#pragma unroll
+    for (int i = 0; i < G::NI; ++i) {
+        const int sr = G::RPI * i + lane / G::PP;
+        const int lp = lane % G::PP;                              // LDS piece lp of a row holds the row's piece lp ^ swz (dma_rows)
+        const f32x4 v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(stage) + sr * G::RB + lp * 16);
+        *reinterpret_cast<f32x4*>(base + (size_t)sr * G::RB + ((lp ^ G::swz(sr)) * 16)) = v;
+    }
+}
+
 // y[ot] += sum_it W[ot][it] . x[it] with the inputs produced one 32-feature tile at a time by `get(it, tile)`: only one
 // input tile is live, which is what lets the d = 64 instantiation keep its register count down
 // RELU: the input tile goes through max(x, 0) before it is multiplied.  bf16 operands: the conversion comes first and the
@@ -1570,6 +1616,9 @@ __device__ __forceinline__ void linear_acc_stream(const float* A, Get get, f32x1
 #endif
 #ifndef GNNMP_MP_FLOW_F32
 #define GNNMP_MP_FLOW_F32 0
+#endif
+#ifndef GNNMP_MP_ROWS_LDS
+#define GNNMP_MP_ROWS_LDS 1          // bf16 kernels, node phase: R rows in through LDS-DMA, X' / A' / PT rows out through LDS as whole rows
 #endif
 #ifndef GNNMP_MP_F32_NEWLOOP
 #define GNNMP_MP_F32_NEWLOOP 0       // experiment: the straight-line two-chunk loop for the round-3 flow as well
@@ -1645,7 +1694,7 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
     float* ytile = hpart + 32 * D;
     if constexpr (!kCoop) {
         // workgroups of the unused tail of the padded tile space (up to 22 % of the grid) leave before they stage anything
-        if (p.tpw > 0) {
+        if (p.tpw > 0 && p.order != 2) {
             const int q8 = blockIdx.x >> 3, per = ((((p.node_ptr_pad[p.G] >> 7) + p.tpw - 1) / p.tpw) + 7) >> 3;
             if (q8 >= per) return;
         }
@@ -1678,6 +1727,22 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
     // tiles actually in use (the prep stage's padded total): the XCD eighths are cut from those, not from the launch's upper bound
     const int real_tiles = min(p.n_tiles, p.node_ptr_pad[p.G] >> 5);
     XcdWalk wk(kCoop ? real_tiles : (real_tiles + 3) / 4);
+    if (!kCoop && p.order == 2) {
+        const int blocks = p.node_ptr_pad[p.G] >> 8, perb = (blocks + 7) >> 3;
+        wk.snake = 1;
+        wk.U = gridDim.x >> 3;
+        wk.u = blockIdx.x >> 3;
+        wk.blk0 = (blockIdx.x & 7) * perb;
+        wk.B = max(0, min(perb, blocks - wk.blk0));
+        wk.span = p.blk_span;
+        wk.k = 0;
+        const int s0 = wk.pos(0);
+        int2 sp0 = make_int2(0, 0);
+        if (s0 < 2 * wk.B) sp0 = p.blk_span[wk.blk_of(s0)];
+        wk.cur = 0;
+        wk.snake_set(s0, sp0);
+        wk.ns = 2 * wk.B;                       // (until the first prefetch)
+    } else
     if (!kCoop && p.tpw > 0) {                 // tpw == 0 (experiment): persistent workgroups, strided walk of the XCD's eighth
         // every workgroup takes p.tpw ADJACENT four-tile groups, one after the other (the launcher picks tpw so that the
         // workgroups fill whole rounds of the resident slots: launch_mp_fused_t)
@@ -1719,6 +1784,7 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
         // is one dense front in HBM and neighbouring tiles share gathered A rows (tiles pulled one by one from a per-XCD
         // counter, or one contiguous run of tiles per workgroup, both measured 13-18 % slower)
         const int tile = kCoop ? wk.cur : wk.cur * 4 + wave;
+        if constexpr (!kCoop) { if (wk.snake) wk.snake_prefetch(); }
         if (tile >= p.n_tiles) continue;
         const int tg = kCoop ? pre_g : p.ntile_graph[tile];                    // kCoop: the workgroup's only tile, requested above
         if (tg < 0) continue;                                                  // workgroup-uniform when kCoop
@@ -2071,9 +2137,28 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
         // compiler does not hoist those loop-invariant loads out of the job loop into ~70 registers)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         float* rrows = kREarly ? astage : btile;
+        // bf16 kernels, one tile per wave: after the last chunk the A and B stages (adjacent: 2 x 32 bf16 rows = 32 fp32 rows) are
+        // free -- the tile's fp32 R rows come in through them by DMA and its X' / A' / PT rows go out through them as whole
+        // rows.  In the chain layout every lane loads / stores 8-16 bytes of a different row: one L1 / L2 request per lane, 24
+        // such loads and 16-24 such stores per tile (the stores + the last layer were 4.8 of the node phase's 12 us at d = 64).
+        constexpr bool kRowsLds = GNNMP_MP_ROWS_LDS && P == 1 && !kCoop;      // rows IN through the stages (fp32 kernels: always)
+        constexpr bool kStoreLds = GNNMP_MP_ROWS_LDS && !kCoop;               // rows OUT through the stages
+        // (d = 64 reads its X rows here, not at the tile start: bringing those through the A stage too measured 0.521 vs 0.517 ms per
+        // five launches -- one more exposed round trip and 16 more spilled bytes -- and stays off)
+        constexpr bool kXLds = false && kRowsLds && !kHpEarly;
+        StageRaw<1> xraw[kXLds ? NT : 1];
         if constexpr (P != 1) {                                  // fp32 rows fill a whole stage each
             if constexpr (!kHpEarly) dma_rows<D, 0>(p.X, [&](int sr) { return t0 + sr; }, astage, lane);
             if (!(kREarly && r_requested)) dma_rows<D, 0>(p.R, [&](int sr) { return t0 + sr; }, rrows, lane);
+        } else if constexpr (kRowsLds) {
+            if constexpr (kXLds) {                               // X rows (bf16) through the A stage first, then the stages take the R rows
+                dma_rows<D, 1>(p.X, [&](int sr) { return t0 + sr; }, astage, lane);
+                wait_vmcnt<0>();
+#pragma unroll
+                for (int it = 0; it < NT; ++it) read_stage_raw<D, 1>(astage, j, h, it, xraw[it]);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            dma_rows<D, 0>(p.R, [&](int sr) { return t0 + sr; }, astage, lane);        // 32 fp32 rows = the A stage + the B stage
         }
         f32x16 H[NT];
         if constexpr (kHpEarly) {
@@ -2085,6 +2170,7 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
             if constexpr (P != 1) wait_vmcnt<0>();
             linear_acc_stream<P, NT, false>(wn + LN::wlx, [&](int it, f32x16& x) {
                 if constexpr (P != 1) read_stage_tile<D, 0>(astage, j, h, it, x);
+                else if constexpr (kXLds) expand_stage_raw<1>(xraw[it], x);
                 else load_row_tile<1, NT>(p.X, (size_t)node, h, it, x);          // bf16 mode: X rows are stored in bf16
             }, H, lane);
         }
@@ -2104,12 +2190,28 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
             if constexpr (P != 1) {
 #pragma unroll
                 for (int tt = 0; tt < NT; ++tt) read_stage_tile<D, 0>(rrows, j, h, tt, y[tt]);
+            } else if constexpr (kRowsLds) {
+                wait_vmcnt<0>();
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt) read_stage_tile<D, 0>(astage, j, h, tt, y[tt]);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // R rows are in registers: both stages are free again
             } else {
                 load_row<NT>(p.R + (size_t)node * D, y, h);
             }
             linear_acc_p<P, NT, NT>(wn + LN::m1, H, y, lane);
             GNNMP_TRC();                                         // (diagnostics build) Y done
-            store_row_p<P == 1 ? 1 : 0, NT>(p.Xout, (size_t)node, y, h);        // X is only ever read as an MFMA operand: bf16 rows lose nothing
+            if constexpr (kStoreLds) {
+                constexpr int XP = P == 1 ? 1 : 0;                                  // X' rows: bf16 in the bf16 mode, fp32 otherwise
+                float* xs = (P != 1 && !kREarly) ? btile : astage;                  // the stage the R rows were just read from
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                write_stage_tiles<D, XP, NT>(xs, j, h, y);                          // X' rows -> stage -> whole rows out
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                store_rows_coalesced<D, XP>(p.Xout, (size_t)t0, xs, lane);
+            } else {
+                store_row_p<P == 1 ? 1 : 0, NT>(p.Xout, (size_t)node, y, h);        // X is only ever read as an MFMA operand: bf16 rows lose nothing
+            }
             make_ops<P, NT>(y, yop);
         }
         {
@@ -2117,14 +2219,32 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
 #pragma unroll
             for (int tt = 0; tt < NT; ++tt) z[tt] = splat16(0.f);
             linear_acc_ops<P, NT, NT>(wn + LN::m2, yop, z, lane);
-            store_row_p<P, NT>(p.Aout, (size_t)node, z, h);
+            if constexpr (kStoreLds) {
+                float* as = (P != 1 && !kREarly) ? astage : btile;                  // the OTHER stage (X' may still be on its way out)
+                write_stage_tiles<D, P, NT>(as, j, h, z);                           // A' rows -> stage -> whole rows out
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                store_rows_coalesced<D, P>(p.Aout, (size_t)t0, as, lane);
+            } else {
+                store_row_p<P, NT>(p.Aout, (size_t)node, z, h);
+            }
         }
         if (kCoop || p.last) {                                   // one tile per wave: only PT for the policy head -- B' is recomputed by the next iteration
             f32x16 z[NT];
 #pragma unroll
             for (int tt = 0; tt < NT; ++tt) z[tt] = splat16(0.f);
             linear_acc_ops<P, NT, NT>(wn + LN::m3, yop, z, lane);
-            store_row_p<P, NT>(p.Bout, (size_t)node, z, h);
+            if constexpr (kStoreLds) {
+                float* ps = (P != 1 && !kREarly) ? btile : astage;                  // X' stage: its rows have been read out by now
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                write_stage_tiles<D, P, NT>(ps, j, h, z);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                store_rows_coalesced<D, P>(p.Bout, (size_t)t0, ps, lane);
+            } else {
+                store_row_p<P, NT>(p.Bout, (size_t)node, z, h);
+            }
         }
         GNNMP_TRC();
     }
@@ -2484,17 +2604,24 @@ static hipError_t launch_mp_fused_t(const MpFusedParams& p, hipStream_t st) {
             g_mp_trace = tbuf; g_mp_trace_n = need;
         }
 #endif
-        // dispatch order (see the kernel): mirrored pairs when two groups per workgroup do not cost a round of workgroups
-        // (rounds = what the slowest resident slot runs one after the other); GNNMP_MP_ORDER = 0 / 1 forces it (experiments)
+        // dispatch order (see the kernel): more groups than resident workgroup slots -> the resident workgroups stay and share
+        // the groups out on a snake (order 2); otherwise one workgroup per group.  Five launches, plain / mirrored pairs / snake:
+        // configs[2] bf16 0.524 / 0.500 / 0.496 ms, configs[4] bf16 0.509 / - / 0.483, configs[1] fp32 0.701 / - / 0.669.
+        // GNNMP_MP_ORDER = 0 / 1 / 2 forces one (experiments, tests/test_full_size_gpu.py)
         static const int order_env = getenv("GNNMP_MP_ORDER") ? atoi(getenv("GNNMP_MP_ORDER")) : -1;
         q.order = 0;
         if (forced_tpw == 0) {
             const Residency r = resident_workgroups(reinterpret_cast<const void*>(mp_fused_kernel<D, P, COOP>), lds);
             const long long slots = (long long)r.cus * (r.per_cu > 0 ? r.per_cu : 1);
-            const long long rounds1 = (groups_cap + slots - 1) / slots, rounds2 = 2 * ((groups_cap / 2 + slots - 1) / slots);
-            q.order = rounds2 <= rounds1 ? 1 : 0;
-            if (order_env >= 0) q.order = order_env == 1 ? 1 : 0;
+            q.order = groups_cap > slots && slots >= 8 ? 2 : 0;
+            if (order_env >= 0) q.order = order_env;
+            if (q.order == 2 && slots < 8) q.order = 0;
             if (q.order == 1) q.tpw = tpw = 2;
+            if (q.order == 2) {                // persistent: exactly the resident workgroups (a multiple of 8)
+                hipLaunchKernelGGL((mp_fused_kernel<D, P, COOP>), dim3((unsigned)((slots / 8) * 8)), dim3(256), lds, st, q);
+                LAUNCH_CHECK();
+                return hipSuccess;
+            }
         }
         int grid = ((groups_cap + tpw - 1) / tpw + 7) & ~7;
         if (forced_tpw < 0) {                  // experiment: persistent workgroups, -forced_tpw per CU

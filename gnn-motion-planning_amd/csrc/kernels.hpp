@@ -17,6 +17,7 @@ struct PrepParams {
     int4* csr;                                   // [Epad] {source, target, caller column, 0}; -1 = pad slot
     int* goal_node;                              // [G] padded node id
     int* tile_meta;                              // per 32-edge tile, see prep_graph_body
+    int2* blk_span;                              // per 256-row block of the padded node space: its graph's four-tile groups [first, end)
     int* single_out;                             // non-null: ONE graph given by its totals; node_ptr / edge_ptr / obs_ptr point here
     int single_n, single_e, single_o;            //           ([0,N | 0,E | 0,O], written by the prep stage before anything reads them)
     int n_etiles;
@@ -89,7 +90,8 @@ struct MpFusedParams {
     int store_h;
     int tpw;                     // adjacent four-tile groups per workgroup (set by launch_mp_fused)
     int G;                       // graphs: node_ptr_pad[G] / 32 = tiles actually in use (n_tiles is an upper bound)
-    int order;                   // dispatch order of the four-tile groups: 0 plain, 1 mirrored pairs (tpw == 2) (mp_fused_kernel)
+    int order;                   // order of the four-tile groups: 0 plain, 1 mirrored pairs (tpw == 2), 2 persistent workgroups on a snake (mp_fused_kernel)
+    const int2* blk_span;        // order 2: PrepParams::blk_span
     long long* trace;            // diagnostics builds only (-DGNNMP_MP_TRACE): per-wave timestamps, else nullptr
 };
 

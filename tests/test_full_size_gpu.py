@@ -80,7 +80,7 @@ sys.path.insert(0, %r); sys.path.insert(0, %r)
 from conftest import load_weights
 import gnnmp
 from gnnmp.synth import synth_graph
-sizes = [300 + 37 * (i %% 29) + 5 * i for i in range(72)]            # 300 .. 1700 nodes: every graph another number of 256-row blocks
+sizes = [300 + 37 * (i %% 29) + 5 * (i %% 72) for i in range(216)]     # 300 .. 1700 nodes: neighbours differ in their number of 256-row blocks
 graphs = [{k: (v.to('cuda:0') if torch.is_tensor(v) else v) for k, v in synth_graph('maze2', n, 6, seed=900 + i).items()} for i, n in enumerate(sizes)]
 m = gnnmp.EncoderProcessDecoder(2, 2, 32, 2).eval(); m.load_state_dict(load_weights('weights_maze')); m.mlp_dtype = %r
 b = gnnmp.GraphBatch.from_graphs(graphs, 2, 'cuda:0')
@@ -92,9 +92,10 @@ print('HASH', hashlib.sha256(s.cpu().numpy().tobytes()).hexdigest(), int(b.total
 
 @pytest.mark.parametrize('mode', ['fp32', 'bf16'])
 def test_ragged_large_batch_dispatch_orders(mode):
-    """The message-passing launch walks the four-tile groups of a large batch in one of two orders (plain, or mirrored pairs per
-    workgroup: csrc/explorer_kernels.hip mp_fused_kernel): on a RAGGED batch -- 72 graphs of 300 ... 1700 nodes, every graph
-    another number of 256-row blocks -- both give the bytes of the per-graph calls (which run the
+    """The message-passing launch walks the four-tile groups of a large batch in one of three orders (plain, mirrored pairs per
+    workgroup, or resident workgroups on a snake over the XCD's blocks: csrc/explorer_kernels.hip mp_fused_kernel): on a RAGGED
+    batch -- 216 graphs of 300 ... 1700 nodes with differing numbers of 256-row blocks, ~1700 groups, i.e. more than the resident
+    workgroup slots, so the snake takes several turns -- all give the bytes of the per-graph calls (which run the
     tile-per-workgroup form), i.e. every group is visited exactly once whatever the order."""
     import os
     import subprocess
@@ -102,7 +103,7 @@ def test_ragged_large_batch_dispatch_orders(mode):
     here = os.path.dirname(os.path.abspath(__file__))
     code = _RAGGED_SNIPPET % (os.path.dirname(here), here, mode)
     hashes = {}
-    for order in ('0', '1', ''):
+    for order in ('0', '1', '2', ''):
         env = dict(os.environ)
         env.pop('GNNMP_MP_ORDER', None)
         if order:
@@ -113,7 +114,7 @@ def test_ragged_large_batch_dispatch_orders(mode):
     assert len(set(hashes.values())) == 1, hashes
     # and against per-graph calls in this process
     import hashlib
-    sizes = [300 + 37 * (i % 29) + 5 * i for i in range(72)]
+    sizes = [300 + 37 * (i % 29) + 5 * (i % 72) for i in range(216)]
     graphs = [{k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in synth_graph('maze2', n, 6, seed=900 + i).items()} for i, n in enumerate(sizes)]
     m = gnnmp.EncoderProcessDecoder(2, 2, 32, 2).eval()
     m.load_state_dict(load_weights('weights_maze'))
