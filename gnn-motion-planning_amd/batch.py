@@ -11,8 +11,11 @@ class GraphBatch:
     edge_index [2, sumE] (graph-local ids), node_ptr / edge_ptr / obs_ptr int32 [G+1]."""
 
     def __init__(self, v, goal, obstacles, edge_index, node_ptr, edge_ptr, obs_ptr, max_obstacles, dense_floats=None):
-        self.v, self.goal, self.obstacles, self.edge_index = v, goal, obstacles, edge_index
-        self.node_ptr, self.edge_ptr, self.obs_ptr = node_ptr, edge_ptr, obs_ptr
+        # the library reads these through raw pointers as dense row-major arrays (include/gnnmp.h): a strided view (a
+        # transposed or column-major tensor) is copied here once instead of being misread
+        dense = lambda t: t if t is None or t.is_contiguous() else t.contiguous()      # noqa: E731
+        self.v, self.goal, self.obstacles, self.edge_index = dense(v), dense(goal), dense(obstacles), dense(edge_index)
+        self.node_ptr, self.edge_ptr, self.obs_ptr = dense(node_ptr), dense(edge_ptr), dense(obs_ptr)
         self.max_obstacles = int(max_obstacles)
         # node_ptr None: ONE graph described by the tensor shapes alone (no prefix arrays on the device, gnnmp.h)
         self.n_graphs = 1 if node_ptr is None else int(node_ptr.numel() - 1)

@@ -1275,7 +1275,7 @@ extern "C" int gnnmp_graph_build(const gnnmp_graph_batch* b, int64_t* edge_index
 // device-side explore stage for 2-D mazes (eval_gnn.py:198-233 + environment/maze_env.py:270-326)
 // =============================================================================================
 namespace {
-struct MzCarve { size_t in_ptr, cnt, in_eid, pos, prev, rb_val, rb_src, rb_eid, alive, total; };
+struct MzCarve { size_t in_ptr, cnt, in_rec, pos, prev, rb_val, rb_src, rb_eid, total; };
 bool mz_carve(const gnnmp_maze_batch* b, MzCarve& c) {
     if (b->n_problems < 1 || b->total_nodes < 0 || b->total_edges < 0 || b->width < 1) return false;
     size_t o = 0;
@@ -1283,13 +1283,12 @@ bool mz_carve(const gnnmp_maze_batch* b, MzCarve& c) {
     const size_t n = (size_t)b->total_nodes + b->n_problems + 1, e = (size_t)(b->total_edges > 0 ? b->total_edges : 1);
     c.in_ptr = take(sizeof(int) * n);
     c.cnt = take(sizeof(int) * n);
-    c.in_eid = take(sizeof(int) * e);
+    c.in_rec = take(sizeof(int) * 2 * e);
     c.pos = take(sizeof(int) * n);
     c.prev = take(sizeof(int) * n);
     c.rb_val = take(sizeof(float) * n);
     c.rb_src = take(sizeof(int) * n);
     c.rb_eid = take(sizeof(int) * n);
-    c.alive = take(e);
     c.total = o;
     return true;
 }
@@ -1323,8 +1322,8 @@ extern "C" int gnnmp_maze_explore_ex(const gnnmp_maze_batch* b, int32_t dim, con
     p.v = b->v; p.node_ptr = b->node_ptr; p.edge_ptr = b->edge_ptr; p.n_free = b->n_free;
     p.edge_index = reinterpret_cast<const long long*>(b->edge_index); p.scores = b->scores;
     p.maps = b->maps; p.goal_states = b->goal_states;
-    p.in_ptr = at<int>(ws, c.in_ptr); p.cnt = at<int>(ws, c.cnt); p.in_eid = at<int>(ws, c.in_eid);
-    p.pos = at<int>(ws, c.pos); p.prev = at<int>(ws, c.prev); p.alive = at<unsigned char>(ws, c.alive);
+    p.in_ptr = at<int>(ws, c.in_ptr); p.cnt = at<int>(ws, c.cnt); p.in_rec = at<int2>(ws, c.in_rec);
+    p.pos = at<int>(ws, c.pos); p.prev = at<int>(ws, c.prev);
     p.rb_val = at<float>(ws, c.rb_val); p.rb_src = at<int>(ws, c.rb_src); p.rb_eid = at<int>(ws, c.rb_eid);
     p.success = success; p.n_explored = n_explored; p.explored = explored; p.n_pairs = n_pairs;
     p.explored_edges = explored_edges; p.path_len = path_len; p.path = path;

@@ -152,10 +152,10 @@ struct MazeParams {
     const long long* edge_index;          // [2, sumE] graph-local
     const float* scores;                  // [sumE]
     const double *maps, *goal_states;     // [B, w, w], [B, 2]
-    int *in_ptr, *cnt, *in_eid, *pos, *prev;
-    float* rb_val;                        // cached best live cell per explored row (value, column, edge id)
+    int *in_ptr, *cnt, *pos, *prev;
+    int2* in_rec;                         // [sumE] visible cells grouped by row: (column | dead bit 31, score bits)
+    float* rb_val;                        // cached best live cell per explored row (value, column, slot in in_rec)
     int *rb_src, *rb_eid;
-    unsigned char* alive;
     int *success, *n_explored, *explored, *n_pairs, *explored_edges, *path_len, *path;
     long long* checks;
     int dim;                              // 2 (point robot, v [.,2]) or 3 (stick robot, v [.,3])

@@ -78,7 +78,7 @@ __device__ __forceinline__ bool maze_state_fp(MazeCtx& m, float x, float y) {
 }
 
 // iterative form of the recursive bisection (left half first, stop at the first blocked midpoint)
-__device__ bool maze_segment_fp(MazeCtx& m, float ax, float ay, float bx, float by) {
+__device__ __forceinline__ bool maze_segment_fp(MazeCtx& m, float ax, float ay, float bx, float by) {
     float* sx0 = reinterpret_cast<float*>(m.stack), *sy0 = sx0 + 48, *sx1 = sx0 + 96, *sy1 = sx0 + 144;
     int sp = 0;
     sx0[0] = ax; sy0[0] = ay; sx1[0] = bx; sy1[0] = by; sp = 1;
@@ -98,7 +98,7 @@ __device__ bool maze_segment_fp(MazeCtx& m, float ax, float ay, float bx, float 
     return true;
 }
 
-__device__ bool maze_edge_fp(MazeCtx& m, float ax, float ay, float bx, float by) {
+__device__ __forceinline__ bool maze_edge_fp(MazeCtx& m, float ax, float ay, float bx, float by) {
     if (!maze_valid(ax, ay) || !maze_valid(bx, by)) return false;
     if (!maze_state_fp(m, ax, ay)) return false;
     if (!maze_state_fp(m, bx, by)) return false;
@@ -184,47 +184,99 @@ __device__ bool stick_edge_fp(MazeCtx& m, const float* s, const float* t) {     
 
 }  // namespace
 
-// one wave per problem.  DIM = 2: point robot; DIM = 3: stick robot (maze3)
+// diagnostics build (-DGNNMP_MAZE_TRACE, tools/diag/maze_trace.py): cycles per phase of the greedy loop, per problem
+#ifdef GNNMP_MAZE_TRACE
+__device__ long long g_maze_trace[8 * 4096];
+#define MZ_T0() long long mz_t = wall_clock64(); long long mz_acc[6] = {0, 0, 0, 0, 0, 0}
+#define MZ_LAP(k) { const long long mz_n = wall_clock64(); mz_acc[k] += mz_n - mz_t; mz_t = mz_n; }
+#else
+#define MZ_T0()
+#define MZ_LAP(k)
+#endif
+
+// ---- wave-wide maximum of a 64-bit key.  The greedy loop is one dependent chain per problem and every step ends in two
+// or three of these: as six rounds of ds_bpermute shuffles of three or four values each they were ~0.5 us of a 3.7 us step;
+// four DPP rounds inside the rows of 16 lanes plus four readlanes are ~0.1 us.  All 64 lanes must be active.
+template <int CTRL>
+__device__ __forceinline__ unsigned long long dpp_u64(unsigned long long k) {
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)k, CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(k >> 32), CTRL, 0xf, 0xf, true);
+    return ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
+}
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long k) {
+    unsigned long long o;
+    o = dpp_u64<0xB1>(k); k = o > k ? o : k;                   // quad_perm [1, 0, 3, 2]
+    o = dpp_u64<0x4E>(k); k = o > k ? o : k;                   // quad_perm [2, 3, 0, 1]
+    o = dpp_u64<0x141>(k); k = o > k ? o : k;                  // row_half_mirror
+    o = dpp_u64<0x140>(k); k = o > k ? o : k;                  // row_mirror: every lane of a row holds the row's maximum
+    unsigned long long r = 0;
+#pragma unroll
+    for (int row = 0; row < 4; ++row) {
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)k, 16 * row);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(k >> 32), 16 * row);
+        const unsigned long long c = ((unsigned long long)hi << 32) | lo;
+        r = c > r ? c : r;
+    }
+    return r;
+}
+// order-preserving map of a float onto an unsigned (never 0 for a finite value or -inf: 0 stands for "no cell")
+__device__ __forceinline__ unsigned maze_ord(float x) {
+    const unsigned u = __float_as_uint(x);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// one workgroup of four waves per problem: all four group the cells by row, then wave 0 walks the greedy loop alone.
+// DIM = 2: point robot; DIM = 3: stick robot (maze3)
 template <int DIM>
-__global__ __launch_bounds__(64) void maze_explore_kernel(MazeParams p) {
-    const int b = blockIdx.x, lane = threadIdx.x;
+__global__ __launch_bounds__(256) void maze_explore_kernel(MazeParams p) {
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int n0 = p.node_ptr[b], N = p.node_ptr[b + 1] - n0;
     const int e0 = p.edge_ptr[b], E = p.edge_ptr[b + 1] - e0;
     const int F = p.n_free[b];
     const long long* src = p.edge_index + e0;
     const long long* dst = p.edge_index + (size_t)p.total_edges + e0;
     const float* sc = p.scores + e0;
-    const float* v = p.v + (size_t)n0 * DIM;
+    MZ_T0();
     // Per-node state of problems up to kMazeLdsNodes nodes lives in LDS: every step of the greedy loop reads the cached row
-    // maxima of the whole frontier, the explored list, row ranges and explored positions -- from the workspace in global
-    // memory each of them was a dependent round trip of ~1 us inside a loop of ~2 000 steps.  (Generic pointers: the same
-    // code addresses LDS or, for larger problems, the workspace.)
+    // maxima of the whole frontier, the explored list, row ranges, explored positions and two node rows -- from the
+    // workspace in global memory each of them was a dependent round trip of ~1 us inside a loop of ~2 000 steps.  (Generic
+    // pointers: the same code addresses LDS or, for larger problems, the workspace.)
     __shared__ int s_in_ptr[kMazeLdsNodes + 1], s_pos[kMazeLdsNodes], s_explored[kMazeLdsNodes];
     __shared__ int s_rb_src[kMazeLdsNodes], s_rb_eid[kMazeLdsNodes];
-    __shared__ float s_rb_val[kMazeLdsNodes];
+    __shared__ unsigned s_rb_key[kMazeLdsNodes];
+    __shared__ float s_v[kMazeLdsNodes * DIM];
     const bool in_lds = N <= kMazeLdsNodes;
     int* in_ptr = in_lds ? s_in_ptr : p.in_ptr + n0 + b;              // [N + 1] per problem
-    int* cnt = p.cnt + n0;
-    int* in_eid = p.in_eid + e0;
-    unsigned char* alive = p.alive + e0;
+    int* cnt = in_lds ? s_rb_src : p.cnt + n0;                         // (build only: the row caches are set up afterwards)
+    // The matrix cells the loop can ever pick -- off the diagonal, non-zero score, free row and column (eval_gnn.py:
+    // 189-196) -- grouped by row (= edge target) as (column | dead bit, score) records: a row scan is ONE coalesced read
+    // (edge ids + separate alive / source / score arrays made every scan two dependent round trips).
+    int2* rec = p.in_rec + e0;
+    constexpr int kDead = (int)0x80000000;
     int* pos = in_lds ? s_pos : p.pos + n0;                            // position in the explored list or -1
     int* explored = in_lds ? s_explored : p.explored + n0;            // (copied to p.explored at the end)
     int* prev = p.prev + n0;
     int* ee = p.explored_edges + 2 * ((size_t)2 * e0 + b);      // [2E + 1] (a, b) pairs per problem
-
-    // ---- CSR by target + live cells
-    for (int i = lane; i < N; i += 64) { cnt[i] = 0; pos[i] = -1; }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    for (int e = lane; e < E; e += 64) {
-        const int s = (int)src[e], t = (int)dst[e];
-        const bool ok = s != t && sc[e] != 0.0f && s < F && t < F;        // diagonal, zeros, collided rows / columns
-        alive[e] = ok ? 1 : 0;
-        atomicAdd(&cnt[t], 1);
+    const float* v = p.v + (size_t)n0 * DIM;
+    if (in_lds) {
+        for (int i = tid; i < N * DIM; i += 256) s_v[i] = v[i];
+        v = s_v;
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    {
+
+    // ---- visible cells by row (~55 k edges per problem at the published setting: 1.5 ms for one wave, half of the mean
+    // problem's time, 0.4 ms for four)
+    for (int i = tid; i < N; i += 256) { cnt[i] = 0; pos[i] = -1; }
+    __syncthreads();
+    auto visible = [&](int e, int& s, int& t) {
+        s = (int)src[e]; t = (int)dst[e];
+        return s != t && sc[e] != 0.0f && s < F && t < F;                  // diagonal, zeros, collided rows / columns
+    };
+    for (int e = tid; e < E; e += 256) {
+        int s, t;
+        if (visible(e, s, t)) atomicAdd(&cnt[t], 1);
+    }
+    __syncthreads();
+    if (tid < 64) {
         int run = 0;                                                       // wave-wide exclusive scan, 64 rows a time
         for (int base = 0; base < N; base += 64) {
             const int i = base + lane;
@@ -240,14 +292,13 @@ __global__ __launch_bounds__(64) void maze_explore_kernel(MazeParams p) {
         }
         if (lane == 0) in_ptr[N] = run;
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    for (int e = lane; e < E; e += 64) {
-        const int t = (int)dst[e];
-        in_eid[in_ptr[t] + atomicAdd(&cnt[t], 1)] = e;
+    __syncthreads();
+    for (int e = tid; e < E; e += 256) {
+        int s, t;
+        if (visible(e, s, t)) rec[in_ptr[t] + atomicAdd(&cnt[t], 1)] = make_int2(s, __float_as_int(sc[e]));
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
+    if (tid >= 64) return;                                                 // (no workgroup barrier below this line)
 
     __shared__ unsigned char occ_lds[kMazeLdsCells];
     MazeCtx m;
@@ -273,64 +324,70 @@ __global__ __launch_bounds__(64) void maze_explore_kernel(MazeParams p) {
             const int r = flat[i], c = flat[M + i];
             if (r >= N) continue;
             for (int q = in_ptr[r]; q < in_ptr[r + 1]; ++q)
-                if ((int)src[in_eid[q]] == c) alive[in_eid[q]] = 0;
+                if ((rec[q].x & ~kDead) == c) rec[q].x = c | kDead;
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
 
-    // Cached best live cell of every explored row i: (value, column, edge id), first maximum in column order.
-    // A row's best only changes when that very cell dies -- its column gets explored, or the edge is found
+    // Cached best live cell of every explored row i: (ordered value or 0 = none, column, slot in rec), first maximum in
+    // column order.  A row's best only changes when that very cell dies -- its column gets explored, or the edge is found
     // blocked -- so a step rescans one to three rows instead of the whole frontier.
-    float* rb_val = in_lds ? s_rb_val : p.rb_val + n0;
+    unsigned* rb_key = in_lds ? s_rb_key : reinterpret_cast<unsigned*>(p.rb_val) + n0;
     int* rb_src = in_lds ? s_rb_src : p.rb_src + n0;
     int* rb_eid = in_lds ? s_rb_eid : p.rb_eid + n0;
-    auto rescan = [&](int i) {
+    // `pre` (when have_pre): the first 64 records of the row, loaded earlier (and patched with this step's kills)
+    auto rescan = [&](int i, bool have_pre, int2 pre) {
         const int a = explored[i];
-        float bv = -INFINITY;
-        int bb = 0x7fffffff, be = -1;
-        for (int q = in_ptr[a] + lane; q < in_ptr[a + 1]; q += 64) {
-            const int e = in_eid[q];
-            if (!alive[e]) continue;
-            const int s = (int)src[e];
-            if (pos[s] >= 0) continue;                                     // column already explored
-            const float val = sc[e];
-            if (val > bv || (val == bv && s < bb)) { bv = val; bb = s; be = e; }
+        const int q0 = in_ptr[a], q1 = in_ptr[a + 1];
+        unsigned long long best = 0;
+        int bq = -1;
+        for (int base = q0; base < q1; base += 64) {
+            const int q = base + lane;
+            int2 r = make_int2(kDead, 0);
+            if (have_pre && base == q0) r = pre;
+            else if (q < q1) r = rec[q];
+            if (q < q1 && r.x >= 0 && pos[r.x] < 0) {                      // live cell, column not explored yet
+                const unsigned long long key = ((unsigned long long)maze_ord(__int_as_float(r.y)) << 32) | (0xffffffffu - (unsigned)r.x);
+                if (key > best) { best = key; bq = q; }                    // value desc, column asc
+            }
         }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const float ov = __shfl_xor(bv, off, 64);
-            const int ob = __shfl_xor(bb, off, 64), oe = __shfl_xor(be, off, 64);
-            if (oe >= 0 && (be < 0 || ov > bv || (ov == bv && ob < bb))) { bv = ov; bb = ob; be = oe; }
+        const unsigned long long w = wave_max_u64(best);
+        int be = -1, bb = 0x7fffffff;
+        if (w) {
+            const int wl = __builtin_ctzll(__ballot(best == w));
+            be = __builtin_amdgcn_readlane(bq, wl);
+            bb = (int)(0xffffffffu - (unsigned)w);
         }
-        if (lane == 0) { rb_val[i] = bv; rb_src[i] = bb; rb_eid[i] = be; }
+        if (lane == 0) { rb_key[i] = (unsigned)(w >> 32); rb_src[i] = bb; rb_eid[i] = be; }
     };
     auto sync = [&]() {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
     };
-    for (int i = 0; i < n_expl; ++i) rescan(i);
+    for (int i = 0; i < n_expl; ++i) rescan(i, false, make_int2(kDead, 0));
     sync();
+    MZ_LAP(0);
 
     while (true) {
         // ---- argmax over the cached row maxima: key (value desc, row position asc); the column is the row's own
-        float bv = -INFINITY;
-        int bp = 0x7fffffff, bb = 0x7fffffff, be = -1;
+        unsigned long long best = 0;
         for (int i = lane; i < n_expl; i += 64) {
-            const int e = rb_eid[i];
-            if (e < 0) continue;
-            const float val = rb_val[i];
-            if (val > bv || (val == bv && i < bp)) { bv = val; bp = i; bb = rb_src[i]; be = e; }
+            const unsigned k = rb_key[i];
+            const unsigned long long key = ((unsigned long long)k << 32) | (0xffffffffu - (unsigned)i);
+            if (k && key > best) best = key;
         }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const float ov = __shfl_xor(bv, off, 64);
-            const int op = __shfl_xor(bp, off, 64), ob = __shfl_xor(bb, off, 64), oe = __shfl_xor(be, off, 64);
-            const bool take = (oe >= 0) && (be < 0 || ov > bv || (ov == bv && op < bp));
-            if (take) { bv = ov; bp = op; bb = ob; be = oe; }
-        }
-        if (be < 0) break;                                                 // nothing left on the frontier
-        const int a = explored[bp], nb = bb;
+        const unsigned long long w = wave_max_u64(best);
+        if (!w) break;                                                     // nothing left on the frontier
+        const int bp = (int)(0xffffffffu - (unsigned)w);
+        const int a = explored[bp], nb = rb_src[bp], be = rb_eid[bp];
+        MZ_LAP(1);
+        // the rows this step rescans (row a when the edge is blocked, the new row nb when it is free) and the row that
+        // holds the mirrored cell (nb, a) are requested BEFORE the collision check: lane 0 needs ~1 us for it
+        const int qa0 = in_ptr[a], qa1 = in_ptr[a + 1], qn0 = in_ptr[nb], qn1 = in_ptr[nb + 1];
+        int2 ra = make_int2(kDead, 0), rn = make_int2(kDead, 0);
+        if (qa0 + lane < qa1) ra = rec[qa0 + lane];
+        if (qn0 + lane < qn1) rn = rec[qn0 + lane];
         int free_edge = 0, goal_hit = 0;
         if (lane == 0) {
             ee[2 * n_pairs] = a; ee[2 * n_pairs + 1] = nb;
@@ -352,39 +409,51 @@ __global__ __launch_bounds__(64) void maze_explore_kernel(MazeParams p) {
                     if (d < 0.05) goal_hit = stick_state_fp(m, v[3 * nb], v[3 * nb + 1], v[3 * nb + 2]) ? 1 : 0;
                 }
             } else {
-                alive[be] = 0;                                             // cell (a, nb)
+                rec[be].x = nb | kDead;                                    // cell (a, nb)
             }
         }
         n_pairs += 2;
-        free_edge = __shfl(free_edge, 0, 64);
-        goal_hit = __shfl(goal_hit, 0, 64);
+        free_edge = __builtin_amdgcn_readfirstlane(free_edge);
+        goal_hit = __builtin_amdgcn_readfirstlane(goal_hit);
+        MZ_LAP(2);
         if (!free_edge) {
-            // cell (nb, a): edge a -> nb, looked up among nb's incoming edges by the whole wave (one lane walking the ~50
-            // dependent loads of that list was most of a blocked step, and most steps are blocked edges)
-            for (int q = in_ptr[nb] + lane; q < in_ptr[nb + 1]; q += 64) {
-                const int e = in_eid[q];
-                if ((int)src[e] == a) alive[e] = 0;
-            }
+            if (qa0 + lane == be) ra.x = nb | kDead;                       // ... in the copy of row a as well
+            // cell (nb, a): looked up among nb's cells by the whole wave (one lane walking the ~50 dependent loads of that
+            // list was most of a blocked step, and most steps are blocked edges)
+            if (qn0 + lane < qn1 && (rn.x & ~kDead) == a) rec[qn0 + lane].x = a | kDead;
+            for (int q = qn0 + 64 + lane; q < qn1; q += 64)
+                if ((rec[q].x & ~kDead) == a) rec[q].x = a | kDead;
         }
         sync();
+        MZ_LAP(3);
         if (free_edge) {
             ++n_expl;
             if (goal_hit) { success = 1; break; }
-            // column nb is gone: every row whose cached best sat in it looks again; the new row is scanned
+            // column nb is gone: every row whose cached best sat in it looks again (row a is one of them); the new row is scanned
             for (int base = 0; base < n_expl - 1; base += 64) {
                 const int i = base + lane;
-                unsigned long long stale = __ballot(i < n_expl - 1 && rb_eid[i] >= 0 && rb_src[i] == nb);
+                unsigned long long stale = __ballot(i < n_expl - 1 && rb_key[i] != 0 && rb_src[i] == nb);
                 while (stale) {
-                    rescan(base + __builtin_ctzll(stale));
+                    const int row = base + __builtin_ctzll(stale);
+                    rescan(row, row == bp, ra);
                     stale &= stale - 1;
                 }
             }
-            rescan(n_expl - 1);
+            rescan(n_expl - 1, true, rn);
         } else {
-            rescan(bp);                                                    // cell (a, nb) died
+            rescan(bp, true, ra);                                          // cell (a, nb) died
         }
         sync();
+        MZ_LAP(4);
     }
+#ifdef GNNMP_MAZE_TRACE
+    if (lane == 0 && b < 4096) {
+        for (int k = 0; k < 5; ++k) g_maze_trace[8 * b + k] = mz_acc[k];
+        g_maze_trace[8 * b + 5] = n_pairs / 2;
+        g_maze_trace[8 * b + 6] = n_expl;
+        g_maze_trace[8 * b + 7] = E;
+    }
+#endif
     if (lane == 0) {
         if (success) {                                                     // back-track prev[] to the start node
             int node = explored[n_expl - 1], len = 0;
@@ -477,9 +546,20 @@ hipError_t launch_maze_steer(const MazeSteerParams& p, hipStream_t st) {
 
 hipError_t launch_maze_explore(const MazeParams& p, hipStream_t st) {
     if (p.B <= 0) return hipSuccess;
-    if (p.dim == 3) hipLaunchKernelGGL(maze_explore_kernel<3>, dim3(p.B), dim3(64), 0, st, p);
-    else hipLaunchKernelGGL(maze_explore_kernel<2>, dim3(p.B), dim3(64), 0, st, p);
+    if (p.dim == 3) hipLaunchKernelGGL(maze_explore_kernel<3>, dim3(p.B), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(maze_explore_kernel<2>, dim3(p.B), dim3(256), 0, st, p);
     return hipGetLastError();
 }
+
+#ifdef GNNMP_MAZE_TRACE
+}  // namespace gnnmp
+// copies the counters of the last explore launch (8 per problem: cycles of build / argmax / check / kill / rescan at 100 MHz,
+// steps, explored nodes, edges) to `dst` [8 * n]
+extern "C" int gnnmp_debug_maze_trace(long long* dst, int n) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(gnnmp::g_maze_trace), sizeof(long long) * 8 * (size_t)(n > 4096 ? 4096 : n)) == hipSuccess ? 0 : -1;
+}
+namespace gnnmp {
+#endif
 
 }  // namespace gnnmp

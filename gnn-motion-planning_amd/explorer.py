@@ -189,7 +189,7 @@ class EncoderProcessDecoder(nn.Module):
 
     def __getstate__(self):                 # copy.deepcopy / pickle: the native handle and buffers stay with the original
         st = self.__dict__.copy()
-        st.update(_handle=None, _handle_key=None, _ws=None, _wt=None, _manifest=None)
+        st.update(_handle=None, _handle_key=None, _ws=None, _ws_streams={}, _wt=None, _manifest=None)
         return st
 
     def _dims(self):
@@ -273,13 +273,22 @@ class EncoderProcessDecoder(nn.Module):
         need = ctypes.c_size_t()
         _lib.check(_lib.lib().gnnmp_explorer_workspace_bytes(h, ctypes.byref(cb), ctypes.byref(need)),
                    'gnnmp_explorer_workspace_bytes')
-        if self._ws is None or self._ws.numel() < need.value or self._ws.device != torch.device(device):
+        # one buffer per (device, stream): planner workers run forwards of the same module concurrently on their own
+        # streams (planner.eval_gnn_device), and a workspace must never be in use on two streams at once
+        key = (str(torch.device(device)), torch.cuda.current_stream(device).cuda_stream)
+        cache = self.__dict__.setdefault('_ws_streams', {})
+        ws = cache.get(key)
+        if ws is None or ws.numel() < need.value:
             # grown with head room: a planner calls with a slightly different edge count every time, and every
             # re-allocation is a device malloc of tens of MB (milliseconds)
-            grow = 0 if self._ws is None or self._ws.device != torch.device(device) else need.value // 3
-            self._ws = None
-            self._ws = torch.empty(need.value + grow, dtype=torch.uint8, device=device)
-        return self._ws
+            grow = 0 if ws is None else need.value // 3
+            cache.pop(key, None)
+            ws = None
+            if len(cache) >= 8:                                # streams come and go: keep the cache bounded
+                cache.clear()
+            ws = cache[key] = torch.empty(need.value + grow, dtype=torch.uint8, device=device)
+        self._ws = ws
+        return ws
 
     # ------------------------------------------------------------------ batched entry points
     @torch.no_grad()

@@ -183,6 +183,23 @@ def chain_edge_index(n):
     return torch.cat((e, torch.stack((loops, loops))), dim=1)
 
 
+def _chain_edge_indices(lengths):
+    """:func:`chain_edge_index` of every path length in ``lengths``, side by side ([2, sum (3 n - 2)] int64, path-local ids):
+    one numpy pass instead of seven torch calls per path."""
+    n = np.asarray(lengths, dtype=np.int64)
+    per = 3 * n - 2
+    off = np.zeros(len(n) + 1, dtype=np.int64)
+    off[1:] = np.cumsum(per)
+    j = np.arange(off[-1], dtype=np.int64) - np.repeat(off[:-1], per)          # position inside the path's block
+    nn = np.repeat(n, per)
+    out = np.empty((2, off[-1]), dtype=np.int64)
+    fwd, bwd = j < nn - 1, (j >= nn - 1) & (j < 2 * nn - 2)
+    loop = j - (2 * nn - 2)
+    out[0] = np.where(fwd, j + 1, np.where(bwd, j - (nn - 1), loop))
+    out[1] = np.where(fwd, j, np.where(bwd, j - (nn - 1) + 1, loop))
+    return out
+
+
 @torch.no_grad()
 def model_smooth(model, free, collided, old_path, env, device, iters=5, trace=None):
     """smoother.py:233-246: 5 x (smoother forward with loop=1 -> collision-checked steering)."""
@@ -292,11 +309,24 @@ def eval_gnn(env, indexes, model, model_s, seed=1234, smooth=True, batch=500, t_
             total_time_explore)
 
 
+def _path_cost_rows(path):
+    """:func:`path_cost` of a float32 [P, dim] array without a Python loop over the segments: per-segment sqrt(x . x) in
+    float32, accumulated left to right (cumsum) like the reference's running sum -- the same bits (tests/test_planner_host.py).  (27 k np.linalg.norm calls per 1024 maze
+    problems were a fifth of the device planner's host time.)"""
+    p = np.asarray(path)
+    if p.ndim != 2 or p.shape[0] < 2:
+        return 0.0
+    if p.dtype != np.float32:                  # (float64 rows: numpy's dot and einsum differ in the last bit; the planner's are float32)
+        return path_cost(p)
+    d = p[1:] - p[:-1]
+    return float(np.cumsum(np.sqrt(np.einsum('ij,ij->i', d, d)))[-1])
+
+
 def _collect(res, wall, t_explore, sol, paths, smooth_paths, rows_out):
     for r in res:
         paths.append(r['path'] if r['success'] else [])
         smooth_paths.append(r['smooth_path'] if r['success'] else [])
-        sol.append((r['success'], path_cost(paths[-1]), path_cost(smooth_paths[-1]), r['c_explore'], r['c_smooth'],
+        sol.append((r['success'], _path_cost_rows(paths[-1]), _path_cost_rows(smooth_paths[-1]), r['c_explore'], r['c_smooth'],
                     wall, t_explore))
         if rows_out is not None:
             rows_out.append(sol[-1][:5] + (len(paths[-1]), len(r['explored'])))
@@ -315,8 +345,21 @@ def skip_maze_sampling(env, indexes, batch=500):
     stream.close()
 
 
-def eval_gnn_device(env, indexes, model, model_s, seed=1234, batch=500, k=30, device='cuda', loop=5, chunk=512,
-                    rows_out=None, shard=None):
+_WORKER_STREAMS = {}
+
+
+def _worker_stream(dev, i):
+    """Stream of device-pass worker ``i`` on ``dev``, created once per process: torch's caching allocator keeps a pool per
+    stream (and the modules a workspace per stream), so fresh streams per call would allocate the whole working set -- GBs
+    at 512 problems per pass -- again every time."""
+    key = (str(dev), i)
+    if key not in _WORKER_STREAMS:
+        _WORKER_STREAMS[key] = torch.cuda.Stream(dev)
+    return _WORKER_STREAMS[key]
+
+
+def eval_gnn_device(env, indexes, model, model_s, seed=1234, batch=500, k=30, device='cuda', loop=5, chunk=128,
+                    rows_out=None, shard=None, workers=3):
     """:func:`eval_gnn` for 2-D maze environments with the planner itself on the device
     (:func:`explore_maze_batch`, ``chunk`` problems per device pass): same return tuple as ``eval_gnn``
     (eval_gnn.py:96-145), same per-problem decisions and collision-check counts as the one-by-one loop at the
@@ -325,7 +368,14 @@ def eval_gnn_device(env, indexes, model, model_s, seed=1234, batch=500, k=30, de
     list that receives one (success, path cost, smoothed cost, c_explore, c_smooth, path length, explored) per problem.
     ``shard = (rank, world)``: evaluate only this rank's contiguous block of ``indexes`` (``dist.shard_range``) after
     skipping the sampling of the blocks before it, so the union over ranks equals the sequential run problem by
-    problem; the aggregates returned are those of the local block (gather with ``dist.gather_problem_results``)."""
+    problem; the aggregates returned are those of the local block (gather with ``dist.gather_problem_results``).
+    ``workers``: host threads that run device passes, each on its own stream (chunk i on worker i % workers): the host
+    part of a pass (index tables, result rows, the blocking copies between the stages) leaves the GPU idle for ~40 % of a
+    pass, and a second pass in flight fills that; the chunks are independent and their results are collected in order,
+    so every per-problem number is the same for any ``workers``.  Measured at 1024 problems of the published setting
+    (tools/diag/planner_chunks.py, problems/s): workers 1 / 2 / 3 at chunk 512: 5.9 k / 4.9 k / 5.5 k, chunk 256: 5.3 k /
+    5.7 k / 6.0 k, chunk 128: 4.5 k / 6.5 k / 6.4 k -- small passes start the pipeline early and keep the per-stream pools of
+    the caching allocator small (55 GB reserved at three workers with passes of 512)."""
     model.eval()                       # eval_gnn.py:109-110
     if model_s is not None:
         model_s.eval()
@@ -339,27 +389,81 @@ def eval_gnn_device(env, indexes, model, model_s, seed=1234, batch=500, k=30, de
         indexes = indexes[lo:hi]
     sol, paths, smooth_paths = [], [], []
     from concurrent.futures import ThreadPoolExecutor
+    dev = torch.device(device)
+    if dev.type == 'cuda' and dev.index is None:
+        dev = torch.device('cuda', torch.cuda.current_device())
+    workers = max(1, int(workers))
+    # the weight handles are built here, once, not by whichever worker comes first
+    model._native(dev)
+    if model_s is not None:
+        model_s._native(dev)
 
-    def prepare(c0):
+    def prepare(span):
         pr = [dict(map=env.maps[i], init_state=env.init_states[i], goal_state=env.goal_states[i])
-              for i in indexes[c0:c0 + chunk]]
+              for i in indexes[span[0]:span[1]]]
         return pr, sample_maze_problems(pr, batch, k)
-    # the samples of chunk i+1 are drawn on a host thread while the device works on chunk i; the draws stay in
-    # problem order (one sampler at a time, started only after the previous one has finished)
-    t_begin = time.perf_counter()
-    t_smooth = 0.
-    with ThreadPoolExecutor(max_workers=1) as pool:
-        starts = list(range(0, len(indexes), chunk))
-        nxt = pool.submit(prepare, starts[0]) if starts else None
-        for ci, c0 in enumerate(starts):
-            problems, pre = nxt.result()
-            if ci + 1 < len(starts):
-                nxt = pool.submit(prepare, starts[ci + 1])
-            tm = {}
+
+    streams = [_worker_stream(dev, i) for i in range(workers)] if workers > 1 else [None]
+
+    def device_pass(ci, sampled):
+        problems, pre = sampled.result()
+        tm = {}
+        if streams[ci % workers] is None:
             res = explore_maze_batch(problems, model, device, batch=batch, k=k, loop=loop, model_s=model_s, timings=tm,
                                      presampled=pre)
-            t_smooth += tm.get('smoothing', 0.)
-            _collect(res, 0., 0., sol, paths, smooth_paths, rows_out)
+        else:
+            with torch.cuda.device(dev), torch.cuda.stream(streams[ci % workers]):
+                res = explore_maze_batch(problems, model, device, batch=batch, k=k, loop=loop, model_s=model_s,
+                                         timings=tm, presampled=pre)
+                torch.cuda.current_stream().synchronize()
+        return res, tm
+    # the samples are drawn on ONE host thread, chunk after chunk in problem order (the global numpy stream is consumed
+    # exactly like the one-by-one loop), at most `workers + 1` chunks ahead of the device passes
+    def _run_passes():
+        nonlocal t_smooth
+        with ThreadPoolExecutor(max_workers=1) as sampler, ThreadPoolExecutor(max_workers=workers) as pool:
+            sampled, passes, submitted = {}, {}, set()
+
+            def submit(ci):
+                if ci < len(starts) and ci not in submitted:
+                    submitted.add(ci)
+                    sampled[ci] = sampler.submit(prepare, starts[ci])
+                    if workers > 1:
+                        passes[ci] = pool.submit(device_pass, ci, sampled[ci])
+            for ci in range(min(workers + 1, len(starts))):
+                submit(ci)
+            for ci in range(len(starts)):
+                if workers > 1:
+                    res, tm = passes.pop(ci).result()
+                else:
+                    submit(ci + 1)
+                    res, tm = device_pass(ci, sampled[ci])
+                sampled.pop(ci, None)
+                submit(ci + workers + 1)
+                t_smooth += tm.get('smoothing', 0.)
+                _collect(res, 0., 0., sol, paths, smooth_paths, rows_out)
+    t_begin = time.perf_counter()
+    t_smooth = 0.
+    # passes of `chunk` problems behind a short ramp (chunk / 4, chunk / 2): nothing overlaps the sampling of the first pass,
+    # so it is kept small (44 of 250 ms at 1024 problems in passes of 512)
+    starts, c0 = [], 0
+    for size in (max(chunk // 4, 1), max(chunk // 2, 1)):
+        if len(indexes) - c0 > chunk:
+            starts.append((c0, c0 + size))
+            c0 += size
+    while c0 < len(indexes):
+        starts.append((c0, min(c0 + chunk, len(indexes))))
+        c0 += chunk
+    import sys
+    switch = sys.getswitchinterval()
+    if workers > 1:
+        # a worker coming back from a blocking device copy must not wait 5 ms (the default) for the interpreter lock while
+        # another one runs a Python loop: a pass has dozens of such points
+        sys.setswitchinterval(2e-4)
+    try:
+        _run_passes()
+    finally:
+        sys.setswitchinterval(switch)
     # wall clock of the whole evaluation (sampling of chunk i+1 overlaps the device pass of chunk i), spread evenly
     wall = (time.perf_counter() - t_begin) / max(len(sol), 1)
     t_explore = wall - t_smooth / max(len(sol), 1)
@@ -478,7 +582,7 @@ def explore_maze_batch(problems, model, device, batch=500, k=30, loop=5, model_s
     def mark(name, t_prev):
         if timings is None:
             return t_prev
-        torch.cuda.synchronize()
+        torch.cuda.current_stream().synchronize()      # (this pass's stream only: other passes may be in flight)
         now = time.perf_counter()
         timings[name] = timings.get(name, 0.) + now - t_prev
         return now
@@ -494,12 +598,15 @@ def explore_maze_batch(problems, model, device, batch=500, k=30, loop=5, model_s
     v = torch.cat(vs).to(device)
     ei, edge_ptr = build_edges_gpu(v, node_ptr, n_free, k1s)
     tm = mark('graph_build', tm)
-    obs = [torch.tensor(np.asarray(e.obstacles), dtype=torch.float32).reshape(-1, 2) for e in envs]
-    optr = torch.zeros(B + 1, dtype=torch.int64)
-    optr[1:] = torch.tensor([o.shape[0] for o in obs]).cumsum(0)
+    obs = [np.asarray(e.obstacles).reshape(-1, 2) for e in envs]
+    ocount = np.array([o.shape[0] for o in obs], dtype=np.int64)
+    optr = np.zeros(B + 1, dtype=np.int32)
+    optr[1:] = np.cumsum(ocount)
     goals = torch.tensor(np.asarray([e.goal_state for e in envs]), dtype=torch.float32).to(device)
-    gb = GraphBatch(v, goals, torch.cat(obs).to(device), ei, node_ptr, edge_ptr, optr.to(torch.int32).to(device),
-                    max(o.shape[0] for o in obs))
+    # (the per-problem arrays come from np.argwhere and are column-major: the joined array is made row-major explicitly)
+    obs_all = np.ascontiguousarray(np.concatenate(obs), dtype=np.float32)
+    gb = GraphBatch(v, goals, torch.from_numpy(obs_all).to(device), ei, node_ptr, edge_ptr,
+                    torch.from_numpy(optr).to(device), int(ocount.max()))
     scores = model.forward_batch(gb, loop)
     tm = mark('explorer_forward', tm)
     w = int(np.asarray(problems[0]['map']).shape[0])
@@ -539,17 +646,17 @@ def _smooth_maze_batch(model_s, sel, v, nptr, n_free, path, plen, maps, w, iters
     from .smoother import SmoothBatch
     total_n = int(v.shape[0])
     v_ext = torch.cat((v, torch.zeros(1, 2, device=device)))          # row total_n: the reference's zero filler row
-    widx, fidx, cidx, eis, pc, fc, cc, ec = [], [], [], [], [], [], [], []
+    widx, fidx, cidx, pc, fc, cc, ec = [], [], [], [], [], [], []
     for b in sel:
         nb = nptr[b + 1] - nptr[b]
         widx.append(path[nptr[b]:nptr[b] + plen[b]].astype(np.int64) + nptr[b])
         nf, nc = min(n_free[b], 500), min(nb - n_free[b], 500)
         fidx.append(np.arange(nf, dtype=np.int64) + nptr[b] if nf else np.array([total_n], dtype=np.int64))
         cidx.append(np.arange(nc, dtype=np.int64) + nptr[b] + n_free[b] if nc else np.array([total_n], dtype=np.int64))
-        eis.append(chain_edge_index(plen[b]))
-        pc.append(plen[b]); fc.append(len(fidx[-1])); cc.append(len(cidx[-1])); ec.append(eis[-1].shape[1])
+        pc.append(plen[b]); fc.append(len(fidx[-1])); cc.append(len(cidx[-1])); ec.append(3 * plen[b] - 2)
     take = lambda parts: v_ext[torch.from_numpy(np.concatenate(parts)).to(device)]      # noqa: E731
-    sb = SmoothBatch.from_device(take(widx), take(fidx), take(cidx), torch.cat(eis, dim=1).to(device), pc, fc, cc, ec)
+    sb = SmoothBatch.from_device(take(widx), take(fidx), take(cidx), torch.from_numpy(_chain_edge_indices(pc)).to(device),
+                                 pc, fc, cc, ec)
     maps_sel = maps[torch.tensor(sel, device=device)].contiguous()
     checks = torch.zeros(len(sel), dtype=torch.int64, device=device)
     tmp = torch.empty_like(sb.path)

@@ -212,7 +212,7 @@ class ModelSmoother(nn.Module):
 
     def __getstate__(self):                 # copy.deepcopy / pickle: the native handle and buffers stay with the original
         st = self.__dict__.copy()
-        st.update(_handle=None, _handle_key=None, _ws=None, _wt=None, _manifest=None)
+        st.update(_handle=None, _handle_key=None, _ws=None, _ws_streams={}, _wt=None, _manifest=None)
         return st
 
     def _apply(self, fn, *a, **k):
@@ -271,15 +271,23 @@ class ModelSmoother(nn.Module):
         need = ctypes.c_size_t()
         _lib.check(_lib.lib().gnnmp_smoother_workspace_bytes(h, ctypes.byref(cb), ctypes.byref(need)),
                    'gnnmp_smoother_workspace_bytes')
-        if self._ws is None or self._ws.numel() < need.value or self._ws.device != dev:
-            grow = 0 if self._ws is None or self._ws.device != dev else need.value // 3      # see EncoderProcessDecoder._workspace
-            self._ws = None
-            self._ws = torch.empty(need.value + grow, dtype=torch.uint8, device=dev)
+        # one buffer per (device, stream), see EncoderProcessDecoder._workspace
+        key = (str(dev), torch.cuda.current_stream(dev).cuda_stream)
+        cache = self.__dict__.setdefault('_ws_streams', {})
+        ws = cache.get(key)
+        if ws is None or ws.numel() < need.value:
+            grow = 0 if ws is None else need.value // 3
+            cache.pop(key, None)
+            ws = None
+            if len(cache) >= 8:
+                cache.clear()
+            ws = cache[key] = torch.empty(need.value + grow, dtype=torch.uint8, device=dev)
+        self._ws = ws
         out = torch.empty_like(sb.path)
         with torch.cuda.device(dev):
             st = torch.cuda.current_stream().cuda_stream
             _lib.check(_lib.lib().gnnmp_smoother_forward(h, ctypes.byref(cb), int(loop), out.data_ptr(),
-                                                         self._ws.data_ptr(), self._ws.numel(), st),
+                                                         ws.data_ptr(), ws.numel(), st),
                        'gnnmp_smoother_forward')
         return out
 

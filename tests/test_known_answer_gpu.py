@@ -77,6 +77,25 @@ def test_sharded_evaluation_equals_sequential():
     assert np.array_equal(np.array(whole), np.array(parts))
 
 
+def test_worker_threads_do_not_change_any_problem():
+    """Device passes of several chunks in flight on their own streams (``workers`` host threads): the per-problem rows of
+    192 problems in chunks of 32 are the same with 1, 2 and 3 workers (chunks are independent, the sampling stays on one
+    thread in problem order, and each stream has its own workspaces)."""
+    with np.load(os.path.join(GOLDEN, 'evalset_mazehard_first1000.npz')) as f:
+        env = Maze2D(f['maps'], f['init_states'], f['goal_states'])
+    m = gnnmp.EncoderProcessDecoder(2, 2, 32, 2).eval()
+    m.load_state_dict(load_weights('weights_maze'))
+    ms = gnnmp.ModelSmoother(workspace_size=2, config_size=2, embed_size=128, obs_size=6).eval()
+    ms.load_state_dict(load_weights('smooth_2d_attv3'))
+    rows = {}
+    for workers in (1, 2, 3):
+        rows[workers] = []
+        out = planner.eval_gnn_device(env, range(192), m, ms, device=DEV, chunk=32, workers=workers, rows_out=rows[workers])
+        assert out[0] == sum(r[0] for r in rows[workers])
+    assert np.array_equal(np.array(rows[1]), np.array(rows[2]))
+    assert np.array_equal(np.array(rows[1]), np.array(rows[3]))
+
+
 def test_second_setting_400_problems():
     """The same problem set under another planner setting (batch = t_max = 200, k = 16, seed 7; smaller graphs, some
     problems unsolved in one round): per-problem outcomes of the unmodified reference (tools/gen_golden.py evalset 400

@@ -255,3 +255,37 @@ def test_sparse_frontier_equals_dense_on_random_ties(seed):
     assert sd['explored'] == ss['explored']
     assert sd['explored_edges'] == ss['explored_edges']
     assert env_d.collision_check_count == env_s.collision_check_count
+
+
+def test_vectorised_host_helpers_equal_the_loops():
+    """The device planner's host side replaces per-path Python loops by array passes: the path cost equals
+    planner.path_cost (eval_gnn.py:53-58) bit for bit on float32 / float64 waypoint arrays, and the joined chain edge
+    lists equal chain_edge_index (smoother.py:238-241) path by path."""
+    rng = np.random.default_rng(5)
+    for trial in range(400):
+        n = int(rng.integers(0, 40))
+        p = (rng.random((n, 2)) - 0.5).astype(np.float32 if trial % 2 else np.float64)
+        assert planner._path_cost_rows(p if n else []) == planner.path_cost(p if n else [])
+    lengths = [2, 3, 17, 1, 40, 5]
+    joined = planner._chain_edge_indices(lengths)
+    ref = torch.cat([planner.chain_edge_index(n) for n in lengths], dim=1).numpy()
+    assert joined.dtype == np.int64 and np.array_equal(joined, ref)
+
+
+def test_graph_batch_takes_strided_tensors():
+    """np.argwhere output is column-major (Maze2D.obstacles), and the library reads raw pointers as dense row-major arrays:
+    GraphBatch copies strided views into dense tensors (an obstacle array handed over column-major changed 156 of 300 maze
+    problems before this was pinned)."""
+    from gnnmp.batch import GraphBatch
+    obstacles = torch.arange(20, dtype=torch.float32).reshape(2, 10).t()          # [10, 2] with strides (1, 10)
+    v = torch.arange(12, dtype=torch.float32).reshape(2, 6).t()
+    ei = torch.tensor([[0, 1], [1, 2], [2, 0]]).t()
+    assert not obstacles.is_contiguous() and not ei.is_contiguous()
+    b = GraphBatch(v, torch.zeros(1, 2), obstacles, ei, torch.tensor([0, 6], dtype=torch.int32),
+                   torch.tensor([0, 3], dtype=torch.int32), torch.tensor([0, 10], dtype=torch.int32), 10)
+    for t, src in ((b.obstacles, obstacles), (b.v, v), (b.edge_index, ei)):
+        assert t.is_contiguous() and torch.equal(t, src)
+    env = Maze2D(np.array([[[0, 1, 1], [0, 0, 1], [1, 0, 0]]], dtype=np.float64), np.zeros((1, 2)), np.zeros((1, 2)))
+    env.init_new_problem(0)
+    joined = np.ascontiguousarray(np.concatenate([np.asarray(env.obstacles).reshape(-1, 2)] * 2), dtype=np.float32)
+    assert torch.from_numpy(joined).is_contiguous()
