@@ -226,9 +226,13 @@ __device__ __forceinline__ unsigned maze_ord(float x) {
 }
 
 // one workgroup of four waves per problem: all four group the cells by row, then wave 0 walks the greedy loop alone.
-// DIM = 2: point robot; DIM = 3: stick robot (maze3)
-template <int DIM>
-__global__ __launch_bounds__(256) void maze_explore_kernel(MazeParams p) {
+// DIM = 2: point robot; DIM = 3: stick robot (maze3).  LDS: the problem's per-node state fits the LDS arrays -- a template
+// parameter, not a run-time choice of pointers: pointers that may address LDS or global memory make every access a FLAT
+// instruction, which counts against both the vector-memory and the LDS counter, so the loop could not keep a row request
+// in flight across an LDS read.
+struct MazeShared { int *in_ptr, *pos, *explored, *rb_src, *rb_eid; unsigned* rb_key; float* v; unsigned char* occ; };
+template <int DIM, bool LDS>
+__device__ __forceinline__ void maze_explore_body(const MazeParams& p, const MazeShared& sh) {
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int n0 = p.node_ptr[b], N = p.node_ptr[b + 1] - n0;
     const int e0 = p.edge_ptr[b], E = p.edge_ptr[b + 1] - e0;
@@ -239,13 +243,11 @@ __global__ __launch_bounds__(256) void maze_explore_kernel(MazeParams p) {
     MZ_T0();
     // Per-node state of problems up to kMazeLdsNodes nodes lives in LDS: every step of the greedy loop reads the cached row
     // maxima of the whole frontier, the explored list, row ranges, explored positions and two node rows -- from the
-    // workspace in global memory each of them was a dependent round trip of ~1 us inside a loop of ~2 000 steps.  (Generic
-    // pointers: the same code addresses LDS or, for larger problems, the workspace.)
-    __shared__ int s_in_ptr[kMazeLdsNodes + 1], s_pos[kMazeLdsNodes], s_explored[kMazeLdsNodes];
-    __shared__ int s_rb_src[kMazeLdsNodes], s_rb_eid[kMazeLdsNodes];
-    __shared__ unsigned s_rb_key[kMazeLdsNodes];
-    __shared__ float s_v[kMazeLdsNodes * DIM];
-    const bool in_lds = N <= kMazeLdsNodes;
+    // workspace in global memory each of them was a dependent round trip of ~1 us inside a loop of ~2 000 steps.
+    int* const s_in_ptr = sh.in_ptr; int* const s_pos = sh.pos; int* const s_explored = sh.explored;
+    int* const s_rb_src = sh.rb_src; int* const s_rb_eid = sh.rb_eid; unsigned* const s_rb_key = sh.rb_key;
+    float* const s_v = sh.v; unsigned char* const occ_lds = sh.occ;
+    constexpr bool in_lds = LDS;
     int* in_ptr = in_lds ? s_in_ptr : p.in_ptr + n0 + b;              // [N + 1] per problem
     int* cnt = in_lds ? s_rb_src : p.cnt + n0;                         // (build only: the row caches are set up afterwards)
     // The matrix cells the loop can ever pick -- off the diagonal, non-zero score, free row and column (eval_gnn.py:
@@ -300,7 +302,6 @@ __global__ __launch_bounds__(256) void maze_explore_kernel(MazeParams p) {
     __syncthreads();
     if (tid >= 64) return;                                                 // (no workgroup barrier below this line)
 
-    __shared__ unsigned char occ_lds[kMazeLdsCells];
     MazeCtx m;
     maze_ctx_init(m, p.maps + (size_t)b * p.w * p.w, p.w, occ_lds, lane);
     const double* goal = p.goal_states + (size_t)DIM * b;
@@ -385,9 +386,9 @@ __global__ __launch_bounds__(256) void maze_explore_kernel(MazeParams p) {
         // the rows this step rescans (row a when the edge is blocked, the new row nb when it is free) and the row that
         // holds the mirrored cell (nb, a) are requested BEFORE the collision check: lane 0 needs ~1 us for it
         const int qa0 = in_ptr[a], qa1 = in_ptr[a + 1], qn0 = in_ptr[nb], qn1 = in_ptr[nb + 1];
-        int2 ra = make_int2(kDead, 0), rn = make_int2(kDead, 0);
-        if (qa0 + lane < qa1) ra = rec[qa0 + lane];
-        if (qn0 + lane < qn1) rn = rec[qn0 + lane];
+        // (unconditional loads from clamped slots: behind a lane mask the compiler waits for them at the end of the branch)
+        int2 ra = rec[min(qa0 + lane, qa1 - 1)];                           // row a holds the cell `be`: not empty
+        int2 rn = rec[max(min(qn0 + lane, qn1 - 1), 0)];
         int free_edge = 0, goal_hit = 0;
         if (lane == 0) {
             ee[2 * n_pairs] = a; ee[2 * n_pairs + 1] = nb;
@@ -416,6 +417,8 @@ __global__ __launch_bounds__(256) void maze_explore_kernel(MazeParams p) {
         free_edge = __builtin_amdgcn_readfirstlane(free_edge);
         goal_hit = __builtin_amdgcn_readfirstlane(goal_hit);
         MZ_LAP(2);
+        if (qa0 + lane >= qa1) ra.x = kDead;
+        if (qn0 + lane >= qn1) rn.x = kDead;
         if (!free_edge) {
             if (qa0 + lane == be) ra.x = nb | kDead;                       // ... in the copy of row a as well
             // cell (nb, a): looked up among nb's cells by the whole wave (one lane walking the ~50 dependent loads of that
@@ -471,6 +474,19 @@ __global__ __launch_bounds__(256) void maze_explore_kernel(MazeParams p) {
     }
     if (in_lds)
         for (int i = lane; i < n_expl; i += 64) p.explored[n0 + i] = explored[i];
+}
+
+template <int DIM>
+__global__ __launch_bounds__(256) void maze_explore_kernel(MazeParams p) {
+    __shared__ int s_in_ptr[kMazeLdsNodes + 1], s_pos[kMazeLdsNodes], s_explored[kMazeLdsNodes];
+    __shared__ int s_rb_src[kMazeLdsNodes], s_rb_eid[kMazeLdsNodes];
+    __shared__ unsigned s_rb_key[kMazeLdsNodes];
+    __shared__ float s_v[kMazeLdsNodes * DIM];
+    __shared__ unsigned char occ_lds[kMazeLdsCells];
+    const MazeShared sh{s_in_ptr, s_pos, s_explored, s_rb_src, s_rb_eid, s_rb_key, s_v, occ_lds};
+    const int N = p.node_ptr[blockIdx.x + 1] - p.node_ptr[blockIdx.x];
+    if (N <= kMazeLdsNodes) maze_explore_body<DIM, true>(p, sh);
+    else maze_explore_body<DIM, false>(p, sh);
 }
 
 // ---------------------------------------------------------------------------------------------------------

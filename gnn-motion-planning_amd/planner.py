@@ -359,7 +359,7 @@ def _worker_stream(dev, i):
 
 
 def eval_gnn_device(env, indexes, model, model_s, seed=1234, batch=500, k=30, device='cuda', loop=5, chunk=128,
-                    rows_out=None, shard=None, workers=3):
+                    rows_out=None, shard=None, workers=2):
     """:func:`eval_gnn` for 2-D maze environments with the planner itself on the device
     (:func:`explore_maze_batch`, ``chunk`` problems per device pass): same return tuple as ``eval_gnn``
     (eval_gnn.py:96-145), same per-problem decisions and collision-check counts as the one-by-one loop at the
@@ -373,9 +373,9 @@ def eval_gnn_device(env, indexes, model, model_s, seed=1234, batch=500, k=30, de
     part of a pass (index tables, result rows, the blocking copies between the stages) leaves the GPU idle for ~40 % of a
     pass, and a second pass in flight fills that; the chunks are independent and their results are collected in order,
     so every per-problem number is the same for any ``workers``.  Measured at 1024 problems of the published setting
-    (tools/diag/planner_chunks.py, problems/s): workers 1 / 2 / 3 at chunk 512: 5.9 k / 4.9 k / 5.5 k, chunk 256: 5.3 k /
-    5.7 k / 6.0 k, chunk 128: 4.5 k / 6.5 k / 6.4 k -- small passes start the pipeline early and keep the per-stream pools of
-    the caching allocator small (55 GB reserved at three workers with passes of 512)."""
+    (tools/diag/planner_chunks.py, problems/s, median of 3): workers 1 / 2 / 3 at chunk 512: 5.5 k / 5.1 k / 6.1 k, chunk 256:
+    5.1 k / 5.8 k / 6.5 k, chunk 128: 4.7 k / 7.1 k / 6.7 k -- small passes start the pipeline early and keep the per-stream
+    pools of the caching allocator small (45 GB reserved at two workers, 55 GB at three)."""
     model.eval()                       # eval_gnn.py:109-110
     if model_s is not None:
         model_s.eval()
