@@ -180,11 +180,12 @@ def planner_leg(n_host, n_device, dev):
                           'host_ms_per_problem': round(1e3 * (tot - fwd) / n_host, 2),
                           'collision_checks_per_problem': round(checks / n_host, 1),
                           'what': 'dense drop-in forward on the GPU; sampling, greedy loop, collision checks, steering on one host core'},
-            'device_planner': {'problems': n_device, 'problems_per_s': round(n_device / wall_dev, 1), 'host_cores': 1,
+            'device_planner': {'problems': n_device, 'problems_per_s': round(n_device / wall_dev, 1), 'host_cores': 3,
                                'timing': 'median of 3 passes over the same %d problems: %s problems/s' % (
                                    n_device, ' / '.join('%.0f' % (n_device / w) for w in walls)),
                                'success': int(out[0]), 'collision_checks_per_problem': round(out[1], 2),
-                               'what': 'sampling on one host core; graphs, forwards, greedy loop, collision checks, steering on the GPU'}}
+                               'what': 'sampling on one host thread, two more host threads drive device passes of 128 problems on their '
+                                       'own streams; graphs, forwards, greedy loop, collision checks, steering on the GPU'}}
 
 
 def main():

@@ -1617,6 +1617,9 @@ __device__ __forceinline__ void linear_acc_stream(const float* A, Get get, f32x1
 #ifndef GNNMP_MP_FLOW_F32
 #define GNNMP_MP_FLOW_F32 0
 #endif
+#ifndef GNNMP_MP_SUM_MFMA
+#define GNNMP_MP_SUM_MFMA 0          // bf16 kernels: A[src] + B[dst] + K_e summed by the matrix pipe (packed rows x a 0/1 matrix), see the chunk body
+#endif
 #ifndef GNNMP_MP_ROWS_LDS
 #define GNNMP_MP_ROWS_LDS 1          // bf16 kernels, node phase: R rows in through LDS-DMA, X' / A' / PT rows out through LDS as whole rows
 #endif
@@ -1666,12 +1669,20 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
     constexpr bool kSplitNode = kCoop && D == 32;
     constexpr bool kNewFlow = P == 1 ? (GNNMP_MP_FLOW_BF16 != 0) : (GNNMP_MP_FLOW_F32 != 0);
     constexpr bool kAsmTail = kNewFlow, kAEarly = kNewFlow, kUncond = kNewFlow, kLaunder = kNewFlow;
+    constexpr bool kSumMfma = GNNMP_MP_SUM_MFMA != 0 && P == 1 && kNewFlow;
     using LE = MpEBlob<D, P>;
     using LN = MpNBlob<D, P>;
     using G = RowGeom<D, P>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* wl = lds;                                             // MpEBlob
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
+    bf16x8 sel[2];                                               // kSumMfma: the 0/1 matrix's A operands (see the chunk body)
+    if constexpr (kSumMfma) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int t = 0; t < 8; ++t) sel[m][t] = j == 16 * m + 8 * (t >> 2) + 4 * h + (t & 3) ? (__bf16)1.0f : (__bf16)0.0f;
+    }
 #ifdef GNNMP_MP_TRACE
     // diagnostics build: [0] wave start, then per tile: start, end of the edge phase, end of the node phase (100 MHz clock)
     long long* trc = p.trace ? p.trace + ((size_t)blockIdx.x * (blockDim.x >> 6) + wave) * 8 : nullptr;
@@ -1985,6 +1996,29 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
             }
             // hidden = relu(A[src] + B[dst] + K_e), one 32-feature tile at a time, straight into the swapped MFMA
             linear_acc_stream<P, NT, true, true>(wl + LE::w2, [&](int it, f32x16& x) {
+                if constexpr (kSumMfma) {
+                    // The three packed bf16 tiles are B operands as they are: register r of lane (edge, h) is feature
+                    // phi(r, h), so D = S . X with the 0/1 matrix S[i][k-slot (m, h, t)] = [i == phi(8 m + t, h)] puts
+                    // every value into the accumulator register it belongs to -- in fp32, exactly (1.0 x v, fifteen zero
+                    // products), and summing the three tiles is the accumulation: (A + B) + K_e like the vector form.
+                    // 6 MFMAs (192 matrix-pipe cycles, a pipe that idles 90 % of this loop) replace 48 conversion and 16
+                    // packed-add VALU instructions (256 issue cycles) per 32-feature tile.
+                    using bf16x8v = bf16x8;
+                    const bf16x8v alo = __builtin_shufflevector(araw[it].q[0], araw[it].q[1], 0, 1, 2, 3, 4, 5, 6, 7);
+                    const bf16x8v ahi = __builtin_shufflevector(araw[it].q[2], araw[it].q[3], 0, 1, 2, 3, 4, 5, 6, 7);
+                    const bf16x8v blo = __builtin_shufflevector(braw[it].q[0], braw[it].q[1], 0, 1, 2, 3, 4, 5, 6, 7);
+                    const bf16x8v bhi = __builtin_shufflevector(braw[it].q[2], braw[it].q[3], 0, 1, 2, 3, 4, 5, 6, 7);
+                    f32x16 acc = splat16(0.f);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sel[0], alo, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sel[1], ahi, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sel[0], blo, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sel[1], bhi, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sel[0], cur[it < PF ? it : 0].lo, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sel[1], cur[it < PF ? it : 0].hi, acc, 0, 0, 0);
+                    x = acc;
+                    if (it == NT - 1) ke_fetch(c0 + KD * STEP, fill);
+                    return;
+                }
                 f32x16 a, b;
                 if (it < PF) expand_raw<P>(cur[it < PF ? it : 0], x); else load_edge_slot_tile<P, NT>(p.Ke, eslot, h, it, x);
                 if constexpr (kAEarly) {

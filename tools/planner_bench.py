@@ -32,6 +32,9 @@ def main():
                     help='explore stage of ALL problems in one device pass (graphs, forward, greedy loop, collision checks)')
     ap.add_argument('--device-smooth', action='store_true',
                     help='with --device-explore: the smoothing stage too (batched smoother forwards + steering on the device)')
+    ap.add_argument('--device-eval', action='store_true',
+                    help='planner.eval_gnn_device at its defaults (passes of 128 problems on 2 worker threads / streams, sampling '
+                         'ahead on its own thread): the evaluation loop a user runs; median of 3 passes over --problems')
     ap.add_argument('--batch', type=int, default=500)
     ap.add_argument('--k', type=int, default=30)
     a = ap.parse_args()
@@ -43,6 +46,23 @@ def main():
     m.load_state_dict(load_weights('weights_maze'))
     ms = gnnmp.ModelSmoother(workspace_size=2, config_size=2, embed_size=128, obs_size=6).eval()
     ms.load_state_dict(load_weights('smooth_2d_attv3'))
+    if a.device_eval:
+        idx = [i % maps.shape[0] for i in range(a.problems)]
+        planner.eval_gnn_device(env, idx, m, ms, batch=a.batch, k=a.k, device=dev)               # warm-up (allocator pools of the worker streams)
+        walls = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            out = planner.eval_gnn_device(env, idx, m, ms, batch=a.batch, k=a.k, device=dev)
+            torch.cuda.synchronize()
+            walls.append(time.perf_counter() - t0)
+        wall = sorted(walls)[1]
+        print(json.dumps({'problems': a.problems, 'success': int(out[0]), 'stage': 'planner.eval_gnn_device (whole planner, defaults: passes of 128, 2 workers)',
+                          'problems_per_s': round(a.problems / wall, 1), 'three_passes': [round(a.problems / w, 1) for w in walls],
+                          'collision_checks_total': round(out[1], 2), 'collision_checks_explore': round(out[7], 2),
+                          'path_cost': round(out[3], 4), 'host_threads': 'main + 1 sampler + 2 device-pass workers',
+                          'config': 'maze2 hard, batch=%d, k=%d, smoothing on' % (a.batch, a.k)}))
+        return
     if a.device_explore:
         probs = [dict(map=maps[i % maps.shape[0]], init_state=init[i % maps.shape[0]], goal_state=goal[i % maps.shape[0]])
                  for i in range(a.problems)]

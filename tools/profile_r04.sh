@@ -38,6 +38,7 @@ cp gpurun_out/pmc_r04c3/summary.txt $O/pmc_cfg3_bf16.txt
 PMC_GROUPS="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES;FETCH_SIZE;WRITE_SIZE;GRBM_GUI_ACTIVE" bash tools/pmc_passes.sh r04c5 -- python $R/bench.py --steps 3 --warmup 1 $BA $C5 > $O/pmc_cfg5.log 2>&1
 cp gpurun_out/pmc_r04c5/summary.txt $O/pmc_cfg5_bf16.txt
 find $O gpurun_out/pmc_r04 gpurun_out/pmc_r04c3 gpurun_out/pmc_r04c5 -name "*.db" -delete
+GNNMP_LIB=$R/gnn-motion-planning_amd/libgnnmp_mztrace.so python tools/diag/maze_trace.py 2>&1 | grep -v "GNNMP_LIB\|amdgpu.ids" > $O/maze_explore_phases.txt
 # 5. per-wave timelines of the message-passing launch (diagnostics build, when present), stream microbenchmark
 if [ -f gnn-motion-planning_amd/libgnnmp_trace.so ]; then
   for a in "kuka7 2000 10 64 bf16" "maze2 1000 8 256 fp32" "kuka14 5000 16 32 bf16"; do
@@ -54,7 +55,7 @@ python tools/mixed_bench.py > $O/cfg4_mixed.txt 2>&1
 python tools/cfg5_pipeline.py > $O/cfg5_pipeline.json 2>/dev/null
 python tools/planner_parity.py > $O/planner_parity.txt 2>&1
 python tools/train_bench.py > $O/train_step.txt 2>&1
-for f in "" "--sparse" "--sparse --gpu-graph" "--device-explore --problems 1024" "--device-explore --device-smooth --problems 1024"; do
+for f in "" "--sparse" "--sparse --gpu-graph" "--device-explore --problems 1024" "--device-explore --device-smooth --problems 1024" "--device-eval --problems 1024"; do
   timeout 600 python tools/planner_bench.py $f 2>/dev/null | tail -1
 done > $O/planner_bench.txt
 ls -la $O
