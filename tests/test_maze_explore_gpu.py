@@ -219,12 +219,14 @@ def test_unsolvable_problem_matches_host_planner():
     assert d['c_explore'] - d['env'].collision_check_count == env.collision_check_count
 
 
-@pytest.mark.parametrize('batch,k,density,seed', [(150, 12, 0.2, 0), (260, 18, 0.4, 1)])
+@pytest.mark.parametrize('batch,k,density,seed', [(150, 12, 0.2, 0), (260, 18, 0.4, 1), (620, 10, 0.3, 2)])
 def test_device_planner_equals_host_planner_on_random_maps(batch, k, density, seed):
     """Random occupancy maps (not from the reference's data set; the dense ones contain unsolvable problems), other
     batch / k settings: every problem through the device planner and through planner.explore (host frontier, host
     collision checks, host steering) -- same success flag, collision-check counts of both stages, explored order
-    and bit-identical smoothed path.  (A 200-problem version of this loop was run once per shape with 0 mismatches.)"""
+    and bit-identical smoothed path.  (A 200-problem version of this loop was run once per shape with 0 mismatches.)
+    The third shape has ~1240 nodes per problem: beyond the 1024 the explore kernel keeps in LDS, i.e. its instantiation
+    with the per-node state in the workspace."""
     rng = np.random.RandomState(2024 + seed)
     B = 14
     maps = (rng.rand(B, 15, 15) < density).astype(np.float64)
