@@ -345,6 +345,22 @@ def skip_maze_sampling(env, indexes, batch=500):
     stream.close()
 
 
+def _pass_spans(n, chunk):
+    """[lo, hi) problem ranges of the device passes of an evaluation of ``n`` problems: passes of ``chunk`` problems behind a short
+    ramp (chunk / 4, chunk / 2) -- nothing overlaps the sampling of the first pass, so it is kept small (44 of 250 ms at 1024
+    problems in passes of 512).  The spans partition range(n) in order."""
+    chunk = max(int(chunk), 1)
+    spans, c0 = [], 0
+    for size in (max(chunk // 4, 1), max(chunk // 2, 1)):
+        if n - c0 > chunk:
+            spans.append((c0, c0 + size))
+            c0 += size
+    while c0 < n:
+        spans.append((c0, min(c0 + chunk, n)))
+        c0 += chunk
+    return spans
+
+
 _WORKER_STREAMS = {}
 
 
@@ -444,16 +460,7 @@ def eval_gnn_device(env, indexes, model, model_s, seed=1234, batch=500, k=30, de
                 _collect(res, 0., 0., sol, paths, smooth_paths, rows_out)
     t_begin = time.perf_counter()
     t_smooth = 0.
-    # passes of `chunk` problems behind a short ramp (chunk / 4, chunk / 2): nothing overlaps the sampling of the first pass,
-    # so it is kept small (44 of 250 ms at 1024 problems in passes of 512)
-    starts, c0 = [], 0
-    for size in (max(chunk // 4, 1), max(chunk // 2, 1)):
-        if len(indexes) - c0 > chunk:
-            starts.append((c0, c0 + size))
-            c0 += size
-    while c0 < len(indexes):
-        starts.append((c0, min(c0 + chunk, len(indexes))))
-        c0 += chunk
+    starts = _pass_spans(len(indexes), chunk)
     import sys
     switch = sys.getswitchinterval()
     if workers > 1:

@@ -289,3 +289,17 @@ def test_graph_batch_takes_strided_tensors():
     env.init_new_problem(0)
     joined = np.ascontiguousarray(np.concatenate([np.asarray(env.obstacles).reshape(-1, 2)] * 2), dtype=np.float32)
     assert torch.from_numpy(joined).is_contiguous()
+
+
+@pytest.mark.parametrize('n,chunk', [(0, 128), (1, 128), (127, 128), (128, 128), (129, 128), (1000, 512), (1024, 128), (77, 1), (5000, 3)])
+def test_device_pass_spans_partition_the_problems(n, chunk):
+    """planner.eval_gnn_device cuts an evaluation into device passes (a short ramp, then passes of `chunk`): whatever the sizes,
+    the spans cover range(n) exactly once and in order -- the sampler thread consumes the global numpy stream in that order."""
+    spans = planner._pass_spans(n, chunk)
+    flat = [i for lo, hi in spans for i in range(lo, hi)]
+    assert flat == list(range(n))
+    assert all(0 < hi - lo <= chunk for lo, hi in spans)
+    if n > chunk >= 4:
+        assert spans[0][1] - spans[0][0] == chunk // 4
+        if n - chunk // 4 > chunk:
+            assert spans[1][1] - spans[1][0] == chunk // 2
