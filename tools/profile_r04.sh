@@ -38,7 +38,9 @@ cp gpurun_out/pmc_r04c3/summary.txt $O/pmc_cfg3_bf16.txt
 PMC_GROUPS="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES;FETCH_SIZE;WRITE_SIZE;GRBM_GUI_ACTIVE" bash tools/pmc_passes.sh r04c5 -- python $R/bench.py --steps 3 --warmup 1 $BA $C5 > $O/pmc_cfg5.log 2>&1
 cp gpurun_out/pmc_r04c5/summary.txt $O/pmc_cfg5_bf16.txt
 find $O gpurun_out/pmc_r04 gpurun_out/pmc_r04c3 gpurun_out/pmc_r04c5 -name "*.db" -delete
-GNNMP_LIB=$R/gnn-motion-planning_amd/libgnnmp_mztrace.so python tools/diag/maze_trace.py 2>&1 | grep -v "GNNMP_LIB\|amdgpu.ids" > $O/maze_explore_phases.txt
+# (diagnostics builds, made beforehand on any machine with hipcc: tools/diag/build_variant.sh trace -DGNNMP_MP_TRACE ;
+#  tools/diag/build_variant.sh mztrace -DGNNMP_MAZE_TRACE)
+[ -f gnn-motion-planning_amd/libgnnmp_mztrace.so ] && GNNMP_LIB=$R/gnn-motion-planning_amd/libgnnmp_mztrace.so python tools/diag/maze_trace.py 2>&1 | grep -v "GNNMP_LIB\|amdgpu.ids" > $O/maze_explore_phases.txt
 # 5. per-wave timelines of the message-passing launch (diagnostics build, when present), stream microbenchmark
 if [ -f gnn-motion-planning_amd/libgnnmp_trace.so ]; then
   for a in "kuka7 2000 10 64 bf16" "maze2 1000 8 256 fp32" "kuka14 5000 16 32 bf16"; do
