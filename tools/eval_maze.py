@@ -32,7 +32,8 @@ def main():
     ap.add_argument('--seed', type=int, default=1234)
     ap.add_argument('--batch', type=int, default=500)
     ap.add_argument('--k', type=int, default=30)
-    ap.add_argument('--chunk', type=int, default=512)
+    ap.add_argument('--chunk', type=int, default=128, help='problems per device pass')
+    ap.add_argument('--workers', type=int, default=2, help='host threads driving device passes')
     a = ap.parse_args()
     rank, local, world = (int(os.environ.get(k, d)) for k, d in (('RANK', 0), ('LOCAL_RANK', 0), ('WORLD_SIZE', 1)))
     torch.cuda.set_device(local)
@@ -49,7 +50,7 @@ def main():
     rows = []
     t0 = time.perf_counter()
     planner.eval_gnn_device(env, range(n), m, ms, seed=a.seed, batch=a.batch, k=a.k, device=dev, chunk=a.chunk,
-                            rows_out=rows, shard=(rank, world) if world > 1 else None)
+                            workers=a.workers, rows_out=rows, shard=(rank, world) if world > 1 else None)
     local_rows = torch.tensor(np.array(rows, dtype=np.float64).reshape(-1, 7), device=dev)
     allrows = gather_problem_results(local_rows).cpu().numpy()
     if world > 1:
