@@ -9,8 +9,14 @@ owns its own 256 problems (weak scaling, no data-path collective); the only RCCL
 result gather after the timed region.
 
     python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus 8 --steps 20 --warmup 5          # no launcher: bench.py starts its own 8 ranks (self_launch)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
         --master-port P bench.py --gpus N --steps K --warmup W
+
+`value` is timed with the per-stage HIP events switched OFF; the stage split and the roofline kernel's launch time come
+from a second loop of the same K steps with the events on (`config.ms_per_step_with_stage_events`).  Every run also times
+a STRONG-scaling leg (`config.strong_leg`: a fixed set of --strong-leg problems split over the ranks) next to the weak
+headline, so one driver sweep over N = 1, 2, 4, 8 yields both curves.
 """
 import argparse
 import json
@@ -188,6 +194,30 @@ def planner_leg(n_host, n_device, dev):
                                        'own streams; graphs, forwards, greedy loop, collision checks, steering on the GPU'}}
 
 
+def self_launch(n_gpus):
+    """`python bench.py --gpus N` with N > 1 and no launcher environment (RANK / WORLD_SIZE unset): start the N ranks ourselves
+    -- the same `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P
+    bench.py <same flags>` the driver would have used, on a free port -- let rank 0's one JSON line through on stdout and
+    return the launcher's exit status (a failing rank's traceback arrives on stderr through the inherited stream, and
+    torch.distributed.run names the failing rank).  What is sharded and what is gathered: eval_gnn.py:113-122."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')        # dmabuf IPC only on this driver (RCCL needs it across processes)
+    env.setdefault('OMP_NUM_THREADS', '8')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n_gpus), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print('[bench] no launcher environment: starting %d ranks: %s' % (n_gpus, ' '.join(cmd)), file=sys.stderr, flush=True)
+    rc = subprocess.call(cmd, env=env)
+    if rc != 0:
+        print('[bench] the %d-rank run failed with exit status %d (the failing rank is named above)' % (n_gpus, rc), file=sys.stderr, flush=True)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -215,44 +245,64 @@ def main():
     ap.add_argument('--unique', type=int, default=0, help='distinct synthetic graphs per GPU (0 = all)')
     ap.add_argument('--planner-problems', type=int, default=16,
                     help='host-loop planner problems timed next to the forward benchmark (0 = skip the planner leg)')
+    ap.add_argument('--strong-leg', type=int, default=1024, metavar='N_TOTAL',
+                    help='also time a strong-scaling leg in the same run: the FIXED problem set 0 .. N_TOTAL - 1 split over the ranks, '
+                         'reported as config.strong_leg next to the weak headline (0 = skip; ignored with --strong)')
+    ap.add_argument('--strong-steps', type=int, default=5, help='timed steps of the strong leg')
+    ap.add_argument('--launch-check', action='store_true',
+                    help='start the ranks, connect them (init_process_group + one all_reduce), print one JSON line and exit without '
+                         'running the workload (tests the launcher on a box without GPUs: GNNMP_BENCH_BACKEND=gloo)')
     args = ap.parse_args()
 
+    have_launcher = 'RANK' in os.environ and 'WORLD_SIZE' in os.environ
+    if args.gpus > 1 and not have_launcher:
+        # the driver's N = 1 command shape with a larger N: be our own launcher instead of failing
+        raise SystemExit(self_launch(args.gpus))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if world != args.gpus:
-        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d -- launch one rank per GPU: python -m torch.distributed.run '
-                         '--nnodes=1 --nproc-per-node %d --master-addr 127.0.0.1 --master-port P bench.py --gpus %d ...'
-                         % (args.gpus, world, args.gpus, args.gpus))
-    if local >= torch.cuda.device_count():
-        raise SystemExit('bench.py: LOCAL_RANK %d but only %d GPU(s) visible' % (local, torch.cuda.device_count()))
-    torch.cuda.set_device(local)
-    dev = torch.device('cuda', local)
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d -- either launch one rank per GPU (python -m torch.distributed.run '
+                         '--nnodes=1 --nproc-per-node %d --master-addr 127.0.0.1 --master-port P bench.py --gpus %d ...) or run '
+                         '`python bench.py --gpus %d` WITHOUT RANK / WORLD_SIZE in the environment and it starts the ranks itself'
+                         % (args.gpus, world, args.gpus, args.gpus, args.gpus))
+    # GNNMP_BENCH_BACKEND=gloo: collectives over gloo on host tensors (launcher tests on a box without GPUs; two ranks sharing
+    # one GPU, which RCCL refuses).  Default nccl = RCCL over xGMI on device tensors.
+    backend = os.environ.get('GNNMP_BENCH_BACKEND', 'nccl')
+    if backend not in ('nccl', 'gloo'):
+        raise SystemExit('bench.py: GNNMP_BENCH_BACKEND must be nccl or gloo, got %r' % backend)
+    if args.strong > 0 and args.strong < world:
+        # every rank sees the same arguments and leaves together (a rank bailing out alone would leave the others in a collective)
+        raise SystemExit('bench.py: --strong %d is fewer problems than ranks (%d)' % (args.strong, world))
+    if args.launch_check:
+        if backend == 'nccl':
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend, **({'device_id': torch.device('cuda', local)} if backend == 'nccl' else {}))
+        ones = torch.ones(1, dtype=torch.float64, device=torch.device('cuda', local) if backend == 'nccl' else 'cpu')
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        if rank == 0:
+            print(json.dumps({'launch_check': True, 'n_gpus': world, 'ranks_seen': int(round(float(ones.item()))), 'backend': backend,
+                              'self_launched': os.environ.get('TORCHELASTIC_RUN_ID') is not None}), flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
+    n_dev = torch.cuda.device_count()
+    if n_dev < 1:
+        raise SystemExit('bench.py: no GPU visible (the forward has no CPU path)')
+    if backend == 'nccl' and local >= n_dev:
+        raise SystemExit('bench.py: LOCAL_RANK %d but only %d GPU(s) visible' % (local, n_dev))
+    torch.cuda.set_device(local % n_dev)
+    dev = torch.device('cuda', local % n_dev)
     # GNNMP_BENCH_FORCE_DIST=1 exercises the RCCL code path (init, barrier, all_reduce, all_gather) with one rank
     use_dist = world > 1 or os.environ.get('GNNMP_BENCH_FORCE_DIST') == '1'
+    cdev = dev if backend == 'nccl' else torch.device('cpu')       # where the collectives' tensors live
     if use_dist:
-        dist.init_process_group('nccl', device_id=dev)
+        dist.init_process_group(backend, **({'device_id': dev} if backend == 'nccl' else {}))
 
     import gnnmp
     from gnnmp.weights import load_weights
     from gnnmp.synth import ENVS, synth_batch_gpu
     e = ENVS[args.env]
-    if args.strong > 0:
-        # strong scaling: the job is the fixed problem set 0 .. N_TOTAL - 1 (problem i = seed 1234 + i whatever the rank count);
-        # rank r scores the contiguous block shard_range gives it (equal-size graphs: no weights needed)
-        from gnnmp.dist import shard_range
-        lo, hi = shard_range(args.strong, rank, world)
-        G, seed0 = hi - lo, 1234 + lo
-        if G < 1:
-            raise SystemExit('bench.py: --strong %d leaves rank %d of %d without a problem' % (args.strong, rank, world))
-    else:
-        G, seed0 = args.graphs, 1234 + rank * args.graphs
-    uniq = G if args.unique <= 0 else min(G, args.unique)
-    # same node / obstacle draws as synth_graph(seed = seed0 + i); the kNN edge lists are built by the
-    # device graph builder (bit-identical to the host builder) so start-up takes seconds instead of half a minute
-    base = synth_batch_gpu(args.env, args.nodes, args.k1, uniq, dev, seed0=seed0)
-    graphs = [base[i % uniq] for i in range(G)]
-    batch = gnnmp.GraphBatch.from_graphs(graphs, e['S'], dev)
     model = gnnmp.EncoderProcessDecoder(e['workspace'], e['C'], e['d'], e['S']).eval()
     model.load_state_dict(load_weights(e['ckpt']), strict=True)
     model.mlp_dtype = args.mlp_dtype
@@ -263,33 +313,93 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    scores = None
-    for _ in range(args.warmup):
-        scores = model.forward_batch(batch, args.loop)
+    def problem_set(G, seed0, unique=0):
+        """G problems, problem i = synth_graph(seed = seed0 + i): same node / obstacle draws as the host generator; the kNN
+        edge lists come from the device graph builder (bit-identical to the host builder), so start-up takes seconds."""
+        uniq = G if unique <= 0 else min(G, unique)
+        base = synth_batch_gpu(args.env, args.nodes, args.k1, uniq, dev, seed0=seed0)
+        graphs = [base[i % uniq] for i in range(G)]
+        return graphs, gnnmp.GraphBatch.from_graphs(graphs, e['S'], dev)
+
+    def timed(batch, warmup, steps):
+        """W untimed steps, then exactly K steps between barrier + synchronize on both sides; this rank's seconds."""
+        out = None
+        for _ in range(warmup):
+            out = model.forward_batch(batch, args.loop)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = model.forward_batch(batch, args.loop)
+        sync()
+        return time.perf_counter() - t0, out
+
+    def over_ranks(elapsed, G):
+        """(every rank's seconds, the job's graph count): one all_gather of two numbers per rank."""
+        if not use_dist:
+            return [elapsed], G
+        mine = torch.tensor([elapsed, float(G)], dtype=torch.float64, device=cdev)
+        allr = torch.empty(2 * world, dtype=torch.float64, device=cdev)
+        dist.all_gather_into_tensor(allr, mine)
+        allr = allr.view(world, 2).cpu()
+        return [float(x) for x in allr[:, 0]], int(round(float(allr[:, 1].sum())))
+
+    if args.strong > 0:
+        # strong scaling: the job is the fixed problem set 0 .. N_TOTAL - 1 (problem i = seed 1234 + i whatever the rank count);
+        # rank r scores the contiguous block shard_range gives it (equal-size graphs: no weights needed)
+        from gnnmp.dist import shard_range
+        lo, hi = shard_range(args.strong, rank, world)
+        G, seed0 = hi - lo, 1234 + lo
+    else:
+        G, seed0 = args.graphs, 1234 + rank * args.graphs
+    graphs, batch = problem_set(G, seed0, args.unique)
+
+    # `value`: W warm-up steps, K timed steps, per-stage events OFF
+    elapsed, scores = timed(batch, args.warmup, args.steps)
+    # the same K steps once more with the per-stage HIP events on (12 events per step on the forward's own stream): stage split
+    # and the roofline kernel's launch time; its step time is reported next to `ms_per_step`, never as `value`
     model.profile(dev, True)
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        scores = model.forward_batch(batch, args.loop)
-    sync()
-    elapsed = time.perf_counter() - t0
+    elapsed_prof, _ = timed(batch, 1, args.steps)
     prof = model.profile_read(dev)
     model.profile(dev, False)
+    for k_ in prof:                       # the warm-up step of the profiled loop is in the sums: scale to the K timed steps
+        prof[k_] = (prof[k_][0] * args.steps / (args.steps + 1), prof[k_][1] * args.steps // (args.steps + 1))
     # multi-GPU self-checks (they also run with one rank under GNNMP_BENCH_FORCE_DIST=1): how many ranks the collective
     # library really connected (an all_reduce of ones), every rank's own step time (min / max show imbalance; `value` uses
     # the MAX), the job's total graph count
-    ranks_seen, rank_ms, total_graphs = 1, [elapsed / args.steps * 1e3], G
+    ranks_seen = 1
     if use_dist:
-        ones = torch.ones(1, dtype=torch.float64, device=dev)
+        ones = torch.ones(1, dtype=torch.float64, device=cdev)
         dist.all_reduce(ones, op=dist.ReduceOp.SUM)
         ranks_seen = int(round(float(ones.item())))
-        mine = torch.tensor([elapsed, float(G)], dtype=torch.float64, device=dev)
-        allr = torch.empty(2 * world, dtype=torch.float64, device=dev)
-        dist.all_gather_into_tensor(allr, mine)
-        allr = allr.view(world, 2).cpu()
-        rank_ms = [float(x) / args.steps * 1e3 for x in allr[:, 0]]
-        total_graphs = int(round(float(allr[:, 1].sum())))
-        elapsed = float(allr[:, 0].max())
+    rank_s, total_graphs = over_ranks(elapsed, G)
+    rank_ms = [x / args.steps * 1e3 for x in rank_s]
+    elapsed = max(rank_s)
+    elapsed_prof = max(over_ranks(elapsed_prof, G)[0])
+
+    # strong-scaling leg of the same run: a FIXED set of --strong-leg problems (seeds 5000 + i) split over the ranks by
+    # shard_range; whole-set rate = N_TOTAL * steps / the slowest rank's time.  One driver sweep over N then gives both curves.
+    strong_leg = None
+    if args.strong == 0 and args.strong_leg >= world and args.strong_leg > 0:
+        from gnnmp.dist import shard_range
+        lo, hi = shard_range(args.strong_leg, rank, world)
+        _, sbatch = problem_set(hi - lo, 5000 + lo)
+        s_el, s_scores = timed(sbatch, 2, args.strong_steps)
+        s_rank_s, s_total = over_ranks(s_el, hi - lo)
+        s_sum = float(s_scores.double().sum().item())
+        if use_dist:
+            t_ = torch.tensor([s_sum], dtype=torch.float64, device=cdev)
+            dist.all_reduce(t_, op=dist.ReduceOp.SUM)
+            s_sum = float(t_.item())
+        strong_leg = {'scaling': 'strong', 'problems_total': s_total, 'problems_this_rank0': hi - lo, 'steps': args.strong_steps,
+                      'ms_per_step': round(max(s_rank_s) / args.strong_steps * 1e3, 4),
+                      'graphs_per_s': round(s_total * args.strong_steps / max(s_rank_s), 2),
+                      'rank_ms_per_step': [round(x / args.strong_steps * 1e3, 4) for x in s_rank_s],
+                      # sum over ranks of the per-rank score sums: depends on the split only through fp64 summation order
+                      'result_checksum': s_sum,
+                      'what': 'fixed set of %d problems (seed 5000 + i), contiguous shards by gnnmp.dist.shard_range; '
+                              'timed like `value` (barrier + synchronize both sides, max over ranks)' % s_total}
+        del sbatch, s_scores
+        torch.cuda.empty_cache()
 
     # PCIe-inclusive variant (reported next to, never instead of, `value`): the reference's own forward
     # timer spans H2D + compute + D2H (eval_gnn.py:193-196); here inputs start in pinned host memory and
@@ -384,16 +494,17 @@ def main():
     gather_ms = None
     if use_dist:
         from gnnmp.dist import gather_variable
-        parts = gather_variable(scores)                    # one padded buffer, all_gather_into_tensor (RCCL); also the warm-up
+        gsrc = scores if backend == 'nccl' else scores.cpu()   # gloo gathers host tensors
+        parts = gather_variable(gsrc)                      # one padded buffer, all_gather_into_tensor (RCCL); also the warm-up
         checksum = float(torch.stack([p_.double().sum() for p_ in parts]).sum().item())
         ts = []
         for _ in range(max(args.gather_reps, 1)):
             sync()
             t1 = time.perf_counter()
-            parts = gather_variable(scores)
+            parts = gather_variable(gsrc)
             torch.cuda.synchronize(dev)
             ts.append(time.perf_counter() - t1)
-        tg = torch.tensor([sorted(ts)[len(ts) // 2]], dtype=torch.float64, device=dev)
+        tg = torch.tensor([sorted(ts)[len(ts) // 2]], dtype=torch.float64, device=cdev)
         dist.all_reduce(tg, op=dist.ReduceOp.MAX)
         gather_ms = round(float(tg.item()) * 1e3, 4)
         del parts
@@ -513,6 +624,11 @@ def main():
                        'ranks_seen': ranks_seen,
                        'rank_ms_per_step': {'min': round(min(rank_ms), 4), 'max': round(max(rank_ms), 4),
                                             'all': [round(x, 4) for x in rank_ms]},
+                       'collective_backend': (backend if use_dist else None),
+                       'ms_per_step_with_stage_events': round(elapsed_prof / args.steps * 1e3, 4),
+                       'timing': '`value` / `ms_per_step`: %d steps with the per-stage HIP events OFF; stage_ms_per_step, stage_roofline and '
+                                 'roofline.launch_ms: a second loop of the same %d steps with the events on' % (args.steps, args.steps),
+                       'strong_leg': strong_leg,
                        'gather_ms': gather_ms,
                        'gather': None if gather_ms is None else 'per-edge scores of every rank -> every rank: two all_gather_into_tensor '
                                  'calls (lengths, one padded payload of %d floats per rank), median of %d, max over ranks; outside the '

@@ -124,10 +124,6 @@ def lib():
     L.gnnmp_pack_f64_ops.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp]
     L.gnnmp_pack_vec.restype = ctypes.c_int64
     L.gnnmp_pack_vec.argtypes = [vp, ctypes.c_int, vp]
-    for name in ('gnnmp_smoother_manifest', 'gnnmp_smoother_create', 'gnnmp_smoother_destroy',
-                 'gnnmp_smoother_workspace_bytes', 'gnnmp_smoother_forward'):
-        if not hasattr(L, name):
-            continue
     if hasattr(L, 'gnnmp_smoother_create'):
         L.gnnmp_smoother_manifest.argtypes = [ctypes.POINTER(SmootherDims), ctypes.c_int, ctypes.c_char_p, sz, c_int64_p]
         L.gnnmp_smoother_create.argtypes = [ctypes.POINTER(vp), ctypes.POINTER(SmootherDims), vp, sz, ctypes.c_int]

@@ -201,7 +201,8 @@ class MixedJob:
         """One forward per family; returns the per-problem score tensors in the caller's order (views into the job's own
         buffers: valid until the next run())."""
         res = [None] * self.n
-        cur = torch.cuda.current_stream()
+        # the caller's stream ON THE DEVICE THE PROBLEMS LIVE ON (not of whatever device is current)
+        cur = torch.cuda.current_stream(self.parts[0][2].v.device) if self.parts else None
         for env, idxs, b, ws, out, st in self.parts:
             if st is None:
                 sc = self.models[env].forward_batch(b, self.loop, ws=ws, out=out)

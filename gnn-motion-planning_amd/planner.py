@@ -316,10 +316,17 @@ def _path_cost_rows(path):
     p = np.asarray(path)
     if p.ndim != 2 or p.shape[0] < 2:
         return 0.0
-    if p.dtype != np.float32:                  # (float64 rows: numpy's dot and einsum differ in the last bit; the planner's are float32)
+    if p.dtype != np.float32 or p.shape[1] != 2:
+        # float64 rows, and rows of three or more coordinates (maze3): np.linalg.norm's BLAS dot and einsum round
+        # differently in the last bit; only the 2-D float32 rows of the device planner are proven equal -- loop otherwise
         return path_cost(p)
     d = p[1:] - p[:-1]
-    return float(np.cumsum(np.sqrt(np.einsum('ij,ij->i', d, d)))[-1])
+    return float(np.cumsum(np.sqrt(np.einsum('ij,ij->i', d, d)), dtype=_COST_ACC)[-1])
+
+
+# dtype the reference's running sum `0 + float32 + float32 ...` (eval_gnn.py:53-58) accumulates in under the installed NumPy:
+# float32 under NEP 50 (NumPy >= 2: the Python 0 is weak), whatever older promotion rules give otherwise
+_COST_ACC = np.asarray(sum([np.float32(1.0)])).dtype
 
 
 def _collect(res, wall, t_explore, sol, paths, smooth_paths, rows_out):
@@ -385,13 +392,14 @@ def eval_gnn_device(env, indexes, model, model_s, seed=1234, batch=500, k=30, de
     ``shard = (rank, world)``: evaluate only this rank's contiguous block of ``indexes`` (``dist.shard_range``) after
     skipping the sampling of the blocks before it, so the union over ranks equals the sequential run problem by
     problem; the aggregates returned are those of the local block (gather with ``dist.gather_problem_results``).
-    ``workers``: host threads that run device passes, each on its own stream (chunk i on worker i % workers): the host
+    ``workers``: host threads that run device passes, each on its OWN stream (bound to the worker thread, not to the pass number): the host
     part of a pass (index tables, result rows, the blocking copies between the stages) leaves the GPU idle for ~40 % of a
     pass, and a second pass in flight fills that; the chunks are independent and their results are collected in order,
     so every per-problem number is the same for any ``workers``.  Measured at 1024 problems of the published setting
     (tools/diag/planner_chunks.py, problems/s, median of 3): workers 1 / 2 / 3 at chunk 512: 5.5 k / 5.1 k / 6.1 k, chunk 256:
     5.1 k / 5.8 k / 6.5 k, chunk 128: 4.7 k / 7.1 k / 6.7 k -- small passes start the pipeline early and keep the per-stream
-    pools of the caching allocator small (45 GB reserved at two workers, 55 GB at three)."""
+    pools of the caching allocator small.  Memory: the defaults (passes of 128 on two workers) reserve about 45 GB in the caching
+    allocator (55 GB at three workers) -- sized for the 288 GB of an MI355X; pass ``workers=1`` and a smaller ``chunk`` elsewhere."""
     model.eval()                       # eval_gnn.py:109-110
     if model_s is not None:
         model_s.eval()
@@ -419,25 +427,40 @@ def eval_gnn_device(env, indexes, model, model_s, seed=1234, batch=500, k=30, de
               for i in indexes[span[0]:span[1]]]
         return pr, sample_maze_problems(pr, batch, k)
 
+    # INVARIANT: one stream -- and with it one workspace of each module (EncoderProcessDecoder / ModelSmoother._workspace key
+    # on (device, stream)) -- per concurrently running forward.  A stream therefore belongs to a worker THREAD (bound once, in
+    # the pool's initializer), never to a pass number: with passes handed out as `ci % workers`, pass i + workers could start
+    # on pass i's stream while pass i was still running whenever pass i + 1 finished first, and two gnnmp_*_forward calls
+    # (ctypes releases the interpreter lock) would interleave their launches on one stream and one workspace.
+    import itertools
+    import threading
     streams = [_worker_stream(dev, i) for i in range(workers)] if workers > 1 else [None]
+    bound, next_stream = threading.local(), itertools.count()
+
+    def bind_stream():
+        bound.stream = streams[next(next_stream) % workers]          # the pool starts at most `workers` threads: one stream each
 
     def device_pass(ci, sampled):
         problems, pre = sampled.result()
         tm = {}
-        if streams[ci % workers] is None:
+        t_pass = time.perf_counter()
+        st = getattr(bound, 'stream', None)
+        if st is None:
             res = explore_maze_batch(problems, model, device, batch=batch, k=k, loop=loop, model_s=model_s, timings=tm,
                                      presampled=pre)
         else:
-            with torch.cuda.device(dev), torch.cuda.stream(streams[ci % workers]):
+            with torch.cuda.device(dev), torch.cuda.stream(st):
                 res = explore_maze_batch(problems, model, device, batch=batch, k=k, loop=loop, model_s=model_s,
                                          timings=tm, presampled=pre)
                 torch.cuda.current_stream().synchronize()
+        tm['pass'] = time.perf_counter() - t_pass
         return res, tm
     # the samples are drawn on ONE host thread, chunk after chunk in problem order (the global numpy stream is consumed
     # exactly like the one-by-one loop), at most `workers + 1` chunks ahead of the device passes
     def _run_passes():
-        nonlocal t_smooth
-        with ThreadPoolExecutor(max_workers=1) as sampler, ThreadPoolExecutor(max_workers=workers) as pool:
+        nonlocal smooth_share
+        with ThreadPoolExecutor(max_workers=1) as sampler, \
+                ThreadPoolExecutor(max_workers=workers, initializer=bind_stream if workers > 1 else None) as pool:
             sampled, passes, submitted = {}, {}, set()
 
             def submit(ci):
@@ -456,10 +479,12 @@ def eval_gnn_device(env, indexes, model, model_s, seed=1234, batch=500, k=30, de
                     res, tm = device_pass(ci, sampled[ci])
                 sampled.pop(ci, None)
                 submit(ci + workers + 1)
-                t_smooth += tm.get('smoothing', 0.)
+                # smoothing share of THIS pass's own wall clock, weighted by its problem count (passes overlap in time under
+                # workers > 1: summing their smoothing intervals would count the same wall-clock seconds twice)
+                smooth_share += len(res) * min(tm.get('smoothing', 0.) / max(tm.get('pass', 0.), 1e-12), 1.0)
                 _collect(res, 0., 0., sol, paths, smooth_paths, rows_out)
     t_begin = time.perf_counter()
-    t_smooth = 0.
+    smooth_share = 0.
     starts = _pass_spans(len(indexes), chunk)
     import sys
     switch = sys.getswitchinterval()
@@ -473,7 +498,8 @@ def eval_gnn_device(env, indexes, model, model_s, seed=1234, batch=500, k=30, de
         sys.setswitchinterval(switch)
     # wall clock of the whole evaluation (sampling of chunk i+1 overlaps the device pass of chunk i), spread evenly
     wall = (time.perf_counter() - t_begin) / max(len(sol), 1)
-    t_explore = wall - t_smooth / max(len(sol), 1)
+    # total_time_explore of eval_gnn.py: the per-problem wall clock minus the smoothing stage's share of it (a fraction in [0, 1])
+    t_explore = wall * (1.0 - smooth_share / max(len(sol), 1))
     sol = [x[:5] + (wall, t_explore) for x in sol]
     n_success = sum(s[0] for s in sol)
     collision_explore = float(np.mean([s[3] for s in sol]))

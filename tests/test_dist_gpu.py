@@ -86,8 +86,38 @@ def test_bench_strong_mode_is_the_same_fixed_problem_set():
 
 def test_bench_refuses_world_size_mismatch():
     r = subprocess.run([sys.executable, 'bench.py', '--gpus', '2', '--steps', '1'], cwd=REPO, capture_output=True, text=True,
-                       timeout=300, env={k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')})
+                       timeout=300, env=dict(os.environ, RANK='0', LOCAL_RANK='0', WORLD_SIZE='1'))
     assert r.returncode != 0 and 'WORLD_SIZE' in (r.stderr + r.stdout)
+
+
+def test_bench_gpus_2_launches_itself_two_ranks_on_this_gpu():
+    """`python bench.py --gpus 2` with no launcher environment (the driver's N = 1 command shape with a larger N): bench.py starts
+    its own two ranks.  One GPU here, and RCCL refuses two ranks on one device, so the collectives run over gloo
+    (GNNMP_BENCH_BACKEND=gloo, host tensors) while both ranks run the HIP forward on the one GPU.  Weak scaling: rank r owns
+    seeds 1234 + 32 r + i, so the gathered checksum is the checksum of a single-rank run over 64 graphs (up to the order of the
+    fp64 sum); the strong leg's fixed set gives the same checksum for one and two ranks."""
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY='0', GNNMP_BENCH_BACKEND='gloo')
+    extra = ['--strong-leg', '48', '--strong-steps', '2']
+    two = subprocess.run([sys.executable, 'bench.py', '--gpus', '2'] + BENCH_ARGS + extra, cwd=REPO, env=env, capture_output=True,
+                         text=True, timeout=900)
+    assert two.returncode == 0, two.stderr[-3000:]
+    b = _json_line(two.stdout)
+    args = [x for x in BENCH_ARGS]
+    args[args.index('--graphs') + 1] = '64'
+    one = subprocess.run([sys.executable, 'bench.py', '--gpus', '1'] + args + extra, cwd=REPO, env=env, capture_output=True, text=True,
+                         timeout=900)
+    assert one.returncode == 0, one.stderr[-3000:]
+    a = _json_line(one.stdout)
+    cb, ca = b['config'], a['config']
+    assert b['n_gpus'] == 2 and cb['ranks_seen'] == 2 and cb['collective_backend'] == 'gloo'
+    assert cb['graphs_total'] == 64 and cb['graphs_per_gpu'] == 32 and len(cb['rank_ms_per_step']['all']) == 2
+    assert abs(cb['result_checksum'] - ca['result_checksum']) <= 1e-9 * abs(ca['result_checksum'])
+    assert abs(b['value'] - 64 / (b['ms_per_step'] * 1e-3)) <= 1e-3 * b['value']          # whole job over the slowest rank's time
+    sa, sb = ca['strong_leg'], cb['strong_leg']
+    assert sa['problems_total'] == sb['problems_total'] == 48 and sb['scaling'] == 'strong' and len(sb['rank_ms_per_step']) == 2
+    assert abs(sa['result_checksum'] - sb['result_checksum']) <= 1e-9 * abs(sa['result_checksum'])
+    assert cb['gather_ms'] is not None and cb['gather_ms'] > 0
 
 
 _WORKER = r'''

@@ -264,7 +264,8 @@ def test_vectorised_host_helpers_equal_the_loops():
     rng = np.random.default_rng(5)
     for trial in range(400):
         n = int(rng.integers(0, 40))
-        p = (rng.random((n, 2)) - 0.5).astype(np.float32 if trial % 2 else np.float64)
+        dim = 2 + (trial // 2) % 2                         # 2-D point robot rows and 3-D stick robot rows (maze3)
+        p = (rng.random((n, dim)) - 0.5).astype(np.float32 if trial % 2 else np.float64)
         assert planner._path_cost_rows(p if n else []) == planner.path_cost(p if n else [])
     lengths = [2, 3, 17, 1, 40, 5]
     joined = planner._chain_edge_indices(lengths)
