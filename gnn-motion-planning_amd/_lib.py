@@ -6,7 +6,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('GNNMP_LIB') or os.path.join(_HERE, 'libgnnmp.so')      # GNNMP_LIB: an experiment build (tools/diag/build_variant.sh)
 
-ABI_VERSION = 2                        # include/gnnmp.h gnnmp_abi_version(): what this binding was written against
+ABI_VERSION = 3                        # include/gnnmp.h gnnmp_abi_version(): what this binding was written against
 
 c_float_p = ctypes.POINTER(ctypes.c_float)
 c_int32_p = ctypes.POINTER(ctypes.c_int32)
@@ -107,6 +107,12 @@ def lib():
     L.gnnmp_explorer_train_workspace_bytes.argtypes = [vp, ctypes.POINTER(Batch), ctypes.c_int, ctypes.POINTER(sz)]
     L.gnnmp_explorer_train_forward.argtypes = [vp, ctypes.POINTER(Batch), ctypes.c_int, ctypes.c_int, vp, vp, sz, vp]
     L.gnnmp_explorer_train_backward.argtypes = [vp, ctypes.POINTER(Batch), ctypes.c_int, vp, vp, vp, sz, vp]
+    L.gnnmp_explorer_status.argtypes = [vp, ctypes.POINTER(Batch), vp, sz, vp, c_int32_p]
+    L.gnnmp_explorer_status_region.argtypes = [vp, ctypes.POINTER(Batch), ctypes.POINTER(sz), ctypes.POINTER(sz)]
+    L.gnnmp_explorer_status_decode.argtypes = [vp, ctypes.c_int, c_int32_p]
+    L.gnnmp_smoother_status.argtypes = [vp, ctypes.POINTER(SmoothBatch), vp, sz, vp, c_int32_p]
+    L.gnnmp_smoother_status_region.argtypes = [vp, ctypes.POINTER(SmoothBatch), ctypes.POINTER(sz), ctypes.POINTER(sz)]
+    L.gnnmp_smoother_status_decode.argtypes = [vp, ctypes.c_int, c_int32_p]
     L.gnnmp_explorer_profile.argtypes = [vp, ctypes.c_int]
     L.gnnmp_explorer_profile_read.argtypes = [vp, ctypes.POINTER(ctypes.c_double), c_int64_p]
     L.gnnmp_graph_workspace_bytes.argtypes = [ctypes.POINTER(GraphBuildBatch), ctypes.POINTER(sz)]
@@ -140,6 +146,55 @@ def check(status, what):
         msg = L.gnnmp_status_string(status).decode()
         hip = L.gnnmp_last_hip_error().decode()
         raise RuntimeError('%s failed: %s%s' % (what, msg, (' [' + hip + ']') if hip else ''))
+
+
+class StatusWatch:
+    """Non-blocking reader of the device-side status of forwards (gnnmp.h: gnnmp_*_status_region / _decode).
+
+    forward() never synchronises, so what only the device can see -- a graph with more obstacles than the batch promised, a
+    smoothing problem beyond its caps, a node id outside its graph -- lands in a few status words inside the workspace.
+    ``push`` enqueues a copy of those words into pinned host memory behind the forward (same stream) plus an event; ``poll``
+    looks at the copies whose event has completed and raises RuntimeError for the first bad one -- called at the start of the
+    module's NEXT forward (no wait) and by ``check_status()`` (waits).  At most ``depth`` copies stay pending: beyond that the
+    oldest is waited for, so an error can lag by at most ``depth`` forwards."""
+
+    def __init__(self, kind, depth=32):
+        import threading
+        self.kind, self.depth, self.pending = kind, depth, []
+        self.lock = threading.Lock()                    # planner workers run forwards of one module from several host threads
+
+    def push(self, ws, offset, nbytes, n, what):
+        import torch
+        words = torch.empty(nbytes // 4, dtype=torch.int32, pin_memory=True)
+        words.copy_(ws[offset:offset + nbytes].view(torch.int32), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()                                     # current stream = the one the forward and the copy were enqueued on
+        with self.lock:
+            self.pending.append((ev, words, n, what))
+            over = len(self.pending) > self.depth
+        if over:
+            self.poll(wait_oldest=True)
+
+    def poll(self, wait=False, wait_oldest=False):
+        while True:
+            with self.lock:
+                if not self.pending:
+                    return
+                ev, words, n, what = self.pending[0]
+                if not (wait or wait_oldest) and not ev.query():
+                    return
+                self.pending.pop(0)
+            if wait or wait_oldest:
+                ev.synchronize()
+            wait_oldest = False
+            first = ctypes.c_int32(-1)
+            fn = lib().gnnmp_explorer_status_decode if self.kind == 'explorer' else lib().gnnmp_smoother_status_decode
+            rc = fn(words.data_ptr(), n, ctypes.byref(first))
+            if rc != 0:
+                with self.lock:
+                    self.pending.clear()
+                raise RuntimeError('%s: %s (first offending %s: %d) -- the results of that forward are wrong' % (
+                    what, lib().gnnmp_status_string(rc).decode(), 'graph' if self.kind == 'explorer' else 'problem', first.value))
 
 
 def manifest(kind, dims):

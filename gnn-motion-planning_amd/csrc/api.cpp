@@ -241,11 +241,14 @@ extern "C" const char* gnnmp_status_string(int s) {
         case GNNMP_ERR_WORKSPACE: return "workspace too small or misaligned";
         case GNNMP_ERR_HIP: return "HIP runtime error";
         case GNNMP_ERR_ARG: return "bad scalar argument";
+        case GNNMP_ERR_CAPS: return "a caller promise was exceeded on the device (max_obstacles / max_path / max_samples / max_edges): results are wrong";
+        case GNNMP_ERR_INDEX: return "edge_index holds node ids outside [0, N_g): results are wrong";
     }
     return "unknown status";
 }
 extern "C" const char* gnnmp_last_hip_error(void) { return g_hip_error.c_str(); }
-extern "C" int gnnmp_abi_version(void) { return 2; }    // 2: stage list of gnnmp_explorer_profile_read (fused message passing)
+// 2: stage list of gnnmp_explorer_profile_read (fused message passing); 3: device-side status words (gnnmp_*_status*)
+extern "C" int gnnmp_abi_version(void) { return 3; }
 
 // ---------------------------------------------------------------------------------------------
 // explorer handle
@@ -635,7 +638,7 @@ struct Carve {
     // sizes
     int G, Npad, Epad, ot_max, kv_stride, D;
     // offsets in bytes
-    size_t node_ptr_pad, edge_ptr_pad, goal_node, dense_ptr, in_ptrs, prep_hist;
+    size_t node_ptr_pad, edge_ptr_pad, goal_node, dense_ptr, in_ptrs, prep_hist, gstat;
     size_t zero_beg, deg, cursor, zero_end;
     size_t ff_beg, ntile_graph, etile_graph, csr, ff_end, tile_meta, rec32, blk_span;
     size_t row_beg;
@@ -666,6 +669,7 @@ bool carve(const gnnmp_explorer* h, const gnnmp_batch* b, Carve& c) {
     c.goal_node = take(sizeof(int) * c.G);
     c.dense_ptr = take(sizeof(long long) * (c.G + 1));
     c.in_ptrs = take(sizeof(int) * 6);          // prefix arrays of a single graph given by its totals (NULL prefix pointers)
+    c.gstat = take(sizeof(int) * kGstatStride * (size_t)c.G);      // device-side status of the forward (gnnmp_explorer_status)
     c.zero_beg = o;
     c.deg = take(sizeof(int) * c.Npad);
     c.zero_end = o;
@@ -751,6 +755,42 @@ extern "C" int gnnmp_explorer_forward(const gnnmp_explorer* h, const gnnmp_batch
     return forward_impl(h, b, loop, use_obstacles, edge_scores, dense, ws, ws_bytes, hip_stream, nullptr, nullptr, false);
 }
 
+extern "C" int gnnmp_explorer_status_region(const gnnmp_explorer* h, const gnnmp_batch* shape, size_t* offset, size_t* bytes) {
+    if (!h || !shape || !offset || !bytes) return GNNMP_ERR_NULL;
+    Carve c;
+    if (!carve(h, shape, c)) return GNNMP_ERR_ARG;
+    *offset = c.gstat;
+    *bytes = sizeof(int) * kGstatStride * (size_t)c.G;
+    return GNNMP_OK;
+}
+
+extern "C" int gnnmp_explorer_status_decode(const int32_t* words_host, int n_graphs, int32_t* first_graph) {
+    if (!words_host || n_graphs < 0) return GNNMP_ERR_NULL;
+    int caps = -1, ids = -1;
+    for (int g = 0; g < n_graphs; ++g) {
+        if (caps < 0 && (words_host[kGstatStride * g] & 1)) caps = g;
+        for (int k = 1; k < kGstatStride && ids < 0; ++k)
+            if (words_host[kGstatStride * g + k] & 2) ids = g;
+    }
+    if (ids >= 0) { if (first_graph) *first_graph = ids; return GNNMP_ERR_INDEX; }
+    if (caps >= 0) { if (first_graph) *first_graph = caps; return GNNMP_ERR_CAPS; }
+    if (first_graph) *first_graph = -1;
+    return GNNMP_OK;
+}
+
+extern "C" int gnnmp_explorer_status(const gnnmp_explorer* h, const gnnmp_batch* shape, const void* ws, size_t ws_bytes,
+                                     void* hip_stream, int32_t* first_graph) {
+    if (!h || !shape || !ws) return GNNMP_ERR_NULL;
+    Carve c;
+    if (!carve(h, shape, c)) return GNNMP_ERR_ARG;
+    if (ws_bytes < c.total) return GNNMP_ERR_WORKSPACE;
+    std::vector<int32_t> host((size_t)kGstatStride * c.G);
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    HIP_TRY(hipMemcpyAsync(host.data(), static_cast<const char*>(ws) + c.gstat, host.size() * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return gnnmp_explorer_status_decode(host.data(), c.G, first_graph);
+}
+
 namespace {
 // om_nodes / om_edges: optional [Npad, d] / [Epad, d] outputs of the attention stacks (training path); pre_only: stop
 // after the pre kernels (CSR, goal node, NF / EF are what the training path needs)
@@ -792,6 +832,9 @@ int forward_impl(const gnnmp_explorer* h, const gnnmp_batch* b, int loop, int us
     q.goal_node = at<int>(ws, c.goal_node);
     q.tile_meta = at<int>(ws, c.tile_meta); q.n_etiles = c.Epad / 32;
     q.blk_span = at<int2>(ws, c.blk_span);
+    q.obs_ptr = implicit ? nullptr : b->obs_ptr;
+    q.obs_cap = use_obstacles ? 32 * c.ot_max : 0x7fffffff;
+    q.gstat = at<int>(ws, c.gstat);
     HIP_TRY(launch_prep(q, c.Npad, c.Epad, at<int>(ws, c.prep_hist), st));
     // zero-fill of policy_output (model.py:148); sum_g N_g^2 is read from dense_ptr[G] on the device
     if (dense) HIP_TRY(launch_zero_dense(dense, q.dense_ptr + c.G, st));
@@ -1112,7 +1155,7 @@ extern "C" int gnnmp_smoother_destroy(gnnmp_smoother* h) {
 namespace {
 struct SmCarve {
     int ecap, pcap;
-    size_t cur, knn, e_src, e_dst, e_count, seg_beg, seg_cnt, ff_beg, etile, ptile, ff_end, msg, tgt, tflag, total;
+    size_t cur, knn, e_src, e_dst, e_count, stat, seg_beg, seg_cnt, ff_beg, etile, ptile, ff_end, msg, tgt, tflag, total;
 };
 
 bool sm_carve(const gnnmp_smoother* h, const gnnmp_smooth_batch* b, SmCarve& c) {
@@ -1131,6 +1174,7 @@ bool sm_carve(const gnnmp_smoother* h, const gnnmp_smooth_batch* b, SmCarve& c) 
     c.e_src = take(sizeof(int) * c.ecap);
     c.e_dst = take(sizeof(int) * c.ecap);
     c.e_count = take(sizeof(int) * b->n_problems);
+    c.stat = take(sizeof(int) * b->n_problems);                 // device-side status per problem (gnnmp_smoother_status)
     c.seg_beg = take(sizeof(int) * c.pcap);
     c.seg_cnt = take(sizeof(int) * c.pcap);
     c.ff_beg = o;
@@ -1181,6 +1225,7 @@ extern "C" int gnnmp_smoother_forward(const gnnmp_smoother* h, const gnnmp_smoot
     p.cur = at<float>(ws, c.cur); p.cur_next = p.cur;
     p.knn = at<int>(ws, c.knn);
     p.e_src = at<int>(ws, c.e_src); p.e_dst = at<int>(ws, c.e_dst); p.e_count = at<int>(ws, c.e_count);
+    p.stat = at<int>(ws, c.stat);
     p.seg_beg = at<int>(ws, c.seg_beg); p.seg_cnt = at<int>(ws, c.seg_cnt);
     p.etile_prob = at<int>(ws, c.etile); p.ptile_prob = at<int>(ws, c.ptile);
     p.msg = at<float>(ws, c.msg);
@@ -1193,6 +1238,7 @@ extern "C" int gnnmp_smoother_forward(const gnnmp_smoother* h, const gnnmp_smoot
     p.n_etiles = c.ecap / 32; p.n_ptiles = c.pcap / 32;
     p.one_free = b->total_free; p.one_coll = b->total_collided;
     if (loop == 0) {                                         // nothing moves: out = (path / scale) * scale
+        HIP_TRY(hipMemsetAsync(p.stat, 0, sizeof(int) * b->n_problems, st));
         HIP_TRY(launch_sm_init(b->total_path * C, p.scale, b->path, p.cur, st));
         HIP_TRY(launch_sm_final(b->total_path * C, p.scale, p.cur, out_path, st));
         return GNNMP_OK;
@@ -1206,6 +1252,37 @@ extern "C" int gnnmp_smoother_forward(const gnnmp_smoother* h, const gnnmp_smoot
         HIP_TRY(launch_sm_iter(D, h->dims.mlp_dtype, p, st));
     }
     return GNNMP_OK;
+}
+
+
+extern "C" int gnnmp_smoother_status_region(const gnnmp_smoother* h, const gnnmp_smooth_batch* shape, size_t* offset, size_t* bytes) {
+    if (!h || !shape || !offset || !bytes) return GNNMP_ERR_NULL;
+    SmCarve c;
+    if (!sm_carve(h, shape, c)) return GNNMP_ERR_ARG;
+    *offset = c.stat;
+    *bytes = sizeof(int) * (size_t)shape->n_problems;
+    return GNNMP_OK;
+}
+
+extern "C" int gnnmp_smoother_status_decode(const int32_t* words_host, int n_problems, int32_t* first_problem) {
+    if (!words_host || n_problems < 0) return GNNMP_ERR_NULL;
+    for (int b = 0; b < n_problems; ++b)
+        if (words_host[b] != 0) { if (first_problem) *first_problem = b; return GNNMP_ERR_CAPS; }
+    if (first_problem) *first_problem = -1;
+    return GNNMP_OK;
+}
+
+extern "C" int gnnmp_smoother_status(const gnnmp_smoother* h, const gnnmp_smooth_batch* shape, const void* ws, size_t ws_bytes,
+                                     void* hip_stream, int32_t* first_problem) {
+    if (!h || !shape || !ws) return GNNMP_ERR_NULL;
+    SmCarve c;
+    if (!sm_carve(h, shape, c)) return GNNMP_ERR_ARG;
+    if (ws_bytes < c.total) return GNNMP_ERR_WORKSPACE;
+    std::vector<int32_t> host((size_t)shape->n_problems);
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    HIP_TRY(hipMemcpyAsync(host.data(), static_cast<const char*>(ws) + c.stat, host.size() * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return gnnmp_smoother_status_decode(host.data(), shape->n_problems, first_problem);
 }
 
 
@@ -1649,6 +1726,7 @@ void sm_fill_params(const gnnmp_smoother* h, const gnnmp_smooth_batch* b, const 
     p.w = h->w_dev; p.L = h->L;
     p.knn = at<int>(ws, c.knn);
     p.e_src = at<int>(ws, c.e_src); p.e_dst = at<int>(ws, c.e_dst); p.e_count = at<int>(ws, c.e_count);
+    p.stat = at<int>(ws, c.stat);
     p.seg_beg = at<int>(ws, c.seg_beg); p.seg_cnt = at<int>(ws, c.seg_cnt);
     p.etile_prob = at<int>(ws, c.etile); p.ptile_prob = at<int>(ws, c.ptile);
     p.msg = at<float>(ws, c.msg);

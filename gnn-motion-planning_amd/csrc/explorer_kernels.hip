@@ -91,6 +91,14 @@ __device__ __forceinline__ int prep_ep(const PrepParams& q, int i) { return q.si
 // Workgroup `part` of `parts` builds the CSR rows of the target nodes [lo, hi) of graph g (a slice of its padded node
 // range): it walks ALL edge columns of the graph, counts the ones whose target lies below its slice (that count is where
 // its slice starts in the slot space -- no communication between the parts) and ranks / scatters the ones inside.
+// a caller node id as the prep stage uses it: ids outside [0, N_g) (the reference's tensor indexing would raise) are replaced by
+// node 0 -- every later kernel then stays inside the graph's rows -- and reported through gnnmp_explorer_status (gstat)
+__device__ __forceinline__ int prep_id(int x, int Ng, int& bad) {
+    const bool b = (unsigned)x >= (unsigned)Ng;
+    bad |= b ? 1 : 0;
+    return b ? 0 : x;
+}
+
 __device__ __forceinline__ void prep_graph_body(const PrepParams& q, int g, int part, int parts, int n0, int Np, int e0, int e1,
                                                 int* prep_lds) {
     __shared__ int carry;                              // prep_lds: cnt[kPrepCap], rb[kPrepCap], scan[1024]
@@ -115,14 +123,17 @@ __device__ __forceinline__ void prep_graph_body(const PrepParams& q, int g, int 
     // rank) in registers between the ranking and the scatter -- edge_index is read once and the rank never goes to memory
     // (with several slices per graph every workgroup reads all columns and keeps the ones whose target lies in its slice)
     const bool in_regs = Eg <= U * 1024;
+    // node ids outside [0, N_g): see prep_id
+    const int Ng = prep_np(q, g + 1) - prep_np(q, g);
+    int bad_id = 0;
     int sv_r[U], tv_r[U], rk_r[U];
     if (in_regs) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int cc = tid + u * 1024;
             const bool ok = cc < Eg;
-            tv_r[u] = ok ? (int)dsts[cc] : -1;
-            sv_r[u] = ok ? (int)srcs[cc] : 0;
+            tv_r[u] = ok ? prep_id((int)dsts[cc], Ng, bad_id) : -1;
+            sv_r[u] = ok ? prep_id((int)srcs[cc], Ng, bad_id) : 0;
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -136,7 +147,7 @@ __device__ __forceinline__ void prep_graph_body(const PrepParams& q, int g, int 
         for (int c = tid; c < Eg; c += U * 1024) {
             int d[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) d[u] = (c + u * 1024 < Eg) ? (int)dsts[c + u * 1024] : 0x7fffffff;
+            for (int u = 0; u < U; ++u) d[u] = (c + u * 1024 < Eg) ? prep_id((int)dsts[c + u * 1024], Ng, bad_id) : 0x7fffffff;
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 if (d[u] < lo) ++below;
@@ -180,13 +191,13 @@ __device__ __forceinline__ void prep_graph_body(const PrepParams& q, int g, int 
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int cc = c + u * 1024;
-                tv[u] = cc < Eg ? (int)dsts[cc] : -1;
+                tv[u] = cc < Eg ? prep_id((int)dsts[cc], Ng, bad_id) : -1;
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int cc = c + u * 1024;
                 const bool mine = tv[u] >= lo && tv[u] < hi;
-                sv[u] = mine ? (int)srcs[cc] : 0;
+                sv[u] = mine ? prep_id((int)srcs[cc], Ng, bad_id) : 0;
                 rk[u] = mine ? q.cursor[c0 + cc] : 0;
                 if (!mine) tv[u] = -1;
             }
@@ -205,6 +216,8 @@ __device__ __forceinline__ void prep_graph_body(const PrepParams& q, int g, int 
         q.etile_graph[t] = g;
         q.tile_meta[t] = t * 32 < e0 + Eg ? 4 : 0;     // 4 = tile holds at least one edge (the edge pre kernel skips pure padding)
     }
+    const int any_bad = __syncthreads_or(bad_id);
+    if (tid == 0) q.gstat[kGstatStride * g + 1 + part] = any_bad ? 2 : 0;
 }
 
 // goal node of graph g: argmin_i |v_i - goal|^2, lowest index on ties (model.py:132); any power-of-two workgroup
@@ -260,7 +273,7 @@ __device__ __forceinline__ void goal_body(int C, const float* __restrict__ v, co
 // padded prefix sums over the graphs before graph g (every workgroup reduces them itself -- G loads spread over 1024
 // threads -- instead of waiting for a separate scan launch); part 0 publishes the entries of its graph
 template <bool FENCE>
-__device__ __forceinline__ void prep_prefix(const PrepParams& q, int g, int part, int& n0, int& n1, int& e0, int& e1) {
+__device__ __forceinline__ void prep_prefix(const PrepParams& q, int g, int part, int parts, int& n0, int& n1, int& e0, int& e1) {
     __shared__ long long red[3][16];
     const int tid = threadIdx.x;
     if (q.single_out) {                                // one graph given by its totals: its prefix arrays come first
@@ -292,6 +305,11 @@ __device__ __forceinline__ void prep_prefix(const PrepParams& q, int g, int part
     if (tid == 0 && part == 0) {
         if (g == 0) { q.node_ptr_pad[0] = 0; q.edge_ptr_pad[0] = 0; q.dense_ptr[0] = 0; }
         q.node_ptr_pad[g + 1] = n1; q.edge_ptr_pad[g + 1] = e1; q.dense_ptr[g + 1] = ad + (long long)ng_own * ng_own;
+        // more obstacles than the K/V slabs were sized for (gnnmp_batch.max_obstacles is a caller promise): the attention blocks
+        // see only the first obs_cap of them (obs_body clamps) -- reported through gnnmp_explorer_status, never silently
+        const int og = q.obs_ptr ? q.obs_ptr[g + 1] - q.obs_ptr[g] : q.single_o;
+        q.gstat[kGstatStride * g] = og > q.obs_cap ? 1 : 0;
+        for (int pp = parts; pp < kGstatStride - 1; ++pp) q.gstat[kGstatStride * g + 1 + pp] = 0;      // slots of parts this launch does not have
     }
 }
 
@@ -308,7 +326,7 @@ __global__ __launch_bounds__(1024) void prep_small_kernel(PrepParams q, int Npad
     extern __shared__ int prep_lds[];
     const int g = blockIdx.x / parts, part = blockIdx.x - g * parts;
     int n0, n1, e0, e1;
-    prep_prefix<false>(q, g, part, n0, n1, e0, e1);
+    prep_prefix<false>(q, g, part, parts, n0, n1, e0, e1);
     prep_graph_body(q, g, part, parts, n0, n1 - n0, e0, e1, prep_lds);
     if (part == 0) goal_body(q.C, q.v, q.goal, prep_np(q, g), prep_np(q, g + 1) - prep_np(q, g), g, n0, q.goal_node);
     if (g == q.G - 1 && part == parts - 1) prep_trailing(q, n1, e1, Npad, Epad);
@@ -331,7 +349,7 @@ __global__ __launch_bounds__(1024) void prep_hist_kernel(PrepParams q, int Npad,
     const int idx = blockIdx.x >> 3, g = (idx / parts) * 8 + (blockIdx.x & 7), part = idx % parts, tid = threadIdx.x;
     if (g >= q.G) return;
     int n0, n1, e0, e1;
-    prep_prefix<true>(q, g, part, n0, n1, e0, e1);
+    prep_prefix<true>(q, g, part, parts, n0, n1, e0, e1);
     const int Np = n1 - n0;
     const int c0 = q.edge_ptr[g], Eg = q.edge_ptr[g + 1] - c0;
     const int cs = (int)((long long)Eg * part / parts), ce = (int)((long long)Eg * (part + 1) / parts);
@@ -342,15 +360,20 @@ __global__ __launch_bounds__(1024) void prep_hist_kernel(PrepParams q, int Npad,
     for (int i = tid; i < Np; i += 1024) cnt[i] = 0;
     __syncthreads();
     constexpr int U = 16;
+    const int Ng = q.node_ptr[g + 1] - q.node_ptr[g];
+    int bad_id = 0;                                    // see prep_id
     for (int c = cs + tid; c < ce; c += U * 1024) {
         int d[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) d[u] = (c + u * 1024 < ce) ? (int)dsts[c + u * 1024] : -1;
+        for (int u = 0; u < U; ++u) d[u] = (c + u * 1024 < ce) ? prep_id((int)dsts[c + u * 1024], Ng, bad_id) : -1;
 #pragma unroll
         for (int u = 0; u < U; ++u)
             if (d[u] >= 0) q.cursor[c0 + c + u * 1024] = atomicAdd(&cnt[d[u]], 1);
     }
-    __syncthreads();
+    {
+        const int any_bad = __syncthreads_or(bad_id);
+        if (tid == 0) q.gstat[kGstatStride * g + 1 + part] = any_bad ? 2 : 0;
+    }
     if (in_lds)
         for (int i = tid; i < Np; i += 1024) hslice[i] = cnt[i];
     // pad slots and the per-tile maps of the graph, shared out over its parts
@@ -400,14 +423,16 @@ __global__ __launch_bounds__(1024) void prep_scatter_kernel(PrepParams q, int pa
     const long long* srcs = q.edge_index + c0;
     const long long* dsts = q.edge_index + (size_t)q.E + c0;
     constexpr int U = 8;
+    const int Ng = q.node_ptr[g + 1] - q.node_ptr[g];
+    int bad_src = 0;
     for (int c = cs + tid; c < ce; c += U * 1024) {
         int sv[U], tv[U], rk[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int cc = c + u * 1024;
             const bool ok = cc < ce;
-            sv[u] = ok ? (int)srcs[cc] : 0;
-            tv[u] = ok ? (int)dsts[cc] : -1;
+            sv[u] = ok ? prep_id((int)srcs[cc], Ng, bad_src) : 0;
+            tv[u] = ok ? prep_id((int)dsts[cc], Ng, bad_src) : -1;
             rk[u] = ok ? q.cursor[c0 + cc] : 0;
         }
 #pragma unroll
@@ -415,6 +440,7 @@ __global__ __launch_bounds__(1024) void prep_scatter_kernel(PrepParams q, int pa
             if (tv[u] >= 0)                                              // {source, target, caller column}
                 q.csr[bs[tv[u]] + rk[u]] = make_int4(n0 + sv[u], n0 + tv[u], c0 + c + u * 1024, 0);
     }
+    if (__syncthreads_or(bad_src) && tid == 0) q.gstat[kGstatStride * g + 1 + part] = 2;     // (the slot was written by prep_hist)
 }
 
 // =====================================================================================================
@@ -2460,6 +2486,7 @@ hipError_t launch_prep(const PrepParams& q, int Npad, int Epad, int* hist, hipSt
         if (slices > 8) slices = 8;
         if (slices_env > 0) slices = slices_env;
         if (slices < 1) slices = 1;
+        if (slices > kGstatStride - 1) slices = kGstatStride - 1;
         hipLaunchKernelGGL(prep_small_kernel, dim3(q.G * slices), dim3(1024), glds, st, q, Npad, Epad, slices);
         LAUNCH_CHECK();
         return hipSuccess;

@@ -21,7 +21,15 @@ struct PrepParams {
     int* single_out;                             // non-null: ONE graph given by its totals; node_ptr / edge_ptr / obs_ptr point here
     int single_n, single_e, single_o;            //           ([0,N | 0,E | 0,O], written by the prep stage before anything reads them)
     int n_etiles;
+    // device-side status of the forward (gnnmp_explorer_status): 17 ints per graph, every slot written unconditionally by exactly
+    // one thread per forward (no zero-fill, no atomics): [17 g] = GNNMP_STATUS_OBSTACLES when the graph has more obstacles than
+    // obs_cap (the K/V slabs are sized for max_obstacles; the attention then sees only the first obs_cap), [17 g + 1 + part] =
+    // GNNMP_STATUS_NODE_ID when part `part` of the prep stage met a node id outside [0, N_g)
+    const int* obs_ptr;                          // caller prefix array or nullptr (single graph: single_o)
+    int obs_cap;                                 // 32 * ot_max, or INT_MAX when the forward ignores obstacles
+    int* gstat;
 };
+constexpr int kGstatStride = 17;                 // 1 + the largest `parts` of the prep stage
 
 struct ObsParams {
     const float* obstacles;
@@ -125,6 +133,8 @@ struct SmParams {
     int one_free, one_coll;           // path_ptr == nullptr: ONE problem, its sample counts (waypoints / edges: total_path / total_edges)
     int init_from_path;               // first iteration: the knn kernel also writes cur = path / scale
     float* out;                       // last iteration: the node kernel also writes out = cur * scale (else nullptr)
+    int* stat;                        // [B] device-side status (gnnmp_smoother_status): 1 = the problem exceeds the caller's max_path /
+                                      //   max_samples / max_edges promises and got NO edges; written unconditionally by the graph stage
 };
 
 hipError_t launch_sm_init(int n, float scale, const float* path, float* cur, hipStream_t st);

@@ -125,7 +125,10 @@ __global__ __launch_bounds__(256) void sm_edges_kernel(SmParams p) {
     const int F = sm_fp(p, b + 1) - sm_fp(p, b), Co = sm_cp(p, b + 1) - sm_cp(p, b);
     const int M = P + F + Co;
     const int e0 = sm_ep(p, b), ne = sm_ep(p, b + 1) - e0;
-    const int ncand = ne + kSmK * P;
+    // the caps are the caller's promises (gnnmp_smooth_batch.max_*): a problem beyond them gets NO edges (the sort buffers are
+    // sized from them) and is reported through gnnmp_smoother_status
+    const bool fits = P <= p.path_cap && F + Co <= p.samp_cap && ne + kSmK * P <= p.cand_cap;
+    const int ncand = fits ? ne + kSmK * P : 0;
     int* key = sm_lds;                    // [cap]
     int* sorted = sm_lds + p.cand_cap;    // [cap]
     __shared__ int s_scan[256];
@@ -187,7 +190,7 @@ __global__ __launch_bounds__(256) void sm_edges_kernel(SmParams p) {
         __syncthreads();
     }
     const int n = s_carry;
-    if (tid == 0) p.e_count[b] = n;
+    if (tid == 0) { p.e_count[b] = n; p.stat[b] = fits ? 0 : 1; }
     // tile -> problem maps of this problem's whole capacity range (-1 = unused tile; no separate fill launch): the range
     // ends where the next problem's begins, the last problem's at the end of the tile space
     const int et_used = (eoff + sm_round32(n)) / 32, pt_used = (poff + sm_round32(P)) / 32;
@@ -470,7 +473,7 @@ __global__ __launch_bounds__(1024) void sm_graph_kernel(SmParams p) {
         p.seg_cnt[poff + i] = in ? cnt_l[i] : 0;
     }
     const int n = carry;
-    if (tid == 0) p.e_count[b] = n;
+    if (tid == 0) { p.e_count[b] = n; p.stat[b] = fits ? 0 : 1; }
     // tile -> problem maps of this problem's whole capacity range (-1 = unused tile; no separate fill launch): the range
     // ends where the next problem's begins, the last problem's at the end of the tile space
     const int et_used = (eoff + sm_round32(n)) / 32, pt_used = (poff + sm_round32(P)) / 32;

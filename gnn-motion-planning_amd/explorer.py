@@ -167,6 +167,9 @@ class EncoderProcessDecoder(nn.Module):
         # precision of the MFMA operands: 'fp32' (exact, the reference's precision) or 'bf16' (BASELINE configs[2],
         # [4]: bf16 operands, fp32 accumulate); not a constructor argument so the reference signature is kept
         self.mlp_dtype = 'fp32'
+        # device-side status of every forward (obstacle count beyond the batch's promise, node ids outside their graph): copied
+        # to the host behind the forward and looked at on a later call / in check_status(); False switches the copies off
+        self.status_checks = True
         self._handle = None
         self._handle_key = None
         self._ws = None
@@ -316,6 +319,8 @@ class EncoderProcessDecoder(nn.Module):
                              '(model.py:139-145)')
         if _CHECK_IDS:
             _check_edge_ids(batch)
+        watch = self._status_watch()
+        watch.poll()                                   # device-side status of EARLIER forwards whose copy has arrived (no wait)
         h = self._native(dev)
         cb = self._cbatch(batch)
         if ws is None:
@@ -333,7 +338,38 @@ class EncoderProcessDecoder(nn.Module):
             _lib.check(_lib.lib().gnnmp_explorer_forward(
                 h, ctypes.byref(cb), int(loop), 1 if self.use_obstacles else 0, scores.data_ptr(),
                 dn.data_ptr() if dense else None, ws.data_ptr(), ws.numel(), st), 'gnnmp_explorer_forward')
+            if self.status_checks:
+                off, nb = ctypes.c_size_t(), ctypes.c_size_t()
+                _lib.check(_lib.lib().gnnmp_explorer_status_region(h, ctypes.byref(cb), ctypes.byref(off), ctypes.byref(nb)),
+                           'gnnmp_explorer_status_region')
+                watch.push(ws, off.value, nb.value, batch.n_graphs, 'EncoderProcessDecoder forward (%d graphs)' % batch.n_graphs)
         return (scores, dn) if dense else scores
+
+    def _status_watch(self):
+        w = self.__dict__.get('_watch')
+        if w is None:
+            w = self.__dict__['_watch'] = _lib.StatusWatch('explorer')
+        return w
+
+    def check_status(self, batch=None):
+        """With ``batch``: the blocking C-ABI call (gnnmp_explorer_status) on the workspace of the LAST forward, which must have
+        been over ``batch``.  Without: wait for the device-side status of every forward issued so far on this module and raise RuntimeError if one of them
+        saw a graph with more obstacles than its batch's ``max_obstacles`` (the reference attends over ALL obstacles,
+        model.py:125-130: such a forward's scores are wrong) or a node id outside its graph (the reference's indexing would
+        raise).  ``forward`` itself never waits: it looks at the status copies that have already arrived when the NEXT forward
+        starts.  ``status_checks = False`` switches the status copies off (callers that validate their batches themselves)."""
+        if batch is not None:
+            dev = batch.v.device
+            cb = self._cbatch(batch)
+            first = ctypes.c_int32(-1)
+            with torch.cuda.device(dev):
+                rc = _lib.lib().gnnmp_explorer_status(self._native(dev), ctypes.byref(cb), self._ws.data_ptr(), self._ws.numel(),
+                                                     torch.cuda.current_stream().cuda_stream, ctypes.byref(first))
+            if rc != 0:
+                raise RuntimeError('EncoderProcessDecoder forward: %s (first offending graph: %d)'
+                                   % (_lib.lib().gnnmp_status_string(rc).decode(), first.value))
+            return
+        self._status_watch().poll(wait=True)
 
     def capture(self, batch, loop):
         """Capture one forward over ``batch`` into a HIP graph (the C-ABI forward allocates nothing and never

@@ -57,6 +57,7 @@ class SmoothBatch:
         self.max_samples = max(f.shape[0] + c.shape[0] for f, c in zip(frees, collideds))
         self.max_edges = max(e.shape[1] for e in edge_indexes)
         self.path_counts = [t.shape[0] for t in paths]
+        self.caps_from_host = True        # max_* computed from the same host-side counts as the prefix arrays: cannot be exceeded
 
     @classmethod
     def from_device(cls, path, free, collided, edge_index, path_counts, free_counts, coll_counts, edge_counts):
@@ -78,6 +79,7 @@ class SmoothBatch:
         sb.max_samples = max(f + c for f, c in zip(free_counts, coll_counts))
         sb.max_edges = max(edge_counts)
         sb.path_counts = list(path_counts)
+        sb.caps_from_host = True
         return sb
 
 
@@ -193,6 +195,10 @@ class ModelSmoother(nn.Module):
         self.encoder = Lin(d * 2, d)
         self.decoder = Lin(d * 2, d)
         self.mlp_dtype = 'fp32'            # or 'bf16': MFMA operands only (see EncoderProcessDecoder.mlp_dtype)
+        # device-side status of a forward (a problem beyond the batch's max_path / max_samples / max_edges promises gets no edges):
+        # 'auto' copies it to the host only for batches whose caps were NOT derived from host-side counts (SmoothBatch's own
+        # constructors derive them: nothing to check), 'always' for every forward, 'never' for none
+        self.status_checks = 'auto'
         self._handle = None
         self._handle_key = None
         self._manifest = None
@@ -266,6 +272,10 @@ class ModelSmoother(nn.Module):
         if dev.type != 'cuda':
             raise RuntimeError('gnnmp runs on the GPU only (got %s tensors); there is no CPU fallback' % dev)
         _check_limits(sb)
+        watch = self.__dict__.get('_watch')
+        if watch is None:
+            watch = self.__dict__['_watch'] = _lib.StatusWatch('smoother')
+        watch.poll()
         h = self._native(dev)
         cb = _cbatch(sb)
         need = ctypes.c_size_t()
@@ -289,7 +299,32 @@ class ModelSmoother(nn.Module):
             _lib.check(_lib.lib().gnnmp_smoother_forward(h, ctypes.byref(cb), int(loop), out.data_ptr(),
                                                          ws.data_ptr(), ws.numel(), st),
                        'gnnmp_smoother_forward')
+            if self.status_checks == 'always' or (self.status_checks == 'auto' and not getattr(sb, 'caps_from_host', False)):
+                off, nb = ctypes.c_size_t(), ctypes.c_size_t()
+                _lib.check(_lib.lib().gnnmp_smoother_status_region(h, ctypes.byref(cb), ctypes.byref(off), ctypes.byref(nb)),
+                           'gnnmp_smoother_status_region')
+                watch.push(ws, off.value, nb.value, sb.n, 'ModelSmoother forward (%d problems)' % sb.n)
         return out
+
+    def check_status(self, sb=None):
+        """With ``sb``: the blocking C-ABI call (gnnmp_smoother_status) on the workspace of the LAST forward, which must have been
+        over ``sb``.  Without: wait for the status copies of the forwards issued so far (see ``status_checks``).  Raises
+        RuntimeError when a problem exceeded the batch's max_path / max_samples / max_edges: it was smoothed WITHOUT its kNN /
+        chain edges, i.e. its waypoints are wrong."""
+        if sb is not None:
+            dev = sb.path.device
+            cb = _cbatch(sb)
+            first = ctypes.c_int32(-1)
+            with torch.cuda.device(dev):
+                rc = _lib.lib().gnnmp_smoother_status(self._native(dev), ctypes.byref(cb), self._ws.data_ptr(), self._ws.numel(),
+                                                     torch.cuda.current_stream().cuda_stream, ctypes.byref(first))
+            if rc != 0:
+                raise RuntimeError('ModelSmoother forward: %s (first offending problem: %d)'
+                                   % (_lib.lib().gnnmp_status_string(rc).decode(), first.value))
+            return
+        w = self.__dict__.get('_watch')
+        if w is not None:
+            w.poll(wait=True)
 
     def forward_train(self, path, free, collided, obstacles=None, edge_index=None, loop=10, **kwargs):
         """The reference's TRAINING call (train_smoother.py:52 under ``model.train()``): new path [P, C] with a

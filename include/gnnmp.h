@@ -26,7 +26,7 @@
  *   - the library owns only the opaque handle (device copy of the packed weights).  Inputs,
  *     outputs and workspace are caller-allocated; nothing is retained past the call.
  *   - every kernel is enqueued on the hipStream_t passed in (as void*); no hidden device
- *     synchronisation, no allocation inside forward -> forward is hipGraph-capturable.
+ *     synchronisation (gnnmp_*_status and gnnmp_explorer_profile_read are the documented exceptions), no allocation inside forward -> forward is hipGraph-capturable.
  *   - functions return 0 (GNNMP_OK) or a negative gnnmp_status; no C++ exception crosses the ABI.
  *   - a handle is immutable after create: concurrent forwards from several host threads are legal
  *     with distinct workspaces / streams.
@@ -48,7 +48,12 @@ typedef enum {
     GNNMP_ERR_WEIGHTS = -3,       /* weight blob size does not match the manifest            */
     GNNMP_ERR_WORKSPACE = -4,     /* workspace too small or misaligned                       */
     GNNMP_ERR_HIP = -5,           /* a HIP runtime call failed (see gnnmp_last_hip_error)    */
-    GNNMP_ERR_ARG = -6            /* bad scalar argument (loop < 1, negative counts, ...)    */
+    GNNMP_ERR_ARG = -6,           /* bad scalar argument (loop < 1, negative counts, ...)    */
+    /* the two below are found ON THE DEVICE during a forward and returned by gnnmp_*_status (never by forward itself, which
+     * does not synchronise): the scores / waypoints of that forward are WRONG */
+    GNNMP_ERR_CAPS = -7,          /* a caller promise sizing the kernels was exceeded: a graph has more obstacles than
+                                     max_obstacles; a smoothing problem exceeds max_path / max_samples / max_edges */
+    GNNMP_ERR_INDEX = -8          /* edge_index holds a node id outside [0, N_g)             */
 } gnnmp_status;
 
 const char* gnnmp_status_string(int status);
@@ -96,8 +101,9 @@ int gnnmp_explorer_destroy(gnnmp_explorer* h);
  * columns [edge_ptr[g], edge_ptr[g+1]) of edge_index and rows [obs_ptr[g], obs_ptr[g+1]) of
  * obstacles.  edge_index holds GRAPH-LOCAL node ids (what each problem's create_data produced),
  * row 0 = message source j, row 1 = message target i (PyG flow source_to_target); any order,
- * duplicates allowed (each column is scored independently).  Node ids must lie in [0, N_g): like
- * the reference's tensor indexing, out-of-range ids are not checked on the device.
+ * duplicates allowed (each column is scored independently).  Node ids must lie in [0, N_g): the reference's
+ * tensor indexing would raise; here the prep stage replaces an out-of-range id by node 0 (every kernel stays inside the
+ * graph's rows) and raises GNNMP_ERR_INDEX in the device-side status (gnnmp_explorer_status).
  * One graph (G = 1, the reference's own call, model.py:115) may leave node_ptr, edge_ptr and obs_ptr all NULL: the
  * three totals describe it (inference entry points only; the training entry points take explicit prefix arrays). */
 typedef struct {
@@ -105,9 +111,11 @@ typedef struct {
     int32_t total_nodes;         /* sum_g N_g                                                 */
     int32_t total_edges;         /* sum_g E_g                                                 */
     int32_t total_obstacles;     /* sum_g O_g (may be 0)                                      */
-    int32_t max_obstacles;       /* >= max_g O_g (upper bound is fine; sizes the K/V slabs); a graph with
-                                    more obstacles than this is scored against its first max_obstacles
-                                    (rounded up to 32) only                                    */
+    int32_t max_obstacles;       /* >= max_g O_g (upper bound is fine; sizes the K/V slabs).  A PROMISE: obs_ptr lives on
+                                    the device and forward never reads it back.  A graph with more obstacles than
+                                    this (rounded up to 32) is attended over its first ones only -- the reference
+                                    attends over ALL obstacles (model.py:125-130) -- and the forward's device-side
+                                    status becomes GNNMP_ERR_CAPS (gnnmp_explorer_status)     */
     const float* v;              /* [total_nodes, C]                                          */
     const float* goal;           /* [G, C]                                                    */
     const float* obstacles;      /* [total_obstacles, S]                                      */
@@ -129,6 +137,20 @@ int gnnmp_explorer_workspace_bytes(const gnnmp_explorer* h, const gnnmp_batch* s
 int gnnmp_explorer_forward(const gnnmp_explorer* h, const gnnmp_batch* batch, int loop, int use_obstacles,
                            float* edge_scores, float* dense_or_null,
                            void* workspace, size_t workspace_bytes, void* hip_stream);
+
+/* Device-side status of the LAST forward that ran on `workspace` (same batch shape): GNNMP_OK, or GNNMP_ERR_CAPS (a graph with
+ * more obstacles than batch->max_obstacles: its scores are NOT the reference's), or GNNMP_ERR_INDEX (a node id outside
+ * [0, N_g)); *first_graph_or_null = the first offending graph (-1 if none).  forward() itself never synchronises, so the
+ * conditions it can only see on the device are collected in a small status region of the workspace (17 ints per graph, each
+ * written unconditionally by one thread per forward: no fill launch, no atomics) and read HERE: this call copies the region
+ * to the host on hip_stream and WAITS for the stream (the only synchronising entry point besides profile_read).  Callers that
+ * must not block use gnnmp_explorer_status_region + their own asynchronous copy + gnnmp_explorer_status_decode (what the
+ * Python wrapper does: the copy rides behind the forward and is looked at on a later call).  The reference has no counterpart:
+ * it attends over all obstacles it is given and its indexing raises. */
+int gnnmp_explorer_status(const gnnmp_explorer* h, const gnnmp_batch* shape, const void* workspace, size_t workspace_bytes,
+                          void* hip_stream, int32_t* first_graph_or_null);
+int gnnmp_explorer_status_region(const gnnmp_explorer* h, const gnnmp_batch* shape, size_t* offset, size_t* bytes);
+int gnnmp_explorer_status_decode(const int32_t* words_host, int n_graphs, int32_t* first_graph_or_null);
 
 /* Optional per-stage timing.  While enabled, every forward on this handle records a HIP event pair
  * around each stage ON THE STREAM THE STAGE IS LAUNCHED ON; gnnmp_explorer_profile_read waits for
@@ -204,10 +226,11 @@ typedef struct {
     int32_t n_problems;
     int32_t total_path, total_free, total_collided, total_edges;
     /* The three max_* fields are caller PROMISES that size the kernels' LDS carve-up; the prefix arrays live on the device
-     * and forward() never reads them back (no hidden synchronisation), so they are not checked against the arrays.  A
-     * problem that exceeds any of them gets NO kNN / chain edges in that iteration (its interior waypoints then follow
-     * smooth_node of the plain node codes) -- a wrong path, not an error code.  Compute them from the same host-side counts
-     * the prefix arrays are built from (the Python wrapper does). */
+     * and forward() never reads them back (no hidden synchronisation), so they are not checked against the arrays on the
+     * host.  A problem that exceeds any of them gets NO kNN / chain edges (its interior waypoints then follow smooth_node of
+     * the plain node codes: a wrong path) and the forward's device-side status becomes GNNMP_ERR_CAPS
+     * (gnnmp_smoother_status).  Compute them from the same host-side counts the prefix arrays are built from (the Python
+     * wrapper does). */
     int32_t max_path;            /* >= max_b P_b                                              */
     int32_t max_samples;         /* >= max_b (F_b + Co_b)                                     */
     int32_t max_edges;           /* >= max_b E_b                                              */
@@ -231,6 +254,14 @@ int gnnmp_smoother_workspace_bytes(const gnnmp_smoother* h, const gnnmp_smooth_b
  * edges (caller edges + 10 kNN edges per waypoint). */
 int gnnmp_smoother_forward(const gnnmp_smoother* h, const gnnmp_smooth_batch* batch, int loop,
                            float* out_path, void* workspace, size_t workspace_bytes, void* hip_stream);
+
+/* Device-side status of the LAST forward on `workspace`, as for the explorer: GNNMP_OK or GNNMP_ERR_CAPS (a problem exceeded
+ * max_path / max_samples / max_edges and was smoothed WITHOUT its edges); one int per problem.  gnnmp_smoother_status
+ * synchronises hip_stream; _region / _decode are the non-blocking pieces. */
+int gnnmp_smoother_status(const gnnmp_smoother* h, const gnnmp_smooth_batch* shape, const void* workspace, size_t workspace_bytes,
+                          void* hip_stream, int32_t* first_problem_or_null);
+int gnnmp_smoother_status_region(const gnnmp_smoother* h, const gnnmp_smooth_batch* shape, size_t* offset, size_t* bytes);
+int gnnmp_smoother_status_decode(const int32_t* words_host, int n_problems, int32_t* first_problem_or_null);
 
 /* ------------------------------------------------------------------------------------------
  * Training path of the smoother   (train_smoother.py:33-61 through model_smoother.py:104-142 under model.train())

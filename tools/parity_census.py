@@ -12,10 +12,14 @@ in fp32 AND fp64) on EVERY graph of
 
 and prints, per workload, the histogram over graphs of max|gpu - ref64| (the distance to the exact result), of the reference's
 own fp32-vs-fp64 distance `own`, and of max|gpu - ref32|; the worst graphs; how many graphs exceed 1e-5 against fp64; and on
-how many graphs the GPU is further from the exact result than the reference's own fp32 run.
-tests/test_parity_census_gpu.py asserts the per-workload bar through the same functions.
+how many graphs the GPU is further from the exact result than the reference's own fp32 run.  `ref32` is the oracle's
+MATERIALISING form (model.py:178-179 literally: the form that reproduces the reference's recorded fp32 scores bit for bit,
+tests/test_oracle_golden.py), not the contracted one.  Both readings of north_star's "within 1e-5 fp32" are printed per
+workload as ELEMENT counts: |gpu - ref32| > 1e-5, > 2e-5, and the failures of allclose(rtol = 1e-5, atol = 1e-5) against ref32
+(the same three for the reference's own fp32 run against fp64 next to them, as the yardstick).
+tests/test_parity_census_gpu.py asserts the per-workload bar through the same functions, incl. the ABSOLUTE ceilings below.
 
-    python tools/parity_census.py [--quick] > profiles/r04_parity_census.txt
+    python tools/parity_census.py [--quick] > profiles/r05_parity_census.txt
 """
 import os
 import sys
@@ -40,6 +44,21 @@ WORKLOADS = [                                   # (name, env, nodes, k1, graphs,
     ('cfg4  ur5    N=1000 k1=8', 'ur5', 1000, 8, 16, 7000),
     ('cfg4  kuka7  N=1000 k1=8', 'kuka7', 1000, 8, 16, 8000),
 ]
+# Absolute ceilings per workload (round 5; VERDICT r4 weak #1: the quantile-matched bar alone let a 4x regression through at cfg 2):
+# max over graphs of max|gpu - ref64| <= 1.25 x the maximum measured in round 4 (profiles/r04_parity_census.txt), the 7-DoF arm
+# shapes at the bare north_star 1e-5; and the number of scores further than 1e-5 from fp64 <= 1.5 x the measured count + 5.
+CEILINGS = {                                    # name: (max|gpu - ref64| ceiling, measured r4 max, elements > 1e-5 vs fp64 measured r4)
+    'cfg2  maze2  N=1000 k1=8': (2.5e-5, 2.007e-5, 430),
+    'cfg3  kuka7  N=2000 k1=10': (1.0e-5, 7.056e-6, 0),
+    'cfg5  kuka14 N=5000 k1=16': (1.47e-5, 1.170e-5, 12),
+    'cfg4  maze2  N=1000 k1=8': (1.85e-5, 1.477e-5, 29),
+    'cfg4  snake7 N=1000 k1=8': (1.26e-5, 1.007e-5, 1),
+    'cfg4  ur5    N=1000 k1=8': (2.28e-5, 1.823e-5, 136),
+    'cfg4  kuka7  N=1000 k1=8': (1.0e-5, 5.322e-6, 0),
+}
+# workloads on which allclose(gpu, ref32, rtol = 1e-5, atol = 1e-5) holds on EVERY score today (profiles/r05_parity_census.txt);
+# asserted to stay at zero failures
+ALLCLOSE_HOLDS = set()
 EDGES = [0.0, 1e-6, 2e-6, 4e-6, 6e-6, 8e-6, 1e-5, 1.5e-5, 2e-5, 3e-5, 1.0]
 
 
@@ -60,11 +79,22 @@ def census(env, nodes, k1, n_graphs, seed0, loop=5, mlp_dtype='fp32', device=DEV
     rows = []
     for g, s in zip(graphs, parts):
         v, goal, obs, ei = (g[k].cpu() for k in ('v', 'goal', 'obstacles', 'edge_index'))
-        r32 = ref_cpu.explorer_forward(w, v, goal, obs, ei, loop).double()
+        r32 = ref_cpu.explorer_forward(w, v, goal, obs, ei, loop, materialize=True).double()      # the bit-exact pin of the reference
         r64 = ref_cpu.explorer_forward(w64, v.double(), goal.double(), obs.double(), ei, loop)
-        d64 = (s - r64).abs()
-        rows.append((d64.max().item(), (s - r32).abs().max().item(), (r32 - r64).abs().max().item(), int((d64 > 1e-5).sum()), int(ei.shape[1])))
+        d64, d32, o = (s - r64).abs(), (s - r32).abs(), (r32 - r64).abs()
+        rows.append(Row((d64.max().item(), d32.max().item(), o.max().item(), int((d64 > 1e-5).sum()), int(ei.shape[1])),
+                        n32_1e5=int((d32 > 1e-5).sum()), n32_2e5=int((d32 > 2e-5).sum()),
+                        n32_allclose=int((d32 > 1e-5 + 1e-5 * r32.abs()).sum()),
+                        own_1e5=int((o > 1e-5).sum()), own_2e5=int((o > 2e-5).sum()), own_allclose=int((o > 1e-5 + 1e-5 * r64.abs()).sum())))
     return rows
+
+
+class Row(tuple):
+    """(err64, err32, own, #elements > 1e-5 vs ref64, E) of one graph + the element counts of both north_star readings."""
+    def __new__(cls, t, **counts):
+        r = super().__new__(cls, t)
+        r.counts = counts
+        return r
 
 
 def hist(vals):
@@ -91,7 +121,22 @@ def report(name, rows):
         st['med_err64'], st['med_own'], st['n_worse_than_ref'], n))
     print('    quantile-matched bar max(1e-5, 1.25 x own): ' + '; '.join('%s %.3e <= %.3e %s' % (k, st['errs'][k], st['bars'][k], 'ok' if st['errs'][k] <= st['bars'][k] else 'EXCEEDED')
                                                                          for k in ('median', 'p90', 'max')))
+    tot = {k: sum(r.counts[k] for r in rows) for k in rows[0].counts}
+    ne = sum(r[4] for r in rows)
+    print('    elementwise, of %d scores:  |gpu - ref32| > 1e-5: %d   > 2e-5: %d   allclose(rtol 1e-5, atol 1e-5) failures vs ref32: %d' % (
+        ne, tot['n32_1e5'], tot['n32_2e5'], tot['n32_allclose']))
+    print('    yardstick (the reference\'s own fp32 run against fp64):  |ref32 - ref64| > 1e-5: %d   > 2e-5: %d   allclose failures: %d' % (
+        tot['own_1e5'], tot['own_2e5'], tot['own_allclose']))
+    if name in CEILINGS:
+        c = CEILINGS[name]
+        print('    absolute ceiling: max|gpu - ref64| %.3e <= %.3e %s;  elements over 1e-5 vs fp64 %d <= %d %s' % (
+            st['max_err64'], c[0], 'ok' if st['max_err64'] <= c[0] else 'EXCEEDED', sum(r[3] for r in rows), int(1.5 * c[2]) + 5,
+            'ok' if sum(r[3] for r in rows) <= int(1.5 * c[2]) + 5 else 'EXCEEDED'))
     return len(over)
+
+
+def totals(rows):
+    return {k: sum(r.counts[k] for r in rows) for k in rows[0].counts}
 
 
 def stats(rows):
