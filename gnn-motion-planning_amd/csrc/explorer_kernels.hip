@@ -1349,6 +1349,14 @@ struct XcdWalk {
         end = min(n_groups, (xcd + 1) * per);
         step = nb;
     }
+    // the same walk for a VIRTUAL workgroup: index q among the nb (virtual) workgroups of XCD xcd (mp_fused_w8: two four-wave halves
+    // of one real workgroup)
+    __device__ __forceinline__ XcdWalk(int n_groups, int xcd, int q, int nb) {
+        const int per = (n_groups + 7) >> 3;
+        cur = xcd * per + q;
+        end = min(n_groups, (xcd + 1) * per);
+        step = nb;
+    }
     __device__ __forceinline__ bool valid() const { return cur < end; }
     __device__ __forceinline__ void next() {
         if (snake) snake_set(ns, nspan);
@@ -1684,10 +1692,13 @@ template <int D, int P, int COOP>
 #ifndef GNNMP_MP_WGS32B
 #define GNNMP_MP_WGS32B 2     // d = 32, bf16 operands: three workgroups per CU fit the LDS, but at 168 registers the kernel spills (0.54 vs 0.51 ms at the configs[4] shape)
 #endif
+#ifndef GNNMP_MP_NODEW_LDS64
+#define GNNMP_MP_NODEW_LDS64 0  // experiment: d = 64 bf16, the node phase's weights (40 KB) in LDS as well -> ONE 4-wave workgroup per CU
+#endif
 #ifndef GNNMP_MP_DEEP32
 #define GNNMP_MP_DEEP32 0     // experiment switch: K_e two chunks ahead at d = 32 fp32 (measured slower: 0.906 vs 0.875 ms)
 #endif
-__global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 && P != 1) ? 1 : ((P == 2 || D > 32) ? 2 : (P == 1 ? GNNMP_MP_WGS32B : GNNMP_MP_WGS32))) : 1) void mp_fused_kernel(MpFusedParams p) {
+__global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 && (P != 1 || GNNMP_MP_NODEW_LDS64)) ? 1 : ((P == 2 || D > 32) ? 2 : (P == 1 ? GNNMP_MP_WGS32B : GNNMP_MP_WGS32))) : 1) void mp_fused_kernel(MpFusedParams p) {
     constexpr int NT = D / 32;
     constexpr bool kCoop = COOP > 1;
     // few tiles, d = 32: the node phase is spread over waves (below); at d = 64 the eight-wave workgroup has 256 registers per
@@ -1711,13 +1722,26 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
     }
 #ifdef GNNMP_MP_TRACE
     // diagnostics build: [0] wave start, then per tile: start, end of the edge phase, end of the node phase (100 MHz clock)
-    long long* trc = p.trace ? p.trace + ((size_t)blockIdx.x * (blockDim.x >> 6) + wave) * 8 : nullptr;
-    int trc_n = 0;
-#define GNNMP_TRC() do { if (trc && lane == 0 && trc_n < 8) trc[trc_n] = wall_clock64(); ++trc_n; } while (0)
-    if (trc && lane == 0) { for (int i = 0; i < 8; ++i) trc[i] = 0; }
+    // 32 slots per wave: [0] start, [1 + 5 k .. 5 + 5 k] tile k < 5 (start, edge end, H, Y, node end), [28] HW_ID, [29] / [30] the
+    // first two tile ids, [31] wave end
+    long long* trc = p.trace ? p.trace + ((size_t)blockIdx.x * (blockDim.x >> 6) + wave) * 32 : nullptr;
+    int trc_n = 0, trc_tiles = 0;
+#define GNNMP_TRC() do { if (trc && lane == 0 && trc_n < 26) trc[trc_n] = wall_clock64(); ++trc_n; } while (0)
+#define GNNMP_TRC_TILE(t) do { if (trc && lane == 0 && trc_tiles < 2) trc[29 + trc_tiles] = (t); ++trc_tiles; } while (0)
+#define GNNMP_TRC_END() do { if (trc && lane == 0) trc[31] = wall_clock64(); } while (0)
+    if (trc && lane == 0) {
+        for (int i = 0; i < 32; ++i) trc[i] = 0;
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        trc[28] = (long long)hw | ((long long)xcc << 32);
+    }
     GNNMP_TRC();
 #else
 #define GNNMP_TRC() do {} while (0)
+#define GNNMP_TRC_TILE(t) do {} while (0)
+#define GNNMP_TRC_END() do {} while (0)
 #endif
     float* base = lds + ((LE::size + 3) & ~3);
     float* agg = kCoop ? base : base + wave * (32 * D + 32 + 2 * G::STAGE_FLOATS);                   // [32][D]
@@ -1753,7 +1777,7 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
 #ifndef GNNMP_MP_NODEW_LDS
 #define GNNMP_MP_NODEW_LDS 1
 #endif
-    constexpr bool kNodeWInLds = GNNMP_MP_NODEW_LDS && D == 32 && P != 2;          // bf16x3: 31 KB, would leave one workgroup per CU
+    constexpr bool kNodeWInLds = GNNMP_MP_NODEW_LDS && (D == 32 || (GNNMP_MP_NODEW_LDS64 && D == 64 && P == 1 && COOP == 1)) && P != 2;          // bf16x3: 31 KB, would leave one workgroup per CU
     float* wnl = lds + ((LE::size + 3) & ~3) + mp_lds_floats<D, P, COOP>();
     if constexpr (kNodeWInLds) stage(wnl, p.wn, LN::size);
     __syncthreads();
@@ -1832,6 +1856,7 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
         const int end = __builtin_amdgcn_readlane(rb + dg, 31);
         const int n0 = p.node_ptr_pad[tg];
         GNNMP_TRC();
+        GNNMP_TRC_TILE(tile);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the previous job's LDS reads are done
         if constexpr (kCoop) __syncthreads();                    // ... by every wave of the workgroup
         // K_e streams from HBM: PF tiles of a chunk are requested KD chunks ahead and wait in registers
@@ -2308,6 +2333,317 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
         }
         GNNMP_TRC();
     }
+    GNNMP_TRC_END();
+}
+
+
+// =====================================================================================================
+// mp_fused_w8: the same message-passing iteration for d = 64 with bf16 operands and large batches, re-cut around the LDS
+// budget (round 5).  What bounded mp_fused_kernel<64, 1, 1> was its NODE phase: 16 of the ~60 us of a tile, almost all of
+// it waiting for the five 64 x 64 matrices (40 KB) that every tile fetched from L2 as MFMA operands, one dependent round
+// trip per layer -- they did not fit the LDS next to eight waves' tiles (8 x 16.1 KB + 48.4 KB = 177 KB).  Here they do:
+//   * the tile's B' rows (W_dst X: the target's term of the tile's incoming edges) never go to LDS: they stay in 16 packed
+//     registers in the layout the MFMA produced them in (lane = row) and every chunk fetches the row of ITS edge's target
+//     with ds_bpermute (the crossbar of the LDS pipe, no LDS storage): same values, 4 KB per wave freed;
+//   * ONE workgroup of eight waves per CU (the same eight waves per CU as before), so ONE copy of the weights: message
+//     layer 8.4 KB + node phase 40.3 KB + (last iteration only) the standard W_dst 8 KB + 8 x (aggregation tile 8 KB +
+//     offsets + A-row stage 4 KB) = 155.7 KB of the 160;
+//   * with only the A stage and the (by then consumed) aggregation tile free during the node phase, the tile's rows move
+//     through those: X rows in through the A stage (requested under the last chunk's MFMAs), the fp32 R rows in through
+//     the aggregation tile once W_la has read it, X' / A' / PT out as whole rows through the A stage and the two halves
+//     of the aggregation tile.
+// The two four-wave halves of the workgroup behave like two workgroups of mp_fused_kernel (virtual index 2 b + half):
+// same walk over the four-tile groups (XCD eighths, resident workgroups on the heavy / light snake), no barrier after
+// the weights are staged.  Same arithmetic in the same order on the same values as mp_fused_kernel<64, 1, 1>: the scores
+// are bit-identical (tests/test_full_size_bf16_gpu.py compares the two through GNNMP_MP_W8=0).
+// =====================================================================================================
+template <int D>
+__host__ __device__ constexpr int mp_w8_lds_floats() {
+    return ((MpEBlob<D, 1>::size + 3) & ~3) + ((MpNBlob<D, 1>::size + 3) & ~3) + MpNBlob<D, 1>::T + 8 * (32 * D + 32 + RowGeom<D, 1>::STAGE_FLOATS);
+}
+
+template <int D>
+__global__ __launch_bounds__(512, 1) void mp_fused_w8_kernel(MpFusedParams p) {
+    constexpr int P = 1, NT = D / 32;
+    using LE = MpEBlob<D, P>;
+    using LN = MpNBlob<D, P>;
+    using G = RowGeom<D, P>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* wl = lds;                                             // MpEBlob (message layer)
+    float* wnl = lds + ((LE::size + 3) & ~3);                    // MpNBlob (node phase) of THIS iteration
+    float* wm3x = wnl + ((LN::size + 3) & ~3);                   // last iteration: the standard W_dst (its blob holds the policy matrix there)
+    float* base = wm3x + LN::T;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
+    const int sub = wave >> 2, w4 = wave & 3;
+    float* agg = base + wave * (32 * D + 32 + G::STAGE_FLOATS);  // [32][D] fp32; X rows in / R rows in / A' and PT rows out pass through it
+    int* dl = reinterpret_cast<int*>(agg + 32 * D);              // [32] agg row offsets (floats) of this chunk's targets
+    float* astage = agg + 32 * D + 32;                           // gathered A rows of the current chunk; X rows in / X' rows out
+    // virtual four-wave workgroup (XCD vx, index vq of vU on it)
+    const int vx = blockIdx.x & 7, vq = (blockIdx.x >> 3) * 2 + sub, vU = (gridDim.x >> 3) * 2;
+#ifdef GNNMP_MP_TRACE
+    long long* trc = p.trace ? p.trace + ((size_t)blockIdx.x * (blockDim.x >> 6) + wave) * 32 : nullptr;
+    int trc_n = 0, trc_tiles = 0;
+    if (trc && lane == 0) {
+        for (int i = 0; i < 32; ++i) trc[i] = 0;
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        trc[28] = (long long)hw | ((long long)xcc << 32);
+    }
+    GNNMP_TRC();
+#endif
+    stage(wl, p.we, LE::size);
+    stage(wnl, p.wn, LN::size);
+    if (p.last) stage(wm3x, p.wn_std + LN::m3, LN::T);
+    __syncthreads();                                             // the only workgroup barrier
+    const float* wm3 = p.last ? wm3x : wnl + LN::m3;
+    if (p.tpw > 0 && p.order != 2) {                             // virtual workgroups of the unused tail of the padded tile space
+        const int per = ((((p.node_ptr_pad[p.G] >> 7) + p.tpw - 1) / p.tpw) + 7) >> 3;
+        if (vq >= per) { GNNMP_TRC_END(); return; }
+    }
+    float bias[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) bias[t] = wl[LE::b2 + (t * 2 + ((j >> 2) & 1)) * 16 + (j & 3) + 4 * (j >> 3)];
+    const int real_tiles = min(p.n_tiles, p.node_ptr_pad[p.G] >> 5);
+    XcdWalk wk((real_tiles + 3) / 4, vx, vq, vU);
+    if (p.order == 2) {
+        const int blocks = p.node_ptr_pad[p.G] >> 8, perb = (blocks + 7) >> 3;
+        wk.snake = 1;
+        wk.U = vU;
+        wk.u = vq;
+        wk.blk0 = vx * perb;
+        wk.B = max(0, min(perb, blocks - wk.blk0));
+        wk.span = p.blk_span;
+        wk.k = 0;
+        const int s0 = wk.pos(0);
+        int2 sp0 = make_int2(0, 0);
+        if (s0 < 2 * wk.B) sp0 = p.blk_span[wk.blk_of(s0)];
+        wk.cur = 0;
+        wk.snake_set(s0, sp0);
+        wk.ns = 2 * wk.B;
+    } else {
+        const int real_wgs = ((p.node_ptr_pad[p.G] >> 7) + p.tpw - 1) / p.tpw;
+        const int per = (real_wgs + 7) >> 3;
+        const int wg = vq < per ? vx * per + vq : 8 * per + (vq - per) * 8 + vx;
+        wk.cur = wg * p.tpw;
+        wk.end = min((p.n_tiles + 3) / 4, wk.cur + p.tpw);
+        wk.step = 1;
+    }
+    for (; wk.valid(); wk.next()) {
+        const int tile = wk.cur * 4 + w4;
+        if (wk.snake) wk.snake_prefetch();
+        if (tile >= p.n_tiles) continue;
+        const int tg = p.ntile_graph[tile];
+        if (tg < 0) continue;
+        const int t0 = tile * 32;
+        const int node = t0 + j;
+        const int rb = p.row_beg[node], dg = p.deg[node];
+        const int beg = __builtin_amdgcn_readfirstlane(rb);
+        const int end = __builtin_amdgcn_readlane(rb + dg, 31);
+        const int n0 = p.node_ptr_pad[tg];
+        GNNMP_TRC();
+        GNNMP_TRC_TILE(tile);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the previous job's LDS reads (rows on their way out) are done
+        constexpr int PF = NT, KD = 2, LPT = 2, STEP = 32;
+        KeRaw<P> qa[PF], qb[PF];
+        auto ke_fetch = [&](int cc, KeRaw<P> (&dst)[PF]) {      // wave-uniform cc; unconditional (see mp_fused_kernel)
+#pragma unroll
+            for (int t = 0; t < PF; ++t) {
+                const int sl = cc + j < end ? cc + j : beg;
+                load_edge_slot_raw<P, NT>(p.Ke, sl, h, t, dst[t]);
+            }
+        };
+        // ---- tile start: B' = W_dst X of the tile's own rows, kept in registers (packed bf16, lane = row)
+        int pre_rec_c = 0, pre_rec_n = 0;
+        int l0 = lane;                                           // (laundered per tile: see the node phase)
+        asm volatile("" : "+v"(l0));
+        dma_rows<D, 1>(p.X, [&](int sr) { return t0 + sr; }, agg, l0);            // X rows (bf16, 4 KB) through the aggregation tile
+        if (beg + j < end) pre_rec_c = p.rec32[beg + j];
+        if (beg + 32 + j < end) pre_rec_n = p.rec32[beg + 32 + j];
+        wait_vmcnt<0>();
+        // The X rows leave the LDS for registers and the aggregation tile is reset BEFORE anything else is requested: an LDS access
+        // the compiler generates while an LDS-DMA is in flight is guarded by s_waitcnt vmcnt(0) (it cannot tell the A stage from
+        // this tile), which would put the first chunk's A rows and K_e behind a full round trip at every tile start
+        StageRaw<1> xr[NT];
+#pragma unroll
+        for (int it = 0; it < NT; ++it) read_stage_raw<D, 1>(agg, j, h, it, xr[it]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();                        // both halves of every X row have been read
+        {
+            const f32x4 ninf = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};      // agg tile <- -inf
+#pragma unroll
+            for (int q = 0; q < D / 8; ++q) *reinterpret_cast<f32x4*>(agg + j * D + h * (D / 2) + q * 4) = ninf;
+        }
+        const int first = beg;
+        auto src_row = [&](int rec, bool valid) { return valid ? n0 + (rec & 0x7ffffff) : t0; };
+        int rec_c = pre_rec_c, rec_n = pre_rec_n;
+        if (first < end) {                                       // the first chunk's A rows and the first two chunks' K_e travel under the MFMAs below
+            const int mine_row = src_row(rec_c, first + j < end);
+            dma_rows<D, P>(p.A, [&](int sr) { return __builtin_amdgcn_ds_bpermute(sr * 4, mine_row); }, astage, lane);
+            ke_fetch(first, qa);
+            ke_fetch(first + STEP, qb);
+        }
+        BOp<P> bpk[NT];
+        {
+            f32x16 z[NT];
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt) z[tt] = splat16(0.f);
+            linear_acc_stream<P, NT, false>(wm3, [&](int it, f32x16& x) { expand_stage_raw<1>(xr[it], x); }, z, lane);
+            make_ops<P, NT>(z, bpk);                            // rounded to bf16 exactly like the rows mp_fused_kernel writes into its B stage
+        }
+        bool x_requested = false;
+        auto chunk = [&](const int c0, KeRaw<P> (&cur)[PF]) {
+            wait_vmcnt<LPT * PF>();                             // this chunk's rows and K_e have landed; the next chunk's K_e may be in flight
+            asm volatile("" : "+v"(rec_n), "+v"(rec_c));
+#pragma unroll
+            for (int t = 0; t < PF; ++t) asm volatile("" : "+v"(cur[t].lo), "+v"(cur[t].hi));
+            const int slot = c0 + j;
+            const bool valid = slot < end;
+            const int rec = rec_c;
+            const int dloc = valid ? ((rec >> 27) & 31) : 0;
+            if (h == 0) dl[j] = dloc * D;
+            f32x16 M[NT];
+#pragma unroll
+            for (int ot = 0; ot < NT; ++ot) M[ot] = splat16(bias[ot]);
+            StageRaw<P> araw[NT];
+            const int baddr = (dloc + 32 * h) * 4;              // the lane that holds row dloc's features of THIS lane's half
+#pragma unroll
+            for (int it = 0; it < NT; ++it) read_stage_raw<D, P>(astage, j, h, it, araw[it]);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // the next chunk's A rows -- or, behind the last chunk, the tile's X rows for the node phase (the same number of DMA
+            // instructions) -- and the record of the chunk after
+            rec_c = rec_n;
+            if (c0 + STEP < end) {                               // wave-uniform
+                const int mine_row = src_row(rec_c, c0 + STEP + j < end);
+                dma_rows<D, P>(p.A, [&](int sr) { return __builtin_amdgcn_ds_bpermute(sr * 4, mine_row); }, astage, lane);
+            } else {
+                int lx = lane;                                   // (laundered: these addresses must not be hoisted out of the chunk loop)
+                asm volatile("" : "+v"(lx));
+                dma_rows<D, 1>(p.X, [&](int sr) { return t0 + sr; }, astage, lx);
+                x_requested = true;
+            }
+            {
+                const int ri = c0 + 2 * STEP + j;
+                rec_n = p.rec32[ri < end ? ri : end - 1];
+            }
+            linear_acc_stream<P, NT, true, true>(wl + LE::w2, [&](int it, f32x16& x) {
+                // the target row's features of this tile: ds_bpermute moves registers through the LDS crossbar, it reads no LDS
+                // memory, so the compiler does not guard it against the rows in flight to the A stage
+                StageRaw<P> braw;
+                {
+                    const i32x4 lo = __builtin_bit_cast(i32x4, bpk[it].lo), hi = __builtin_bit_cast(i32x4, bpk[it].hi);
+                    i32x4 glo, ghi;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        glo[w] = __builtin_amdgcn_ds_bpermute(baddr, lo[w]);
+                        ghi[w] = __builtin_amdgcn_ds_bpermute(baddr, hi[w]);
+                    }
+                    const bf16x8 blo = __builtin_bit_cast(bf16x8, glo), bhi = __builtin_bit_cast(bf16x8, ghi);
+                    braw.q[0] = __builtin_shufflevector(blo, blo, 0, 1, 2, 3);
+                    braw.q[1] = __builtin_shufflevector(blo, blo, 4, 5, 6, 7);
+                    braw.q[2] = __builtin_shufflevector(bhi, bhi, 0, 1, 2, 3);
+                    braw.q[3] = __builtin_shufflevector(bhi, bhi, 4, 5, 6, 7);
+                }
+                f32x16 a, b;
+                expand_raw<P>(cur[it], x);
+                expand_stage_raw<P>(araw[it], a);
+                expand_stage_raw<P>(braw, b);
+                if (it == NT - 1) ke_fetch(c0 + KD * STEP, cur);
+                x += a + b;
+            }, M, lane);
+            if (end - c0 < 32) {                                 // the last, partial chunk: pad edges aggregate -inf
+                const int nv = end - c0;
+#pragma unroll
+                for (int ot = 0; ot < NT; ++ot)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) M[ot][r] = phi(r, h) < nv ? M[ot][r] : -INFINITY;
+            }
+            __builtin_amdgcn_wave_barrier();
+            i32x4 o4[4];
+            asm volatile("s_nop 15\n\ts_nop 7\n\tds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:32\n\tds_read_b128 %2, %4 offset:64\n\t"
+                         "ds_read_b128 %3, %4 offset:96\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(o4[0]), "=&v"(o4[1]), "=&v"(o4[2]), "=&v"(o4[3])
+                         : "v"(lds_addr(dl) + 16u * h), "v"(M[0][0]), "v"(M[NT - 1][15]) : "memory");
+            const unsigned agg0 = lds_addr(agg) + 4u * j;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const unsigned a = agg0 + 4u * (unsigned)o4[r >> 2][r & 3];
+#pragma unroll
+                for (int ot = 0; ot < NT; ++ot)
+                    asm volatile("ds_max_f32 %0, %1 offset:%2" ::"v"(a), "v"(M[ot][r]), "n"(ot * 128) : "memory");
+            }
+            __builtin_amdgcn_wave_barrier();
+        };
+        {
+            int c0 = first;
+            for (; c0 + STEP < end; c0 += 2 * STEP) { chunk(c0, qa); chunk(c0 + STEP, qb); }
+            if (c0 < end) chunk(c0, qa);
+        }
+        GNNMP_TRC();
+        // ---- node phase, every matrix in LDS
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's aggregation atomics have been performed
+        // (the per-lane address vectors of the row movers below are invariant across tiles; hoisted out of the tile loop they cost
+        // ~40 registers that then spill around the chunk loop: the lane id is laundered per tile so that they are recomputed here)
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        if (!x_requested) dma_rows<D, 1>(p.X, [&](int sr) { return t0 + sr; }, astage, ln);     // a tile without incoming edges
+        f32x16 H[NT];
+        load_vec<NT>(wnl + LN::bl, H, lane);
+        wait_vmcnt<0>();
+        linear_acc_stream<P, NT, false>(wnl + LN::wlx, [&](int it, f32x16& x) { read_stage_tile<D, 1>(astage, j, h, it, x); }, H, lane);
+        linear_acc_stream<P, NT, false>(wnl + LN::wla, [&](int it, f32x16& x) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(agg + j * D + it * 32 + q * 8 + h * 4);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) x[q * 4 + c] = dg == 0 ? 0.f : a[c];      // torch_scatter: no incoming edge -> 0
+            }
+        }, H, lane);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();                        // the aggregation tile has been read by every lane: it takes the R rows
+        dma_rows<D, 0>(p.R, [&](int sr) { return t0 + sr; }, agg, ln);
+        GNNMP_TRC();                                             // (diagnostics build) H done
+        if (p.store_h) store_row<NT>(p.Hout + (size_t)node * D, H, h);
+        BOp<P> yop[NT];
+        {
+            f32x16 y[NT];
+            wait_vmcnt<0>();
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt) read_stage_tile<D, 0>(agg, j, h, tt, y[tt]);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            linear_acc_p<P, NT, NT>(wnl + LN::m1, H, y, lane);
+            GNNMP_TRC();                                         // (diagnostics build) Y done
+            __builtin_amdgcn_wave_barrier();
+            write_stage_tiles<D, 1, NT>(astage, j, h, y);        // X' rows (bf16) -> A stage -> whole rows out
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            store_rows_coalesced<D, 1>(p.Xout, (size_t)t0, astage, ln);
+            make_ops<P, NT>(y, yop);
+        }
+        {
+            f32x16 z[NT];
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt) z[tt] = splat16(0.f);
+            linear_acc_ops<P, NT, NT>(wnl + LN::m2, yop, z, lane);
+            write_stage_tiles<D, P, NT>(agg, j, h, z);           // A' rows -> first half of the aggregation tile -> whole rows out
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            store_rows_coalesced<D, P>(p.Aout, (size_t)t0, agg, ln);
+        }
+        if (p.last) {                                            // PT for the policy head (B' is recomputed by the next iteration otherwise)
+            f32x16 z[NT];
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt) z[tt] = splat16(0.f);
+            linear_acc_ops<P, NT, NT>(wnl + LN::m3, yop, z, lane);
+            float* ps = agg + G::STAGE_FLOATS;                   // second half of the aggregation tile
+            write_stage_tiles<D, P, NT>(ps, j, h, z);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            store_rows_coalesced<D, P>(p.Bout, (size_t)t0, ps, ln);
+        }
+        GNNMP_TRC();
+    }
+    GNNMP_TRC_END();
 }
 
 // =====================================================================================================
@@ -2637,7 +2973,7 @@ extern "C" long long gnnmp_debug_mp_trace(long long* dst, long long cap) {
 #endif
 template <int D, int P, int COOP>
 static hipError_t launch_mp_fused_t(const MpFusedParams& p, hipStream_t st) {
-    const size_t lds = (size_t)(((MpEBlob<D, P>::size + 3) & ~3) + mp_lds_floats<D, P, COOP>() + (GNNMP_MP_NODEW_LDS && D == 32 && P != 2 ? ((MpNBlob<D, P>::size + 3) & ~3) : 0)) * sizeof(float);
+    const size_t lds = (size_t)(((MpEBlob<D, P>::size + 3) & ~3) + mp_lds_floats<D, P, COOP>() + (GNNMP_MP_NODEW_LDS && (D == 32 || (GNNMP_MP_NODEW_LDS64 && D == 64 && P == 1 && COOP == 1)) && P != 2 ? ((MpNBlob<D, P>::size + 3) & ~3) : 0)) * sizeof(float);
     hipError_t e = set_lds(mp_fused_kernel<D, P, COOP>, lds);
     if (e != hipSuccess) return e;
     if (COOP == 1) {
@@ -2659,7 +2995,7 @@ static hipError_t launch_mp_fused_t(const MpFusedParams& p, hipStream_t st) {
         {
             static long long* tbuf = nullptr;
             static size_t tcap = 0;
-            const size_t need = (size_t)(groups_cap + 16) * 4 * 8;
+            const size_t need = (size_t)(groups_cap + 16) * 4 * 32;
             if (tcap < need) { if (tbuf) (void)hipFree(tbuf); (void)hipMalloc(&tbuf, need * sizeof(long long)); tcap = need; }
             q.trace = tbuf;
             g_mp_trace = tbuf; g_mp_trace_n = need;
@@ -2697,6 +3033,47 @@ static hipError_t launch_mp_fused_t(const MpFusedParams& p, hipStream_t st) {
     LAUNCH_CHECK();
     return hipSuccess;
 }
+// d = 64, bf16 operands, large batches: eight waves and every matrix in LDS (mp_fused_w8_kernel)
+template <int D>
+static hipError_t launch_mp_fused_w8(const MpFusedParams& p, hipStream_t st) {
+    const size_t lds = (size_t)mp_w8_lds_floats<D>() * sizeof(float);
+    hipError_t e = set_lds(mp_fused_w8_kernel<D>, lds);
+    if (e != hipSuccess) return e;
+    const int groups_cap = (p.n_tiles + 3) / 4;
+    MpFusedParams q = p;
+    q.tpw = 1;
+#ifdef GNNMP_MP_TRACE
+    {
+        static long long* tbuf = nullptr;
+        static size_t tcap = 0;
+        const size_t need = (size_t)(groups_cap + 600) * 4 * 32;
+        if (tcap < need) { if (tbuf) (void)hipFree(tbuf); (void)hipMalloc(&tbuf, need * sizeof(long long)); tcap = need; }
+        q.trace = tbuf;
+        g_mp_trace = tbuf; g_mp_trace_n = need;
+    }
+#endif
+    // one workgroup per CU stays resident (two virtual four-wave workgroups each); more groups than virtual slots -> the resident
+    // workgroups share the groups out on the snake (order 2), else one virtual workgroup per group
+    Residency r{1, 256};
+    {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        static int cus = 0;
+        if (!cus && hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (cus) r.cus = cus;
+    }
+    const int slots = (r.cus / 8) * 8;
+    static const int order_env = getenv("GNNMP_MP_ORDER") ? atoi(getenv("GNNMP_MP_ORDER")) : -1;
+    q.order = groups_cap > 2 * slots && slots >= 8 ? 2 : 0;
+    if (order_env == 0 || order_env == 2) q.order = order_env;
+    if (q.order == 2 && slots < 8) q.order = 0;
+    unsigned grid = q.order == 2 ? (unsigned)slots : (unsigned)((((groups_cap + 1) / 2) + 7) & ~7);
+    if (grid < 8) grid = 8;
+    hipLaunchKernelGGL((mp_fused_w8_kernel<D>), dim3(grid), dim3(512), lds, st, q);
+    LAUNCH_CHECK();
+    return hipSuccess;
+}
+
 // few tiles (single graphs, small batches): eight waves share a tile
 template <int D, int P>
 static hipError_t launch_mp_fused_dp(const MpFusedParams& p, hipStream_t st) {
@@ -2705,6 +3082,11 @@ static hipError_t launch_mp_fused_dp(const MpFusedParams& p, hipStream_t st) {
     // d = 64 with fp32 / bf16x3 operands: four waves per tile instead of eight -- at eight waves a wave has 256 registers and the
     // kernel spilled 116 of them (single 2000-node kuka7 graph: 42 us per launch)
     if constexpr (D > 32 && P != 1) return coop ? launch_mp_fused_t<D, P, 4>(p, st) : launch_mp_fused_t<D, P, 1>(p, st);
+    else if constexpr (D == 64 && P == 1) {
+        static const int w8 = getenv("GNNMP_MP_W8") ? atoi(getenv("GNNMP_MP_W8")) : 1;      // 0: the four-wave form (mp_fused_kernel<64, 1, 1>), for A/B runs and the bit-identity test
+        if (coop) return launch_mp_fused_t<D, P, 8>(p, st);
+        return w8 ? launch_mp_fused_w8<D>(p, st) : launch_mp_fused_t<D, P, 1>(p, st);
+    }
     else return coop ? launch_mp_fused_t<D, P, 8>(p, st) : launch_mp_fused_t<D, P, 1>(p, st);
 }
 hipError_t launch_mp_fused(int D, int P, const MpFusedParams& p_in, hipStream_t st) {

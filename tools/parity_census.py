@@ -58,7 +58,11 @@ CEILINGS = {                                    # name: (max|gpu - ref64| ceilin
 }
 # workloads on which allclose(gpu, ref32, rtol = 1e-5, atol = 1e-5) holds on EVERY score today (profiles/r05_parity_census.txt);
 # asserted to stay at zero failures
-ALLCLOSE_HOLDS = set()
+ALLCLOSE_HOLDS = {'cfg3  kuka7  N=2000 k1=10', 'cfg5  kuka14 N=5000 k1=16', 'cfg4  snake7 N=1000 k1=8', 'cfg4  ur5    N=1000 k1=8',
+                  'cfg4  kuka7  N=1000 k1=8'}
+# the 116-obstacle maze workloads: allclose failures against ref32 measured in round 5 (the reference's own fp32 run fails the same test
+# against fp64 on 30 / 17 scores there); ceiling 1.5 x + 5 like the other counts
+ALLCLOSE_MEASURED = {'cfg2  maze2  N=1000 k1=8': 37, 'cfg4  maze2  N=1000 k1=8': 13}
 EDGES = [0.0, 1e-6, 2e-6, 4e-6, 6e-6, 8e-6, 1e-5, 1.5e-5, 2e-5, 3e-5, 1.0]
 
 
