@@ -136,3 +136,57 @@ def test_cfg5_smoother_batch_both_modes():
                     assert err <= 2e-2, err
             off += p
     print('\nsmooth_14d batch of %d: bf16 vs fp32 max %.2e' % (B, (outs['bf16'] - outs['fp32']).abs().max()))
+
+
+_W8_SNIPPET = r'''
+import hashlib, sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import torch
+from conftest import load_weights
+import gnnmp
+from gnnmp.synth import ENVS, synth_graph
+e = ENVS['kuka7']
+sizes = [300 + 41 * (i %% 23) + 7 * (i %% 40) for i in range(%d)]
+graphs = [synth_graph('kuka7', n, 6, seed=700 + i) for i, n in enumerate(sizes)]
+m = gnnmp.EncoderProcessDecoder(e['workspace'], e['C'], e['d'], e['S']).eval(); m.load_state_dict(load_weights(e['ckpt'])); m.mlp_dtype = 'bf16'
+b = gnnmp.GraphBatch.from_graphs(graphs, e['S'], 'cuda:0')
+for loop in (1, 4):
+    s = m.forward_batch(b, loop)
+    torch.cuda.synchronize()
+    print('HASH', loop, hashlib.sha256(s.cpu().numpy().tobytes()).hexdigest())
+'''
+
+
+@pytest.mark.parametrize('n_graphs', [40, 400], ids=['one_group_per_virtual_workgroup', 'resident_workgroups_on_the_snake'])
+def test_d64_bf16_eight_wave_kernel_equals_four_wave_kernel(n_graphs):
+    """d = 64 with bf16 operands (kuka7, BASELINE configs[2]) runs mp_fused_w8_kernel on large batches: eight waves per CU, every
+    matrix of the message layer and the node phase in LDS, a tile's B' rows in registers (ds_bpermute per chunk) instead of an LDS
+    stage.  Same arithmetic in the same order as mp_fused_kernel<64, 1, 1> (GNNMP_MP_W8=0): the scores are the same BYTES -- on a
+    ragged batch (graphs of 300 ... 1400 nodes with differing numbers of 256-row blocks) small enough for one group per virtual
+    workgroup (40 graphs) and large enough for the resident workgroups to walk the snake (400 graphs, ~2900 groups > 512 virtual
+    slots), for loop = 1 (first iteration == last: the staged W_dst copy) and loop = 4, and equal to per-graph calls (which run
+    the tile-per-workgroup form)."""
+    import hashlib
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = _W8_SNIPPET % (os.path.dirname(here), here, n_graphs)
+    got = {}
+    for w8, order in (('0', ''), ('1', ''), ('1', '0'), ('1', '2')):
+        env = dict(os.environ, GNNMP_MP_W8=w8)
+        env.pop('GNNMP_MP_ORDER', None)
+        if order:
+            env['GNNMP_MP_ORDER'] = order
+        out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-2000:]
+        got[(w8, order)] = [ln for ln in out.stdout.splitlines() if ln.startswith('HASH')]
+    assert len(got[('0', '')]) == 2
+    assert got[('0', '')] == got[('1', '')] == got[('1', '0')] == got[('1', '2')], got
+    if n_graphs <= 40:
+        e = ENVS['kuka7']
+        sizes = [300 + 41 * (i % 23) + 7 * (i % 40) for i in range(n_graphs)]
+        graphs = [{k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in synth_graph('kuka7', n, 6, seed=700 + i).items()} for i, n in enumerate(sizes)]
+        m = _model('kuka7', 'bf16')
+        alone = torch.cat([m.edge_scores(g['goal'], 4, g['v'], g['obstacles'], g['edge_index']) for g in graphs])
+        assert 'HASH 4 ' + hashlib.sha256(alone.cpu().numpy().tobytes()).hexdigest() == got[('1', '')][1]
