@@ -84,6 +84,34 @@ template <> struct Prec<1> { static constexpr int TF = 512; };
 // fp32 MFMAs (1024 cycles on the VECTOR pipe), and the matrix pipe overlaps with VALU work.
 template <> struct Prec<2> { static constexpr int TF = 1536; };     // 3 pieces x 512
 
+// fp32 -> packed bf16 (round to nearest even), two values per instruction.  Spelled as the instruction: inside the big kernels
+// __builtin_convertvector(f32x8 -> bf16x8) was scalarised to one v_cvt_pk_bf16_f32 PER ELEMENT (second source unused) plus a v_perm_b32
+// per pair -- 3 instead of 1 VALU instructions per pair, 48 instead of 16 per 32-edge chunk of the bf16 message kernel, in
+// kernels that are bound by instruction issue (round 5; isolated test kernels get the packed form, the big ones did not).
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+// (NOT as inline asm: the hazard recognizer does not look into asm statements, and a conversion reading an MFMA's result registers
+// without the wait states the compiler would have inserted returned garbage.)  The pairwise <2 x float> -> <2 x bfloat> fptrunc is the
+// pattern the instruction is selected from.
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
+    const f32x2 p = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(p, bf16x2_t));
+}
+__device__ __forceinline__ bf16x8 to_bf16x8(const f32x8& a) {
+    u32x4_t r;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) r[w] = cvt_pk_bf16(a[2 * w], a[2 * w + 1]);
+    return __builtin_bit_cast(bf16x8, r);
+}
+__device__ __forceinline__ bf16x4_t to_bf16x4(const f32x4& a) {
+    u32x2_t r;
+    r[0] = cvt_pk_bf16(a[0], a[1]);
+    r[1] = cvt_pk_bf16(a[2], a[3]);
+    return __builtin_bit_cast(bf16x4_t, r);
+}
+
 template <int P> struct BOp;                    // one 32-feature activation tile as MFMA B operand
 template <> struct BOp<0> {
     f32x16 v;
@@ -97,8 +125,8 @@ template <> struct BOp<1> {
         f32x8 a, b;
 #pragma unroll
         for (int r = 0; r < 8; ++r) { a[r] = x[r]; b[r] = x[8 + r]; }
-        lo = __builtin_convertvector(a, bf16x8);
-        hi = __builtin_convertvector(b, bf16x8);
+        lo = to_bf16x8(a);
+        hi = to_bf16x8(b);
     }
 };
 
@@ -111,8 +139,8 @@ template <> struct BOp<2> {
         for (int r = 0; r < 8; ++r) { a[r] = x[r]; b[r] = x[8 + r]; }
 #pragma unroll
         for (int pc = 0; pc < 3; ++pc) {
-            lo[pc] = __builtin_convertvector(a, bf16x8);
-            hi[pc] = __builtin_convertvector(b, bf16x8);
+            lo[pc] = to_bf16x8(a);
+            hi[pc] = to_bf16x8(b);
             if (pc < 2) {                                  // exact residual: a - float(bf16(a)) is representable
                 a -= __builtin_convertvector(lo[pc], f32x8);
                 b -= __builtin_convertvector(hi[pc], f32x8);
@@ -290,7 +318,7 @@ __device__ __forceinline__ void linear_in_p(const float* Asmall, int ksteps, Get
             f32x8 b;
 #pragma unroll
             for (int t = 0; t < 8; ++t) b[t] = getin(16 * st + 8 * h + t);      // getin returns 0 beyond the input width
-            const bf16x8 bb = __builtin_convertvector(b, bf16x8);
+            const bf16x8 bb = to_bf16x8(b);
 #pragma unroll
             for (int ot = 0; ot < NTO; ++ot) {
                 const bf16x8 w = *reinterpret_cast<const bf16x8*>(Asmall + ((ot * ksteps + st) * 64 + lane) * 4);
@@ -307,7 +335,7 @@ __device__ __forceinline__ void linear_in_p(const float* Asmall, int ksteps, Get
             bf16x8 xb[3];
 #pragma unroll
             for (int pc = 0; pc < 3; ++pc) {
-                xb[pc] = __builtin_convertvector(b, bf16x8);
+                xb[pc] = to_bf16x8(b);
                 if (pc < 2) b -= __builtin_convertvector(xb[pc], f32x8);
             }
             constexpr int PW[6] = {2, 0, 1, 1, 0, 0}, PX[6] = {0, 2, 1, 0, 1, 0};
@@ -520,7 +548,7 @@ __device__ __forceinline__ void store_row_p(float* array_f32_units, size_t row, 
                 f32x4 a;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) a[c] = x[t][q * 4 + c];
-                *reinterpret_cast<bf16x4*>(base + t * 32 + q * 8 + h * 4) = __builtin_convertvector(a, bf16x4);
+                *reinterpret_cast<bf16x4*>(base + t * 32 + q * 8 + h * 4) = to_bf16x4(a);
             }
     }
 }

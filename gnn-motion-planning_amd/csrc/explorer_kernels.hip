@@ -1574,7 +1574,7 @@ __device__ __forceinline__ void write_stage_tiles(float* stage, int sr, int h, c
         for (int q = 0; q < 4; ++q) {
             const f32x4 a = {x[t][q * 4 + 0], x[t][q * 4 + 1], x[t][q * 4 + 2], x[t][q * 4 + 3]};
             if constexpr (P != 1) *reinterpret_cast<f32x4*>(row + (((t * 8 + q * 2 + h) ^ sw) * 16)) = a;
-            else *reinterpret_cast<bf16x4*>(row + (((t * 4 + q) ^ sw) * 16) + h * 8) = __builtin_convertvector(a, bf16x4);
+            else *reinterpret_cast<bf16x4*>(row + (((t * 4 + q) ^ sw) * 16) + h * 8) = to_bf16x4(a);
         }
 }
 
