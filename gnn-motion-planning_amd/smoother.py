@@ -219,6 +219,7 @@ class ModelSmoother(nn.Module):
     def __getstate__(self):                 # copy.deepcopy / pickle: the native handle and buffers stay with the original
         st = self.__dict__.copy()
         st.update(_handle=None, _handle_key=None, _ws=None, _ws_streams={}, _wt=None, _manifest=None)
+        st.pop('_watch', None)              # pending status copies (pinned buffers, events, a lock) belong to the original
         return st
 
     def _apply(self, fn, *a, **k):
