@@ -2089,6 +2089,15 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
                     ke_fetch(c0 + KD * STEP, fill);
                   }
                 }
+#ifdef GNNMP_DBG_NOB
+                b = splat16(0.f);
+#endif
+#ifdef GNNMP_DBG_NOA
+                a = splat16(0.f);
+#endif
+#ifdef GNNMP_DBG_NOKE
+                x = splat16(0.f);
+#endif
                 x += a + b;                                     // the ReLU is applied by linear_acc_stream
             }, M, lane);
             if (end - c0 < 32) {                                 // wave-uniform: the last, partial chunk -- pad edges aggregate -inf
@@ -2357,22 +2366,30 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
 // the weights are staged.  Same arithmetic in the same order on the same values as mp_fused_kernel<64, 1, 1>: the scores
 // are bit-identical (tests/test_full_size_bf16_gpu.py compares the two through GNNMP_MP_W8=0).
 // =====================================================================================================
-template <int D>
+// P = 1 (bf16 operands): as described above.  P = 0 (exact fp32, round 5 as well): the same eight-wave cut WITHOUT the node-phase
+// matrices in LDS (80 KB in fp32) -- message layer 16.6 KB + 8 x (aggregation tile 8 KB + offsets + A-row stage 8 KB) = 145.7 KB; what
+// it buys there is the second wave per SIMD (mp_fused_kernel<64, 0, 1> keeps three 8 KB stages per wave and fits ONE four-wave
+// workgroup per CU: one wave per SIMD, nothing to cover its waits with -- the launch ran at 0.25 of the HBM roof / 41 % of the
+// matrix pipe).
+template <int D, int P>
 __host__ __device__ constexpr int mp_w8_lds_floats() {
-    return ((MpEBlob<D, 1>::size + 3) & ~3) + ((MpNBlob<D, 1>::size + 3) & ~3) + MpNBlob<D, 1>::T + 8 * (32 * D + 32 + RowGeom<D, 1>::STAGE_FLOATS);
+    return ((MpEBlob<D, P>::size + 3) & ~3) + (P == 1 ? ((MpNBlob<D, P>::size + 3) & ~3) + MpNBlob<D, P>::T : 0) +
+           8 * (32 * D + 32 + RowGeom<D, P>::STAGE_FLOATS);
 }
 
-template <int D>
+template <int D, int P>
 __global__ __launch_bounds__(512, 1) void mp_fused_w8_kernel(MpFusedParams p) {
-    constexpr int P = 1, NT = D / 32;
+    constexpr int NT = D / 32;
+    constexpr int XP = P == 1 ? 1 : 0;                           // X rows are stored in bf16 in the bf16 mode
+    constexpr bool kWLds = P == 1;                               // node-phase matrices in LDS
     using LE = MpEBlob<D, P>;
     using LN = MpNBlob<D, P>;
     using G = RowGeom<D, P>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* wl = lds;                                             // MpEBlob (message layer)
-    float* wnl = lds + ((LE::size + 3) & ~3);                    // MpNBlob (node phase) of THIS iteration
+    float* wnl = lds + ((LE::size + 3) & ~3);                    // MpNBlob (node phase) of THIS iteration (kWLds)
     float* wm3x = wnl + ((LN::size + 3) & ~3);                   // last iteration: the standard W_dst (its blob holds the policy matrix there)
-    float* base = wm3x + LN::T;
+    float* base = kWLds ? wm3x + LN::T : wnl;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
     const int sub = wave >> 2, w4 = wave & 3;
     float* agg = base + wave * (32 * D + 32 + G::STAGE_FLOATS);  // [32][D] fp32; X rows in / R rows in / A' and PT rows out pass through it
@@ -2393,10 +2410,11 @@ __global__ __launch_bounds__(512, 1) void mp_fused_w8_kernel(MpFusedParams p) {
     GNNMP_TRC();
 #endif
     stage(wl, p.we, LE::size);
-    stage(wnl, p.wn, LN::size);
-    if (p.last) stage(wm3x, p.wn_std + LN::m3, LN::T);
+    if constexpr (kWLds) {
+        stage(wnl, p.wn, LN::size);
+        if (p.last) stage(wm3x, p.wn_std + LN::m3, LN::T);
+    }
     __syncthreads();                                             // the only workgroup barrier
-    const float* wm3 = p.last ? wm3x : wnl + LN::m3;
     if (p.tpw > 0 && p.order != 2) {                             // virtual workgroups of the unused tail of the padded tile space
         const int per = ((((p.node_ptr_pad[p.G] >> 7) + p.tpw - 1) / p.tpw) + 7) >> 3;
         if (vq >= per) { GNNMP_TRC_END(); return; }
@@ -2444,7 +2462,14 @@ __global__ __launch_bounds__(512, 1) void mp_fused_w8_kernel(MpFusedParams p) {
         GNNMP_TRC();
         GNNMP_TRC_TILE(tile);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the previous job's LDS reads (rows on their way out) are done
-        constexpr int PF = NT, KD = 2, LPT = 2, STEP = 32;
+        // bf16: both K_e tiles of a chunk wait packed in registers, two chunks ahead; fp32: one tile one chunk ahead (16 registers a
+        // tile), the second is loaded in place under the first tile's sixteen 64-cycle MFMAs
+        constexpr int PF = P == 1 ? NT : 1, KD = P == 1 ? 2 : 1, LPT = P == 1 ? 2 : 4, STEP = 32;
+        // matrices of the node phase / of W_dst: LDS (bf16) or global memory with the pointer laundered per tile (fp32: the loads are
+        // loop-invariant and would be hoisted out of the tile loop into dozens of registers)
+        const float* wn = kWLds ? wnl : p.wn;
+        const float* wm3 = kWLds ? (p.last ? wm3x : wnl + LN::m3) : p.wn_std + LN::m3;
+        if constexpr (!kWLds) asm volatile("" : "+s"(wn), "+s"(wm3));
         KeRaw<P> qa[PF], qb[PF];
         auto ke_fetch = [&](int cc, KeRaw<P> (&dst)[PF]) {      // wave-uniform cc; unconditional (see mp_fused_kernel)
 #pragma unroll
@@ -2457,16 +2482,16 @@ __global__ __launch_bounds__(512, 1) void mp_fused_w8_kernel(MpFusedParams p) {
         int pre_rec_c = 0, pre_rec_n = 0;
         int l0 = lane;                                           // (laundered per tile: see the node phase)
         asm volatile("" : "+v"(l0));
-        dma_rows<D, 1>(p.X, [&](int sr) { return t0 + sr; }, agg, l0);            // X rows (bf16, 4 KB) through the aggregation tile
+        dma_rows<D, XP>(p.X, [&](int sr) { return t0 + sr; }, agg, l0);           // X rows (4 KB bf16 / 8 KB fp32) through the aggregation tile
         if (beg + j < end) pre_rec_c = p.rec32[beg + j];
         if (beg + 32 + j < end) pre_rec_n = p.rec32[beg + 32 + j];
         wait_vmcnt<0>();
         // The X rows leave the LDS for registers and the aggregation tile is reset BEFORE anything else is requested: an LDS access
         // the compiler generates while an LDS-DMA is in flight is guarded by s_waitcnt vmcnt(0) (it cannot tell the A stage from
         // this tile), which would put the first chunk's A rows and K_e behind a full round trip at every tile start
-        StageRaw<1> xr[NT];
+        StageRaw<XP> xr[NT];
 #pragma unroll
-        for (int it = 0; it < NT; ++it) read_stage_raw<D, 1>(agg, j, h, it, xr[it]);
+        for (int it = 0; it < NT; ++it) read_stage_raw<D, XP>(agg, j, h, it, xr[it]);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();                        // both halves of every X row have been read
         {
@@ -2481,26 +2506,31 @@ __global__ __launch_bounds__(512, 1) void mp_fused_w8_kernel(MpFusedParams p) {
             const int mine_row = src_row(rec_c, first + j < end);
             dma_rows<D, P>(p.A, [&](int sr) { return __builtin_amdgcn_ds_bpermute(sr * 4, mine_row); }, astage, lane);
             ke_fetch(first, qa);
-            ke_fetch(first + STEP, qb);
+            if constexpr (KD == 2) ke_fetch(first + STEP, qb);
         }
         BOp<P> bpk[NT];
         {
             f32x16 z[NT];
 #pragma unroll
             for (int tt = 0; tt < NT; ++tt) z[tt] = splat16(0.f);
-            linear_acc_stream<P, NT, false>(wm3, [&](int it, f32x16& x) { expand_stage_raw<1>(xr[it], x); }, z, lane);
-            make_ops<P, NT>(z, bpk);                            // rounded to bf16 exactly like the rows mp_fused_kernel writes into its B stage
+            linear_acc_stream<P, NT, false>(wm3, [&](int it, f32x16& x) { expand_stage_raw<XP>(xr[it], x); }, z, lane);
+            make_ops<P, NT>(z, bpk);                            // (bf16: rounded exactly like the rows mp_fused_kernel writes into its B stage)
         }
         bool x_requested = false;
-        auto chunk = [&](const int c0, KeRaw<P> (&cur)[PF]) {
-            wait_vmcnt<LPT * PF>();                             // this chunk's rows and K_e have landed; the next chunk's K_e may be in flight
+        auto chunk = [&](const int c0, KeRaw<P> (&cur)[PF], KeRaw<P> (&fill)[PF]) {
+            // this chunk's rows and K_e have landed; with KD = 2 the next chunk's K_e may still be in flight
+            if constexpr (KD == 2) wait_vmcnt<LPT * PF>(); else wait_vmcnt<0>();
             asm volatile("" : "+v"(rec_n), "+v"(rec_c));
 #pragma unroll
-            for (int t = 0; t < PF; ++t) asm volatile("" : "+v"(cur[t].lo), "+v"(cur[t].hi));
+            for (int t = 0; t < PF; ++t) {
+                if constexpr (P == 1) asm volatile("" : "+v"(cur[t].lo), "+v"(cur[t].hi));
+                else asm volatile("" : "+v"(cur[t].v[0]), "+v"(cur[t].v[4]), "+v"(cur[t].v[8]), "+v"(cur[t].v[12]));
+            }
             const int slot = c0 + j;
             const bool valid = slot < end;
             const int rec = rec_c;
             const int dloc = valid ? ((rec >> 27) & 31) : 0;
+            const int eslot = valid ? slot : beg;
             if (h == 0) dl[j] = dloc * D;
             f32x16 M[NT];
 #pragma unroll
@@ -2519,7 +2549,7 @@ __global__ __launch_bounds__(512, 1) void mp_fused_w8_kernel(MpFusedParams p) {
             } else {
                 int lx = lane;                                   // (laundered: these addresses must not be hoisted out of the chunk loop)
                 asm volatile("" : "+v"(lx));
-                dma_rows<D, 1>(p.X, [&](int sr) { return t0 + sr; }, astage, lx);
+                dma_rows<D, XP>(p.X, [&](int sr) { return t0 + sr; }, astage, lx);
                 x_requested = true;
             }
             {
@@ -2529,8 +2559,9 @@ __global__ __launch_bounds__(512, 1) void mp_fused_w8_kernel(MpFusedParams p) {
             linear_acc_stream<P, NT, true, true>(wl + LE::w2, [&](int it, f32x16& x) {
                 // the target row's features of this tile: ds_bpermute moves registers through the LDS crossbar, it reads no LDS
                 // memory, so the compiler does not guard it against the rows in flight to the A stage
-                StageRaw<P> braw;
-                {
+                f32x16 a, b;
+                if constexpr (P == 1) {
+                    StageRaw<P> braw;
                     const i32x4 lo = __builtin_bit_cast(i32x4, bpk[it].lo), hi = __builtin_bit_cast(i32x4, bpk[it].hi);
                     i32x4 glo, ghi;
 #pragma unroll
@@ -2543,12 +2574,34 @@ __global__ __launch_bounds__(512, 1) void mp_fused_w8_kernel(MpFusedParams p) {
                     braw.q[1] = __builtin_shufflevector(blo, blo, 4, 5, 6, 7);
                     braw.q[2] = __builtin_shufflevector(bhi, bhi, 0, 1, 2, 3);
                     braw.q[3] = __builtin_shufflevector(bhi, bhi, 4, 5, 6, 7);
+                    expand_stage_raw<P>(braw, b);
+                } else {
+                    // (four registers at a time through vector bit casts: the element-wise form -- bit_cast<int>(v[r]) -> ds_bpermute ->
+                    // bit_cast<float> in a loop over r -- was compiled to ONE ds_bpermute of v[0] broadcast to all sixteen elements)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 part = {bpk[it].v[q * 4 + 0], bpk[it].v[q * 4 + 1], bpk[it].v[q * 4 + 2], bpk[it].v[q * 4 + 3]};
+                        const i32x4 pi = __builtin_bit_cast(i32x4, part);
+                        i32x4 g;
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) g[w] = __builtin_amdgcn_ds_bpermute(baddr, pi[w]);
+                        const f32x4 gf = __builtin_bit_cast(f32x4, g);
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) b[q * 4 + w] = gf[w];
+                    }
                 }
-                f32x16 a, b;
-                expand_raw<P>(cur[it], x);
+                if (it < PF) expand_raw<P>(cur[it < PF ? it : 0], x); else load_edge_slot_tile<P, NT>(p.Ke, eslot, h, it, x);
                 expand_stage_raw<P>(araw[it], a);
-                expand_stage_raw<P>(braw, b);
-                if (it == NT - 1) ke_fetch(c0 + KD * STEP, cur);
+                if (it == NT - 1) ke_fetch(c0 + KD * STEP, KD == 2 ? cur : fill);
+#ifdef GNNMP_DBG_NOB
+                b = splat16(0.f);
+#endif
+#ifdef GNNMP_DBG_NOA
+                a = splat16(0.f);
+#endif
+#ifdef GNNMP_DBG_NOKE
+                x = splat16(0.f);
+#endif
                 x += a + b;
             }, M, lane);
             if (end - c0 < 32) {                                 // the last, partial chunk: pad edges aggregate -inf
@@ -2576,22 +2629,25 @@ __global__ __launch_bounds__(512, 1) void mp_fused_w8_kernel(MpFusedParams p) {
         };
         {
             int c0 = first;
-            for (; c0 + STEP < end; c0 += 2 * STEP) { chunk(c0, qa); chunk(c0 + STEP, qb); }
-            if (c0 < end) chunk(c0, qa);
+            for (; c0 + STEP < end; c0 += 2 * STEP) {
+                if constexpr (KD == 2) { chunk(c0, qa, qa); chunk(c0 + STEP, qb, qb); }
+                else { chunk(c0, qa, qb); chunk(c0 + STEP, qb, qa); }
+            }
+            if (c0 < end) { if constexpr (KD == 2) chunk(c0, qa, qa); else chunk(c0, qa, qb); }
         }
         GNNMP_TRC();
-        // ---- node phase, every matrix in LDS
+        // ---- node phase (bf16: every matrix in LDS)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's aggregation atomics have been performed
         // (the per-lane address vectors of the row movers below are invariant across tiles; hoisted out of the tile loop they cost
         // ~40 registers that then spill around the chunk loop: the lane id is laundered per tile so that they are recomputed here)
         int ln = lane;
         asm volatile("" : "+v"(ln));
-        if (!x_requested) dma_rows<D, 1>(p.X, [&](int sr) { return t0 + sr; }, astage, ln);     // a tile without incoming edges
+        if (!x_requested) dma_rows<D, XP>(p.X, [&](int sr) { return t0 + sr; }, astage, ln);     // a tile without incoming edges
         f32x16 H[NT];
-        load_vec<NT>(wnl + LN::bl, H, lane);
+        load_vec<NT>(wn + LN::bl, H, lane);
         wait_vmcnt<0>();
-        linear_acc_stream<P, NT, false>(wnl + LN::wlx, [&](int it, f32x16& x) { read_stage_tile<D, 1>(astage, j, h, it, x); }, H, lane);
-        linear_acc_stream<P, NT, false>(wnl + LN::wla, [&](int it, f32x16& x) {
+        linear_acc_stream<P, NT, false>(wn + LN::wlx, [&](int it, f32x16& x) { read_stage_tile<D, XP>(astage, j, h, it, x); }, H, lane);
+        linear_acc_stream<P, NT, false>(wn + LN::wla, [&](int it, f32x16& x) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const f32x4 a = *reinterpret_cast<const f32x4*>(agg + j * D + it * 32 + q * 8 + h * 4);
@@ -2611,21 +2667,21 @@ __global__ __launch_bounds__(512, 1) void mp_fused_w8_kernel(MpFusedParams p) {
 #pragma unroll
             for (int tt = 0; tt < NT; ++tt) read_stage_tile<D, 0>(agg, j, h, tt, y[tt]);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            linear_acc_p<P, NT, NT>(wnl + LN::m1, H, y, lane);
+            linear_acc_p<P, NT, NT>(wn + LN::m1, H, y, lane);
             GNNMP_TRC();                                         // (diagnostics build) Y done
             __builtin_amdgcn_wave_barrier();
-            write_stage_tiles<D, 1, NT>(astage, j, h, y);        // X' rows (bf16) -> A stage -> whole rows out
+            write_stage_tiles<D, XP, NT>(astage, j, h, y);       // X' rows -> A stage -> whole rows out
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
-            store_rows_coalesced<D, 1>(p.Xout, (size_t)t0, astage, ln);
+            store_rows_coalesced<D, XP>(p.Xout, (size_t)t0, astage, ln);
             make_ops<P, NT>(y, yop);
         }
         {
             f32x16 z[NT];
 #pragma unroll
             for (int tt = 0; tt < NT; ++tt) z[tt] = splat16(0.f);
-            linear_acc_ops<P, NT, NT>(wnl + LN::m2, yop, z, lane);
-            write_stage_tiles<D, P, NT>(agg, j, h, z);           // A' rows -> first half of the aggregation tile -> whole rows out
+            linear_acc_ops<P, NT, NT>(wn + LN::m2, yop, z, lane);
+            write_stage_tiles<D, P, NT>(agg, j, h, z);           // A' rows -> (bf16: first half of) the aggregation tile -> whole rows out
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
             store_rows_coalesced<D, P>(p.Aout, (size_t)t0, agg, ln);
@@ -2634,8 +2690,13 @@ __global__ __launch_bounds__(512, 1) void mp_fused_w8_kernel(MpFusedParams p) {
             f32x16 z[NT];
 #pragma unroll
             for (int tt = 0; tt < NT; ++tt) z[tt] = splat16(0.f);
-            linear_acc_ops<P, NT, NT>(wnl + LN::m3, yop, z, lane);
-            float* ps = agg + G::STAGE_FLOATS;                   // second half of the aggregation tile
+            linear_acc_ops<P, NT, NT>(wn + LN::m3, yop, z, lane);
+            // bf16: second half of the aggregation tile; fp32 (A' fills the whole tile): the A stage, whose X' rows have been read out
+            float* ps = P == 1 ? agg + G::STAGE_FLOATS : astage;
+            if constexpr (P != 1) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+            }
             write_stage_tiles<D, P, NT>(ps, j, h, z);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
@@ -3034,10 +3095,10 @@ static hipError_t launch_mp_fused_t(const MpFusedParams& p, hipStream_t st) {
     return hipSuccess;
 }
 // d = 64, bf16 operands, large batches: eight waves and every matrix in LDS (mp_fused_w8_kernel)
-template <int D>
+template <int D, int P>
 static hipError_t launch_mp_fused_w8(const MpFusedParams& p, hipStream_t st) {
-    const size_t lds = (size_t)mp_w8_lds_floats<D>() * sizeof(float);
-    hipError_t e = set_lds(mp_fused_w8_kernel<D>, lds);
+    const size_t lds = (size_t)mp_w8_lds_floats<D, P>() * sizeof(float);
+    hipError_t e = set_lds(mp_fused_w8_kernel<D, P>, lds);
     if (e != hipSuccess) return e;
     const int groups_cap = (p.n_tiles + 3) / 4;
     MpFusedParams q = p;
@@ -3069,7 +3130,7 @@ static hipError_t launch_mp_fused_w8(const MpFusedParams& p, hipStream_t st) {
     if (q.order == 2 && slots < 8) q.order = 0;
     unsigned grid = q.order == 2 ? (unsigned)slots : (unsigned)((((groups_cap + 1) / 2) + 7) & ~7);
     if (grid < 8) grid = 8;
-    hipLaunchKernelGGL((mp_fused_w8_kernel<D>), dim3(grid), dim3(512), lds, st, q);
+    hipLaunchKernelGGL((mp_fused_w8_kernel<D, P>), dim3(grid), dim3(512), lds, st, q);
     LAUNCH_CHECK();
     return hipSuccess;
 }
@@ -3081,11 +3142,15 @@ static hipError_t launch_mp_fused_dp(const MpFusedParams& p, hipStream_t st) {
     const bool coop = forced >= 0 ? forced != 0 : p.n_tiles <= (D > 32 ? kCoopMaxTiles64 : kCoopMaxTiles32);
     // d = 64 with fp32 / bf16x3 operands: four waves per tile instead of eight -- at eight waves a wave has 256 registers and the
     // kernel spilled 116 of them (single 2000-node kuka7 graph: 42 us per launch)
-    if constexpr (D > 32 && P != 1) return coop ? launch_mp_fused_t<D, P, 4>(p, st) : launch_mp_fused_t<D, P, 1>(p, st);
+    static const int w8 = getenv("GNNMP_MP_W8") ? atoi(getenv("GNNMP_MP_W8")) : 1;      // 0: the four-wave form (mp_fused_kernel<64, P, 1>), for A/B runs and the bit-identity tests
+    if constexpr (D == 64 && P == 0) {
+        if (coop) return launch_mp_fused_t<D, P, 4>(p, st);
+        return w8 ? launch_mp_fused_w8<D, P>(p, st) : launch_mp_fused_t<D, P, 1>(p, st);
+    }
+    else if constexpr (D > 32 && P != 1) return coop ? launch_mp_fused_t<D, P, 4>(p, st) : launch_mp_fused_t<D, P, 1>(p, st);
     else if constexpr (D == 64 && P == 1) {
-        static const int w8 = getenv("GNNMP_MP_W8") ? atoi(getenv("GNNMP_MP_W8")) : 1;      // 0: the four-wave form (mp_fused_kernel<64, 1, 1>), for A/B runs and the bit-identity test
         if (coop) return launch_mp_fused_t<D, P, 8>(p, st);
-        return w8 ? launch_mp_fused_w8<D>(p, st) : launch_mp_fused_t<D, P, 1>(p, st);
+        return w8 ? launch_mp_fused_w8<D, P>(p, st) : launch_mp_fused_t<D, P, 1>(p, st);
     }
     else return coop ? launch_mp_fused_t<D, P, 8>(p, st) : launch_mp_fused_t<D, P, 1>(p, st);
 }

@@ -148,7 +148,7 @@ from gnnmp.synth import ENVS, synth_graph
 e = ENVS['kuka7']
 sizes = [300 + 41 * (i %% 23) + 7 * (i %% 40) for i in range(%d)]
 graphs = [synth_graph('kuka7', n, 6, seed=700 + i) for i, n in enumerate(sizes)]
-m = gnnmp.EncoderProcessDecoder(e['workspace'], e['C'], e['d'], e['S']).eval(); m.load_state_dict(load_weights(e['ckpt'])); m.mlp_dtype = 'bf16'
+m = gnnmp.EncoderProcessDecoder(e['workspace'], e['C'], e['d'], e['S']).eval(); m.load_state_dict(load_weights(e['ckpt'])); m.mlp_dtype = %r
 b = gnnmp.GraphBatch.from_graphs(graphs, e['S'], 'cuda:0')
 for loop in (1, 4):
     s = m.forward_batch(b, loop)
@@ -157,11 +157,13 @@ for loop in (1, 4):
 '''
 
 
+@pytest.mark.parametrize('mode', ['bf16', 'fp32'])
 @pytest.mark.parametrize('n_graphs', [40, 400], ids=['one_group_per_virtual_workgroup', 'resident_workgroups_on_the_snake'])
-def test_d64_bf16_eight_wave_kernel_equals_four_wave_kernel(n_graphs):
-    """d = 64 with bf16 operands (kuka7, BASELINE configs[2]) runs mp_fused_w8_kernel on large batches: eight waves per CU, every
-    matrix of the message layer and the node phase in LDS, a tile's B' rows in registers (ds_bpermute per chunk) instead of an LDS
-    stage.  Same arithmetic in the same order as mp_fused_kernel<64, 1, 1> (GNNMP_MP_W8=0): the scores are the same BYTES -- on a
+def test_d64_eight_wave_kernel_equals_four_wave_kernel(n_graphs, mode):
+    """d = 64 (kuka7: BASELINE configs[2] in bf16, a member of configs[3] in fp32) runs mp_fused_w8_kernel on large batches: eight
+    waves per CU, a tile's B' rows in registers (ds_bpermute per chunk) instead of an LDS stage and -- bf16 -- every matrix of the
+    message layer and the node phase in LDS.  Same arithmetic in the same order as mp_fused_kernel<64, P, 1> (GNNMP_MP_W8=0): the
+    scores are the same BYTES in both operand modes -- on a
     ragged batch (graphs of 300 ... 1400 nodes with differing numbers of 256-row blocks) small enough for one group per virtual
     workgroup (40 graphs) and large enough for the resident workgroups to walk the snake (400 graphs, ~2900 groups > 512 virtual
     slots), for loop = 1 (first iteration == last: the staged W_dst copy) and loop = 4, and equal to per-graph calls (which run
@@ -171,7 +173,7 @@ def test_d64_bf16_eight_wave_kernel_equals_four_wave_kernel(n_graphs):
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
-    code = _W8_SNIPPET % (os.path.dirname(here), here, n_graphs)
+    code = _W8_SNIPPET % (os.path.dirname(here), here, n_graphs, mode)
     got = {}
     for w8, order in (('0', ''), ('1', ''), ('1', '0'), ('1', '2')):
         env = dict(os.environ, GNNMP_MP_W8=w8)
@@ -187,6 +189,6 @@ def test_d64_bf16_eight_wave_kernel_equals_four_wave_kernel(n_graphs):
         e = ENVS['kuka7']
         sizes = [300 + 41 * (i % 23) + 7 * (i % 40) for i in range(n_graphs)]
         graphs = [{k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in synth_graph('kuka7', n, 6, seed=700 + i).items()} for i, n in enumerate(sizes)]
-        m = _model('kuka7', 'bf16')
+        m = _model('kuka7', mode)
         alone = torch.cat([m.edge_scores(g['goal'], 4, g['v'], g['obstacles'], g['edge_index']) for g in graphs])
         assert 'HASH 4 ' + hashlib.sha256(alone.cpu().numpy().tobytes()).hexdigest() == got[('1', '')][1]
