@@ -529,9 +529,11 @@ def main():
             mp_ms, mp_n = prof['mp']
             mp_avg_ms = mp_ms / max(mp_n, 1)
             mp_bytes = sum(mp_fused_bytes(n, m, e['d'], args.mlp_dtype == 'bf16') for n, m in zip(Ns, Es))
-            roof = {'kernel': 'mp_fused_kernel<%d, %s, ...> (one message-passing iteration: edge MLP second layer, max aggregation, '
-                              'node update; %d launches per step)' % (e['d'], pname, args.loop),
-                    'kernel_like': 'mp_fused_kernel<%d, %s' % (e['d'], pname),
+            # d = 64 runs the eight-wave form (mp_fused_w8_kernel, round 5) in the fp32 and bf16 modes
+            mp_name = 'mp_fused_w8_kernel<64, %s' % pname if (e['d'] == 64 and pname in ('0', '1')) else 'mp_fused_kernel<%d, %s' % (e['d'], pname)
+            roof = {'kernel': '%s...> (one message-passing iteration: edge MLP second layer, max aggregation, '
+                              'node update; %d launches per step)' % (mp_name, args.loop),
+                    'kernel_like': mp_name,
                     'bound': 'hbm', 'achieved': round(mp_bytes / (mp_avg_ms * 1e-3) / 1e9, 1) if mp_avg_ms > 0 else 0.0,
                     'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'launch_ms': round(mp_avg_ms, 4), 'algorithmic_bytes_per_launch': mp_bytes}
         else:
@@ -562,6 +564,20 @@ def main():
             else:
                 ach = work / (ms * 1e-3) / 1e9
                 stage_roof[name] = {'bound': 'hbm', 'ms': round(ms, 4), 'GBs': round(ach, 0), 'frac': round(ach / PEAK_HBM_GBS, 3)}
+        # issue-slot fraction of the edge pre kernel (bf16 mode: it is bound by instruction issue, not by the matrix pipe its FLOPs are
+        # priced against): (4 x SQ_ACTIVE_INST_VALU + SQ_VALU_MFMA_BUSY_CYCLES) / SIMD cycles from separate --pmc passes
+        # (tools/issue_json.py -> profiles/kernel_issue.json, stamped with workload and source hash like the traffic entries)
+        ipath = os.path.join(REPO, 'profiles', 'kernel_issue.json')
+        if os.path.exists(ipath) and 'edge_pre' in stage_roof:
+            try:
+                wk_ = '%s N=%d k1=%d graphs=%d %s' % (args.env, args.nodes, args.k1, G, args.mlp_dtype)
+                for ij in json.load(open(ipath)):
+                    if ij.get('workload') == wk_ and ij.get('stage') == 'edge_pre':
+                        stage_roof['edge_pre']['issue_slots'] = {k_: ij.get(k_) for k_ in (
+                            'issue_slot_frac', 'valu_frac', 'mfma_frac', 'valu_per_32_row_tile', 'mfma_per_32_row_tile', 'measured')}
+                        stage_roof['edge_pre']['issue_slots']['stale'] = ij.get('kernel_source_sha256') != kernel_source_hash()
+            except Exception:
+                pass
         # HBM bytes per launch of that kernel come from separate rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE cannot be
         # read inside this process; tools/traffic_json.py writes profiles/kernel_traffic.json): every entry carries the
         # workload it was measured on, the date of the pass and a hash of the kernel sources; the number is reported only

@@ -60,6 +60,12 @@ class MazeResume(ctypes.Structure):
                 ('n_pairs', ctypes.c_void_p), ('pairs', ctypes.c_void_p), ('pair_ptr', ctypes.c_void_p)]
 
 
+class MazeSampleBatch(ctypes.Structure):
+    _fields_ = [('n_problems', ctypes.c_int32), ('width', ctypes.c_int32), ('n_free', ctypes.c_int32), ('n_attempts', ctypes.c_int64),
+                ('attempts', ctypes.c_void_p), ('maps', ctypes.c_void_p), ('init_states', ctypes.c_void_p),
+                ('goal_states', ctypes.c_void_p)]
+
+
 _lib = None
 
 
@@ -121,6 +127,7 @@ def lib():
     L.gnnmp_maze_explore.argtypes = [ctypes.POINTER(MazeBatch), vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
     L.gnnmp_maze_explore_ex.argtypes = [ctypes.POINTER(MazeBatch), ctypes.c_int32, ctypes.POINTER(MazeResume), vp, vp, vp, vp, vp,
                                         vp, vp, vp, vp, vp, sz, vp]
+    L.gnnmp_maze_sample.argtypes = [ctypes.POINTER(MazeSampleBatch), vp, vp, vp, vp, vp, vp]
     L.gnnmp_maze_steer.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, vp, vp, vp, vp, vp, vp, vp, vp]
     L.gnnmp_pack_a_tiles.restype = ctypes.c_int64
     L.gnnmp_pack_a_tiles.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp]

@@ -1436,6 +1436,21 @@ extern "C" int gnnmp_maze_steer(int32_t n_problems, int32_t total_path, int32_t 
     return GNNMP_OK;
 }
 
+extern "C" int gnnmp_maze_sample(const gnnmp_maze_sample_batch* b, int64_t* cursor, float* v_out, int32_t* node_ptr_out,
+                                 int32_t* used_out, int32_t* ok_out, void* hip_stream) {
+    if (!b || !cursor || !v_out || !node_ptr_out || !used_out || !ok_out) return GNNMP_ERR_NULL;
+    if (!b->attempts || !b->maps || !b->init_states || !b->goal_states) return GNNMP_ERR_NULL;
+    if (b->n_problems < 1 || b->width < 1 || b->n_free < 1 || b->n_attempts < 0) return GNNMP_ERR_ARG;
+    MazeSampleParams p;
+    p.B = b->n_problems; p.w = b->width; p.n = b->n_free;
+    p.attempts = b->attempts; p.M = b->n_attempts;
+    p.maps = b->maps; p.init_states = b->init_states; p.goal_states = b->goal_states;
+    p.v = v_out; p.node_ptr = node_ptr_out; p.used = used_out;
+    p.cursor = reinterpret_cast<long long*>(cursor); p.ok = ok_out;
+    HIP_TRY(launch_maze_sample(p, static_cast<hipStream_t>(hip_stream)));
+    return GNNMP_OK;
+}
+
 // =============================================================================================
 // training path of the explorer (train_explorer.py:156-186)
 // =============================================================================================

@@ -186,6 +186,20 @@ struct MazeSteerParams {
 };
 hipError_t launch_maze_steer(const MazeSteerParams& p, hipStream_t st);
 
+// rejection sampling of the explore stage for 2-D mazes on the device (eval_gnn.py:180-184 through MazeEnv.sample_n_points)
+struct MazeSampleParams {
+    int B, w, n;                          // problems, map width, free samples wanted per problem
+    const double* attempts;               // [M, 2] the raw uniform(-1, 1) draws of the host generator, stream order
+    long long M;
+    const double *maps, *init_states, *goal_states;      // [B, w, w], [B, 2], [B, 2]
+    float* v;                             // out: node rows [init, goal, free x n, rejected x min(rejected, n)] per problem, compact
+    int* node_ptr;                        // out [B + 1]
+    int* used;                            // out [B]: attempts consumed (= collision checks of the sampling)
+    long long* cursor;                    // in / out: index of the next unconsumed attempt
+    int* ok;                              // out: 0 = the stream ran out before the last problem had its n free samples
+};
+hipError_t launch_maze_sample(const MazeSampleParams& p, hipStream_t st);
+
 // ---- training path (train_kernels.hip)
 struct TrainGeom {
     int G, C, Npad, Epad;

@@ -554,6 +554,108 @@ __global__ __launch_bounds__(64) void maze_steer_kernel(MazeSteerParams p) {
     p.checks[b] += m.checks;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Rejection sampling on the device.  The reference samples a problem's nodes one by one (eval_gnn.py:180-184 ->
+// MazeEnv.sample_n_points, maze_env.py): draw a uniform point of [-1, 1)^2 from the GLOBAL numpy generator, keep it if its grid
+// cell is free, until n free points exist; the rejected draws of the same loop become the problem's collided samples (the first n
+// of them), and the NEXT problem continues in the same random stream -- so where problem b + 1 starts depends on how many
+// draws problem b needed.  The draws themselves stay with the host (numpy's Mersenne twister: cheap, and it keeps the recorded
+// known answers); what moves here is everything after them: the classification of every draw (float64 arithmetic of
+// ((x + 1.0) * w / 2.0).astype(int), clipped at w - 1, one map lookup), the position of the n-th free draw, the compaction into
+// the float32 node rows [start, goal, free ..., rejected ...] the graph builder and the explorer read, the per-problem counts.
+// ONE workgroup walks the problems in stream order (the dependency is serial), 1024 draws per step: a block scan of the free
+// flags gives every draw its rank; ~1300 draws per problem at the published setting = two steps, ~3 us.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void maze_sample_kernel(MazeSampleParams p) {
+    __shared__ unsigned char occ[kMazeLdsCells];
+    __shared__ int wsum[16];
+    __shared__ int s_tstar, s_fail;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long cur0 = *p.cursor;
+    long long cur = cur0;
+    int node0 = 0;
+    const bool in_lds = p.w * p.w <= kMazeLdsCells;
+    if (tid == 0) { p.node_ptr[0] = 0; s_fail = 0; }
+    for (int b = 0; b < p.B; ++b) {
+        const double* map = p.maps + (size_t)b * p.w * p.w;
+        __syncthreads();                                        // the previous problem's map is no longer in use
+        if (in_lds)
+            for (int i = tid; i < p.w * p.w; i += 1024) occ[i] = map[i] == 0.0 ? 0 : 1;
+        if (tid == 0) s_tstar = -1;
+        __syncthreads();
+        int free_before = 0, rej_before = 0, rej_total = 0, used = 0;
+        for (long long off = 0;; off += 1024) {
+            const long long idx = cur + off + tid;
+            const bool in = idx < p.M;
+            double x = 0.0, y = 0.0;
+            if (in) { x = p.attempts[2 * idx]; y = p.attempts[2 * idx + 1]; }
+            bool isfree = false;
+            if (in) {
+                const int c = maze_cell64(x, p.w) * p.w + maze_cell64(y, p.w);
+                isfree = in_lds ? occ[c] == 0 : map[c] == 0.0;
+            }
+            // inclusive block scan of the free flags: ballot + popcount inside a wave, the sixteen wave totals through LDS
+            const unsigned long long bal = __builtin_amdgcn_ballot_w64(isfree);
+            const int incl_w = __builtin_popcountll(bal & (~0ull >> (63 - lane)));
+            if (lane == 0) wsum[wave] = __builtin_popcountll(bal);
+            __syncthreads();
+            int before = 0, F = 0;
+#pragma unroll
+            for (int w2 = 0; w2 < 16; ++w2) { const int c = wsum[w2]; before += w2 < wave ? c : 0; F += c; }
+            const int incl = before + incl_w;                   // free draws among this step's draws 0 .. tid
+            if (isfree && free_before + incl == p.n) s_tstar = tid;      // the n-th free draw of the problem
+            __syncthreads();
+            const int tstar = s_tstar;
+            const bool done = tstar >= 0;
+            const int limit = done ? tstar : 1023;
+            if (in && tid <= limit) {
+                if (isfree) {
+                    const size_t row = (size_t)node0 + 2 + free_before + incl - 1;
+                    p.v[2 * row] = (float)x; p.v[2 * row + 1] = (float)y;
+                } else {
+                    const int rr = rej_before + (tid + 1 - incl) - 1;        // rank among the problem's rejected draws
+                    if (rr < p.n) {
+                        const size_t row = (size_t)node0 + 2 + p.n + rr;
+                        p.v[2 * row] = (float)x; p.v[2 * row + 1] = (float)y;
+                    }
+                }
+            }
+            if (done) {
+                // every thread derives the same totals: rejected draws up to and including position tstar
+                const int free_upto = p.n - free_before;                     // free draws of this step up to tstar
+                rej_total = rej_before + (tstar + 1 - free_upto);
+                used = (int)off + tstar + 1;
+                break;
+            }
+            if (cur + off + 1024 >= p.M) {                      // the stream ran out (workgroup-uniform)
+                if (tid == 0) { *p.ok = 0; *p.cursor = cur0; p.node_ptr[b + 1] = -1; }      // nothing is consumed
+                return;
+            }
+            free_before += F;
+            rej_before += 1024 - F;
+            __syncthreads();                                    // wsum / s_tstar are rewritten by the next step
+        }
+        const int Nb = 2 + p.n + (rej_total < p.n ? rej_total : p.n);
+        if (tid == 0) {
+            const double* is = p.init_states + 2 * (size_t)b;
+            const double* gs = p.goal_states + 2 * (size_t)b;
+            p.v[2 * (size_t)node0] = (float)is[0]; p.v[2 * (size_t)node0 + 1] = (float)is[1];
+            p.v[2 * (size_t)node0 + 2] = (float)gs[0]; p.v[2 * (size_t)node0 + 3] = (float)gs[1];
+            p.node_ptr[b + 1] = node0 + Nb;
+            p.used[b] = used;
+        }
+        cur += used;
+        node0 += Nb;
+    }
+    if (tid == 0) { *p.cursor = cur; *p.ok = 1; }
+}
+
+hipError_t launch_maze_sample(const MazeSampleParams& p, hipStream_t st) {
+    if (p.B <= 0) return hipSuccess;
+    hipLaunchKernelGGL(maze_sample_kernel, dim3(1), dim3(1024), 0, st, p);
+    return hipGetLastError();
+}
+
 hipError_t launch_maze_steer(const MazeSteerParams& p, hipStream_t st) {
     if (p.B <= 0) return hipSuccess;
     hipLaunchKernelGGL(maze_steer_kernel, dim3(p.B), dim3(64), 0, st, p);

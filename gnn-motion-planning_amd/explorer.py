@@ -168,9 +168,9 @@ class EncoderProcessDecoder(nn.Module):
         # [4]: bf16 operands, fp32 accumulate); not a constructor argument so the reference signature is kept
         self.mlp_dtype = 'fp32'
         # device-side status of a forward (obstacle count beyond the batch's promise, node ids outside their graph): copied to the
-        # host behind the forward and looked at on a later call / in check_status().  True = every BATCHED forward (prefix arrays
-        # on the device: the promise cannot be checked on the host); the reference's own call shape -- ONE graph given by its
-        # tensor shapes -- is skipped: its obstacle count is exact by construction, and a stream-ordered device-to-host copy
+        # host behind the forward and looked at on a later call / in check_status().  True = every forward over more than one graph and every
+        # hand-built one-graph batch; the reference's own call shape -- ONE graph whose obstacle count is the tensor's row count
+        # (forward(), edge_scores(), _single()) -- is skipped: its promise is exact by construction, and a stream-ordered device-to-host copy
         # behind every call costs 16 us of a 115 us forward (measured).  'always' = those as well; False = none
         self.status_checks = True
         self._handle = None
@@ -342,7 +342,7 @@ class EncoderProcessDecoder(nn.Module):
             _lib.check(_lib.lib().gnnmp_explorer_forward(
                 h, ctypes.byref(cb), int(loop), 1 if self.use_obstacles else 0, scores.data_ptr(),
                 dn.data_ptr() if dense else None, ws.data_ptr(), ws.numel(), st), 'gnnmp_explorer_forward')
-            if self.status_checks == 'always' or (self.status_checks and batch.node_ptr is not None):
+            if self.status_checks == 'always' or (self.status_checks and not (batch.n_graphs == 1 and getattr(batch, 'caps_from_host', False))):
                 off, nb = ctypes.c_size_t(), ctypes.c_size_t()
                 _lib.check(_lib.lib().gnnmp_explorer_status_region(h, ctypes.byref(cb), ctypes.byref(off), ctypes.byref(nb)),
                            'gnnmp_explorer_status_region')
@@ -463,9 +463,11 @@ class EncoderProcessDecoder(nn.Module):
             return GraphBatch(v.float().contiguous(), goal.reshape(1, -1).float().contiguous(), obs.contiguous(),
                               edge_index.long().contiguous(), None, None, None, obs.shape[0])
         i32 = lambda *a: torch.tensor(a, dtype=torch.int32, device=dev)      # noqa: E731
-        return GraphBatch(v.float().contiguous(), goal.reshape(1, -1).float().contiguous(), obs.contiguous(),
-                          edge_index.long().contiguous(), i32(0, v.shape[0]), i32(0, edge_index.shape[1]),
-                          i32(0, obs.shape[0]), obs.shape[0], dense_floats=int(v.shape[0]) ** 2)
+        b = GraphBatch(v.float().contiguous(), goal.reshape(1, -1).float().contiguous(), obs.contiguous(),
+                       edge_index.long().contiguous(), i32(0, v.shape[0]), i32(0, edge_index.shape[1]),
+                       i32(0, obs.shape[0]), obs.shape[0], dense_floats=int(v.shape[0]) ** 2)
+        b.caps_from_host = True                          # the obstacle count is the tensor's own row count
+        return b
 
     @torch.no_grad()
     def edge_scores(self, goal, loop, v, obstacles, edge_index, **_ignored):

@@ -382,7 +382,7 @@ def _worker_stream(dev, i):
 
 
 def eval_gnn_device(env, indexes, model, model_s, seed=1234, batch=500, k=30, device='cuda', loop=5, chunk=128,
-                    rows_out=None, shard=None, workers=2):
+                    rows_out=None, shard=None, workers=2, device_sampling=True):
     """:func:`eval_gnn` for 2-D maze environments with the planner itself on the device
     (:func:`explore_maze_batch`, ``chunk`` problems per device pass): same return tuple as ``eval_gnn``
     (eval_gnn.py:96-145), same per-problem decisions and collision-check counts as the one-by-one loop at the
@@ -425,7 +425,10 @@ def eval_gnn_device(env, indexes, model, model_s, seed=1234, batch=500, k=30, de
     def prepare(span):
         pr = [dict(map=env.maps[i], init_state=env.init_states[i], goal_state=env.goal_states[i])
               for i in indexes[span[0]:span[1]]]
-        return pr, sample_maze_problems(pr, batch, k)
+        # device_sampling: only the uniform draws come from the host (numpy's global generator, this one thread); classification,
+        # n-th-free search and the node rows are the device's (gnnmp_maze_sample) -- same samples, same check counts, same stream
+        # position afterwards as the host sampler (tests/test_maze_sample_gpu.py)
+        return pr, (sample_maze_problems_device(pr, batch, k, dev) if device_sampling else sample_maze_problems(pr, batch, k))
 
     # INVARIANT: one stream -- and with it one workspace of each module (EncoderProcessDecoder / ModelSmoother._workspace key
     # on (device, stream)) -- per concurrently running forward.  A stream therefore belongs to a worker THREAD (bound once, in
@@ -538,6 +541,63 @@ def sample_maze_problems(problems, batch, k):
 
 
 
+_DRAWS_PER_FREE = [3.0]          # running estimate of uniform draws per free sample (sizes the block handed to the device)
+
+
+def sample_maze_problems_device(problems, batch, k, device):
+    """:func:`sample_maze_problems` with everything behind the random draws on the device (``gnnmp_maze_sample``,
+    csrc/maze_kernels.hip): the host only draws the uniform stream (numpy's global generator, one block for the whole list of
+    problems -- same values in the same order as the reference's one-by-one ``uniform_sample`` calls) and hands it over; the
+    device classifies every draw, finds each problem's ``batch``-th free draw in stream order and writes the float32 node
+    rows [start, goal, free ..., rejected[:batch] ...] (eval_gnn.py:180-184) where the graph builder reads them.  The global
+    generator is left where one-by-one sampling would have left it.  Returns a dict for ``explore_maze_batch(presampled=...)``:
+    the node rows never visit the host on their way to the explorer."""
+    import ctypes
+    from . import _lib
+    from .graph_build import k1_of
+    from .maze2d import AttemptStream, Maze2D
+    B = len(problems)
+    dev = torch.device(device)
+    envs = []
+    for pr in problems:
+        env = Maze2D(np.asarray(pr['map'])[None], np.asarray(pr['init_state'])[None], np.asarray(pr['goal_state'])[None])
+        env.init_new_problem(0)
+        envs.append(env)
+    w = int(np.asarray(problems[0]['map']).shape[0])
+    maps = torch.from_numpy(np.ascontiguousarray(np.asarray([np.asarray(pr['map'], dtype=np.float64) for pr in problems]))).to(dev)
+    init64 = torch.from_numpy(np.ascontiguousarray(np.asarray([np.asarray(e.init_state, dtype=np.float64).reshape(2) for e in envs]))).to(dev)
+    goal64 = torch.from_numpy(np.ascontiguousarray(np.asarray([np.asarray(e.goal_state, dtype=np.float64).reshape(2) for e in envs]))).to(dev)
+    v = torch.empty(B * (2 + 2 * batch), 2, dtype=torch.float32, device=dev)
+    node_ptr = torch.empty(B + 1, dtype=torch.int32, device=dev)
+    used = torch.empty(B, dtype=torch.int32, device=dev)
+    state = torch.zeros(2, dtype=torch.int64, device=dev)                  # [cursor, ok (int32 in the low half)]
+    stream = AttemptStream()
+    m = int(B * batch * _DRAWS_PER_FREE[0] * 1.25) + 2048
+    with torch.cuda.device(dev):
+        while True:
+            att = torch.from_numpy(stream.peek(m)).to(dev)
+            state.zero_()
+            sb = _lib.MazeSampleBatch(B, w, int(batch), int(att.shape[0]), att.data_ptr(), maps.data_ptr(), init64.data_ptr(),
+                                      goal64.data_ptr())
+            _lib.check(_lib.lib().gnnmp_maze_sample(ctypes.byref(sb), state.data_ptr(), v.data_ptr(), node_ptr.data_ptr(),
+                                                    used.data_ptr(), state.data_ptr() + 8, torch.cuda.current_stream().cuda_stream),
+                       'gnnmp_maze_sample')
+            cursor, ok = state.cpu().tolist()                                # the one wait of the sampling
+            if ok & 0xffffffff:
+                break
+            m *= 2                                                           # the block was too short: nothing was consumed
+    used_h = used.cpu().numpy()
+    nptr = node_ptr.cpu().numpy().astype(np.int64)
+    stream.consume(int(cursor))
+    stream.close()                                                           # global RNG: as if sampled one by one
+    _DRAWS_PER_FREE[0] = max(1.5, 0.5 * _DRAWS_PER_FREE[0] + 0.5 * float(cursor) / max(B * batch, 1))
+    for e, u in zip(envs, used_h):
+        e.collision_check_count += int(u)                                    # maze_env.py: one check per draw
+    nf = int(batch) + 2
+    return {'envs': envs, 'v': v[:int(nptr[-1])], 'node_ptr': node_ptr, 'node_ptr_host': nptr, 'n_free': [nf] * B,
+            'k1s': [k1_of(k, nf)] * B, 'maps': maps, 'goal64': goal64}
+
+
 def maze_explore_device(v, node_ptr, edge_ptr, n_free, ei, scores, maps, goal64, resume=None, want_prev=False):
     """``gnnmp_maze_explore_ex`` on device tensors: greedy best-edge expansion + grid collision checks of B problems
     (``v`` [sum N, dim] float32 with dim 2 (point robot) or 3 (stick robot), ``ei`` [2, sum E] int64 graph-local,
@@ -622,13 +682,21 @@ def explore_maze_batch(problems, model, device, batch=500, k=30, loop=5, model_s
     tm = time.perf_counter()
     from .batch import GraphBatch
     from .graph_build import build_edges_gpu
-    envs, vs, n_free, k1s = presampled if presampled is not None else sample_maze_problems(problems, batch, k)
-    tm = mark('host_sampling', tm)
     B = len(problems)
-    ptr = torch.zeros(B + 1, dtype=torch.int64)
-    ptr[1:] = torch.tensor([x.shape[0] for x in vs]).cumsum(0)
-    node_ptr = ptr.to(torch.int32).to(device)
-    v = torch.cat(vs).to(device)
+    dsamp = presampled if isinstance(presampled, dict) else None          # sample_maze_problems_device: the rows are on the device
+    if dsamp is not None:
+        envs, n_free, k1s = dsamp['envs'], dsamp['n_free'], dsamp['k1s']
+        v, node_ptr = dsamp['v'], dsamp['node_ptr']
+        ptr = torch.from_numpy(np.asarray(dsamp['node_ptr_host'], dtype=np.int64))
+        vs = None
+        tm = mark('host_sampling', tm)
+    else:
+        envs, vs, n_free, k1s = presampled if presampled is not None else sample_maze_problems(problems, batch, k)
+        tm = mark('host_sampling', tm)
+        ptr = torch.zeros(B + 1, dtype=torch.int64)
+        ptr[1:] = torch.tensor([x.shape[0] for x in vs]).cumsum(0)
+        node_ptr = ptr.to(torch.int32).to(device)
+        v = torch.cat(vs).to(device)
     ei, edge_ptr = build_edges_gpu(v, node_ptr, n_free, k1s)
     tm = mark('graph_build', tm)
     obs = [np.asarray(e.obstacles).reshape(-1, 2) for e in envs]
@@ -643,8 +711,11 @@ def explore_maze_batch(problems, model, device, batch=500, k=30, loop=5, model_s
     scores = model.forward_batch(gb, loop)
     tm = mark('explorer_forward', tm)
     w = int(np.asarray(problems[0]['map']).shape[0])
-    maps = torch.tensor(np.asarray([np.asarray(pr['map'], dtype=np.float64) for pr in problems])).to(device)
-    goal64 = torch.tensor(np.asarray([e.goal_state for e in envs], dtype=np.float64)).to(device)
+    if dsamp is not None:
+        maps, goal64 = dsamp['maps'], dsamp['goal64']
+    else:
+        maps = torch.tensor(np.asarray([np.asarray(pr['map'], dtype=np.float64) for pr in problems])).to(device)
+        goal64 = torch.tensor(np.asarray([e.goal_state for e in envs], dtype=np.float64)).to(device)
     success, n_expl, n_pairs, plen, checks, expl, ee, ee_off, path = maze_explore_device(
         v, node_ptr, edge_ptr, n_free, ei, scores, maps, goal64)
     nptr = ptr.tolist()
@@ -655,7 +726,12 @@ def explore_maze_batch(problems, model, device, batch=500, k=30, loop=5, model_s
                                       smooth_iters, device)
         tm = mark('smoothing', tm)
     out = []
-    vs_np = [x.numpy() for x in vs]
+    if vs is None:                                                       # device sampling: one copy of the node rows for the results
+        v_host = v.cpu().numpy()
+        vs_np = [v_host[nptr[b]:nptr[b + 1]] for b in range(B)]
+        vs = [torch.from_numpy(x) for x in vs_np]
+    else:
+        vs_np = [x.numpy() for x in vs]
     for b in range(B):
         nodes = path[nptr[b]:nptr[b] + plen[b]]
         # results stay numpy arrays (explored [n], explored_edges [m, 2], path [P, 2]): building Python lists for

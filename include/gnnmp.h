@@ -15,6 +15,8 @@
  *       ModelSmoother.forward                                 model_smoother.py:104-142 (call smoother.py:243)
  *   gnnmp_graph_workspace_bytes / gnnmp_graph_build
  *       create_data's edge construction                       eval_gnn.py:159-164
+ *   gnnmp_maze_sample
+ *       explore()'s rejection sampling (classification + compaction)   eval_gnn.py:180-184, environment/maze_env.py
  *   gnnmp_maze_steer
  *       proposed_path_smootherv2 (steering of the smoothing stage)  smoother.py:194-216
  *   gnnmp_maze_explore_workspace_bytes / gnnmp_maze_explore / gnnmp_maze_explore_ex
@@ -364,6 +366,27 @@ int gnnmp_maze_explore_ex(const gnnmp_maze_batch* batch, int32_t dim, const gnnm
 int gnnmp_maze_steer(int32_t n_problems, int32_t total_path, int32_t width, const double* maps, const int32_t* path_ptr,
                      const float* old_path, const float* new_path, float* out_path, float* tmp, int64_t* checks,
                      void* hip_stream);
+
+/* Rejection sampling of the explore stage for 2-D mazes (eval_gnn.py:180-184 through MazeEnv.sample_n_points / uniform_sample,
+ * environment/maze_env.py): the raw draws stay with the host's numpy generator (`attempts` is the stream of uniform(-1, 1) pairs in
+ * draw order, float64, DEVICE memory); the device classifies every draw against the problem's occupancy map (float64 arithmetic of
+ * maze_env's cell lookup), finds the n_free-th free draw of every problem IN STREAM ORDER (problem b + 1 starts behind the last
+ * draw problem b consumed, like the reference's one global generator), and writes the float32 node rows the graph builder and the
+ * explorer read: per problem [init_state, goal_state, the n_free free draws, the first min(rejected, n_free) rejected draws]
+ * (eval_gnn.py:182: collided[:len(free)]), compact, with node_ptr_out [B + 1].  v_out must hold n_problems * (2 + 2 * n_free) rows.
+ * *cursor (device, in / out): index of the first unconsumed draw; used_out [B]: draws consumed per problem (the sampling's collision
+ * checks, maze_env.py counts one per draw); *ok_out = 1, or 0 when the stream ran out before the last problem was complete (nothing
+ * is consumed then: *cursor is unchanged -- append draws and call again).  One launch on hip_stream, no synchronisation. */
+typedef struct {
+    int32_t n_problems, width, n_free;
+    int64_t n_attempts;
+    const double* attempts;      /* [n_attempts, 2]                                           */
+    const double* maps;          /* [B, width, width]                                         */
+    const double* init_states;   /* [B, 2]                                                    */
+    const double* goal_states;   /* [B, 2]                                                    */
+} gnnmp_maze_sample_batch;
+int gnnmp_maze_sample(const gnnmp_maze_sample_batch* batch, int64_t* cursor, float* v_out, int32_t* node_ptr_out,
+                      int32_t* used_out, int32_t* ok_out, void* hip_stream);
 
 /* ------------------------------------------------------------------------------------------
  * Host-only helpers exported for the CPU test-suite (no device needed)

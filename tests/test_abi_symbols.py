@@ -60,7 +60,8 @@ def test_ctypes_structs_mirror_the_header():
         structs[name] = fields
     mirrors = {'gnnmp_explorer_dims': _lib.ExplorerDims, 'gnnmp_batch': _lib.Batch, 'gnnmp_smoother_dims': _lib.SmootherDims,
                'gnnmp_smooth_batch': _lib.SmoothBatch, 'gnnmp_graph_batch': _lib.GraphBuildBatch,
-               'gnnmp_maze_batch': _lib.MazeBatch, 'gnnmp_maze_resume': _lib.MazeResume}
+               'gnnmp_maze_batch': _lib.MazeBatch, 'gnnmp_maze_resume': _lib.MazeResume,
+               'gnnmp_maze_sample_batch': _lib.MazeSampleBatch}
     assert set(mirrors) <= set(structs), sorted(structs)
     for cname, cls in mirrors.items():
         assert [f[0] for f in cls._fields_] == structs[cname], cname
