@@ -2451,11 +2451,14 @@ __global__ __launch_bounds__(512, 1) void mp_fused_w8_kernel(MpFusedParams p) {
         const int tile = wk.cur * 4 + w4;
         if (wk.snake) wk.snake_prefetch();
         if (tile >= p.n_tiles) continue;
-        const int tg = p.ntile_graph[tile];
-        if (tg < 0) continue;
+        // the tile's graph, row range and degrees are requested TOGETHER (row_beg / deg exist for every padded row, so they do not
+        // have to wait for the "is this tile in use" answer): one round trip at the tile start instead of two
         const int t0 = tile * 32;
         const int node = t0 + j;
-        const int rb = p.row_beg[node], dg = p.deg[node];
+        int rb = p.row_beg[node], dg = p.deg[node];
+        int tg = p.ntile_graph[tile];
+        asm volatile("" : "+v"(rb), "+v"(dg), "+v"(tg));        // (all three loads in flight before the first is waited for: the compiler sank rb / dg below the branch)
+        if (tg < 0) continue;
         const int beg = __builtin_amdgcn_readfirstlane(rb);
         const int end = __builtin_amdgcn_readlane(rb + dg, 31);
         const int n0 = p.node_ptr_pad[tg];
