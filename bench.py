@@ -236,7 +236,7 @@ def main():
                     help="MFMA operand precision; the headline metric is fp32 (bf16 = BASELINE configs[2]/[4] mode)")
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--pcie-steps', type=int, default=5, help='extra steps timed incl. H2D/D2H (0 = skip)')
+    ap.add_argument('--pcie-steps', type=int, default=20, help='extra steps timed incl. H2D/D2H (0 = skip)')
     ap.add_argument('--dense-steps', type=int, default=5, help='extra steps timed with the dense N x N output (0 = skip)')
     ap.add_argument('--bf16x3-steps', type=int, default=5,
                     help='extra steps timed in the opt-in bf16x3 mode (fp32-class results from the bf16 matrix pipe, '

@@ -114,6 +114,7 @@ def lib():
     L.gnnmp_explorer_train_forward.argtypes = [vp, ctypes.POINTER(Batch), ctypes.c_int, ctypes.c_int, vp, vp, sz, vp]
     L.gnnmp_explorer_train_backward.argtypes = [vp, ctypes.POINTER(Batch), ctypes.c_int, vp, vp, vp, sz, vp]
     L.gnnmp_explorer_status.argtypes = [vp, ctypes.POINTER(Batch), vp, sz, vp, c_int32_p]
+    L.gnnmp_status_copy.argtypes = [vp, vp, ctypes.c_int32, vp]
     L.gnnmp_explorer_status_region.argtypes = [vp, ctypes.POINTER(Batch), ctypes.POINTER(sz), ctypes.POINTER(sz)]
     L.gnnmp_explorer_status_decode.argtypes = [vp, ctypes.c_int, c_int32_p]
     L.gnnmp_smoother_status.argtypes = [vp, ctypes.POINTER(SmoothBatch), vp, sz, vp, c_int32_p]
@@ -172,8 +173,12 @@ class StatusWatch:
 
     def push(self, ws, offset, nbytes, n, what):
         import torch
+        if torch.cuda.is_current_stream_capturing():    # a caller capturing forwards into a graph: no host-side bookkeeping inside
+            return
         words = torch.empty(nbytes // 4, dtype=torch.int32, pin_memory=True)
-        words.copy_(ws[offset:offset + nbytes].view(torch.int32), non_blocking=True)
+        # a one-block KERNEL writes the pinned buffer (device-visible host memory), not a memcpy: see gnnmp_status_copy
+        check(lib().gnnmp_status_copy(ws.data_ptr() + offset, words.data_ptr(), nbytes // 4, torch.cuda.current_stream().cuda_stream),
+              'gnnmp_status_copy')
         ev = torch.cuda.Event()
         ev.record()                                     # current stream = the one the forward and the copy were enqueued on
         with self.lock:

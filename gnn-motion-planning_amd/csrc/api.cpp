@@ -755,6 +755,14 @@ extern "C" int gnnmp_explorer_forward(const gnnmp_explorer* h, const gnnmp_batch
     return forward_impl(h, b, loop, use_obstacles, edge_scores, dense, ws, ws_bytes, hip_stream, nullptr, nullptr, false);
 }
 
+namespace gnnmp { hipError_t launch_status_copy(const int* src, int* dst_host_mapped, int n, hipStream_t st); }
+extern "C" int gnnmp_status_copy(const int32_t* src_device, int32_t* dst_host_mapped, int32_t n_words, void* hip_stream) {
+    if (!src_device || !dst_host_mapped) return GNNMP_ERR_NULL;
+    if (n_words < 0) return GNNMP_ERR_ARG;
+    HIP_TRY(gnnmp::launch_status_copy(src_device, dst_host_mapped, n_words, static_cast<hipStream_t>(hip_stream)));
+    return GNNMP_OK;
+}
+
 extern "C" int gnnmp_explorer_status_region(const gnnmp_explorer* h, const gnnmp_batch* shape, size_t* offset, size_t* bytes) {
     if (!h || !shape || !offset || !bytes) return GNNMP_ERR_NULL;
     Carve c;

@@ -465,4 +465,15 @@ hipError_t launch_graph_build(const GbParams& p, hipStream_t st) {
     return hipSuccess;
 }
 
+// device status words -> a host-mapped (pinned) buffer, as a KERNEL on the forward's stream: a hipMemcpyAsync there would put the next
+// forward behind a DMA engine that may be busy with a caller's large result copy (measured: the two-batches-in-flight pipeline lost 6 %)
+__global__ void status_copy_kernel(const int* __restrict__ src, int* __restrict__ dst, int n) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) dst[i] = src[i];
+}
+hipError_t launch_status_copy(const int* src, int* dst_host_mapped, int n, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(status_copy_kernel, dim3(1), dim3(256), 0, st, src, dst_host_mapped, n);
+    return hipGetLastError();
+}
+
 }  // namespace gnnmp

@@ -152,6 +152,10 @@ int gnnmp_explorer_forward(const gnnmp_explorer* h, const gnnmp_batch* batch, in
 int gnnmp_explorer_status(const gnnmp_explorer* h, const gnnmp_batch* shape, const void* workspace, size_t workspace_bytes,
                           void* hip_stream, int32_t* first_graph_or_null);
 int gnnmp_explorer_status_region(const gnnmp_explorer* h, const gnnmp_batch* shape, size_t* offset, size_t* bytes);
+/* The non-blocking copy itself: n_words ints from a status region (device) into HOST memory that the device can write (pinned /
+ * hipHostMalloc'ed), as a one-block kernel on hip_stream -- not a hipMemcpyAsync, which would order the next forward behind a DMA
+ * engine that may be busy with the caller's own result copies.  Record an event behind it, decode when the event has completed. */
+int gnnmp_status_copy(const int32_t* src_device, int32_t* dst_host_mapped, int32_t n_words, void* hip_stream);
 int gnnmp_explorer_status_decode(const int32_t* words_host, int n_graphs, int32_t* first_graph_or_null);
 
 /* Optional per-stage timing.  While enabled, every forward on this handle records a HIP event pair
