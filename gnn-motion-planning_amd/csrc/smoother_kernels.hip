@@ -664,6 +664,13 @@ __device__ __forceinline__ void sm_node_code_tile(const SmParams& p, const SmNod
 // the polling budget, the edge tile computes the target half itself (same bits), so the wait can never hang a launch.
 // Registers: without a bound the compiler spreads the chain's operand prefetch over 94 VGPRs + 80 AGPRs (two workgroups per
 // CU); asked for four workgroups per CU it fits 124 without spilling.
+#ifdef GNNMP_SM_TRACE
+// diagnostics build: eight 100 MHz stamps per workgroup of the LAST split message launch (tools/diag/sm_trace.py)
+__device__ long long g_sm_trace[8 * 8192];
+#define SM_TRC(k) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_sm_trace[blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define SM_TRC(k) do {} while (0)
+#endif
 template <int D, int P>
 __global__ __launch_bounds__(D * 2, D == 128 ? 4 : 1) void sm_msg_split_kernel(SmParams p) {
     constexpr int NT = D / 32;
@@ -694,11 +701,23 @@ __global__ __launch_bounds__(D * 2, D == 128 ? 4 : 1) void sm_msg_split_kernel(S
         trow = sm_poff(p, b) + dst;                      // the target's row in the padded path space
     }
     bool target_half = trole;                            // does this workgroup compute b00 + (W_c - W_a) x_i itself?
+#ifdef GNNMP_SM_TRACE
+    if (threadIdx.x == 0 && blockIdx.x < 8192) {
+        for (int i = 0; i < 8; ++i) g_sm_trace[blockIdx.x * 8 + i] = 0;
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_sm_trace[blockIdx.x * 8 + 6] = (long long)hw | ((long long)xcc << 32);
+        g_sm_trace[blockIdx.x * 8 + 7] = trole ? 1 : 0;
+    }
+#endif
+    SM_TRC(0);
     if (!trole) {
         // source half first: it does not depend on the target rows.  The tile stays in xbuf[1] until it is needed
         f32x16 mine;
         sm_node_code_tile<NT, P>(p, sm_node_in(p, b, src), wave, mine, lane);      // x_j (source)
         sm_exchange_put(xbuf[1], wave, mine, lane);
+        SM_TRC(1);
         if (n_troles > 0) {
             if (wave == 0) {                             // the flags of the path tiles this edge tile's targets live in
                 bool ready = false;
@@ -713,6 +732,7 @@ __global__ __launch_bounds__(D * 2, D == 128 ? 4 : 1) void sm_msg_split_kernel(S
             }
             __syncthreads();
             target_half = s_ready == 0;                  // the rare path: a flag did not show up in time
+            SM_TRC(2);
         } else {
             target_half = true;
         }
@@ -725,10 +745,12 @@ __global__ __launch_bounds__(D * 2, D == 128 ? 4 : 1) void sm_msg_split_kernel(S
         sm_exchange<NT>(xbuf[0], wave, mine, x, lane);
         linear_acc_p<P, 1, NT>(W + p.L.wdst + (size_t)wave * NT * TF, x, z, lane);   // (W_c - W_a) x_i
         if (trole) {
+            SM_TRC(3);
             store_row<1>(p.tgt + (size_t)trow * D + wave * 32, z, h);
             __threadfence();                             // the rows are visible device-wide before the flag is
             __syncthreads();
             if (threadIdx.x == 0) __hip_atomic_store(&p.tgt_flag[blockIdx.x], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            SM_TRC(5);
             return;
         }
         __syncthreads();                                 // every wave has read xbuf[0] before the z exchange below reuses it
@@ -736,17 +758,20 @@ __global__ __launch_bounds__(D * 2, D == 128 ? 4 : 1) void sm_msg_split_kernel(S
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         load_row<1>(p.tgt + (size_t)trow * D + wave * 32, z, h);
     }
+    SM_TRC(3);
     {
         f32x16 xs[NT];
         sm_exchange_get<NT>(xbuf[1], xs, lane);
         linear_acc_p<P, 1, NT>(W + p.L.wsrc + (size_t)wave * NT * TF, xs, z, lane);  // (W_a + W_b) x_j
     }
     relu_<1>(z);
+    SM_TRC(4);
     f32x16 zall[NT], m[1];
     sm_exchange<NT>(xbuf[0], wave, z[0], zall, lane);
     load_vec<1>(W + p.L.b02 + wave * 32, m, lane);
     linear_acc_p<P, 1, NT>(W + p.L.w02 + (size_t)wave * NT * TF, zall, m, lane);
     store_row<1>(p.msg + (size_t)e * D + wave * 32, m, h);
+    SM_TRC(5);
 }
 
 template <int D, int P>
@@ -902,3 +927,10 @@ hipError_t launch_sm_iter(int D, int P, const SmParams& p, hipStream_t st) {
 }
 
 }  // namespace gnnmp
+
+#ifdef GNNMP_SM_TRACE
+extern "C" int gnnmp_debug_sm_trace(long long* dst, int n_wgs) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(gnnmp::g_sm_trace), sizeof(long long) * 8 * (size_t)(n_wgs > 8192 ? 8192 : n_wgs)) == hipSuccess ? 0 : -1;
+}
+#endif
