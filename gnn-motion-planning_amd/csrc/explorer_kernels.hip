@@ -1384,6 +1384,11 @@ struct XcdWalk {
 // =====================================================================================================
 // one 32-feature tile `t` of edge slot `slot` (per-edge tiles are stored tile-native, [slot / 32][NT][...][64 lanes][...],
 // chain.hpp store_tile_p; a chunk need not start on a tile boundary, so every lane addresses its own slot)
+#ifdef GNNMP_DBG_KE_T
+#define GNNMP_KE_LOAD(p) (*(p))
+#else
+#define GNNMP_KE_LOAD(p) __builtin_nontemporal_load(p)
+#endif
 template <int P, int NT>
 __device__ __forceinline__ void load_edge_slot_tile(const float* base_f32_units, int slot, int h, int t, f32x16& x) {
     const size_t tile = (size_t)(slot >> 5);
@@ -1392,14 +1397,14 @@ __device__ __forceinline__ void load_edge_slot_tile(const float* base_f32_units,
         const float* b = base_f32_units + tile * NT * 1024 + ln * 4;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const f32x4 a = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(b + (t * 4 + q) * 256));
+            const f32x4 a = GNNMP_KE_LOAD(reinterpret_cast<const f32x4*>(b + (t * 4 + q) * 256));
 #pragma unroll
             for (int c = 0; c < 4; ++c) x[q * 4 + c] = a[c];
         }
     } else {
         const __bf16* b = reinterpret_cast<const __bf16*>(base_f32_units) + tile * NT * 1024 + ln * 8;
-        const bf16x8 lo = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(b + (t * 2 + 0) * 512));
-        const bf16x8 hi = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(b + (t * 2 + 1) * 512));
+        const bf16x8 lo = GNNMP_KE_LOAD(reinterpret_cast<const bf16x8*>(b + (t * 2 + 0) * 512));
+        const bf16x8 hi = GNNMP_KE_LOAD(reinterpret_cast<const bf16x8*>(b + (t * 2 + 1) * 512));
         const f32x8 a = __builtin_convertvector(lo, f32x8), c = __builtin_convertvector(hi, f32x8);
 #pragma unroll
         for (int r = 0; r < 8; ++r) { x[r] = a[r]; x[8 + r] = c[r]; }
@@ -1417,8 +1422,8 @@ __device__ __forceinline__ void load_edge_slot_raw(const float* base_f32_units, 
         const size_t tile = (size_t)(slot >> 5);
         const int ln = (slot & 31) + 32 * h;
         const __bf16* b = reinterpret_cast<const __bf16*>(base_f32_units) + tile * NT * 1024 + ln * 8;
-        r.lo = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(b + (t * 2 + 0) * 512));
-        r.hi = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(b + (t * 2 + 1) * 512));
+        r.lo = GNNMP_KE_LOAD(reinterpret_cast<const bf16x8*>(b + (t * 2 + 0) * 512));
+        r.hi = GNNMP_KE_LOAD(reinterpret_cast<const bf16x8*>(b + (t * 2 + 1) * 512));
     }
 }
 template <int P>
@@ -1498,7 +1503,8 @@ struct RowGeom {
 };
 
 // stage <- 32 rows; `row_id(sr)` = array row of stage row sr as seen by THIS lane (the caller shuffles if needed)
-template <int D, int P, class RowId>
+// AUX: cache policy bits of the instruction (2 = nt: rows that are read once per launch should not displace the gathered A rows in L2)
+template <int D, int P, int AUX = 0, class RowId>
 __device__ __forceinline__ void dma_rows(const float* array_f32_units, RowId row_id, float* stage, int lane) {
     using G = RowGeom<D, P>;
     const char* base = reinterpret_cast<const char*>(array_f32_units);
@@ -1508,7 +1514,7 @@ __device__ __forceinline__ void dma_rows(const float* array_f32_units, RowId row
         const int pc = (lane % G::PP) ^ G::swz(sr);
         const char* g = base + (size_t)row_id(sr) * G::RB + pc * 16;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                         (__attribute__((address_space(3))) void*)(stage + i * 256), 16, 0, 0);
+                                         (__attribute__((address_space(3))) void*)(stage + i * 256), 16, 0, AUX);
     }
 }
 
@@ -1581,7 +1587,7 @@ __device__ __forceinline__ void write_stage_tiles(float* stage, int sr, int h, c
 // 32 staged rows -> 32 CONSECUTIVE rows of a [rows, D] array, the inverse of dma_rows for a contiguous block: lane l stores LDS piece
 // (l % PP) of stage row (l / PP) of its instruction, i.e. PP lanes write one whole row (64 .. 256 contiguous bytes) instead of every
 // lane writing 8 / 16 bytes of a different row (a store in the chain layout is one L2 write request per lane)
-template <int D, int P>
+template <int D, int P, bool NT_STORE = false>
 __device__ __forceinline__ void store_rows_coalesced(float* array_f32_units, size_t row0, const float* stage, int lane) {
     using G = RowGeom<D, P>;
     char* base = reinterpret_cast<char*>(array_f32_units) + row0 * G::RB;
@@ -1590,7 +1596,9 @@ __device__ __forceinline__ void store_rows_coalesced(float* array_f32_units, siz
         const int sr = G::RPI * i + lane / G::PP;
         const int lp = lane % G::PP;                              // LDS piece lp of a row holds the row's piece lp ^ swz (dma_rows)
         const f32x4 v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(stage) + sr * G::RB + lp * 16);
-        *reinterpret_cast<f32x4*>(base + (size_t)sr * G::RB + ((lp ^ G::swz(sr)) * 16)) = v;
+        f32x4* dst = reinterpret_cast<f32x4*>(base + (size_t)sr * G::RB + ((lp ^ G::swz(sr)) * 16));
+        if constexpr (NT_STORE) __builtin_nontemporal_store(v, dst);
+        else *dst = v;
     }
 }
 
@@ -1683,6 +1691,9 @@ __host__ __device__ constexpr int mp_lds_floats() {
 // go round-robin to the waves, which all aggregate into the shared LDS tile (float atomics: order-free, exact), and
 // wave 0 runs the node phase.  A single 1000-node graph has 32 tiles of ~12 chunks: 25 us per launch with one wave
 // per tile, ~9 us with eight.
+// X', A', B' / PT rows leave with non-temporal stores: nothing reads them again in this launch, and they would displace the gathered A
+// rows in L2 (configs[1] shape: mp 0.667 -> 0.656 ms; neutral at the bf16 shapes)
+constexpr bool kNtW4 = true;
 template <int D, int P, int COOP>
 // d = 64 with fp32 / bf16x3 operands: the LDS tiles leave ONE 4-wave workgroup per CU anyway, so the wave may use the whole
 // register file (no spills)
@@ -2306,7 +2317,7 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
                 write_stage_tiles<D, XP, NT>(xs, j, h, y);                          // X' rows -> stage -> whole rows out
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
-                store_rows_coalesced<D, XP>(p.Xout, (size_t)t0, xs, lane);
+                store_rows_coalesced<D, XP, kNtW4>(p.Xout, (size_t)t0, xs, lane);
             } else {
                 store_row_p<P == 1 ? 1 : 0, NT>(p.Xout, (size_t)node, y, h);        // X is only ever read as an MFMA operand: bf16 rows lose nothing
             }
@@ -2322,7 +2333,7 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
                 write_stage_tiles<D, P, NT>(as, j, h, z);                           // A' rows -> stage -> whole rows out
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
-                store_rows_coalesced<D, P>(p.Aout, (size_t)t0, as, lane);
+                store_rows_coalesced<D, P, kNtW4>(p.Aout, (size_t)t0, as, lane);
             } else {
                 store_row_p<P, NT>(p.Aout, (size_t)node, z, h);
             }
@@ -2339,7 +2350,7 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
                 write_stage_tiles<D, P, NT>(ps, j, h, z);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
-                store_rows_coalesced<D, P>(p.Bout, (size_t)t0, ps, lane);
+                store_rows_coalesced<D, P, kNtW4>(p.Bout, (size_t)t0, ps, lane);
             } else {
                 store_row_p<P, NT>(p.Bout, (size_t)node, z, h);
             }
@@ -2381,9 +2392,22 @@ __host__ __device__ constexpr int mp_w8_lds_floats() {
            8 * (32 * D + 32 + RowGeom<D, P>::STAGE_FLOATS);
 }
 
+#ifdef GNNMP_DBG_ROWS0
+#define GNNMP_ROW0(x) 0
+#else
+#define GNNMP_ROW0(x) (x)
+#endif
 template <int D, int P>
 __global__ __launch_bounds__(512, 1) void mp_fused_w8_kernel(MpFusedParams p) {
     constexpr int NT = D / 32;
+    // bf16 (measured at the configs[2] shape, profiles/r05_mp_traffic_attribution.txt): the X', A', PT rows leave with non-temporal
+    // stores (they are not read again in this launch and would displace the gathered A rows in L2: mp 0.454 -> 0.440 ms), and the
+    // chunks start on the 32-slot tiles K_e is stored in (kAl below: 0.440 -> 0.431 ms, K_e lines fetched 2.14 M -> 1.90 M per launch).
+    // fp32: neither pays (the stores are neutral, the extra partial chunk per tile costs 1.5 %); non-temporal X / R row reads cost 2 %
+    // in both modes (the second read of the X rows then always misses).
+    constexpr int kNtR = 0;
+    constexpr bool kNtW = P == 1;
+    constexpr bool kAl = P == 1;
     constexpr int XP = P == 1 ? 1 : 0;                           // X rows are stored in bf16 in the bf16 mode
     constexpr bool kWLds = P == 1;                               // node-phase matrices in LDS
     using LE = MpEBlob<D, P>;
@@ -2477,11 +2501,19 @@ __global__ __launch_bounds__(512, 1) void mp_fused_w8_kernel(MpFusedParams p) {
         const float* wn = kWLds ? wnl : p.wn;
         const float* wm3 = kWLds ? (p.last ? wm3x : wnl + LN::m3) : p.wn_std + LN::m3;
         if constexpr (!kWLds) asm volatile("" : "+s"(wn), "+s"(wm3));
+        // chunks start on the 32-slot tiles K_e is stored in (kAl): every K_e request is four whole 128-byte lines per half wave; the
+        // first chunk's leading lanes (slots of the previous node tile) and the last chunk's trailing lanes are masked
+        const int first = kAl ? (beg & ~31) : beg;
+        const int end_al = (end + 31) & ~31;
         KeRaw<P> qa[PF], qb[PF];
         auto ke_fetch = [&](int cc, KeRaw<P> (&dst)[PF]) {      // wave-uniform cc; unconditional (see mp_fused_kernel)
 #pragma unroll
             for (int t = 0; t < PF; ++t) {
-                const int sl = cc + j < end ? cc + j : beg;
+#ifdef GNNMP_DBG_KE0
+                const int sl = beg;                              // (traffic attribution: no K_e stream)
+#else
+                const int sl = cc + j < (kAl ? end_al : end) ? cc + j : beg;
+#endif
                 load_edge_slot_raw<P, NT>(p.Ke, sl, h, t, dst[t]);
             }
         };
@@ -2489,9 +2521,9 @@ __global__ __launch_bounds__(512, 1) void mp_fused_w8_kernel(MpFusedParams p) {
         int pre_rec_c = 0, pre_rec_n = 0;
         int l0 = lane;                                           // (laundered per tile: see the node phase)
         asm volatile("" : "+v"(l0));
-        dma_rows<D, XP>(p.X, [&](int sr) { return t0 + sr; }, agg, l0);           // X rows (4 KB bf16 / 8 KB fp32) through the aggregation tile
-        if (beg + j < end) pre_rec_c = p.rec32[beg + j];
-        if (beg + 32 + j < end) pre_rec_n = p.rec32[beg + 32 + j];
+        dma_rows<D, XP, kNtR>(p.X, [&](int sr) { return GNNMP_ROW0(t0 + sr); }, agg, l0);           // X rows (4 KB bf16 / 8 KB fp32) through the aggregation tile
+        if (first + j >= beg && first + j < end) pre_rec_c = p.rec32[first + j];
+        if (first + 32 + j < end) pre_rec_n = p.rec32[first + 32 + j];
         wait_vmcnt<0>();
         // The X rows leave the LDS for registers and the aggregation tile is reset BEFORE anything else is requested: an LDS access
         // the compiler generates while an LDS-DMA is in flight is guarded by s_waitcnt vmcnt(0) (it cannot tell the A stage from
@@ -2506,11 +2538,14 @@ __global__ __launch_bounds__(512, 1) void mp_fused_w8_kernel(MpFusedParams p) {
 #pragma unroll
             for (int q = 0; q < D / 8; ++q) *reinterpret_cast<f32x4*>(agg + j * D + h * (D / 2) + q * 4) = ninf;
         }
-        const int first = beg;
+#ifdef GNNMP_DBG_AOWN
+        auto src_row = [&](int rec, bool valid) { return t0 + j; };           // (traffic attribution: no gather)
+#else
         auto src_row = [&](int rec, bool valid) { return valid ? n0 + (rec & 0x7ffffff) : t0; };
+#endif
         int rec_c = pre_rec_c, rec_n = pre_rec_n;
-        if (first < end) {                                       // the first chunk's A rows and the first two chunks' K_e travel under the MFMAs below
-            const int mine_row = src_row(rec_c, first + j < end);
+        if (beg < end) {                                         // the first chunk's A rows and the first two chunks' K_e travel under the MFMAs below
+            const int mine_row = src_row(rec_c, first + j >= beg && first + j < end);
             dma_rows<D, P>(p.A, [&](int sr) { return __builtin_amdgcn_ds_bpermute(sr * 4, mine_row); }, astage, lane);
             ke_fetch(first, qa);
             if constexpr (KD == 2) ke_fetch(first + STEP, qb);
@@ -2534,7 +2569,7 @@ __global__ __launch_bounds__(512, 1) void mp_fused_w8_kernel(MpFusedParams p) {
                 else asm volatile("" : "+v"(cur[t].v[0]), "+v"(cur[t].v[4]), "+v"(cur[t].v[8]), "+v"(cur[t].v[12]));
             }
             const int slot = c0 + j;
-            const bool valid = slot < end;
+            const bool valid = slot < end && (!kAl || slot >= beg);
             const int rec = rec_c;
             const int dloc = valid ? ((rec >> 27) & 31) : 0;
             const int eslot = valid ? slot : beg;
@@ -2556,7 +2591,7 @@ __global__ __launch_bounds__(512, 1) void mp_fused_w8_kernel(MpFusedParams p) {
             } else {
                 int lx = lane;                                   // (laundered: these addresses must not be hoisted out of the chunk loop)
                 asm volatile("" : "+v"(lx));
-                dma_rows<D, XP>(p.X, [&](int sr) { return t0 + sr; }, astage, lx);
+                dma_rows<D, XP, kNtR>(p.X, [&](int sr) { return GNNMP_ROW0(t0 + sr); }, astage, lx);
                 x_requested = true;
             }
             {
@@ -2611,12 +2646,12 @@ __global__ __launch_bounds__(512, 1) void mp_fused_w8_kernel(MpFusedParams p) {
 #endif
                 x += a + b;
             }, M, lane);
-            if (end - c0 < 32) {                                 // the last, partial chunk: pad edges aggregate -inf
-                const int nv = end - c0;
+            if (end - c0 < 32 || (kAl && c0 < beg)) {            // a partial chunk (wave-uniform): pad edges aggregate -inf
+                const int nv = end - c0, n0v = kAl ? beg - c0 : 0;
 #pragma unroll
                 for (int ot = 0; ot < NT; ++ot)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) M[ot][r] = phi(r, h) < nv ? M[ot][r] : -INFINITY;
+                    for (int r = 0; r < 16; ++r) M[ot][r] = (phi(r, h) < nv && phi(r, h) >= n0v) ? M[ot][r] : -INFINITY;
             }
             __builtin_amdgcn_wave_barrier();
             i32x4 o4[4];
@@ -2635,7 +2670,7 @@ __global__ __launch_bounds__(512, 1) void mp_fused_w8_kernel(MpFusedParams p) {
             __builtin_amdgcn_wave_barrier();
         };
         {
-            int c0 = first;
+            int c0 = beg < end ? first : end;
             for (; c0 + STEP < end; c0 += 2 * STEP) {
                 if constexpr (KD == 2) { chunk(c0, qa, qa); chunk(c0 + STEP, qb, qb); }
                 else { chunk(c0, qa, qb); chunk(c0 + STEP, qb, qa); }
@@ -2649,7 +2684,7 @@ __global__ __launch_bounds__(512, 1) void mp_fused_w8_kernel(MpFusedParams p) {
         // ~40 registers that then spill around the chunk loop: the lane id is laundered per tile so that they are recomputed here)
         int ln = lane;
         asm volatile("" : "+v"(ln));
-        if (!x_requested) dma_rows<D, XP>(p.X, [&](int sr) { return t0 + sr; }, astage, ln);     // a tile without incoming edges
+        if (!x_requested) dma_rows<D, XP, kNtR>(p.X, [&](int sr) { return GNNMP_ROW0(t0 + sr); }, astage, ln);     // a tile without incoming edges
         f32x16 H[NT];
         load_vec<NT>(wn + LN::bl, H, lane);
         wait_vmcnt<0>();
@@ -2664,7 +2699,7 @@ __global__ __launch_bounds__(512, 1) void mp_fused_w8_kernel(MpFusedParams p) {
         }, H, lane);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();                        // the aggregation tile has been read by every lane: it takes the R rows
-        dma_rows<D, 0>(p.R, [&](int sr) { return t0 + sr; }, agg, ln);
+        dma_rows<D, 0, kNtR>(p.R, [&](int sr) { return GNNMP_ROW0(t0 + sr); }, agg, ln);
         GNNMP_TRC();                                             // (diagnostics build) H done
         if (p.store_h) store_row<NT>(p.Hout + (size_t)node * D, H, h);
         BOp<P> yop[NT];
@@ -2680,7 +2715,7 @@ __global__ __launch_bounds__(512, 1) void mp_fused_w8_kernel(MpFusedParams p) {
             write_stage_tiles<D, XP, NT>(astage, j, h, y);       // X' rows -> A stage -> whole rows out
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
-            store_rows_coalesced<D, XP>(p.Xout, (size_t)t0, astage, ln);
+            store_rows_coalesced<D, XP, kNtW>(p.Xout, (size_t)t0, astage, ln);
             make_ops<P, NT>(y, yop);
         }
         {
@@ -2691,7 +2726,7 @@ __global__ __launch_bounds__(512, 1) void mp_fused_w8_kernel(MpFusedParams p) {
             write_stage_tiles<D, P, NT>(agg, j, h, z);           // A' rows -> (bf16: first half of) the aggregation tile -> whole rows out
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
-            store_rows_coalesced<D, P>(p.Aout, (size_t)t0, agg, ln);
+            store_rows_coalesced<D, P, kNtW>(p.Aout, (size_t)t0, agg, ln);
         }
         if (p.last) {                                            // PT for the policy head (B' is recomputed by the next iteration otherwise)
             f32x16 z[NT];
@@ -2707,7 +2742,7 @@ __global__ __launch_bounds__(512, 1) void mp_fused_w8_kernel(MpFusedParams p) {
             write_stage_tiles<D, P, NT>(ps, j, h, z);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
-            store_rows_coalesced<D, P>(p.Bout, (size_t)t0, ps, ln);
+            store_rows_coalesced<D, P, kNtW>(p.Bout, (size_t)t0, ps, ln);
         }
         GNNMP_TRC();
     }

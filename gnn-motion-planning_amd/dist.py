@@ -8,6 +8,7 @@ backend on GPUs and gloo in the CPU tests.  Payloads are small (about 45 KB of s
 graph), so the gather is latency-bound; it is padded to the largest shard because all_gather needs
 equal sizes.
 """
+import os
 import torch
 import torch.distributed as dist
 
@@ -195,7 +196,10 @@ class MixedJob:
             b = GraphBatch.from_graphs([problems[i] for i in idxs], m.obs_size, dev)
             ws = torch.empty(m.workspace_bytes(b), dtype=torch.uint8, device=dev)
             out = torch.empty(max(b.total_edges, 1), dtype=torch.float32, device=dev)
-            self.parts.append((env, idxs, b, ws, out, torch.cuda.Stream(dev) if concurrent else None))
+            # the most expensive family sets the job's critical path: its stream gets the higher hardware-queue priority, the other
+            # families' workgroups fill the slots its launches leave
+            prio = -1 if (not self.parts and os.environ.get('GNNMP_MIXED_PRIO', '1') != '0') else 0
+            self.parts.append((env, idxs, b, ws, out, torch.cuda.Stream(dev, priority=prio) if concurrent else None))
 
     def run(self):
         """One forward per family; returns the per-problem score tensors in the caller's order (views into the job's own
