@@ -196,10 +196,9 @@ class MixedJob:
             b = GraphBatch.from_graphs([problems[i] for i in idxs], m.obs_size, dev)
             ws = torch.empty(m.workspace_bytes(b), dtype=torch.uint8, device=dev)
             out = torch.empty(max(b.total_edges, 1), dtype=torch.float32, device=dev)
-            # the most expensive family sets the job's critical path: its stream gets the higher hardware-queue priority, the other
-            # families' workgroups fill the slots its launches leave
-            prio = -1 if (not self.parts and os.environ.get('GNNMP_MIXED_PRIO', '1') != '0') else 0
-            self.parts.append((env, idxs, b, ws, out, torch.cuda.Stream(dev, priority=prio) if concurrent else None))
+            # (a higher hardware-queue priority for the most expensive family's stream was measured and dropped: 59.4 k -> 57.1 k graphs/s,
+            # profiles/r05_cfg4_mixed.txt)
+            self.parts.append((env, idxs, b, ws, out, torch.cuda.Stream(dev) if concurrent else None))
 
     def run(self):
         """One forward per family; returns the per-problem score tensors in the caller's order (views into the job's own
