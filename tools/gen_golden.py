@@ -321,6 +321,47 @@ def eval_set_case(n_problems=12, batch=500, k=30, seed=1234, rows_only=False, t_
                         columns=np.array(['success', 'path_cost', 'smooth_cost', 'c_explore', 'c_smooth', 'path_len', 'explored']))
 
 
+def bf16_anchor_cases():
+    """What the UNMODIFIED reference modules produce when they are cast to bfloat16 (``module.to(torch.bfloat16)``,
+    bf16 inputs; the only way the reference runs in bf16 at all -- ``torch.autocast`` fails at model.py:134 on a dtype
+    mismatch).  Written next to the reference's fp32 scores of the same inputs as tests/golden/refbf16_*.npz: the
+    externally produced yardstick for ``mlp_dtype='bf16'`` (the kernels round only MFMA operands and keep fp32
+    accumulators, LayerNorm, softmax statistics and the max aggregation, so they must be at least as close to the
+    reference's fp32 run as the reference's own bf16 run is)."""
+    torch.set_num_threads(8)
+    for fn in sorted(os.listdir(OUT)):
+        if not (fn.startswith('explorer_kuka') and fn.endswith('.npz')):
+            continue
+        with np.load(os.path.join(OUT, fn)) as f:
+            r = {k: f[k] for k in f.files}
+        env = fn.split('_')[1]
+        sd = torch.load(os.path.join(REF, 'data', 'weights', ENVS[env]['ckpt'] + '.pt'), map_location='cpu')
+        g = dict(v=torch.from_numpy(r['v']), goal=torch.from_numpy(r['goal']), obstacles=torch.from_numpy(r['obstacles']),
+                 edge_index=torch.from_numpy(r['edge_index']), n_free=int(r['n_free']))
+        s32, _ = run_explorer(env, sd, g, int(r['loop']), bool(r['use_obstacles']), torch.float32, False)
+        assert np.array_equal(s32.numpy(), r['scores_fp32']), fn                     # same inputs, same reference run
+        sb, _ = run_explorer(env, sd, g, int(r['loop']), bool(r['use_obstacles']), torch.bfloat16, False)
+        d = (sb.float() - s32).abs()
+        np.savez_compressed(os.path.join(OUT, 'refbf16_' + fn), of=fn, scores_ref_bf16=sb.float().numpy())
+        print('%-48s reference in bf16 vs its fp32 run: max %.4f mean %.4f' % ('refbf16_' + fn, d.max(), d.mean()))
+    # the two bf16 BASELINE shapes at full size (configs[2]: kuka7 2000-node k=10; configs[4]: kuka14 5000-node k=16), one graph
+    # each by seed; inputs are regenerated from the seed by gnnmp.synth.synth_graph (checked through edge_index / v checksums)
+    for env, n, k, seed in (('kuka7', 2000, 10, 4242), ('kuka14', 5000, 16, 4242)):
+        sd = torch.load(os.path.join(REF, 'data', 'weights', ENVS[env]['ckpt'] + '.pt'), map_location='cpu')
+        g = synth_graph(env, n, k, seed=seed)
+        s32, _ = run_explorer(env, sd, g, 5, True, torch.float32, False)
+        sb, _ = run_explorer(env, sd, g, 5, True, torch.bfloat16, False)
+        d = (sb.float() - s32).abs()
+        fn = 'refbf16_full_%s_N%d_k%d_s%d.npz' % (env, n, k, seed)
+        np.savez_compressed(os.path.join(OUT, fn), env=env, n=n, k=k, seed=seed, loop=5,
+                            v_sum=float(g['v'].double().sum()), n_edges=int(g['edge_index'].shape[1]),
+                            ei_sum=int(g['edge_index'].long().sum()),
+                            scores_fp32=s32.numpy(), scores_ref_bf16=sb.float().numpy().astype(np.float32))
+        print('%-48s E=%d reference in bf16 vs its fp32 run: max %.4f mean %.4f' % (fn, g['edge_index'].shape[1], d.max(), d.mean()))
+    # (the reference SMOOTHER cannot be run in bf16 unmodified: model_smoother.py:131-135 concatenates the bf16 nodes with a
+    # float32 one-hot block, the promoted fp32 rows then meet bf16 weights; its bf16 mode keeps the emulation bar only)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -346,6 +387,7 @@ def main():
     smoother_knn32_case()
     planner_cases(sds)
     eval_set_case()
+    bf16_anchor_cases()
 
 
 if __name__ == '__main__':
@@ -356,6 +398,8 @@ if __name__ == '__main__':
         torch.set_num_threads(8)
         eval_set_case(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), dim=3,
                       map_file='maze_files/mazes_hard_3.npz', t_max=int(sys.argv[6]) if len(sys.argv) > 6 else None)
+    elif len(sys.argv) > 1 and sys.argv[1] == 'bf16anchor':
+        bf16_anchor_cases()
     elif len(sys.argv) > 1 and sys.argv[1] == 'knn32':
         smoother_knn32_case()
     elif len(sys.argv) > 1 and sys.argv[1] == 'evalset':
