@@ -1630,6 +1630,42 @@ __device__ __forceinline__ void linear_acc_stream(const float* A, Get get, f32x1
     }
 }
 
+// Exact-fp32 layers whose weights stay in GLOBAL memory (mp_fused_w8_kernel<64, 0>: 80 KB of node-phase matrices do not fit the LDS
+// next to eight waves' tiles).  Read where they are used (mfma_tile_p on the laundered pointer) they were FLAT loads -- the pointer
+// had lost its address space, so every wait was s_waitcnt vmcnt(0) lgkmcnt(0) -- requested four at a time right in front of their
+// MFMAs: eight dependent L2 round trips per 64 x 64 layer, 40 per tile (the 31 us node phase of round 5's timeline against 8.5 us
+// of matrix-pipe time).  GlobalW requests ALL operand slices of a layer at once, as global_load_dwordx4 on an address-space-1
+// pointer (NT * NT * 4 = 16 requests, 64 registers at d = 64: one round trip per layer, the MFMAs start as the slices arrive), and
+// a layer's slices can be requested while the previous layer's MFMAs run (the registers of the chunk loop are dead in the node
+// phase).  Same operands, same order of accumulation per output tile as linear_acc_ops / linear_acc_stream: same bits.
+template <int NT>
+struct GlobalW {
+    f32x4 w[NT * NT * 4];
+    __device__ __forceinline__ void request(const float* A, int lane) {
+        // scalar base + 32-bit lane offset + immediate: one address register for all sixteen requests (per-lane 64-bit addresses
+        // cost a register pair per 4 KB tile, the immediate reaches 4095 bytes)
+        typedef const __attribute__((address_space(1))) char* gbytes;
+        typedef const __attribute__((address_space(1))) f32x4* gvec;
+        const gbytes base = (gbytes)A;
+        const unsigned off = (unsigned)lane * 16u;
+#pragma unroll
+        for (int t = 0; t < NT * NT; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) w[t * 4 + q] = *(gvec)(base + t * 4096 + q * 1024 + off);   // A + t * 1024 + (q * 64 + lane) * 4 floats
+        __builtin_amdgcn_sched_barrier(0);                       // (the scheduler sinks the requests back in front of their MFMAs otherwise)
+    }
+    // y[ot] += A[ot][it] . x   for every ot (the order linear_acc_ops / linear_acc_stream use)
+    __device__ __forceinline__ void apply(int it, const f32x16& x, f32x16 (&y)[NT]) const {
+#pragma unroll
+        for (int ot = 0; ot < NT; ++ot)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    y[ot] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[(ot * NT + it) * 4 + q][c], x[q * 4 + c], y[ot], 0, 0, 0);
+    }
+};
+
 // ablation switches of mp_fused for attribution runs (tools/diag/build_variant.sh abl_x -DGNNMP_ABL_X=1): WRONG results, timing only
 #ifndef GNNMP_ABL_NO_KE
 #define GNNMP_ABL_NO_KE 0            // no K_e stream (zeros instead)
@@ -1670,6 +1706,15 @@ __device__ __forceinline__ void linear_acc_stream(const float* A, Get get, f32x1
 #endif
 #ifndef GNNMP_MP_ASM_WAITS
 #define GNNMP_MP_ASM_WAITS 0         // experiment: round 3's inline-asm waits in the round-3 flow
+#endif
+#ifndef GNNMP_MP_GLOBALW
+// mp_fused_w8_kernel<64, 0>, experiment (round 5, profiles/r05_mp_w8f_globalw.txt): 0 = the layers' operands are read where they are
+// used (shipped); 1 = whole layers requested at once through GlobalW, two register sets, every layer requested under an earlier
+// layer's MFMAs (94 spilled registers); 2 = one register set, no spills.  The node phase of a tile shrinks (31.9 -> 23.5 us with 2)
+// and the OTHER wave of the SIMD pays for it (6.55 -> 6.81 us per chunk): the launch takes the same time (1.349 / 1.396 / 1.338 ms per
+// five launches at 2000 nodes x 64, 0.657 / 0.702 / 0.672 at 1000 x 64) -- the two waves of a SIMD share a throughput, the node
+// phase's round trips were being covered already.  Bit-identical in all three.
+#define GNNMP_MP_GLOBALW 0
 #endif
 #ifndef GNNMP_ABL_NO_EDGE
 #define GNNMP_ABL_NO_EDGE 0          // no edge phase at all (tile start + node phase only)
@@ -2410,6 +2455,7 @@ __global__ __launch_bounds__(512, 1) void mp_fused_w8_kernel(MpFusedParams p) {
     constexpr bool kAl = P == 1;
     constexpr int XP = P == 1 ? 1 : 0;                           // X rows are stored in bf16 in the bf16 mode
     constexpr bool kWLds = P == 1;                               // node-phase matrices in LDS
+    constexpr bool kWGlobal = P == 0 && GNNMP_MP_GLOBALW;        // fp32: whole layers requested at once from global memory (GlobalW)
     using LE = MpEBlob<D, P>;
     using LN = MpNBlob<D, P>;
     using G = RowGeom<D, P>;
@@ -2555,7 +2601,18 @@ __global__ __launch_bounds__(512, 1) void mp_fused_w8_kernel(MpFusedParams p) {
             f32x16 z[NT];
 #pragma unroll
             for (int tt = 0; tt < NT; ++tt) z[tt] = splat16(0.f);
-            linear_acc_stream<P, NT, false>(wm3, [&](int it, f32x16& x) { expand_stage_raw<XP>(xr[it], x); }, z, lane);
+            if constexpr (kWGlobal) {
+                GlobalW<NT> gw;
+                gw.request(wm3, lane);
+#pragma unroll
+                for (int it = 0; it < NT; ++it) {
+                    f32x16 x;
+                    expand_stage_raw<XP>(xr[it], x);
+                    gw.apply(it, x, z);
+                }
+            } else {
+                linear_acc_stream<P, NT, false>(wm3, [&](int it, f32x16& x) { expand_stage_raw<XP>(xr[it], x); }, z, lane);
+            }
             make_ops<P, NT>(z, bpk);                            // (bf16: rounded exactly like the rows mp_fused_kernel writes into its B stage)
         }
         bool x_requested = false;
@@ -2685,64 +2742,157 @@ __global__ __launch_bounds__(512, 1) void mp_fused_w8_kernel(MpFusedParams p) {
         int ln = lane;
         asm volatile("" : "+v"(ln));
         if (!x_requested) dma_rows<D, XP, kNtR>(p.X, [&](int sr) { return GNNMP_ROW0(t0 + sr); }, astage, ln);     // a tile without incoming edges
-        f32x16 H[NT];
-        load_vec<NT>(wn + LN::bl, H, lane);
-        wait_vmcnt<0>();
-        linear_acc_stream<P, NT, false>(wn + LN::wlx, [&](int it, f32x16& x) { read_stage_tile<D, XP>(astage, j, h, it, x); }, H, lane);
-        linear_acc_stream<P, NT, false>(wn + LN::wla, [&](int it, f32x16& x) {
+        if constexpr (kWGlobal) {
+            // exact fp32: two register sets of layer operands (GlobalW), each layer requested while an earlier layer's MFMAs run
+#if GNNMP_MP_GLOBALW == 2
+            GlobalW<NT> ga;
+            GlobalW<NT>& gb = ga;
+            ga.request(wn + LN::wlx, lane);
+#else
+            GlobalW<NT> ga, gb;
+            ga.request(wn + LN::wlx, lane);
+            gb.request(wn + LN::wla, lane);
+#endif
+            f32x16 H[NT];
+            load_vec<NT>(wn + LN::bl, H, lane);
+            wait_vmcnt<0>();                                     // X rows in the A stage, both layers' operands
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 a = *reinterpret_cast<const f32x4*>(agg + j * D + it * 32 + q * 8 + h * 4);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) x[q * 4 + c] = dg == 0 ? 0.f : a[c];      // torch_scatter: no incoming edge -> 0
+            for (int it = 0; it < NT; ++it) {
+                f32x16 x;
+                read_stage_tile<D, XP>(astage, j, h, it, x);
+                ga.apply(it, x, H);
             }
-        }, H, lane);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_wave_barrier();                        // the aggregation tile has been read by every lane: it takes the R rows
-        dma_rows<D, 0, kNtR>(p.R, [&](int sr) { return GNNMP_ROW0(t0 + sr); }, agg, ln);
-        GNNMP_TRC();                                             // (diagnostics build) H done
-        if (p.store_h) store_row<NT>(p.Hout + (size_t)node * D, H, h);
-        BOp<P> yop[NT];
-        {
+#if GNNMP_MP_GLOBALW == 2
+            gb.request(wn + LN::wla, lane);
+#else
+            ga.request(wn + LN::m1, lane);                       // (under W_la's MFMAs)
+#endif
+#pragma unroll
+            for (int it = 0; it < NT; ++it) {
+                f32x16 x;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(agg + j * D + it * 32 + q * 8 + h * 4);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) x[q * 4 + c] = dg == 0 ? 0.f : a[c];      // torch_scatter: no incoming edge -> 0
+                }
+                gb.apply(it, x, H);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();                    // the aggregation tile has been read by every lane: it takes the R rows
+            dma_rows<D, 0, kNtR>(p.R, [&](int sr) { return GNNMP_ROW0(t0 + sr); }, agg, ln);
+#if GNNMP_MP_GLOBALW == 2
+            ga.request(wn + LN::m1, lane);
+#else
+            gb.request(wn + LN::m2, lane);
+#endif
+            GNNMP_TRC();                                         // (diagnostics build) H done
+            if (p.store_h) store_row<NT>(p.Hout + (size_t)node * D, H, h);
             f32x16 y[NT];
-            wait_vmcnt<0>();
+            wait_vmcnt<0>();                                     // R rows, M1, M2
 #pragma unroll
             for (int tt = 0; tt < NT; ++tt) read_stage_tile<D, 0>(agg, j, h, tt, y[tt]);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            linear_acc_p<P, NT, NT>(wn + LN::m1, H, y, lane);
+#pragma unroll
+            for (int it = 0; it < NT; ++it) ga.apply(it, H[it], y);
+#if GNNMP_MP_GLOBALW == 2
+            gb.request(wn + LN::m2, lane);
+#else
+            if (p.last) ga.request(wn + LN::m3, lane);
+#endif
             GNNMP_TRC();                                         // (diagnostics build) Y done
             __builtin_amdgcn_wave_barrier();
             write_stage_tiles<D, XP, NT>(astage, j, h, y);       // X' rows -> A stage -> whole rows out
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
             store_rows_coalesced<D, XP, kNtW>(p.Xout, (size_t)t0, astage, ln);
-            make_ops<P, NT>(y, yop);
-        }
-        {
-            f32x16 z[NT];
+            {
+                f32x16 z[NT];
 #pragma unroll
-            for (int tt = 0; tt < NT; ++tt) z[tt] = splat16(0.f);
-            linear_acc_ops<P, NT, NT>(wn + LN::m2, yop, z, lane);
-            write_stage_tiles<D, P, NT>(agg, j, h, z);           // A' rows -> (bf16: first half of) the aggregation tile -> whole rows out
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_wave_barrier();
-            store_rows_coalesced<D, P, kNtW>(p.Aout, (size_t)t0, agg, ln);
-        }
-        if (p.last) {                                            // PT for the policy head (B' is recomputed by the next iteration otherwise)
-            f32x16 z[NT];
+                for (int tt = 0; tt < NT; ++tt) z[tt] = splat16(0.f);
 #pragma unroll
-            for (int tt = 0; tt < NT; ++tt) z[tt] = splat16(0.f);
-            linear_acc_ops<P, NT, NT>(wn + LN::m3, yop, z, lane);
-            // bf16: second half of the aggregation tile; fp32 (A' fills the whole tile): the A stage, whose X' rows have been read out
-            float* ps = P == 1 ? agg + G::STAGE_FLOATS : astage;
-            if constexpr (P != 1) {
+                for (int it = 0; it < NT; ++it) gb.apply(it, y[it], z);
+#if GNNMP_MP_GLOBALW == 2
+                if (p.last) ga.request(wn + LN::m3, lane);
+#endif
+                write_stage_tiles<D, P, NT>(agg, j, h, z);       // A' rows -> the aggregation tile -> whole rows out
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
+                store_rows_coalesced<D, P, kNtW>(p.Aout, (size_t)t0, agg, ln);
             }
-            write_stage_tiles<D, P, NT>(ps, j, h, z);
+            if (p.last) {                                        // PT for the policy head
+                f32x16 z[NT];
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt) z[tt] = splat16(0.f);
+#pragma unroll
+                for (int it = 0; it < NT; ++it) ga.apply(it, y[it], z);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the A stage's X' rows have been read out
+                __builtin_amdgcn_wave_barrier();
+                write_stage_tiles<D, P, NT>(astage, j, h, z);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                store_rows_coalesced<D, P, kNtW>(p.Bout, (size_t)t0, astage, ln);
+            }
+        } else {
+            f32x16 H[NT];
+            load_vec<NT>(wn + LN::bl, H, lane);
+            wait_vmcnt<0>();
+            linear_acc_stream<P, NT, false>(wn + LN::wlx, [&](int it, f32x16& x) { read_stage_tile<D, XP>(astage, j, h, it, x); }, H, lane);
+            linear_acc_stream<P, NT, false>(wn + LN::wla, [&](int it, f32x16& x) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(agg + j * D + it * 32 + q * 8 + h * 4);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) x[q * 4 + c] = dg == 0 ? 0.f : a[c];      // torch_scatter: no incoming edge -> 0
+                }
+            }, H, lane);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_wave_barrier();
-            store_rows_coalesced<D, P, kNtW>(p.Bout, (size_t)t0, ps, ln);
+            __builtin_amdgcn_wave_barrier();                        // the aggregation tile has been read by every lane: it takes the R rows
+            dma_rows<D, 0, kNtR>(p.R, [&](int sr) { return GNNMP_ROW0(t0 + sr); }, agg, ln);
+            GNNMP_TRC();                                             // (diagnostics build) H done
+            if (p.store_h) store_row<NT>(p.Hout + (size_t)node * D, H, h);
+            BOp<P> yop[NT];
+            {
+                f32x16 y[NT];
+                wait_vmcnt<0>();
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt) read_stage_tile<D, 0>(agg, j, h, tt, y[tt]);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                linear_acc_p<P, NT, NT>(wn + LN::m1, H, y, lane);
+                GNNMP_TRC();                                         // (diagnostics build) Y done
+                __builtin_amdgcn_wave_barrier();
+                write_stage_tiles<D, XP, NT>(astage, j, h, y);       // X' rows -> A stage -> whole rows out
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                store_rows_coalesced<D, XP, kNtW>(p.Xout, (size_t)t0, astage, ln);
+                make_ops<P, NT>(y, yop);
+            }
+            {
+                f32x16 z[NT];
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt) z[tt] = splat16(0.f);
+                linear_acc_ops<P, NT, NT>(wn + LN::m2, yop, z, lane);
+                write_stage_tiles<D, P, NT>(agg, j, h, z);           // A' rows -> (bf16: first half of) the aggregation tile -> whole rows out
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                store_rows_coalesced<D, P, kNtW>(p.Aout, (size_t)t0, agg, ln);
+            }
+            if (p.last) {                                            // PT for the policy head (B' is recomputed by the next iteration otherwise)
+                f32x16 z[NT];
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt) z[tt] = splat16(0.f);
+                linear_acc_ops<P, NT, NT>(wn + LN::m3, yop, z, lane);
+                // bf16: second half of the aggregation tile; fp32 (A' fills the whole tile): the A stage, whose X' rows have been read out
+                float* ps = P == 1 ? agg + G::STAGE_FLOATS : astage;
+                if constexpr (P != 1) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_wave_barrier();
+                }
+                write_stage_tiles<D, P, NT>(ps, j, h, z);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                store_rows_coalesced<D, P, kNtW>(p.Bout, (size_t)t0, ps, ln);
+            }
         }
         GNNMP_TRC();
     }
