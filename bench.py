@@ -564,6 +564,14 @@ def main():
             else:
                 ach = work / (ms * 1e-3) / 1e9
                 stage_roof[name] = {'bound': 'hbm', 'ms': round(ms, 4), 'GBs': round(ach, 0), 'frac': round(ach / PEAK_HBM_GBS, 3)}
+                if name.startswith('mp'):
+                    # the same launch against the matrix pipe: 2 d^2 FLOP per edge (message layer) + 10 d^2 per padded node row (W_dst X,
+                    # W_lx X, W_la agg, M1 H, M2 Y; the last iteration's M3 is not counted).  At d = 64 in fp32 the two roofs meet
+                    # (16 FLOP per algorithmic byte against a ridge of 19.7): the launch is priced against both
+                    d_ = e['d']
+                    fl = sum(2.0 * d_ * d_ * m + 5 * 2.0 * d_ * d_ * (((n + 31) // 32) * 32) for n, m in zip(Ns, Es))
+                    tf = fl / (ms * 1e-3) / 1e12
+                    stage_roof[name].update({'TFLOPs': round(tf, 1), 'frac_mfma': round(tf / mfma_peak, 3)})
         # issue-slot fraction of the edge pre kernel (bf16 mode: it is bound by instruction issue, not by the matrix pipe its FLOPs are
         # priced against): (4 x SQ_ACTIVE_INST_VALU + SQ_VALU_MFMA_BUSY_CYCLES) / SIMD cycles from separate --pmc passes
         # (tools/issue_json.py -> profiles/kernel_issue.json, stamped with workload and source hash like the traffic entries)

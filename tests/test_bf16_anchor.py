@@ -111,3 +111,16 @@ def test_full_size_bf16_shapes_against_the_reference_in_bf16(path):
     batch = gnnmp.GraphBatch.from_graphs([others[0], g, others[1]], ENVS[env]['S'], dev)
     parts = batch.split_edges(m.forward_batch(batch, int(a['loop'])))
     assert torch.equal(parts[1].cpu(), s)
+
+
+def test_full_size_yardstick_belongs_to_the_seeded_graphs():
+    """CPU: tests/golden/refbf16_stats_full.npz was recorded on synth_graph(env, n, k, seed) -- the oracle's materialising fp32 form
+    (bit-identical to the reference's fp32 run) reproduces the recorded sum of the reference's fp32 scores for the first kuka7 graph."""
+    from oracle import ref_cpu
+    with np.load(os.path.join(GOLDEN, 'refbf16_stats_full.npz')) as f:
+        st = {k: f[k] for k in f.files}
+    assert len(st['seed']) == 17 and float(st['err_mean'].max()) < 0.06 and float(st['err_max'].max()) < 0.5
+    i = int(np.nonzero((st['env'] == 'kuka7') & (st['seed'] == 1234))[0][0])
+    g = synth_graph('kuka7', int(st['n'][i]), int(st['k'][i]), seed=1234)
+    s = ref_cpu.explorer_forward(load_weights(ENVS['kuka7']['ckpt']), g['v'], g['goal'], g['obstacles'], g['edge_index'], 5, materialize=True)
+    assert float(s.double().sum()) == float(st['ref32_sum'][i])

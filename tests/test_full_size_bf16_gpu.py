@@ -10,12 +10,16 @@ properties (the style of tests/test_full_size_gpu.py):
  (b) two runs give identical bytes;
  (c) sampled graphs: fp32 mode against the fp32 / fp64 oracle with the per-fixture bar of tests/parity_bar.py;
      bf16 mode against the CPU emulation of the same rounding points (oracle/ref_bf16.py) and against the fp32 oracle
-     with the accuracy bars of tests/test_explorer_bf16.py;
+     with the reference's own bf16 run of the same graph as the yardstick (tests/golden/refbf16_stats_full.npz);
  (d) device-built graphs == host builder for the sampled seeds (so the oracle sees the same inputs)."""
+import math
+import os
+
+import numpy as np
 import pytest
 import torch
 
-from conftest import load_weights
+from conftest import GOLDEN, load_weights
 import gnnmp
 from gnnmp.synth import ENVS, synth_batch_gpu, synth_graph
 from oracle import ref_bf16
@@ -31,6 +35,14 @@ def _model(env, dtype):
     m.load_state_dict(load_weights(e['ckpt']), strict=True)
     m.mlp_dtype = dtype
     return m
+
+
+def _yardstick(env, n, k, seed):
+    """(max, mean) of |reference in bf16 - reference in fp32| on synth_graph(env, n, k, seed): the recorded reference runs"""
+    with np.load(os.path.join(GOLDEN, 'refbf16_stats_full.npz')) as f:
+        sel = (f['env'] == env) & (f['n'] == n) & (f['k'] == k) & (f['seed'] == seed)
+        assert int(sel.sum()) == 1, (env, n, k, seed)
+        return float(f['err_max'][sel][0]), float(f['err_mean'][sel][0])
 
 
 def _argmax_agreement(s, ref, ei, margin):
@@ -51,7 +63,7 @@ def _argmax_agreement(s, ref, ei, margin):
     return agree, tot
 
 
-@pytest.mark.parametrize('env,G,N,K1,sample', [('kuka7', 64, 2000, 10, (0, 41)), ('kuka14', 32, 5000, 16, (3,))],
+@pytest.mark.parametrize('env,G,N,K1,sample', [('kuka7', 64, 2000, 10, (0, 41)), ('kuka14', 32, 5000, 16, (1, 3))],
                          ids=['cfg3_kuka7_2000_k10_x64', 'cfg5_kuka14_5000_k16_x32'])
 def test_full_size_both_modes(env, G, N, K1, sample):
     e = ENVS[env]
@@ -67,6 +79,7 @@ def test_full_size_both_modes(env, G, N, K1, sample):
     print('\n%s: E per graph %d, in-degree %d-%d' % (env, host[sample[0]]['edge_index'].shape[1], int(deg.min()), int(deg.max())))
     assert int(deg.max()) > 32                                   # rows that span several 32-edge tiles are present
     for dtype in ('fp32', 'bf16'):
+        ratios = []
         m = _model(env, dtype)
         s1 = m.forward_batch(b, 5).clone()
         s2 = m.forward_batch(b, 5)
@@ -92,10 +105,19 @@ def test_full_size_both_modes(env, G, N, K1, sample):
                       'agreement %.2f %% of %d targets' % (env, i, d_emu.max(), d_emu.mean(), d_ref.max(), d_ref.mean(),
                                                            100.0 * agree / max(tot, 1), tot))
                 assert float(d_emu.max()) <= 0.15 and float(d_emu.mean()) <= 1e-2
-                # the accuracy cost of bf16 operands grows with graph size (more rounding flips per max-aggregation):
-                # 0.007-0.019 mean at the 64-200-node goldens, ~0.03 at 5000 nodes / in-degree up to 90
-                assert float(d_ref.mean()) <= 0.04 and float(d_ref.max()) <= 0.5
+                # accuracy against the fp32 reference, measured with the reference's OWN bf16 run of the same graph as the yardstick
+                # (tests/golden/refbf16_stats_full.npz: the unmodified module cast to bfloat16, recorded by tools/gen_golden.py
+                # bf16anchor).  Over sixteen full-size graphs the kernels' mean error is 0.50-0.81 x the reference-in-bf16's on
+                # fifteen and 1.26 x on one (kuka14 seed 1237, sampled here on purpose); per graph the bar is 1.5 x (mean) and
+                # 1.6 x (max) of the yardstick, over the sampled graphs of a shape the geometric mean of the ratio stays <= 1
+                ya_max, ya_mean = _yardstick(env, N, K1, 1234 + i)
+                print('   reference in bf16 on the same graph: max %.3f mean %.4f  -> ratio max %.2f mean %.2f' %
+                      (ya_max, ya_mean, float(d_ref.max()) / ya_max, float(d_ref.mean()) / ya_mean))
+                assert float(d_ref.mean()) <= 1.5 * ya_mean and float(d_ref.max()) <= 1.6 * ya_max
+                ratios.append(float(d_ref.mean()) / ya_mean)
                 assert agree >= 0.96 * tot
+        if dtype == 'bf16':
+            assert math.exp(sum(math.log(r) for r in ratios) / len(ratios)) <= 1.0, ratios
 
 
 def test_cfg5_smoother_batch_both_modes():

@@ -358,6 +358,22 @@ def bf16_anchor_cases():
                             ei_sum=int(g['edge_index'].long().sum()),
                             scores_fp32=s32.numpy(), scores_ref_bf16=sb.float().numpy().astype(np.float32))
         print('%-48s E=%d reference in bf16 vs its fp32 run: max %.4f mean %.4f' % (fn, g['edge_index'].shape[1], d.max(), d.mean()))
+    # the same yardstick as summary figures for the graphs tests/test_full_size_bf16_gpu.py samples (seed 1234 + graph index) and a series of
+    # eight seeds per shape: max / mean of |reference in bf16 - reference in fp32| per graph (the test recomputes the fp32 scores with the
+    # oracle's materialising form, which reproduces the reference's fp32 run bit for bit)
+    rows = []
+    for env, n, k, seeds in (('kuka7', 2000, 10, list(range(1234, 1242)) + [1275]), ('kuka14', 5000, 16, list(range(1234, 1242)))):
+        sd = torch.load(os.path.join(REF, 'data', 'weights', ENVS[env]['ckpt'] + '.pt'), map_location='cpu')
+        for seed in seeds:
+            g = synth_graph(env, n, k, seed=seed)
+            s32, _ = run_explorer(env, sd, g, 5, True, torch.float32, False)
+            sb, _ = run_explorer(env, sd, g, 5, True, torch.bfloat16, False)
+            d = (sb.float() - s32).abs()
+            rows.append((env, n, k, seed, float(d.max()), float(d.mean()), float(s32.double().sum())))
+            print('refbf16_stats_full: %s N=%d k=%d seed %d: reference in bf16 vs its fp32 run: max %.4f mean %.4f' % (env, n, k, seed, d.max(), d.mean()))
+    np.savez_compressed(os.path.join(OUT, 'refbf16_stats_full.npz'), env=np.array([r[0] for r in rows]), n=np.array([r[1] for r in rows]),
+                        k=np.array([r[2] for r in rows]), seed=np.array([r[3] for r in rows]), err_max=np.array([r[4] for r in rows]),
+                        err_mean=np.array([r[5] for r in rows]), ref32_sum=np.array([r[6] for r in rows]))
     # (the reference SMOOTHER cannot be run in bf16 unmodified: model_smoother.py:131-135 concatenates the bf16 nodes with a
     # float32 one-hot block, the promoted fp32 rows then meet bf16 weights; its bf16 mode keeps the emulation bar only)
 
