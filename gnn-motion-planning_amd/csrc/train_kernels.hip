@@ -76,13 +76,26 @@ __global__ __launch_bounds__(256) void rows_linear_dw_partial_kernel(int R, int 
         out[O * K + o] = acc;
     }
 }
-__global__ void dw_reduce_kernel(int nblk, int OK, int O, const float* __restrict__ part, float* __restrict__ dW, float* __restrict__ db) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= OK + O) return;
+// second stage: element i of dW / db += the nblk partials in a FIXED order -- eight contiguous slices of the block range summed side by
+// side (ascending inside a slice), the eight slice sums added in ascending order.  (One serial loop over all blocks per element was
+// 26 us per layer at 88 blocks and 170 us at 700: the second largest item of a training step.)
+__global__ __launch_bounds__(256) void dw_reduce_kernel(int nblk, int OK, int O, const float* __restrict__ part, float* __restrict__ dW, float* __restrict__ db) {
+    __shared__ float sm[8][32];
+    const int l = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + l;
+    const int per = (nblk + 7) >> 3, b0 = sl * per, b1 = min(nblk, b0 + per);
     float acc = 0.f;
-    for (int b = 0; b < nblk; ++b) acc += part[(size_t)b * (OK + O) + i];
-    if (i < OK) dW[i] += acc;
-    else if (db) db[i - OK] += acc;
+    if (i < OK + O)
+        for (int b = b0; b < b1; ++b) acc += part[(size_t)b * (OK + O) + i];
+    sm[sl][l] = acc;
+    __syncthreads();
+    if (sl == 0 && i < OK + O) {
+        float t = sm[0][l];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) t += sm[q][l];
+        if (i < OK) dW[i] += t;
+        else if (db) db[i - OK] += t;
+    }
 }
 
 
@@ -187,47 +200,52 @@ __global__ __launch_bounds__(256) void rows_linear_dx_mfma_kernel(int R, int K, 
 }
 
 // partial dW of one chunk of kDwRowsM rows: part[blk][o, k] = sum_{r in chunk} dY[r, o] X[r, k], part[blk][O K + o] = sum_r dY[r, o].
-// Wave w of the block owns the (o-tile, k-tile) pairs w, w + 4, ...: A[i = o][r] = dY[r, o], B[r][j = k] = X[r, k].
+// A[i = o][r] = dY[r, o], B[r][j = k] = X[r, k].  Round 5 (the two dW kernels were 52 % of a training step's GPU time,
+// profiles/r05_train_step.txt): wave w owns ROWS r0 + 32 w .. + 32 of the chunk for every (o-tile, k-tile) pair -- all 32 operand loads
+// of a pair are in flight before its 16 MFMAs, a 32 x 32 layer keeps four waves busy instead of one -- and the four partial tiles are
+// added through LDS in ascending wave order; the bias gradient is column K of the same product (X extended by a column of ones) instead
+// of a serial 128-row loop per output.  Still no float atomics and a fixed summation order: the same inputs give the same bits.
 constexpr int kDwRowsM = 128;
 __global__ __launch_bounds__(256) void rows_linear_dw_mfma_kernel(int R, int K, int O, const float* __restrict__ dY,
                                                                   const float* __restrict__ X, float* __restrict__ part) {
+    __shared__ float red[4][1024];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
     const int r0 = blockIdx.x * kDwRowsM, r1 = min(R, r0 + kDwRowsM);
+    const int rw0 = r0 + 32 * wave;
     float* out = part + (size_t)blockIdx.x * ((size_t)O * K + O);
-    const int otiles = (O + 31) >> 5, ktiles = (K + 31) >> 5;
-    for (int t = wave; t < otiles * ktiles; t += 4) {
+    const int otiles = (O + 31) >> 5, ktiles = (K + 1 + 31) >> 5;          // column K: ones (bias gradient)
+    for (int t = 0; t < otiles * ktiles; ++t) {
         const int ot = t / ktiles, kt = t % ktiles;
         const int o = ot * 32 + j, kc = kt * 32 + j;
-        const float om = o < O ? 1.f : 0.f, km = kc < K ? 1.f : 0.f;
         const int oc = o < O ? o : 0, kcc = kc < K ? kc : 0;
+        float av[16], bv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int r = rw0 + 2 * u + h;
+            const bool ok = r < r1;
+            const size_t rr = ok ? r : r0;
+            const float a = dY[rr * O + oc], x = X[rr * K + kcc];
+            av[u] = (ok && o < O) ? a : 0.f;
+            bv[u] = !ok ? 0.f : (kc < K ? x : (kc == K ? 1.f : 0.f));
+        }
         t_f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        // 16 rows (eight steps) per round: all sixteen loads are issued before the first multiply needs one
-        for (int r = r0; r < r1; r += 16) {
-            float av[8], bv[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const bool ok = r + 2 * u + h < r1;
-                const size_t rr = ok ? r + 2 * u + h : r0;
-                av[u] = dY[rr * O + oc] * (ok ? om : 0.f);
-                bv[u] = X[rr * K + kcc] * (ok ? km : 0.f);
-            }
+        for (int u = 0; u < 16; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
+        if (t > 0) __syncthreads();                                         // the previous pair's partial tiles have been read
 #pragma unroll
-            for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
-        }
-        if (kc < K) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int oo = ot * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (oo < O) out[(size_t)oo * K + kc] = acc[r];
+        for (int r = 0; r < 16; ++r) red[wave][r * 64 + lane] = acc[r];
+        __syncthreads();
+        for (int e = threadIdx.x; e < 1024; e += 256) {
+            const float v = ((red[0][e] + red[1][e]) + red[2][e]) + red[3][e];
+            const int r = e >> 6, l = e & 63;
+            const int oo = ot * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), kk = kt * 32 + (l & 31);
+            if (oo < O) {
+                if (kk < K) out[(size_t)oo * K + kk] = v;
+                else if (kk == K) out[(size_t)O * K + oo] = v;
             }
         }
-    }
-    for (int o = threadIdx.x; o < O; o += 256) {
-        float acc = 0.f;
-        for (int r = r0; r < r1; ++r) acc += dY[(size_t)r * O + o];
-        out[(size_t)O * K + o] = acc;
     }
 }
 
@@ -523,7 +541,7 @@ hipError_t t_linear_dw(int R, int K, int O, const float* dY, const float* X, flo
         hipLaunchKernelGGL(rows_linear_dw_partial_kernel, dim3(nblk), dim3(256), 0, st, R, K, O, dY, X, scratch);
     }
     TRAIN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(dw_reduce_kernel, dim3(blocks((size_t)O * K + O)), dim3(256), 0, st, nblk, O * K, O, scratch, dW, db);
+    hipLaunchKernelGGL(dw_reduce_kernel, dim3((unsigned)(((size_t)O * K + O + 31) / 32)), dim3(256), 0, st, nblk, O * K, O, scratch, dW, db);
     TRAIN_LAUNCH_CHECK();
     return hipSuccess;
 }
