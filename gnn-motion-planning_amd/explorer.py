@@ -251,13 +251,16 @@ class EncoderProcessDecoder(nn.Module):
                 and all(map(operator.is_, hk[3], wt)):
             return self._handle
         self._drop_handle()
-        parts = []
         for (n, numel), t in zip(self._manifest, wt):
-            t = t.detach().to('cpu', torch.float32).contiguous().reshape(-1)
             if t.numel() != numel:
                 raise RuntimeError('parameter %s has %d elements, library expects %d' % (n, t.numel(), numel))
-            parts.append(t)
-        blob = torch.cat(parts).contiguous()
+        # one concatenation per device the parameters live on, ONE copy to the host for each (a training loop re-packs after
+        # every optimizer step: 142 separate .to('cpu') calls were 142 stream synchronisations when the model is on the GPU)
+        devs = {t.device for t in wt}
+        if len(devs) == 1:
+            blob = torch.cat([t.detach().reshape(-1).to(torch.float32) for t in wt]).to('cpu').contiguous()
+        else:
+            blob = torch.cat([t.detach().to('cpu', torch.float32).reshape(-1) for t in wt]).contiguous()
         h = ctypes.c_void_p()
         dims = self._dims()
         with torch.cuda.device(idx):            # the library also restores the caller's current device itself

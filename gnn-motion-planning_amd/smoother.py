@@ -256,7 +256,10 @@ class ModelSmoother(nn.Module):
             if for_training and all(a == b for i, (a, b) in enumerate(zip(hk[3], key[3])) if i not in self._bn_slots):
                 return self._handle
         self._drop_handle()
-        blob = torch.cat([t.detach().to('cpu', torch.float32).reshape(-1) for t in wt]).contiguous()
+        if len({t.device for t in wt}) == 1:       # one copy to the host instead of one per tensor (see EncoderProcessDecoder._native)
+            blob = torch.cat([t.detach().reshape(-1).to(torch.float32) for t in wt]).to('cpu').contiguous()
+        else:
+            blob = torch.cat([t.detach().to('cpu', torch.float32).reshape(-1) for t in wt]).contiguous()
         h = ctypes.c_void_p()
         dims = self._dims()
         with torch.cuda.device(idx):

@@ -26,6 +26,7 @@ dgraphs = [{k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in g.items()} f
 w = load_weights('weights_maze')
 m = gnnmp.EncoderProcessDecoder(2, 2, 32, 2)
 m.load_state_dict(w)
+m.to(DEV)                             # train_explorer.py:105: the reference trains with the model on the device
 m.train()
 params = [p for n, p in m.named_parameters() if n.split('.')[0] in TRAINABLE]
 opt = torch.optim.Adam(params, lr=1e-4)
