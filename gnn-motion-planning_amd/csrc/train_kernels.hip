@@ -206,6 +206,8 @@ __global__ __launch_bounds__(256) void rows_linear_dx_mfma_kernel(int R, int K, 
 // added through LDS in ascending wave order; the bias gradient is column K of the same product (X extended by a column of ones) instead
 // of a serial 128-row loop per output.  Still no float atomics and a fixed summation order: the same inputs give the same bits.
 constexpr int kDwRowsM = 128;
+constexpr int kDwPairs = 4;             // (o-tile, k-tile) pairs per workgroup: blockIdx.y walks the pair groups (the smoother's 128 x 385 layer has 52 pairs
+                                        // over ~8 row chunks: one workgroup per chunk left the device empty)
 __global__ __launch_bounds__(256) void rows_linear_dw_mfma_kernel(int R, int K, int O, const float* __restrict__ dY,
                                                                   const float* __restrict__ X, float* __restrict__ part) {
     __shared__ float red[4][1024];
@@ -214,7 +216,8 @@ __global__ __launch_bounds__(256) void rows_linear_dw_mfma_kernel(int R, int K, 
     const int rw0 = r0 + 32 * wave;
     float* out = part + (size_t)blockIdx.x * ((size_t)O * K + O);
     const int otiles = (O + 31) >> 5, ktiles = (K + 1 + 31) >> 5;          // column K: ones (bias gradient)
-    for (int t = 0; t < otiles * ktiles; ++t) {
+    const int t_begin = blockIdx.y * kDwPairs, t_end = min(otiles * ktiles, t_begin + kDwPairs);
+    for (int t = t_begin; t < t_end; ++t) {
         const int ot = t / ktiles, kt = t % ktiles;
         const int o = ot * 32 + j, kc = kt * 32 + j;
         const int oc = o < O ? o : 0, kcc = kc < K ? kc : 0;
@@ -233,7 +236,7 @@ __global__ __launch_bounds__(256) void rows_linear_dw_mfma_kernel(int R, int K, 
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
         for (int u = 0; u < 16; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
-        if (t > 0) __syncthreads();                                         // the previous pair's partial tiles have been read
+        if (t > t_begin) __syncthreads();                                   // the previous pair's partial tiles have been read
 #pragma unroll
         for (int r = 0; r < 16; ++r) red[wave][r * 64 + lane] = acc[r];
         __syncthreads();
@@ -536,7 +539,8 @@ hipError_t t_linear_dw(int R, int K, int O, const float* dY, const float* X, flo
     int nblk = (R + kDwRows - 1) / kDwRows;
     if (O >= 8 && K >= 4) {
         nblk = (R + kDwRowsM - 1) / kDwRowsM;             // fewer, larger chunks: the scratch sized for kDwRows covers them
-        hipLaunchKernelGGL(rows_linear_dw_mfma_kernel, dim3(nblk), dim3(256), 0, st, R, K, O, dY, X, scratch);
+        const int pairs = ((O + 31) / 32) * ((K + 1 + 31) / 32);
+        hipLaunchKernelGGL(rows_linear_dw_mfma_kernel, dim3(nblk, (pairs + kDwPairs - 1) / kDwPairs), dim3(256), 0, st, R, K, O, dY, X, scratch);
     } else {
         hipLaunchKernelGGL(rows_linear_dw_partial_kernel, dim3(nblk), dim3(256), 0, st, R, K, O, dY, X, scratch);
     }

@@ -105,3 +105,37 @@ print('  (b) one batched forward / backward of the 8 problems + Adam step      %
 print('  (c) CPU oracle through torch.autograd (%d torch threads), extrapolated from 2 problems  %8.0f ms / optimizer step'
       % (torch.get_num_threads(), cpu_ms))
 print('  gradients of two identical backward passes bit-identical: %s' % identical)
+
+# ---- the smoother's training step in the reference's shape (train_smoother.py:33-61): eight replay entries per optimizer step, one
+# forward each under model.train() (BatchNorm with batch statistics), loop drawn from 1..9 (fixed to 5 here), MSE on the inner
+# waypoints, ONE backward of the summed loss, SGD with momentum (train_smoother.py:81)
+from gnnmp.planner import chain_edge_index  # noqa: E402
+ws_ = load_weights('smooth_2d_attv3')
+sm = gnnmp.ModelSmoother(workspace_size=2, config_size=2, embed_size=128, obs_size=6)
+sm.load_state_dict(ws_)
+sm.to(DEV)
+sm.train()
+sopt = torch.optim.SGD(sm.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-4)
+gen = torch.Generator().manual_seed(11)
+replay = []
+for _ in range(NPROB):
+    P_ = 20
+    path = (torch.rand(P_, 2, generator=gen) * 2 - 1).to(DEV)
+    free, coll = (torch.rand(500, 2, generator=gen) * 2 - 1).to(DEV), (torch.rand(500, 2, generator=gen) * 2 - 1).to(DEV)
+    target = (path + 0.05 * torch.randn(P_, 2, generator=gen).to(DEV))
+    replay.append((path, free, coll, chain_edge_index(P_).to(DEV), target))
+
+
+def smoother_step():
+    sopt.zero_grad()
+    loss = 0.
+    for path, free, coll, ei, target in replay:
+        pred = sm(path=path, free=free, collided=coll, obstacles=None, edge_index=ei, loop=5)
+        loss = loss + torch.nn.MSELoss()(target[1:-1], pred[1:-1])
+    (loss / len(replay)).backward()
+    sopt.step()
+
+
+ms_sm = timeit(smoother_step, 5)
+print('smoother training step (train_smoother.py:33-61 shape: 8 replay entries of 20 waypoints + 500 + 500 samples, loop 5, smooth_2d_attv3,\n'
+      '  model.train(), one backward of the summed MSE, SGD + momentum)       %8.2f ms / optimizer step' % ms_sm)
