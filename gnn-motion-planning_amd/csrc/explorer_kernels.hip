@@ -56,6 +56,7 @@ __device__ __forceinline__ int find_graph(const int* __restrict__ ptr, int G, in
 // 1000 nodes at d = 32, 8-12 graphs of 2000 nodes at d = 64)
 constexpr int kCoopMaxTiles32 = 384, kCoopMaxTiles64 = 600;
 constexpr int kPrepCap = 8192;
+constexpr int kGoalSplitNodes = 4096;     // big-graph prep: from this many nodes the goal arg-min is spread over the graph's part workgroups
 constexpr int kPrepEdgesPerPart = 8192;  // prep stage: one workgroup per this many edges of a graph (at least one, at most kPrepMaxParts)
 
 // inclusive prefix sum over the 1024 threads of a workgroup: wave-level shuffles, then the 16 wave totals through LDS
@@ -262,6 +263,39 @@ __device__ __forceinline__ void goal_body(int C, const float* __restrict__ v, co
     if (tid == 0) goal_node[g] = (n > 0) ? n0_pad + s_i[0] : -1;
 }
 
+// the same arg-min over the nodes [lo, hi) of graph g only: out[0] = distance bits, out[1] = index within the graph (0x7fffffff if
+// the slice is empty); combined over the parts by prep_scatter_kernel
+__device__ __forceinline__ void goal_partial(int C, const float* __restrict__ v, const float* __restrict__ goal,
+                                             int n0, int lo, int hi, int g, int* __restrict__ out) {
+    __shared__ float p_d[16];
+    __shared__ int p_i[16];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    float best = INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = lo + tid; i < hi; i += nt) {
+        float d = 0.f;
+        for (int c = 0; c < C; ++c) {
+            const float x = v[(size_t)(n0 + i) * C + c] - goal[(size_t)g * C + c];
+            d = fmaf(x, x, d);
+        }
+        if (d < best) { best = d; bi = i; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float od = __shfl_down(best, off);
+        const int oi = __shfl_down(bi, off);
+        if (od < best || (od == best && oi < bi)) { best = od; bi = oi; }
+    }
+    if ((tid & 63) == 0) { p_d[tid >> 6] = best; p_i[tid >> 6] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < (nt >> 6); ++w)
+            if (p_d[w] < best || (p_d[w] == best && p_i[w] < bi)) { best = p_d[w]; bi = p_i[w]; }
+        out[0] = __float_as_int(best);
+        out[1] = bi;
+    }
+}
+
 // -----------------------------------------------------------------------------------------------------
 // The whole prep stage in ONE launch, `parts` workgroups per graph (1 for graphs up to ~12 k edges, up to 16 for large
 // ones): padded prefix arrays (every workgroup reduces the entries before its own graph itself), CSR rows of its slice
@@ -385,7 +419,16 @@ __global__ __launch_bounds__(1024) void prep_hist_kernel(PrepParams q, int Npad,
         q.etile_graph[t] = g;
         q.tile_meta[t] = t * 32 < e0 + Eg ? 4 : 0;
     }
-    if (part == parts - 1) goal_body(q.C, q.v, q.goal, q.node_ptr[g], q.node_ptr[g + 1] - q.node_ptr[g], g, n0, q.goal_node);
+    if (in_lds && q.node_ptr[g + 1] - q.node_ptr[g] >= kGoalSplitNodes) {
+        // the goal arg-min (model.py:132) of a 5000-node graph on ONE of its part workgroups was most of the 31 us this kernel spent
+        // outside its counting loop: every part takes a slice of the nodes and leaves (distance, local index) in the half of the
+        // histogram workspace that graphs of up to kPrepCap rows do not use; prep_scatter_kernel combines them in part order
+        const int Ngl = q.node_ptr[g + 1] - q.node_ptr[g];
+        const int lo = (int)((long long)Ngl * part / parts), hi = (int)((long long)Ngl * (part + 1) / parts);
+        goal_partial(q.C, q.v, q.goal, q.node_ptr[g], lo, hi, g, H + (size_t)parts * Npad + (size_t)n0 * parts + 2 * part);
+    } else if (part == parts - 1) {
+        goal_body(q.C, q.v, q.goal, q.node_ptr[g], q.node_ptr[g + 1] - q.node_ptr[g], g, n0, q.goal_node);
+    }
     if (g == q.G - 1 && part == 0) prep_trailing(q, n1, e1, Npad, Epad);
 }
 
@@ -399,6 +442,51 @@ __global__ __launch_bounds__(1024) void prep_scatter_kernel(PrepParams q, int pa
     const int* hg = H + (size_t)n0 * parts;
     int* bs = Np <= kPrepCap ? prep_lds : Bs + (size_t)n0 * parts + (size_t)part * Np;     // first slot of my columns per node
     int* scan = prep_lds + kPrepCap;
+    if (Np <= kPrepCap) {
+        // rows up to the LDS cap: every thread owns ceil(Np / 1024) <= 8 CONSECUTIVE rows, all of their part counts are requested at
+        // once and ONE block scan places them (five rounds of loads + scan at 5000 rows were 43 of this kernel's 94 us at the
+        // configs[4] shape, repeated by every part)
+        constexpr int RPT = kPrepCap / 1024;
+        const int rpt = (Np + 1023) >> 10;                 // consecutive rows per thread: all 1024 threads take part whatever Np is
+        int tot[RPT], mine[RPT], local = 0;
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            const int i = tid * rpt + k;
+            tot[k] = 0; mine[k] = 0;
+            if (k < rpt && i < Np)
+                for (int pp = 0; pp < parts; ++pp) {
+                    const int hv = hg[(size_t)pp * Np + i];
+                    tot[k] += hv;
+                    mine[k] += pp < part ? hv : 0;
+                }
+            local += tot[k];
+        }
+        int all;
+        int run = e0 + block_scan_1024(local, scan, all) - local;
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            const int i = tid * rpt + k;
+            if (k < rpt && i < Np) {
+                bs[i] = run + mine[k];
+                if (part == 0) { q.row_beg[n0 + i] = run; q.deg[n0 + i] = tot[k]; }
+            }
+            run += tot[k];
+        }
+        // goal node of the graph from the parts' partial minima (prep_hist_kernel), in part order: lowest distance, lowest index on ties
+        const int Ngl = q.node_ptr[g + 1] - q.node_ptr[g];
+        if (part == 0 && tid < 64 && Ngl >= kGoalSplitNodes) {          // (one wave: lane = part, at most 16 parts)
+            const int* gp = Bs + (size_t)n0 * parts;
+            float best = tid < parts ? __int_as_float(gp[2 * tid]) : INFINITY;
+            int bi = tid < parts ? gp[2 * tid + 1] : 0x7fffffff;
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) {
+                const float od = __shfl_down(best, off);
+                const int oi = __shfl_down(bi, off);
+                if (od < best || (od == best && oi < bi)) { best = od; bi = oi; }
+            }
+            if (tid == 0) q.goal_node[g] = n0 + bi;
+        }
+    } else {
     int carry_run = e0;
     for (int base = 0; base < Np; base += 1024) {
         const int i = base + tid;
@@ -417,6 +505,7 @@ __global__ __launch_bounds__(1024) void prep_scatter_kernel(PrepParams q, int pa
             if (part == 0) { q.row_beg[n0 + i] = r; q.deg[n0 + i] = tot; }
         }
         carry_run += chunk_total;
+    }
     }
     __threadfence_block();
     __syncthreads();                                   // bs is complete
