@@ -238,6 +238,11 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--pcie-steps', type=int, default=20, help='extra steps timed incl. H2D/D2H (0 = skip)')
     ap.add_argument('--dense-steps', type=int, default=5, help='extra steps timed with the dense N x N output (0 = skip)')
+    ap.add_argument('--inflight-steps', type=int, default=20,
+                    help='extra steps timed with TWO batches in flight on two HIP streams (own workspaces and score buffers): what a '
+                         'serving loop over independent batches gets when one forward fills the launch tails of the other; reported next '
+                         'to, never instead of, `value` (0 = skip)')
+    ap.add_argument('--inflight-depth', type=int, default=2, help='batches in flight for --inflight-steps (streams, workspaces, score buffers)')
     ap.add_argument('--bf16x3-steps', type=int, default=5,
                     help='extra steps timed in the opt-in bf16x3 mode (fp32-class results from the bf16 matrix pipe, '
                          'DESIGN.md 4.2b); reported next to, never instead of, `value`; only with --mlp-dtype fp32')
@@ -436,6 +441,37 @@ def main():
         if not torch.equal(outs[0], scores.cpu()) or not torch.equal(outs[1], scores.cpu()):
             raise SystemExit('pipelined scores differ from the resident-input run')
         del pipe
+
+    # secondary: two resident batches in flight (stream A scores batch 0 while stream B scores batch 1, each with its own workspace and
+    # score buffer): the launch tails of one forward are filled by the other's workgroups.  `value` stays the one-stream figure (its
+    # ms_per_step is a step's latency and adds up from the stage times); scores are checked against the one-stream run.
+    inflight_rate = None
+    if args.inflight_steps > 0 and not use_dist:
+        depth = max(2, args.inflight_depth)
+        sts = [torch.cuda.Stream(dev) for _ in range(depth)]
+        bufs = [(torch.empty(model.workspace_bytes(batch), dtype=torch.uint8, device=dev),
+                 torch.empty(max(batch.total_edges, 1), dtype=torch.float32, device=dev)) for _ in range(depth)]
+        def two_in_flight(n):
+            cur = torch.cuda.current_stream(dev)
+            for st_ in sts:
+                st_.wait_stream(cur)
+            for i in range(n):
+                ws_, out_ = bufs[i % depth]
+                with torch.cuda.stream(sts[i % depth]):
+                    model.forward_batch(batch, args.loop, ws=ws_, out=out_)
+            for st_ in sts:
+                cur.wait_stream(st_)
+        two_in_flight(2 * depth)
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        two_in_flight(args.inflight_steps)
+        torch.cuda.synchronize(dev)
+        inflight_rate = G * args.inflight_steps / (time.perf_counter() - t1)
+        for _, out_ in bufs:
+            if not torch.equal(out_[:batch.total_edges], scores):
+                raise SystemExit('scores of the two-batches-in-flight loop differ from the one-stream run')
+        del bufs
+        torch.cuda.empty_cache()
 
     # secondary: drop-in output format (the reference's zero-filled dense [N, N] block per graph, model.py:148-149)
     dense_rate = None
@@ -667,6 +703,7 @@ def main():
                        'pcie_inclusive_graphs_per_s_per_gpu': None if e2e is None else round(e2e, 1),
                        'pcie_inclusive_one_batch_at_a_time': None if e2e_serial is None else round(e2e_serial, 1),
                        'dense_output_graphs_per_s_per_gpu': None if dense_rate is None else round(dense_rate, 1),
+                       'batches_in_flight_graphs_per_s_per_gpu': None if inflight_rate is None else {'depth': max(2, args.inflight_depth), 'graphs_per_s': round(inflight_rate, 1)},
                        'bf16x3_mode_graphs_per_s_per_gpu': None if x3_rate is None else round(x3_rate, 1),
                        'single_graph_us': single_us},
             'roofline': roof,
