@@ -10,7 +10,7 @@ CFG = {'2': [], '3': '--env kuka7 --nodes 2000 --k1 10 --graphs 64 --mlp-dtype b
        '2b': '--mlp-dtype bf16'.split()}
 cfg, variants = sys.argv[1], sys.argv[2:]
 base = [sys.executable, os.path.join(R, 'bench.py'), '--steps', '20', '--warmup', '5', '--no-cpu-baseline', '--pcie-steps', '0', '--dense-steps', '0',
-        '--bf16x3-steps', '0', '--single-steps', '0', '--planner-problems', '0', '--strong-leg', '0'] + CFG[cfg]
+        '--bf16x3-steps', '0', '--single-steps', '0', '--inflight-steps', '0', '--planner-problems', '0', '--strong-leg', '0'] + CFG[cfg]
 for rep in range(2):
     for v in variants:
         parts = v.split(',')
