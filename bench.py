@@ -102,7 +102,8 @@ def cpu_baseline(env, n_nodes, k1, budget_s, seed0):
     graphs = [synth_graph(env, n_nodes, k1, seed=seed0 + i) for i in range(4)]
     run = lambda g: ref_cpu.explorer_forward(w, g['v'], g['goal'], g['obstacles'], g['edge_index'], 5,  # noqa: E731
                                              materialize=True)
-    all_threads = torch.get_num_threads()
+    from gnnmp.hostenv import cpu_quota
+    all_threads = min(torch.get_num_threads(), cpu_quota())         # what this container may really use (cgroup quota), not the machine's cores
     results = []
     for threads in sorted({min(8, all_threads), all_threads}):      # 8 = the survey container's count; all = this host
         torch.set_num_threads(threads)
@@ -139,6 +140,218 @@ def cpu_baseline(env, n_nodes, k1, budget_s, seed0):
             'other_configs_graphs_per_s': others}
 
 
+def roofline_blocks(w, e, G, prof, Ns, Es, Os):
+    """(`roofline` block of the dominant kernel, every stage against the roof that bounds it) of one workload `w` (env, nodes, k1,
+    mlp_dtype, loop) from the per-stage HIP-event times `prof` of its profiled loop.  Work counts: SURVEY.md section 8(d)."""
+    is_bf16 = w.mlp_dtype == 'bf16'
+    ep_flops = sum(edge_pre_flops(m, o, e['C'], e['d']) for m, o in zip(Es, Os))
+    ep_ms, ep_n = prof['edge_pre']
+    ep_avg_ms = ep_ms / max(ep_n, 1)
+    achieved = ep_flops / (ep_avg_ms * 1e-3) / 1e12 if ep_avg_ms > 0 else 0.0
+    # the roofline block describes the DOMINANT kernel of this workload: the stage with the largest share of the step
+    stage_tot = {k: v[0] for k, v in prof.items()}
+    dom = max(stage_tot, key=stage_tot.get)
+    if dom not in ('edge_pre', 'mp'):
+        dom = 'edge_pre'
+    # bf16 shapes where the two stages are within 3 % of each other (configs[4] shape: 0.474 / 0.476 ms): keep the block on the
+    # message-passing kernel, so that it does not flip between runs (the edge stage is in stage_roofline either way)
+    if w.mlp_dtype == 'bf16' and dom == 'edge_pre' and stage_tot.get('mp', 0.0) >= 0.97 * stage_tot['edge_pre']:
+        dom = 'mp'
+    pname = {'fp32': '0', 'bf16': '1', 'bf16x3': '2'}[w.mlp_dtype]
+    if dom == 'mp':
+        mp_ms, mp_n = prof['mp']
+        mp_avg_ms = mp_ms / max(mp_n, 1)
+        mp_bytes = sum(mp_fused_bytes(n, m, e['d'], w.mlp_dtype == 'bf16') for n, m in zip(Ns, Es))
+        # d = 64 runs the eight-wave form (mp_fused_w8_kernel, round 5) in the fp32 and bf16 modes
+        mp_name = 'mp_fused_w8_kernel<64, %s' % pname if (e['d'] == 64 and pname in ('0', '1')) else 'mp_fused_kernel<%d, %s' % (e['d'], pname)
+        roof = {'kernel': '%s...> (one message-passing iteration: edge MLP second layer, max aggregation, '
+                          'node update; %d launches per step)' % (mp_name, w.loop),
+                'kernel_like': mp_name,
+                'bound': 'hbm', 'achieved': round(mp_bytes / (mp_avg_ms * 1e-3) / 1e9, 1) if mp_avg_ms > 0 else 0.0,
+                'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'launch_ms': round(mp_avg_ms, 4), 'algorithmic_bytes_per_launch': mp_bytes}
+    else:
+        peak = PEAK_BF16_TFLOPS if w.mlp_dtype == 'bf16' else PEAK_FP32_TFLOPS
+        roof = {'kernel': '%s<%d, %s, EDGE> (edge encoders + 3 obstacle-attention blocks)' % ('pre_resident_kernel' if (pname == '1' or (pname == '0' and e['d'] == 32)) else 'pre_kernel', e['d'], pname),
+                'kernel_like': '%s<%d, %s, true' % ('pre_resident_kernel' if (pname == '1' or (pname == '0' and e['d'] == 32)) else 'pre_kernel', e['d'], pname),
+                'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
+                'launch_ms': round(ep_avg_ms, 4), 'algorithmic_flops_per_launch': ep_flops}
+    roof['frac'] = round(roof['achieved'] / roof['peak'], 4)
+    # every stage against the roof that bounds it (the `roofline` block above is the dominant one of these)
+    is_bf16 = w.mlp_dtype == 'bf16'
+    mfma_peak = PEAK_BF16_TFLOPS if is_bf16 else PEAK_FP32_TFLOPS
+    def per_launch(stage):
+        ms, n = prof.get(stage, (0.0, 0))
+        return ms / max(n, 1)
+    stage_roof = {}
+    ns_ms = per_launch('obs') + per_launch('node_pre')
+    ns_flops = sum(node_side_flops(n, o, e['C'], e['d'], e['S']) for n, o in zip(Ns, Os))
+    for name, ms, work, bound in (
+            ('edge_pre', ep_avg_ms, ep_flops, 'mfma'), ('obs+node_pre', ns_ms, ns_flops, 'mfma'),
+            ('mp (per launch)', per_launch('mp'), sum(mp_fused_bytes(n, m, e['d'], is_bf16) for n, m in zip(Ns, Es)), 'hbm'),
+            ('policy', per_launch('policy'), sum(policy_bytes(n, m, e['d'], is_bf16) for n, m in zip(Ns, Es)), 'hbm')):
+        if ms <= 0:
+            continue
+        if bound == 'mfma':
+            ach = work / (ms * 1e-3) / 1e12
+            stage_roof[name] = {'bound': 'mfma', 'ms': round(ms, 4), 'TFLOPs': round(ach, 1), 'frac': round(ach / mfma_peak, 3)}
+        else:
+            ach = work / (ms * 1e-3) / 1e9
+            stage_roof[name] = {'bound': 'hbm', 'ms': round(ms, 4), 'GBs': round(ach, 0), 'frac': round(ach / PEAK_HBM_GBS, 3)}
+            if name.startswith('mp'):
+                # the same launch against the matrix pipe: 2 d^2 FLOP per edge (message layer) + 10 d^2 per padded node row (W_dst X,
+                # W_lx X, W_la agg, M1 H, M2 Y; the last iteration's M3 is not counted).  At d = 64 in fp32 the two roofs meet
+                # (16 FLOP per algorithmic byte against a ridge of 19.7): the launch is priced against both
+                d_ = e['d']
+                fl = sum(2.0 * d_ * d_ * m + 5 * 2.0 * d_ * d_ * (((n + 31) // 32) * 32) for n, m in zip(Ns, Es))
+                tf = fl / (ms * 1e-3) / 1e12
+                stage_roof[name].update({'TFLOPs': round(tf, 1), 'frac_mfma': round(tf / mfma_peak, 3)})
+    # issue-slot fraction of the edge pre kernel (bf16 mode: it is bound by instruction issue, not by the matrix pipe its FLOPs are
+    # priced against): (4 x SQ_ACTIVE_INST_VALU + SQ_VALU_MFMA_BUSY_CYCLES) / SIMD cycles from separate --pmc passes
+    # (tools/issue_json.py -> profiles/kernel_issue.json, stamped with workload and source hash like the traffic entries)
+    ipath = os.path.join(REPO, 'profiles', 'kernel_issue.json')
+    if os.path.exists(ipath) and 'edge_pre' in stage_roof:
+        try:
+            wk_ = '%s N=%d k1=%d graphs=%d %s' % (w.env, w.nodes, w.k1, G, w.mlp_dtype)
+            for ij in json.load(open(ipath)):
+                if ij.get('workload') == wk_ and ij.get('stage') == 'edge_pre':
+                    stage_roof['edge_pre']['issue_slots'] = {k_: ij.get(k_) for k_ in (
+                        'issue_slot_frac', 'valu_frac', 'mfma_frac', 'valu_per_32_row_tile', 'mfma_per_32_row_tile', 'measured')}
+                    stage_roof['edge_pre']['issue_slots']['stale'] = ij.get('kernel_source_sha256') != kernel_source_hash()
+        except Exception:
+            pass
+    # HBM bytes per launch of that kernel come from separate rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE cannot be
+    # read inside this process; tools/traffic_json.py writes profiles/kernel_traffic.json): every entry carries the
+    # workload it was measured on, the date of the pass and a hash of the kernel sources; the number is reported only
+    # for the same workload and while that hash still matches the sources of the library in use
+    wkey = '%s N=%d k1=%d graphs=%d %s' % (w.env, w.nodes, w.k1, G, w.mlp_dtype)
+    roof['traffic'] = None
+    tpath = os.path.join(REPO, 'profiles', 'kernel_traffic.json')
+    if os.path.exists(tpath):
+        try:
+            for tj in json.load(open(tpath)):
+                if tj.get('kernel_like') == roof['kernel_like'] and tj.get('workload') == wkey:
+                    fresh = tj.get('kernel_source_sha256') == kernel_source_hash()
+                    roof['traffic'] = tj.get('hbm_bytes_per_launch') if fresh else None
+                    roof['traffic_source'] = {'file': 'profiles/kernel_traffic.json', 'measured': tj.get('measured'),
+                                              'kernel_source_sha256': tj.get('kernel_source_sha256', '')[:16],
+                                              'stale': not fresh, 'how': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, '
+                                              'gfx950 corrections of MI355X_MICROARCH.md'}
+        except Exception:
+            pass
+    # launch time of the roofline kernel as the committed rocprofv3 --kernel-trace run saw it (timed launches only, warm-ups
+    # dropped: tools/rocprof_summary.py --warmup / --steps -> profiles/kernel_launch_ms.json), next to the in-process HIP-event
+    # figure `launch_ms`; the profiler's own overhead sits in the gap between the two
+    lpath = os.path.join(REPO, 'profiles', 'kernel_launch_ms.json')
+    if os.path.exists(lpath):
+        try:
+            for lj in json.load(open(lpath)):
+                if lj.get('kernel_like') == roof['kernel_like'] and lj.get('workload') == wkey:
+                    roof['launch_ms_rocprof'] = lj.get('avg_ms_timed_launches')
+                    work = roof.get('algorithmic_flops_per_launch', roof.get('algorithmic_bytes_per_launch'))
+                    unit = 1e12 if roof['bound'] == 'mfma' else 1e9
+                    roof['frac_rocprof'] = round(work / (lj['avg_ms_timed_launches'] * 1e-3) / unit / roof['peak'], 4)
+                    roof['launch_ms_rocprof_source'] = {'file': 'profiles/kernel_launch_ms.json', 'measured': lj.get('measured'),
+                                                        'launches': lj.get('launches'), 'stale': lj.get('kernel_source_sha256') != kernel_source_hash()}
+        except Exception:
+            pass
+    return roof, stage_roof
+
+
+def executed_mfma(wkey):
+    """Matrix-pipe FLOPs one step of workload `wkey` EXECUTES (padding rows, recomputation and all), from profiles/kernel_mfma.json:
+    per kernel, SQ_INSTS_VALU_MFMA_MOPS_* x 512 (or SQ_INSTS_MFMA x the FLOPs of the kernel's MFMA shape) per launch x its
+    launches per step, written by tools/mfma_json.py from separate rocprofv3 --pmc passes and stamped with the kernel source hash
+    like the traffic entries.  None when there is no entry for this workload."""
+    path = os.path.join(REPO, 'profiles', 'kernel_mfma.json')
+    if not os.path.exists(path):
+        return None
+    try:
+        for ent in json.load(open(path)):
+            if ent.get('workload') == wkey:
+                return {'flops_per_step': float(ent['executed_mfma_flops_per_step']), 'measured': ent.get('measured'),
+                        'stale': ent.get('kernel_source_sha256') != kernel_source_hash(), 'how': ent.get('how')}
+    except Exception:
+        pass
+    return None
+
+
+def whole_forward_block(wkey, flops_step, bytes_step, step_s, is_bf16):
+    """The whole forward against the peaks of one GPU.  `credited_*`: FLOPs of the REFERENCE formulation (SURVEY.md section 8(d):
+    what the reference would have computed for these graphs) over the step time -- the kernels reach the same results with fewer
+    operations (algebraic rewrites, SURVEY.md Appendix E), so a credited fraction can exceed what the matrix pipe executed and even 1.0;
+    `executed_*`: the MFMA FLOPs the kernels really issue per step (counter-measured, executed_mfma) over the same time."""
+    peak = PEAK_BF16_TFLOPS if is_bf16 else PEAK_FP32_TFLOPS
+    peak_name = 'bf16_mfma_peak' if is_bf16 else 'fp32_peak'
+    out = {'credited_TFLOPs': round(flops_step / step_s / 1e12, 2), 'credited_frac_' + peak_name: round(flops_step / step_s / 1e12 / peak, 4),
+           'credited': 'reference-formulation FLOPs (SURVEY.md 8(d)) / step time; not a utilisation figure -- see executed_*',
+           'algorithmic_GBs': round(bytes_step / step_s / 1e9, 3), 'frac_hbm_peak': round(bytes_step / step_s / 1e9 / PEAK_HBM_GBS, 6),
+           'executed_TFLOPs': None, 'frac_executed': None}
+    ex = executed_mfma(wkey)
+    if ex is not None:
+        out.update({'executed_TFLOPs': round(ex['flops_per_step'] / step_s / 1e12, 2),
+                    'frac_executed': round(ex['flops_per_step'] / step_s / 1e12 / peak, 4),
+                    'executed_source': {'file': 'profiles/kernel_mfma.json', 'measured': ex['measured'], 'stale': ex['stale'],
+                                        'mfma_flops_per_step': ex['flops_per_step'], 'how': ex['how']}})
+    return out
+
+
+OTHER_CONFIGS = (      # (key, env, nodes, k1, problems per batch, MFMA operand mode): the bf16 shapes of BASELINE configs[2] and [4] (str2name.py:46-64)
+    ('cfg2_kuka7_N2000_k10_bf16', 'kuka7', 2000, 10, 64, 'bf16'),
+    ('cfg4_kuka14_N5000_k16_bf16', 'kuka14', 5000, 16, 32, 'bf16'))
+
+
+def other_config_leg(key, env, nodes, k1, G, mlp_dtype, loop, steps, warmup, dev):
+    """One of the OTHER BASELINE shapes under the same clock as the headline: `warmup` + `steps` forwards timed like `value`
+    (synchronize both sides, per-stage events off), then the same `steps` once more with the events on for the stage split and
+    the dominant kernel's roofline block (same rules as the headline's: roofline_blocks)."""
+    import gnnmp
+    from gnnmp.weights import load_weights
+    from gnnmp.synth import ENVS, synth_batch_gpu
+    e = ENVS[env]
+    model = gnnmp.EncoderProcessDecoder(e['workspace'], e['C'], e['d'], e['S']).eval()
+    model.load_state_dict(load_weights(e['ckpt']), strict=True)
+    model.mlp_dtype = mlp_dtype
+    graphs = synth_batch_gpu(env, nodes, k1, G, dev, seed0=1234)
+    batch = gnnmp.GraphBatch.from_graphs(graphs, e['S'], dev)
+
+    def loop_of(n):
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            out = model.forward_batch(batch, loop)
+        torch.cuda.synchronize(dev)
+        return time.perf_counter() - t0, out
+    loop_of(warmup)
+    el, scores = loop_of(steps)
+    model.profile(dev, True)
+    loop_of(1)
+    model.profile_read(dev)                                # drop the warm-up step of the profiled loop
+    loop_of(steps)
+    prof = model.profile_read(dev)
+    model.profile(dev, False)
+    Ns = [int(g['v'].shape[0]) for g in graphs]
+    Es = [int(g['edge_index'].shape[1]) for g in graphs]
+    Os = [g['obstacles'].reshape(-1, e['S']).shape[0] for g in graphs]
+    w = argparse.Namespace(env=env, nodes=nodes, k1=k1, mlp_dtype=mlp_dtype, loop=loop)
+    roof, stage_roof = roofline_blocks(w, e, G, prof, Ns, Es, Os)
+    wkey = '%s N=%d k1=%d graphs=%d %s' % (env, nodes, k1, G, mlp_dtype)
+    flops = sum(algorithmic_flops(n, m, o, e['C'], e['d'], e['S'], loop) for n, m, o in zip(Ns, Es, Os))
+    nbytes = sum(algorithmic_bytes(n, m, o, e['C'], e['S']) for n, m, o in zip(Ns, Es, Os))
+    res = {'workload': '%s: batch of %d problems, %d-node k1=%d RGGs (mean E=%.0f, O=%d), loop=%d, real %s checkpoint, %s operands'
+                       % (env, G, nodes, k1, sum(Es) / len(Es), Os[0], loop, e['ckpt'], mlp_dtype),
+           'graphs_per_s': round(G * steps / el, 1), 'ms_per_step': round(el / steps * 1e3, 4), 'steps': steps, 'warmup': warmup,
+           'dtype': mlp_dtype, 'stage_ms_per_step': {k_: round(v_[0] / max(steps, 1), 4) for k_, v_ in prof.items()},
+           'roofline': {k_: roof.get(k_) for k_ in ('kernel_like', 'bound', 'achieved', 'peak', 'unit', 'frac', 'launch_ms', 'traffic',
+                                                    'algorithmic_bytes_per_launch', 'algorithmic_flops_per_launch') if roof.get(k_) is not None or k_ == 'traffic'},
+           'traffic_stale': (roof.get('traffic_source') or {}).get('stale'),
+           'stage_frac': {k_: (v_['frac'], v_['bound']) for k_, v_ in stage_roof.items()},
+           'whole_forward': whole_forward_block(wkey, flops, nbytes, el / steps, mlp_dtype == 'bf16'),
+           'result_checksum': float(scores.double().sum().item())}
+    del model, batch, graphs, scores
+    torch.cuda.empty_cache()
+    return res
+
+
 def planner_leg(n_host, n_device, dev):
     """north_star: "collision checks and the sequential planner control flow stay on the host CPU and are timed in the
     same run (core count stated)".  Reference split first -- GNN forwards on the GPU, sampling + greedy loop + every
@@ -156,17 +369,25 @@ def planner_leg(n_host, n_device, dev):
     m.load_state_dict(load_weights('weights_maze'))
     ms = gnnmp.ModelSmoother(workspace_size=2, config_size=2, embed_size=128, obs_size=6).eval()
     ms.load_state_dict(load_weights('smooth_2d_attv3'))
+    # `host_cores: 1` is enforced, not assumed: torch's intra-op pool (sized from the machine, not from the container's CPU quota)
+    # would otherwise spin on every core it can get between the loop's small parallel ops and get the process throttled
+    # (gnnmp/hostenv.py; the 0.86 -> 5.0 ms `gnn_forward_ms_per_problem` of BENCH_r05 was exactly that)
+    threads0 = torch.get_num_threads()
+    torch.set_num_threads(1)
     np.random.seed(1234)
     for i in range(3):                                                                           # warm-up (first use of every kernel variant)
         env.init_new_problem(i)
         planner.explore(env, m, ms, True, batch=500, t_max=500, k=30, device=dev)
     fwd = tot = 0.0
     checks = 0
+    split = {}
     t0 = time.perf_counter()
     for i in range(n_host):
         env.init_new_problem(i)
         r = planner.explore(env, m, ms, True, batch=500, t_max=500, k=30, device=dev)
         fwd += r['forward']; tot += r['total']; checks += r['c_explore'] + r['c_smooth']
+        for k_, v_ in r['forward_split'].items():
+            split[k_] = split.get(k_, 0) + v_
     wall_host = time.perf_counter() - t0
     # the device planner is quoted at ONE size everywhere (README, DESIGN, this line): n_device problems (the evaluation set
     # cycled), median of three timed passes after a warm-up pass at the same size (allocator, kernel variants)
@@ -180,9 +401,15 @@ def planner_leg(n_host, n_device, dev):
         torch.cuda.synchronize(dev)
         walls.append(time.perf_counter() - t0)
     wall_dev = sorted(walls)[1]
+    torch.set_num_threads(threads0)
     return {'problems': 'mazes_hard.npz (2-D maze), batch = t_max = 500, k = 30, smoothing on',
             'host_loop': {'problems': n_host, 'problems_per_s': round(n_host / wall_host, 2), 'host_cores': 1,
                           'gnn_forward_ms_per_problem': round(1e3 * fwd / n_host, 2),
+                          # what that span (eval_gnn.py:193-196) is made of, ms per problem: obs_data = host tensors of the samples +
+                          # their H2D copies, h2d = graph tensors, module_call = host time of model(**kw) (enqueue only),
+                          # d2h_wait = .cpu() of the dense [N, N] block (kernels finishing + the 4 MB pageable copy)
+                          'gnn_forward_split_ms': {k_: round(1e3 * v_ / n_host, 3) for k_, v_ in split.items() if k_ != 'calls'},
+                          'gnn_forwards_per_problem': round(split.get('calls', 0) / n_host, 2),
                           'host_ms_per_problem': round(1e3 * (tot - fwd) / n_host, 2),
                           'collision_checks_per_problem': round(checks / n_host, 1),
                           'what': 'dense drop-in forward on the GPU; sampling, greedy loop, collision checks, steering on one host core'},
@@ -255,6 +482,9 @@ def main():
                     help='also time a strong-scaling leg in the same run: the FIXED problem set 0 .. N_TOTAL - 1 split over the ranks, '
                          'reported as config.strong_leg next to the weak headline (0 = skip; ignored with --strong)')
     ap.add_argument('--strong-steps', type=int, default=5, help='timed steps of the strong leg')
+    ap.add_argument('--other-configs-steps', type=int, default=10,
+                    help='timed steps of each of the other BASELINE shapes (configs[2] kuka7 2000 x 64 bf16, configs[4] kuka14 5000 x 32 bf16) '
+                         'run after the headline workload and reported as config.other_configs_gpu; only with the default workload on one GPU (0 = skip)')
     ap.add_argument('--launch-check', action='store_true',
                     help='start the ranks, connect them (init_process_group + one all_reduce), print one JSON line and exit without '
                          'running the workload (tests the launcher on a box without GPUs: GNNMP_BENCH_BACKEND=gloo)')
@@ -277,6 +507,12 @@ def main():
     backend = os.environ.get('GNNMP_BENCH_BACKEND', 'nccl')
     if backend not in ('nccl', 'gloo'):
         raise SystemExit('bench.py: GNNMP_BENCH_BACKEND must be nccl or gloo, got %r' % backend)
+    if world > 1:
+        # a scaling line needs the warm-up, `value`, the strong leg, the profiled loop and the gather -- not N copies of the PCIe,
+        # dense-output, bf16x3, in-flight and planner legs; rank 0 alone keeps the single-graph latency
+        args.pcie_steps = args.dense_steps = args.bf16x3_steps = args.inflight_steps = args.other_configs_steps = 0
+        if rank != 0:
+            args.single_steps = 0
     if args.strong > 0 and args.strong < world:
         # every rank sees the same arguments and leaves together (a rank bailing out alone would leave the others in a collective)
         raise SystemExit('bench.py: --strong %d is fewer problems than ranks (%d)' % (args.strong, world))
@@ -308,6 +544,10 @@ def main():
     import gnnmp
     from gnnmp.weights import load_weights
     from gnnmp.synth import ENVS, synth_batch_gpu
+    from gnnmp.hostenv import cpu_quota, limit_host_threads
+    machine_threads = torch.get_num_threads()
+    # the container's CPU quota shared by the ranks of this node (16 CPUs on the MI355X job boxes, where torch would start 128 threads)
+    host_threads = limit_host_threads(max(1, cpu_quota() // max(world, 1)))
     e = ENVS[args.env]
     model = gnnmp.EncoderProcessDecoder(e['workspace'], e['C'], e['d'], e['S']).eval()
     model.load_state_dict(load_weights(e['ckpt']), strict=True)
@@ -552,100 +792,9 @@ def main():
         Os = [g['obstacles'].reshape(-1, e['S']).shape[0] for g in graphs]
         flops_batch = sum(algorithmic_flops(n, m, o, e['C'], e['d'], e['S'], args.loop) for n, m, o in zip(Ns, Es, Os))
         bytes_batch = sum(algorithmic_bytes(n, m, o, e['C'], e['S']) for n, m, o in zip(Ns, Es, Os))
-        ep_flops = sum(edge_pre_flops(m, o, e['C'], e['d']) for m, o in zip(Es, Os))
-        ep_ms, ep_n = prof['edge_pre']
-        ep_avg_ms = ep_ms / max(ep_n, 1)
-        achieved = ep_flops / (ep_avg_ms * 1e-3) / 1e12 if ep_avg_ms > 0 else 0.0
-        # the roofline block describes the DOMINANT kernel of this workload: the stage with the largest share of the step
-        stage_tot = {k: v[0] for k, v in prof.items()}
-        dom = max(stage_tot, key=stage_tot.get)
-        if dom not in ('edge_pre', 'mp'):
-            dom = 'edge_pre'
-        # bf16 shapes where the two stages are within 3 % of each other (configs[4] shape: 0.474 / 0.476 ms): keep the block on the
-        # message-passing kernel, so that it does not flip between runs (the edge stage is in stage_roofline either way)
-        if args.mlp_dtype == 'bf16' and dom == 'edge_pre' and stage_tot.get('mp', 0.0) >= 0.97 * stage_tot['edge_pre']:
-            dom = 'mp'
-        pname = {'fp32': '0', 'bf16': '1', 'bf16x3': '2'}[args.mlp_dtype]
-        if dom == 'mp':
-            mp_ms, mp_n = prof['mp']
-            mp_avg_ms = mp_ms / max(mp_n, 1)
-            mp_bytes = sum(mp_fused_bytes(n, m, e['d'], args.mlp_dtype == 'bf16') for n, m in zip(Ns, Es))
-            # d = 64 runs the eight-wave form (mp_fused_w8_kernel, round 5) in the fp32 and bf16 modes
-            mp_name = 'mp_fused_w8_kernel<64, %s' % pname if (e['d'] == 64 and pname in ('0', '1')) else 'mp_fused_kernel<%d, %s' % (e['d'], pname)
-            roof = {'kernel': '%s...> (one message-passing iteration: edge MLP second layer, max aggregation, '
-                              'node update; %d launches per step)' % (mp_name, args.loop),
-                    'kernel_like': mp_name,
-                    'bound': 'hbm', 'achieved': round(mp_bytes / (mp_avg_ms * 1e-3) / 1e9, 1) if mp_avg_ms > 0 else 0.0,
-                    'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'launch_ms': round(mp_avg_ms, 4), 'algorithmic_bytes_per_launch': mp_bytes}
-        else:
-            peak = PEAK_BF16_TFLOPS if args.mlp_dtype == 'bf16' else PEAK_FP32_TFLOPS
-            roof = {'kernel': '%s<%d, %s, EDGE> (edge encoders + 3 obstacle-attention blocks)' % ('pre_resident_kernel' if (pname == '1' or (pname == '0' and e['d'] == 32)) else 'pre_kernel', e['d'], pname),
-                    'kernel_like': '%s<%d, %s, true' % ('pre_resident_kernel' if (pname == '1' or (pname == '0' and e['d'] == 32)) else 'pre_kernel', e['d'], pname),
-                    'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
-                    'launch_ms': round(ep_avg_ms, 4), 'algorithmic_flops_per_launch': ep_flops}
-        roof['frac'] = round(roof['achieved'] / roof['peak'], 4)
-        # every stage against the roof that bounds it (the `roofline` block above is the dominant one of these)
+        roof, stage_roof = roofline_blocks(args, e, G, prof, Ns, Es, Os)
         is_bf16 = args.mlp_dtype == 'bf16'
         mfma_peak = PEAK_BF16_TFLOPS if is_bf16 else PEAK_FP32_TFLOPS
-        def per_launch(stage):
-            ms, n = prof.get(stage, (0.0, 0))
-            return ms / max(n, 1)
-        stage_roof = {}
-        ns_ms = per_launch('obs') + per_launch('node_pre')
-        ns_flops = sum(node_side_flops(n, o, e['C'], e['d'], e['S']) for n, o in zip(Ns, Os))
-        for name, ms, work, bound in (
-                ('edge_pre', ep_avg_ms, ep_flops, 'mfma'), ('obs+node_pre', ns_ms, ns_flops, 'mfma'),
-                ('mp (per launch)', per_launch('mp'), sum(mp_fused_bytes(n, m, e['d'], is_bf16) for n, m in zip(Ns, Es)), 'hbm'),
-                ('policy', per_launch('policy'), sum(policy_bytes(n, m, e['d'], is_bf16) for n, m in zip(Ns, Es)), 'hbm')):
-            if ms <= 0:
-                continue
-            if bound == 'mfma':
-                ach = work / (ms * 1e-3) / 1e12
-                stage_roof[name] = {'bound': 'mfma', 'ms': round(ms, 4), 'TFLOPs': round(ach, 1), 'frac': round(ach / mfma_peak, 3)}
-            else:
-                ach = work / (ms * 1e-3) / 1e9
-                stage_roof[name] = {'bound': 'hbm', 'ms': round(ms, 4), 'GBs': round(ach, 0), 'frac': round(ach / PEAK_HBM_GBS, 3)}
-                if name.startswith('mp'):
-                    # the same launch against the matrix pipe: 2 d^2 FLOP per edge (message layer) + 10 d^2 per padded node row (W_dst X,
-                    # W_lx X, W_la agg, M1 H, M2 Y; the last iteration's M3 is not counted).  At d = 64 in fp32 the two roofs meet
-                    # (16 FLOP per algorithmic byte against a ridge of 19.7): the launch is priced against both
-                    d_ = e['d']
-                    fl = sum(2.0 * d_ * d_ * m + 5 * 2.0 * d_ * d_ * (((n + 31) // 32) * 32) for n, m in zip(Ns, Es))
-                    tf = fl / (ms * 1e-3) / 1e12
-                    stage_roof[name].update({'TFLOPs': round(tf, 1), 'frac_mfma': round(tf / mfma_peak, 3)})
-        # issue-slot fraction of the edge pre kernel (bf16 mode: it is bound by instruction issue, not by the matrix pipe its FLOPs are
-        # priced against): (4 x SQ_ACTIVE_INST_VALU + SQ_VALU_MFMA_BUSY_CYCLES) / SIMD cycles from separate --pmc passes
-        # (tools/issue_json.py -> profiles/kernel_issue.json, stamped with workload and source hash like the traffic entries)
-        ipath = os.path.join(REPO, 'profiles', 'kernel_issue.json')
-        if os.path.exists(ipath) and 'edge_pre' in stage_roof:
-            try:
-                wk_ = '%s N=%d k1=%d graphs=%d %s' % (args.env, args.nodes, args.k1, G, args.mlp_dtype)
-                for ij in json.load(open(ipath)):
-                    if ij.get('workload') == wk_ and ij.get('stage') == 'edge_pre':
-                        stage_roof['edge_pre']['issue_slots'] = {k_: ij.get(k_) for k_ in (
-                            'issue_slot_frac', 'valu_frac', 'mfma_frac', 'valu_per_32_row_tile', 'mfma_per_32_row_tile', 'measured')}
-                        stage_roof['edge_pre']['issue_slots']['stale'] = ij.get('kernel_source_sha256') != kernel_source_hash()
-            except Exception:
-                pass
-        # HBM bytes per launch of that kernel come from separate rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE cannot be
-        # read inside this process; tools/traffic_json.py writes profiles/kernel_traffic.json): every entry carries the
-        # workload it was measured on, the date of the pass and a hash of the kernel sources; the number is reported only
-        # for the same workload and while that hash still matches the sources of the library in use
-        wkey = '%s N=%d k1=%d graphs=%d %s' % (args.env, args.nodes, args.k1, G, args.mlp_dtype)
-        roof['traffic'] = None
-        tpath = os.path.join(REPO, 'profiles', 'kernel_traffic.json')
-        if os.path.exists(tpath):
-            try:
-                for tj in json.load(open(tpath)):
-                    if tj.get('kernel_like') == roof['kernel_like'] and tj.get('workload') == wkey:
-                        fresh = tj.get('kernel_source_sha256') == kernel_source_hash()
-                        roof['traffic'] = tj.get('hbm_bytes_per_launch') if fresh else None
-                        roof['traffic_source'] = {'file': 'profiles/kernel_traffic.json', 'measured': tj.get('measured'),
-                                                  'kernel_source_sha256': tj.get('kernel_source_sha256', '')[:16],
-                                                  'stale': not fresh, 'how': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, '
-                                                  'gfx950 corrections of MI355X_MICROARCH.md'}
-            except Exception:
-                pass
         shape = (args.env, args.nodes, args.k1, args.mlp_dtype)
         cfg_name = 'BASELINE configs[1]' if shape == ('maze2', 1000, 8, 'fp32') and G == 256 \
             else ('BASELINE configs[2] shape' if shape == ('kuka7', 2000, 10, 'bf16')
@@ -653,22 +802,6 @@ def main():
                         else ('BASELINE configs[0] shape, batched' if shape == ('maze2', 200, 6, 'fp32') else 'custom workload')))
         ms_step = elapsed / args.steps * 1e3
         value = total_graphs * args.steps / elapsed          # whole job: the graphs ALL ranks scored per step / the slowest rank's time
-        # launch time of the roofline kernel as the committed rocprofv3 --kernel-trace run saw it (timed launches only, warm-ups
-        # dropped: tools/rocprof_summary.py --warmup / --steps -> profiles/kernel_launch_ms.json), next to the in-process HIP-event
-        # figure `launch_ms`; the profiler's own overhead sits in the gap between the two
-        lpath = os.path.join(REPO, 'profiles', 'kernel_launch_ms.json')
-        if os.path.exists(lpath):
-            try:
-                for lj in json.load(open(lpath)):
-                    if lj.get('kernel_like') == roof['kernel_like'] and lj.get('workload') == wkey:
-                        roof['launch_ms_rocprof'] = lj.get('avg_ms_timed_launches')
-                        work = roof.get('algorithmic_flops_per_launch', roof.get('algorithmic_bytes_per_launch'))
-                        unit = 1e12 if roof['bound'] == 'mfma' else 1e9
-                        roof['frac_rocprof'] = round(work / (lj['avg_ms_timed_launches'] * 1e-3) / unit / roof['peak'], 4)
-                        roof['launch_ms_rocprof_source'] = {'file': 'profiles/kernel_launch_ms.json', 'measured': lj.get('measured'),
-                                                            'launches': lj.get('launches'), 'stale': lj.get('kernel_source_sha256') != kernel_source_hash()}
-            except Exception:
-                pass
         stages = {k: round(v[0] / max(args.steps, 1), 4) for k, v in prof.items()}
         res = {
             'metric': 'RGG graphs/sec (GNN explorer forward), %d-node k=%d' % (args.nodes, args.k1),
@@ -682,6 +815,8 @@ def main():
                                    'per-edge scores' % (cfg_name, args.env, G, args.nodes, args.k1, sum(Es) / len(Es), Os[0],
                                                         args.loop, e['ckpt'], args.mlp_dtype),
                        'graphs_per_gpu': G, 'graphs_total': total_graphs,
+                       'host': {'cpus_visible': os.cpu_count(), 'cpu_quota': cpu_quota(), 'torch_threads_default': machine_threads,
+                                'torch_threads_used': host_threads},
                        'parallelism': 'problem-sharded x%d (%s)' % (world, 'fixed set of %d problems split by shard_range' % args.strong
                                                                   if args.strong > 0 else '%d problems per GPU' % G),
                        # multi-GPU self-checks: ranks the collective library connected, every rank's own ms per step, the result
@@ -699,11 +834,8 @@ def main():
                                  'calls (lengths, one padded payload of %d floats per rank), median of %d, max over ranks; outside the '
                                  'timed region' % (int(scores.numel()), max(args.gather_reps, 1)),
                        # rank 0's share of the job against the peaks of ONE GPU (rank 0's FLOPs / bytes over the job's step time)
-                       'whole_forward': {'algorithmic_TFLOPs': round(flops_batch * args.steps / elapsed / 1e12, 2),
-                                         'algorithmic_GBs': round(bytes_batch * args.steps / elapsed / 1e9, 3),
-                                         ('frac_bf16_mfma_peak' if is_bf16 else 'frac_fp32_peak'):
-                                             round(flops_batch * args.steps / elapsed / 1e12 / mfma_peak, 4),
-                                         'frac_hbm_peak': round(bytes_batch * args.steps / elapsed / 1e9 / PEAK_HBM_GBS, 6)},
+                       'whole_forward': whole_forward_block('%s N=%d k1=%d graphs=%d %s' % (args.env, args.nodes, args.k1, G, args.mlp_dtype),
+                                                            flops_batch, bytes_batch, elapsed / args.steps, is_bf16),
                        'stage_ms_per_step': stages, 'stage_roofline': stage_roof, 'result_checksum': checksum,
                        'pcie_inclusive_graphs_per_s_per_gpu': None if e2e is None else round(e2e, 1),
                        'pcie_inclusive_one_batch_at_a_time': None if e2e_serial is None else round(e2e_serial, 1),
@@ -713,6 +845,11 @@ def main():
                        'single_graph_us': single_us},
             'roofline': roof,
         }
+        if world == 1 and args.other_configs_steps > 0 and (args.env, args.nodes, args.k1, args.mlp_dtype) == ('maze2', 1000, 8, 'fp32'):
+            del batch
+            torch.cuda.empty_cache()
+            res['config']['other_configs_gpu'] = {key: other_config_leg(key, oe, on, ok, og, od, args.loop, args.other_configs_steps, 5, dev)
+                                                  for key, oe, on, ok, og, od in OTHER_CONFIGS}
         if world == 1 and args.planner_problems > 0 and (args.env, args.mlp_dtype) == ('maze2', 'fp32'):
             res['config']['planner'] = planner_leg(args.planner_problems, 1024, dev)
         if world == 1 and not args.no_cpu_baseline:

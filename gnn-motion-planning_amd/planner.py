@@ -26,10 +26,15 @@ def path_cost(path):
     return float(sum(np.linalg.norm(p[i + 1] - p[i]) for i in range(len(p) - 1)))
 
 
-def obs_data(env, free, collided, device, for_smoother=False):
+def obs_data(env, free, collided, device, for_smoother=False, obstacles_only=False):
     """Tensors handed to the models next to the graph (explorer: eval_gnn.py:25-36, collided truncated
     to len(free); smoother: smoother.py:52-64, empty lists replaced by one zero row -- appended to the
-    CALLER's list like the reference does -- and both truncated to 500)."""
+    CALLER's list like the reference does -- and both truncated to 500).
+    ``obstacles_only``: just the obstacle tensor.  The explorer's forward accepts ``free`` / ``collided`` and never reads them
+    (model.py:115: they are not used anywhere in the body), so the host loop need not build two [n, C] tensors from lists of
+    rows and copy them to the device before every forward (0.15 ms of the 0.9 ms span at n = 500)."""
+    if obstacles_only:
+        return {'obstacles': torch.tensor(np.asarray(env.obstacles), dtype=torch.float32).to(device)}
     if for_smoother:
         if not len(free):
             free.append([0. for _ in range(env.config_dim)])
@@ -216,11 +221,17 @@ def model_smooth(model, free, collided, old_path, env, device, iters=5, trace=No
 
 @torch.no_grad()
 def explore(env, model, model_s, smooth=True, batch=500, t_max=1000, k=30, smoother='model', loop=5, device='cuda',
-            trace=None, sparse=False, gpu_graph=False):
+            trace=None, sparse=False, gpu_graph=False, reference_kwargs=None):
     """Counterpart of ``explore`` (eval_gnn.py:168-276).  Returns the same result dict.
+    ``reference_kwargs=True`` hands the model every keyword the reference does (``free``, ``collided``, ``labels``: built, copied to
+    the device and then ignored by the forward, model.py:115); ``False`` passes only what the forward reads -- same output.  Default
+    (None): False for this package's ``EncoderProcessDecoder``, True for any other model (one with the reference's signature needs them).
     ``sparse=True`` asks the model for per-edge scores (``edge_scores``) and runs the heap-based
     frontier instead of pulling the dense N x N matrix to the host; decisions are identical.
     ``gpu_graph=True`` builds the kNN graph on the device (graph_kernels.hip; same edge_index)."""
+    if reference_kwargs is None:
+        from .explorer import EncoderProcessDecoder
+        reference_kwargs = not isinstance(model, EncoderProcessDecoder)
     c0 = env.collision_check_count
     t0 = time.time()
     forward = 0.
@@ -229,25 +240,45 @@ def explore(env, model, model_s, smooth=True, batch=500, t_max=1000, k=30, smoot
     collided = collided[:len(free)]
     free = [env.init_state] + [env.goal_state] + list(free)
     state = {'explored': [0], 'explored_edges': [[0, 0]], 'costs': {0: 0.}, 'prev': {0: 0}}
+    # what `forward` (the span eval_gnn.py:193-196 times) is made of, seconds: obs_data (host tensors + their copies), h2d (graph
+    # tensors), module_call (host time of model(**kw): enqueue only, nothing waits), d2h_wait (.cpu(): kernels finishing + the copy)
+    split = {'obs_data': 0., 'h2d': 0., 'module_call': 0., 'd2h_wait': 0., 'calls': 0}
     make_data = (lambda f, c: create_data_gpu(f, c, env.goal_state, k, device)) if gpu_graph else \
         (lambda f, c: create_data(f, c, env.goal_state, k))
     data = make_data(free, collided)
     while not success and (len(free) - 2) <= t_max:
         t1 = time.time()
-        od = obs_data(env, free, collided, device)
-        kw = dict(goal=data['goal'].to(device), v=data.get('v_dev', data['v']).to(device), labels=data['labels'].to(device),
+        od = obs_data(env, free, collided, device, obstacles_only=not reference_kwargs)
+        t2 = time.time()
+        kw = dict(goal=data['goal'].to(device), v=data.get('v_dev', data['v']).to(device),
                   edge_index=data['edge_index'].to(device), loop=loop, **od)
+        if reference_kwargs:
+            kw['labels'] = data['labels'].to(device)
+        t3 = time.time()
         ei = data['edge_index'].cpu().numpy()
         v = data['v'].numpy()
+        split['obs_data'] += t2 - t1
+        split['h2d'] += t3 - t2
+        split['calls'] += 1
         if sparse:
-            sc = model.edge_scores(**kw).detach().cpu().numpy()      # E floats instead of N^2
+            t4 = time.time()
+            sc = model.edge_scores(**kw)
+            t5 = time.time()
+            sc = sc.detach().cpu().numpy()                           # E floats instead of N^2
             forward += time.time() - t1
+            split['module_call'] += t5 - t4
+            split['d2h_wait'] += time.time() - t5
             if trace is not None:
                 trace.setdefault('forwards', []).append({'v': v.copy(), 'edge_index': ei.copy(), 'scores': sc.copy()})
             found = greedy_expand_sparse(sc, ei, data['labels'].numpy(), v, env, state)
         else:
-            P = model(**kw).detach().cpu().numpy()                   # the implicit sync of eval_gnn.py:195
+            t4 = time.time()
+            P = model(**kw)
+            t5 = time.time()
+            P = P.detach().cpu().numpy()                             # the implicit sync of eval_gnn.py:195
             forward += time.time() - t1
+            split['module_call'] += t5 - t4
+            split['d2h_wait'] += time.time() - t5
             if trace is not None:
                 trace.setdefault('forwards', []).append({'v': v.copy(), 'edge_index': ei.copy(),
                                                          'scores': P[ei[1], ei[0]].copy()})
@@ -278,7 +309,7 @@ def explore(env, model, model_s, smooth=True, batch=500, t_max=1000, k=30, smoot
     if not smooth:
         return list(data['v'][path].numpy()), free, collided
     return {'c_explore': c_explore, 'c_smooth': c_smooth, 'data': data, 'explored': state['explored'],
-            'forward': forward, 'total': time.time() - t0, 'total_explore': t1 - t0, 'success': success, 't0': t0,
+            'forward': forward, 'forward_split': split, 'total': time.time() - t0, 'total_explore': t1 - t0, 'success': success, 't0': t0,
             'path': path, 'smooth_path': smooth_path, 'explored_edges': state['explored_edges']}
 
 
@@ -288,6 +319,8 @@ def eval_gnn(env, indexes, model, model_s, seed=1234, smooth=True, batch=500, t_
     model.eval()                       # eval_gnn.py:109-110
     if model_s is not None:
         model_s.eval()
+    from .hostenv import warn_if_oversubscribed
+    warn_if_oversubscribed()           # a torch pool larger than the CPU quota stalls this one-core loop (hostenv.py)
     np.random.seed(seed)
     torch.manual_seed(seed)
     sol, paths, smooth_paths = [], [], []

@@ -10,7 +10,7 @@ esac
 shift
 for v in "$@"; do
   if [ "$v" = base ]; then unset GNNMP_LIB; else export GNNMP_LIB=$R/gnn-motion-planning_amd/libgnnmp_$v.so; fi
-  python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --pcie-steps 0 --dense-steps 0 --bf16x3-steps 0 --single-steps 0 --inflight-steps 0 --planner-problems 0 $A 2>&1 | tail -1 | python -c "
+  python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --pcie-steps 0 --dense-steps 0 --bf16x3-steps 0 --single-steps 0 --inflight-steps 0 --other-configs-steps 0 --planner-problems 0 $A 2>&1 | tail -1 | python -c "
 import json,sys
 t=sys.stdin.read()
 try:

@@ -11,7 +11,7 @@ C=$1
 shift
 for v in "$@"; do
   E=""; [ "$v" != "-" ] && E="$v"
-  env $E python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --pcie-steps 0 --dense-steps 0 --bf16x3-steps 0 --single-steps 0 --inflight-steps 0 --planner-problems 0 --strong-leg 0 $A 2>&1 | tail -1 | python -c "
+  env $E python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --pcie-steps 0 --dense-steps 0 --bf16x3-steps 0 --single-steps 0 --inflight-steps 0 --other-configs-steps 0 --planner-problems 0 --strong-leg 0 $A 2>&1 | tail -1 | python -c "
 import json,sys
 t=sys.stdin.read()
 try:

@@ -5,7 +5,7 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/r03f
 rm -rf $O; mkdir -p $O
 cd $R
-BA="--no-cpu-baseline --planner-problems 0 --pcie-steps 0 --dense-steps 0 --bf16x3-steps 0 --single-steps 0 --inflight-steps 0"
+BA="--no-cpu-baseline --planner-problems 0 --pcie-steps 0 --dense-steps 0 --bf16x3-steps 0 --single-steps 0 --inflight-steps 0 --other-configs-steps 0"
 bash tools/diag/traffic_pass.sh 'pre_resident_kernel<32, 0, true' 'maze2 N=1000 k1=8 graphs=256 fp32' > $O/traffic_edge_pre.log 2>&1
 bash tools/diag/traffic_pass.sh 'mp_fused_kernel<32, 0' 'maze2 N=1000 k1=8 graphs=256 fp32' > $O/traffic_mp_cfg2.log 2>&1
 bash tools/diag/traffic_pass.sh 'mp_fused_kernel<64, 1' 'kuka7 N=2000 k1=10 graphs=64 bf16' --env kuka7 --nodes 2000 --k1 10 --graphs 64 --mlp-dtype bf16 > $O/traffic_mp_cfg3.log 2>&1

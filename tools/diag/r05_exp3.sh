@@ -5,7 +5,7 @@ cd /tmp; export TMPDIR=/tmp
 for v in ${VARIANTS:-base lds64}; do
   if [ $v = base ]; then unset GNNMP_LIB; else export GNNMP_LIB=$R/gnn-motion-planning_amd/libgnnmp_$v.so; fi
   rm -rf /tmp/prof_$v
-  rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_$v -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --pcie-steps 0 --dense-steps 0 --bf16x3-steps 0 --single-steps 0 --inflight-steps 0 --planner-problems 0 --strong-leg 0 --env kuka7 --nodes 2000 --k1 10 --graphs 64 --mlp-dtype bf16 > /dev/null 2>&1
+  rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_$v -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --pcie-steps 0 --dense-steps 0 --bf16x3-steps 0 --single-steps 0 --inflight-steps 0 --other-configs-steps 0 --planner-problems 0 --strong-leg 0 --env kuka7 --nodes 2000 --k1 10 --graphs 64 --mlp-dtype bf16 > /dev/null 2>&1
   f=$(find /tmp/prof_$v -name "*kernel_trace.csv" | head -1)
   echo "== $v ($f)"
   python - "$f" <<'PY'

@@ -1,6 +1,6 @@
 set -u
 mkdir -p gpurun_out/s4
-BA="--no-cpu-baseline --planner-problems 0 --strong-leg 0 --pcie-steps 0 --dense-steps 0 --bf16x3-steps 0 --single-steps 0 --inflight-steps 0"
+BA="--no-cpu-baseline --planner-problems 0 --strong-leg 0 --pcie-steps 0 --dense-steps 0 --bf16x3-steps 0 --single-steps 0 --inflight-steps 0 --other-configs-steps 0"
 timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/s4/pytest.log 2>&1; echo "pytest rc $?" >> gpurun_out/s4/pytest.log
 tail -5 gpurun_out/s4/pytest.log
 timeout 300 python bench.py $BA 2>/dev/null | tail -1 > gpurun_out/s4/b_cfg2.json

@@ -3,7 +3,7 @@
 # the per-rank batch): where does the per-graph cost double between 256 and 64 graphs?
 R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/s4; mkdir -p $O
-BA="--no-cpu-baseline --planner-problems 0 --strong-leg 0 --pcie-steps 0 --dense-steps 0 --bf16x3-steps 0 --single-steps 0 --inflight-steps 0 --steps 20 --warmup 5"
+BA="--no-cpu-baseline --planner-problems 0 --strong-leg 0 --pcie-steps 0 --dense-steps 0 --bf16x3-steps 0 --single-steps 0 --inflight-steps 0 --other-configs-steps 0 --steps 20 --warmup 5"
 {
 for env in maze2 kuka7 ur5; do
 for g in 16 32 64 128 256; do

@@ -2,7 +2,7 @@
 # A/B of mp_fused_w8_kernel<64, 0> variants: bit-identity test + kuka7 fp32 bench lines
 R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/s4; mkdir -p $O
-BA="--no-cpu-baseline --planner-problems 0 --strong-leg 0 --pcie-steps 0 --dense-steps 0 --bf16x3-steps 0 --single-steps 0 --inflight-steps 0 --steps 20 --warmup 5"
+BA="--no-cpu-baseline --planner-problems 0 --strong-leg 0 --pcie-steps 0 --dense-steps 0 --bf16x3-steps 0 --single-steps 0 --inflight-steps 0 --other-configs-steps 0 --steps 20 --warmup 5"
 {
 true
 for lib in "" $@; do unset GNNMP_LIB

@@ -5,7 +5,7 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/r04
 rm -rf $O; mkdir -p $O
 cd $R
-BA="--no-cpu-baseline --planner-problems 0 --pcie-steps 0 --dense-steps 0 --bf16x3-steps 0 --single-steps 0 --inflight-steps 0"
+BA="--no-cpu-baseline --planner-problems 0 --pcie-steps 0 --dense-steps 0 --bf16x3-steps 0 --single-steps 0 --inflight-steps 0 --other-configs-steps 0"
 C3="--env kuka7 --nodes 2000 --k1 10 --graphs 64 --mlp-dtype bf16"
 C5="--env kuka14 --nodes 5000 --k1 16 --graphs 32 --mlp-dtype bf16"
 # 1. traffic passes first (bench.py reports roofline.traffic from profiles/kernel_traffic.json when the source hash matches)
@@ -28,7 +28,7 @@ cp profiles/kernel_launch_ms.json $O/
 timeout 900 python bench.py > $O/bench.json 2> $O/bench.err
 timeout 300 python bench.py $BA $C3 2>/dev/null | tail -1 > $O/bench_cfg3_kuka7_bf16.json
 timeout 300 python bench.py $BA $C5 2>/dev/null | tail -1 > $O/bench_cfg5_kuka14_bf16.json
-timeout 300 python bench.py --no-cpu-baseline --planner-problems 0 --pcie-steps 0 --dense-steps 0 --single-steps 0 --inflight-steps 0 --mlp-dtype bf16x3 2>/dev/null | tail -1 > $O/bench_cfg2_bf16x3.json
+timeout 300 python bench.py --no-cpu-baseline --planner-problems 0 --pcie-steps 0 --dense-steps 0 --single-steps 0 --inflight-steps 0 --other-configs-steps 0 --mlp-dtype bf16x3 2>/dev/null | tail -1 > $O/bench_cfg2_bf16x3.json
 GNNMP_BENCH_FORCE_DIST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29517 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 timeout 300 python bench.py $BA --strong 256 2>/dev/null | grep '^{' | tail -1 > $O/bench_strong256_forced_dist.json
 # 4. SQ counters of the three shapes
 PMC_GROUPS="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES;SQ_INSTS_VALU_MFMA_F64 SQ_INSTS_VALU_MFMA_F32 SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_WAVES;FETCH_SIZE;WRITE_SIZE;GRBM_GUI_ACTIVE" bash tools/pmc_passes.sh r04 -- python $R/bench.py --steps 3 --warmup 1 $BA > $O/pmc.log 2>&1

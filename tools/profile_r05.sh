@@ -6,9 +6,9 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/r05p
 rm -rf $O; mkdir -p $O
 cd $R
-BA="--no-cpu-baseline --planner-problems 0 --strong-leg 0 --pcie-steps 0 --dense-steps 0 --bf16x3-steps 0 --single-steps 0 --inflight-steps 0"
+BA="--no-cpu-baseline --planner-problems 0 --strong-leg 0 --pcie-steps 0 --dense-steps 0 --bf16x3-steps 0 --single-steps 0 --inflight-steps 0 --other-configs-steps 0"
 # the committed bench LINES keep the two-batches-in-flight leg; kernel traces and counter passes do not (its overlapped launches would enter the per-launch averages)
-BL="--no-cpu-baseline --planner-problems 0 --strong-leg 0 --pcie-steps 0 --dense-steps 0 --bf16x3-steps 0 --single-steps 0 --inflight-steps 20"
+BL="--no-cpu-baseline --planner-problems 0 --strong-leg 0 --pcie-steps 0 --dense-steps 0 --bf16x3-steps 0 --single-steps 0 --inflight-steps 20 --other-configs-steps 0"
 C3="--env kuka7 --nodes 2000 --k1 10 --graphs 64 --mlp-dtype bf16"
 C3F="--env kuka7 --nodes 2000 --k1 10 --graphs 64"
 C5="--env kuka14 --nodes 5000 --k1 16 --graphs 32 --mlp-dtype bf16"
@@ -52,7 +52,7 @@ timeout 300 python bench.py $BL 2>/dev/null | tail -1 > $O/bench_cfg2_two_in_fli
 timeout 300 python bench.py $BL $C3 2>/dev/null | tail -1 > $O/bench_cfg3_kuka7_bf16.json
 timeout 300 python bench.py $BL $C3F 2>/dev/null | tail -1 > $O/bench_cfg3_kuka7_fp32.json
 timeout 300 python bench.py $BL $C5 2>/dev/null | tail -1 > $O/bench_cfg5_kuka14_bf16.json
-timeout 300 python bench.py --no-cpu-baseline --planner-problems 0 --strong-leg 0 --pcie-steps 0 --dense-steps 0 --single-steps 0 --inflight-steps 20 --mlp-dtype bf16x3 2>/dev/null | tail -1 > $O/bench_cfg2_bf16x3.json
+timeout 300 python bench.py --no-cpu-baseline --planner-problems 0 --strong-leg 0 --pcie-steps 0 --dense-steps 0 --single-steps 0 --inflight-steps 20 --other-configs-steps 0 --mlp-dtype bf16x3 2>/dev/null | tail -1 > $O/bench_cfg2_bf16x3.json
 GNNMP_BENCH_BACKEND=gloo timeout 600 python bench.py --gpus 2 $BA --strong-leg 512 2>/dev/null | grep '^{' | tail -1 > $O/bench_selflaunch_2ranks_gloo_one_gpu.json
 # 5. per-wave timelines of the message-passing launch (diagnostics build, when present)
 if [ -f gnn-motion-planning_amd/libgnnmp_trace.so ]; then
