@@ -6,7 +6,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('GNNMP_LIB') or os.path.join(_HERE, 'libgnnmp.so')      # GNNMP_LIB: an experiment build (tools/diag/build_variant.sh)
 
-ABI_VERSION = 3                        # include/gnnmp.h gnnmp_abi_version(): what this binding was written against
+ABI_VERSION = 4                        # include/gnnmp.h gnnmp_abi_version(): what this binding was written against
 
 c_float_p = ctypes.POINTER(ctypes.c_float)
 c_int32_p = ctypes.POINTER(ctypes.c_int32)
@@ -113,6 +113,8 @@ def lib():
     L.gnnmp_explorer_train_workspace_bytes.argtypes = [vp, ctypes.POINTER(Batch), ctypes.c_int, ctypes.POINTER(sz)]
     L.gnnmp_explorer_train_forward.argtypes = [vp, ctypes.POINTER(Batch), ctypes.c_int, ctypes.c_int, vp, vp, sz, vp]
     L.gnnmp_explorer_train_backward.argtypes = [vp, ctypes.POINTER(Batch), ctypes.c_int, vp, vp, vp, sz, vp]
+    L.gnnmp_explorer_forward_ex.argtypes = [vp, ctypes.POINTER(Batch), ctypes.c_int, ctypes.c_int, vp, vp, vp, sz, vp, vp]
+    L.gnnmp_explorer_status_words.argtypes = [ctypes.POINTER(Batch), ctypes.POINTER(sz)]
     L.gnnmp_explorer_status.argtypes = [vp, ctypes.POINTER(Batch), vp, sz, vp, c_int32_p]
     L.gnnmp_status_copy.argtypes = [vp, vp, ctypes.c_int32, vp]
     L.gnnmp_explorer_status_region.argtypes = [vp, ctypes.POINTER(Batch), ctypes.POINTER(sz), ctypes.POINTER(sz)]
@@ -144,6 +146,7 @@ def lib():
         L.gnnmp_smoother_destroy.argtypes = [vp]
         L.gnnmp_smoother_workspace_bytes.argtypes = [vp, ctypes.POINTER(SmoothBatch), ctypes.POINTER(sz)]
         L.gnnmp_smoother_forward.argtypes = [vp, ctypes.POINTER(SmoothBatch), ctypes.c_int, vp, vp, sz, vp]
+        L.gnnmp_smoother_forward_ex.argtypes = [vp, ctypes.POINTER(SmoothBatch), ctypes.c_int, vp, vp, sz, vp, vp]
     _lib = L
     return L
 
@@ -157,56 +160,83 @@ def check(status, what):
 
 
 class StatusWatch:
-    """Non-blocking reader of the device-side status of forwards (gnnmp.h: gnnmp_*_status_region / _decode).
+    """Non-blocking reader of the device-side status of forwards (gnnmp.h: gnnmp_*_forward_ex / _status_decode).
 
     forward() never synchronises, so what only the device can see -- a graph with more obstacles than the batch promised, a
-    smoothing problem beyond its caps, a node id outside its graph -- lands in a few status words inside the workspace.
-    ``push`` enqueues a copy of those words into pinned host memory behind the forward (same stream) plus an event; ``poll``
-    looks at the copies whose event has completed and raises RuntimeError for the first bad one -- called at the start of the
-    module's NEXT forward (no wait) and by ``check_status()`` (waits).  At most ``depth`` copies stay pending: beyond that the
-    oldest is waited for, so an error can lag by at most ``depth`` forwards."""
+    smoothing problem beyond its caps, a node id outside its graph -- is written by the forward's own kernels into a slot of
+    PINNED host memory handed to gnnmp_*_forward_ex (no copy, no extra launch).  ``acquire`` picks the next slot of a ring that is
+    allocated once (a slot's buffer only ever grows), ``commit`` records the slot's event behind the forward, ``poll`` decodes the
+    slots whose event has completed and raises RuntimeError naming every bad forward among them -- called at the start of the
+    module's NEXT forward (no wait) and by ``check_status()`` (waits).  When all ``depth`` slots are pending the oldest is waited
+    for, so an error can lag by at most ``depth`` forwards.  Slots that have not completed stay pending across an error (their
+    kernels may still be writing them); nothing is ever handed back to an allocator while a forward could write it."""
+
+    class _Slot:
+        __slots__ = ('words', 'event', 'n', 'what')
+
+        def __init__(self):
+            self.words, self.event, self.n, self.what = None, None, 0, ''
 
     def __init__(self, kind, depth=32):
         import threading
-        self.kind, self.depth, self.pending = kind, depth, []
+        self.kind, self.depth = kind, depth
+        self.free = [StatusWatch._Slot() for _ in range(depth)]
+        self.order = []                                 # pending slots, oldest first
         self.lock = threading.Lock()                    # planner workers run forwards of one module from several host threads
 
-    def push(self, ws, offset, nbytes, n, what):
+    def acquire(self, n_words, n, what):
+        """A slot of >= n_words pinned ints for the forward about to be enqueued, or None while the stream is being captured."""
         import torch
         if torch.cuda.is_current_stream_capturing():    # a caller capturing forwards into a graph: no host-side bookkeeping inside
-            return
-        words = torch.empty(nbytes // 4, dtype=torch.int32, pin_memory=True)
-        # a one-block KERNEL writes the pinned buffer (device-visible host memory), not a memcpy: see gnnmp_status_copy
-        check(lib().gnnmp_status_copy(ws.data_ptr() + offset, words.data_ptr(), nbytes // 4, torch.cuda.current_stream().cuda_stream),
-              'gnnmp_status_copy')
-        ev = torch.cuda.Event()
-        ev.record()                                     # current stream = the one the forward and the copy were enqueued on
-        with self.lock:
-            self.pending.append((ev, words, n, what))
-            over = len(self.pending) > self.depth
-        if over:
-            self.poll(wait_oldest=True)
-
-    def poll(self, wait=False, wait_oldest=False):
+            return None
         while True:
             with self.lock:
-                if not self.pending:
-                    return
-                ev, words, n, what = self.pending[0]
-                if not (wait or wait_oldest) and not ev.query():
-                    return
-                self.pending.pop(0)
+                slot = self.free.pop() if self.free else None
+            if slot is not None:
+                break
+            self.poll(wait_oldest=True)
+        if slot.words is None or slot.words.numel() < n_words:
+            slot.words = torch.empty(max(int(n_words), 64), dtype=torch.int32, pin_memory=True)       # only ever grows
+        if slot.event is None:
+            slot.event = torch.cuda.Event()
+        slot.n, slot.what = n, what
+        return slot
+
+    def commit(self, slot):
+        slot.event.record()                             # current stream = the one the forward was enqueued on
+        with self.lock:
+            self.order.append(slot)
+
+    def release(self, slot):                            # the forward call itself failed: nothing was enqueued
+        with self.lock:
+            self.free.append(slot)
+
+    def poll(self, wait=False, wait_oldest=False):
+        import torch
+        if torch.cuda.is_current_stream_capturing():    # hipEventQuery is not capture-safe
+            return
+        bad = []
+        while True:
+            with self.lock:
+                if not self.order:
+                    break
+                slot = self.order[0]
+                if not (wait or wait_oldest) and not slot.event.query():
+                    break
+                self.order.pop(0)
             if wait or wait_oldest:
-                ev.synchronize()
+                slot.event.synchronize()
             wait_oldest = False
             first = ctypes.c_int32(-1)
             fn = lib().gnnmp_explorer_status_decode if self.kind == 'explorer' else lib().gnnmp_smoother_status_decode
-            rc = fn(words.data_ptr(), n, ctypes.byref(first))
+            rc = fn(slot.words.data_ptr(), slot.n, ctypes.byref(first))
             if rc != 0:
-                with self.lock:
-                    self.pending.clear()
-                raise RuntimeError('%s: %s (first offending %s: %d) -- the results of that forward are wrong' % (
-                    what, lib().gnnmp_status_string(rc).decode(), 'graph' if self.kind == 'explorer' else 'problem', first.value))
+                bad.append('%s (%d %ss): %s (first offending %s: %d)' % (slot.what[0], slot.what[1], 'graph' if self.kind == 'explorer' else 'problem', lib().gnnmp_status_string(rc).decode(),
+                                                               'graph' if self.kind == 'explorer' else 'problem', first.value))
+            with self.lock:
+                self.free.append(slot)
+        if bad:
+            raise RuntimeError('; '.join(bad) + ' -- the results of %s wrong' % ('that forward are' if len(bad) == 1 else 'those forwards are'))
 
 
 def manifest(kind, dims):

@@ -21,9 +21,6 @@ class GraphBatch:
         self.n_graphs = 1 if node_ptr is None else int(node_ptr.numel() - 1)
         # sum_g N_g^2 when the host knows it (sizes the dense output without reading node_ptr back from the device)
         self.dense_floats = int(v.shape[0]) ** 2 if (node_ptr is None and dense_floats is None) else dense_floats
-        # True when max_obstacles was computed from the same host-side counts as obs_ptr (from_graphs, the one-graph forms): the
-        # promise cannot be broken, so a single-graph forward need not copy its device-side status back (explorer.status_checks)
-        self.caps_from_host = node_ptr is None
 
     @property
     def total_nodes(self):
@@ -58,7 +55,6 @@ class GraphBatch:
             prefix([x.shape[0] for x in vs]).to(device), prefix([x.shape[1] for x in eis]).to(device),
             prefix([x.shape[0] for x in obs]).to(device), max([x.shape[0] for x in obs] + [0]),
             dense_floats=sum(int(x.shape[0]) ** 2 for x in vs))
-        b.caps_from_host = True
         return b
 
     def split_edges(self, scores):

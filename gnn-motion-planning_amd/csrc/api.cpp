@@ -248,7 +248,7 @@ extern "C" const char* gnnmp_status_string(int s) {
 }
 extern "C" const char* gnnmp_last_hip_error(void) { return g_hip_error.c_str(); }
 // 2: stage list of gnnmp_explorer_profile_read (fused message passing); 3: device-side status words (gnnmp_*_status*)
-extern "C" int gnnmp_abi_version(void) { return 3; }
+extern "C" int gnnmp_abi_version(void) { return 4; }
 
 // ---------------------------------------------------------------------------------------------
 // explorer handle
@@ -748,11 +748,22 @@ extern "C" int gnnmp_explorer_workspace_bytes(const gnnmp_explorer* h, const gnn
 
 namespace {
 int forward_impl(const gnnmp_explorer* h, const gnnmp_batch* b, int loop, int use_obstacles, float* edge_scores, float* dense,
-                 void* ws, size_t ws_bytes, void* hip_stream, float* om_nodes, float* om_edges, bool pre_only);
+                 void* ws, size_t ws_bytes, void* hip_stream, float* om_nodes, float* om_edges, bool pre_only, int32_t* status_out = nullptr);
 }
 extern "C" int gnnmp_explorer_forward(const gnnmp_explorer* h, const gnnmp_batch* b, int loop, int use_obstacles,
                                       float* edge_scores, float* dense, void* ws, size_t ws_bytes, void* hip_stream) {
     return forward_impl(h, b, loop, use_obstacles, edge_scores, dense, ws, ws_bytes, hip_stream, nullptr, nullptr, false);
+}
+extern "C" int gnnmp_explorer_forward_ex(const gnnmp_explorer* h, const gnnmp_batch* b, int loop, int use_obstacles,
+                                         float* edge_scores, float* dense, void* ws, size_t ws_bytes, void* hip_stream,
+                                         int32_t* status_out) {
+    return forward_impl(h, b, loop, use_obstacles, edge_scores, dense, ws, ws_bytes, hip_stream, nullptr, nullptr, false, status_out);
+}
+extern "C" int gnnmp_explorer_status_words(const gnnmp_batch* shape, size_t* n_words) {
+    if (!shape || !n_words) return GNNMP_ERR_NULL;
+    if (shape->n_graphs < 1) return GNNMP_ERR_ARG;
+    *n_words = (size_t)kGstatStride * (size_t)shape->n_graphs;
+    return GNNMP_OK;
 }
 
 namespace gnnmp { hipError_t launch_status_copy(const int* src, int* dst_host_mapped, int n, hipStream_t st); }
@@ -803,7 +814,7 @@ namespace {
 // om_nodes / om_edges: optional [Npad, d] / [Epad, d] outputs of the attention stacks (training path); pre_only: stop
 // after the pre kernels (CSR, goal node, NF / EF are what the training path needs)
 int forward_impl(const gnnmp_explorer* h, const gnnmp_batch* b, int loop, int use_obstacles, float* edge_scores, float* dense,
-                 void* ws, size_t ws_bytes, void* hip_stream, float* om_nodes, float* om_edges, bool pre_only) {
+                 void* ws, size_t ws_bytes, void* hip_stream, float* om_nodes, float* om_edges, bool pre_only, int32_t* status_out) {
     if (!h || !b || !ws) return GNNMP_ERR_NULL;
     if (!b->v || !b->goal) return GNNMP_ERR_NULL;
     // ONE graph may be given by its totals alone (all three prefix pointers NULL): the reference's call (model.py:115)
@@ -842,7 +853,9 @@ int forward_impl(const gnnmp_explorer* h, const gnnmp_batch* b, int loop, int us
     q.blk_span = at<int2>(ws, c.blk_span);
     q.obs_ptr = implicit ? nullptr : b->obs_ptr;
     q.obs_cap = use_obstacles ? 32 * c.ot_max : 0x7fffffff;
-    q.gstat = at<int>(ws, c.gstat);
+    // the status words of this forward: the workspace region (read back by gnnmp_explorer_status), or -- gnnmp_explorer_forward_ex --
+    // memory of the caller's that the device can write (pinned host memory: no copy behind the forward, the words simply arrive)
+    q.gstat = status_out ? reinterpret_cast<int*>(status_out) : at<int>(ws, c.gstat);
     HIP_TRY(launch_prep(q, c.Npad, c.Epad, at<int>(ws, c.prep_hist), st));
     // zero-fill of policy_output (model.py:148); sum_g N_g^2 is read from dense_ptr[G] on the device
     if (dense) HIP_TRY(launch_zero_dense(dense, q.dense_ptr + c.G, st));
@@ -1205,8 +1218,14 @@ extern "C" int gnnmp_smoother_workspace_bytes(const gnnmp_smoother* h, const gnn
     return GNNMP_OK;
 }
 
+extern "C" int gnnmp_smoother_forward_ex(const gnnmp_smoother* h, const gnnmp_smooth_batch* b, int loop, float* out_path,
+                                         void* ws, size_t ws_bytes, void* hip_stream, int32_t* status_out);
 extern "C" int gnnmp_smoother_forward(const gnnmp_smoother* h, const gnnmp_smooth_batch* b, int loop, float* out_path,
                                       void* ws, size_t ws_bytes, void* hip_stream) {
+    return gnnmp_smoother_forward_ex(h, b, loop, out_path, ws, ws_bytes, hip_stream, nullptr);
+}
+extern "C" int gnnmp_smoother_forward_ex(const gnnmp_smoother* h, const gnnmp_smooth_batch* b, int loop, float* out_path,
+                                         void* ws, size_t ws_bytes, void* hip_stream, int32_t* status_out) {
     if (!h || !b || !ws || !out_path) return GNNMP_ERR_NULL;
     if (!b->path) return GNNMP_ERR_NULL;
     // ONE problem may be given by its totals alone (the four prefix pointers NULL): the reference's call has no prefix
@@ -1233,7 +1252,7 @@ extern "C" int gnnmp_smoother_forward(const gnnmp_smoother* h, const gnnmp_smoot
     p.cur = at<float>(ws, c.cur); p.cur_next = p.cur;
     p.knn = at<int>(ws, c.knn);
     p.e_src = at<int>(ws, c.e_src); p.e_dst = at<int>(ws, c.e_dst); p.e_count = at<int>(ws, c.e_count);
-    p.stat = at<int>(ws, c.stat);
+    p.stat = status_out ? reinterpret_cast<int*>(status_out) : at<int>(ws, c.stat);      // one word per problem (gnnmp_smoother_forward_ex)
     p.seg_beg = at<int>(ws, c.seg_beg); p.seg_cnt = at<int>(ws, c.seg_cnt);
     p.etile_prob = at<int>(ws, c.etile); p.ptile_prob = at<int>(ws, c.ptile);
     p.msg = at<float>(ws, c.msg);

@@ -54,6 +54,7 @@ _VERSION = operator.attrgetter('_version')
 # GNNMP_CHECK_EDGE_INDEX=1: validate edge_index against the node counts before every forward (one device read-back per
 # call).  Like the reference's tensor indexing on the GPU, the kernels themselves do not check node ids (gnnmp.h).
 _CHECK_IDS = os.environ.get('GNNMP_CHECK_EDGE_INDEX', '0') not in ('', '0')
+_GSTAT_STRIDE = 17                     # status words per graph (gnnmp.h: gnnmp_explorer_status_words = 17 x n_graphs)
 
 
 def _check_edge_ids(batch):
@@ -167,11 +168,11 @@ class EncoderProcessDecoder(nn.Module):
         # precision of the MFMA operands: 'fp32' (exact, the reference's precision) or 'bf16' (BASELINE configs[2],
         # [4]: bf16 operands, fp32 accumulate); not a constructor argument so the reference signature is kept
         self.mlp_dtype = 'fp32'
-        # device-side status of a forward (obstacle count beyond the batch's promise, node ids outside their graph): copied to the
-        # host behind the forward and looked at on a later call / in check_status().  True = every forward over more than one graph and every
-        # hand-built one-graph batch; the reference's own call shape -- ONE graph whose obstacle count is the tensor's row count
-        # (forward(), edge_scores(), _single()) -- is skipped: its promise is exact by construction, and a stream-ordered device-to-host copy
-        # behind every call costs 16 us of a 115 us forward (measured).  'always' = those as well; False = none
+        # device-side status of a forward (obstacle count beyond the batch's promise, node ids outside their graph): the forward's own
+        # kernels write it into a slot of pinned host memory (gnnmp_explorer_forward_ex; no copy, no extra launch), looked at on a later
+        # call / in check_status().  True (default) = every forward, the reference's own one-graph call included (an out-of-range
+        # edge_index id there is clamped to node 0 by the kernels and would otherwise yield finite, wrong scores where the reference's
+        # indexing raises); False = none (the words then go to the workspace, where the blocking gnnmp_explorer_status finds them)
         self.status_checks = True
         self._handle = None
         self._handle_key = None
@@ -342,14 +343,17 @@ class EncoderProcessDecoder(nn.Module):
             dn = torch.empty(total, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             st = torch.cuda.current_stream().cuda_stream
-            _lib.check(_lib.lib().gnnmp_explorer_forward(
+            slot = watch.acquire(_GSTAT_STRIDE * batch.n_graphs, batch.n_graphs, ('EncoderProcessDecoder forward', batch.n_graphs)) \
+                if self.status_checks else None
+            rc = _lib.lib().gnnmp_explorer_forward_ex(
                 h, ctypes.byref(cb), int(loop), 1 if self.use_obstacles else 0, scores.data_ptr(),
-                dn.data_ptr() if dense else None, ws.data_ptr(), ws.numel(), st), 'gnnmp_explorer_forward')
-            if self.status_checks == 'always' or (self.status_checks and not (batch.n_graphs == 1 and getattr(batch, 'caps_from_host', False))):
-                off, nb = ctypes.c_size_t(), ctypes.c_size_t()
-                _lib.check(_lib.lib().gnnmp_explorer_status_region(h, ctypes.byref(cb), ctypes.byref(off), ctypes.byref(nb)),
-                           'gnnmp_explorer_status_region')
-                watch.push(ws, off.value, nb.value, batch.n_graphs, 'EncoderProcessDecoder forward (%d graphs)' % batch.n_graphs)
+                dn.data_ptr() if dense else None, ws.data_ptr(), ws.numel(), st, None if slot is None else slot.words.data_ptr())
+            if slot is not None:
+                if rc == 0:
+                    watch.commit(slot)
+                else:
+                    watch.release(slot)
+            _lib.check(rc, 'gnnmp_explorer_forward')
         return (scores, dn) if dense else scores
 
     def _status_watch(self):
@@ -358,25 +362,30 @@ class EncoderProcessDecoder(nn.Module):
             w = self.__dict__['_watch'] = _lib.StatusWatch('explorer')
         return w
 
-    def check_status(self, batch=None):
-        """With ``batch``: the blocking C-ABI call (gnnmp_explorer_status) on the workspace of the LAST forward, which must have
-        been over ``batch``.  Without: wait for the device-side status of every forward issued so far on this module and raise RuntimeError if one of them
-        saw a graph with more obstacles than its batch's ``max_obstacles`` (the reference attends over ALL obstacles,
-        model.py:125-130: such a forward's scores are wrong) or a node id outside its graph (the reference's indexing would
-        raise).  ``forward`` itself never waits: it looks at the status copies that have already arrived when the NEXT forward
-        starts.  ``status_checks = False`` switches the status copies off (callers that validate their batches themselves)."""
-        if batch is not None:
+    def check_status(self, batch=None, ws=None):
+        """Wait for the device-side status of every forward issued so far on this module and raise RuntimeError if one of them saw
+        a graph with more obstacles than its batch's ``max_obstacles`` (the reference attends over ALL obstacles, model.py:125-130:
+        such a forward's scores are wrong) or a node id outside its graph (the reference's indexing would raise).  ``forward``
+        itself never waits: it looks at the status slots that have already arrived when the NEXT forward starts.
+        ``status_checks = False`` switches the slots off (callers that validate their batches themselves); the status words of a
+        forward then stay in its workspace, and ``check_status(batch)`` reads them through the blocking C-ABI call
+        (gnnmp_explorer_status) from ``ws`` -- default: this module's workspace for (``batch``'s device, the CURRENT stream), i.e.
+        call it on the stream the forward over ``batch`` ran on."""
+        self._status_watch().poll(wait=True)
+        if batch is not None and not self.status_checks:
             dev = batch.v.device
+            if ws is None:
+                ws = self.__dict__.get('_ws_streams', {}).get((str(torch.device(dev)), torch.cuda.current_stream(dev).cuda_stream))
+            if ws is None:
+                raise RuntimeError('check_status(batch): no forward of this module has run on the current stream of %s' % dev)
             cb = self._cbatch(batch)
             first = ctypes.c_int32(-1)
             with torch.cuda.device(dev):
-                rc = _lib.lib().gnnmp_explorer_status(self._native(dev), ctypes.byref(cb), self._ws.data_ptr(), self._ws.numel(),
+                rc = _lib.lib().gnnmp_explorer_status(self._native(dev), ctypes.byref(cb), ws.data_ptr(), ws.numel(),
                                                      torch.cuda.current_stream().cuda_stream, ctypes.byref(first))
             if rc != 0:
                 raise RuntimeError('EncoderProcessDecoder forward: %s (first offending graph: %d)'
                                    % (_lib.lib().gnnmp_status_string(rc).decode(), first.value))
-            return
-        self._status_watch().poll(wait=True)
 
     def capture(self, batch, loop):
         """Capture one forward over ``batch`` into a HIP graph (the C-ABI forward allocates nothing and never
@@ -466,11 +475,9 @@ class EncoderProcessDecoder(nn.Module):
             return GraphBatch(v.float().contiguous(), goal.reshape(1, -1).float().contiguous(), obs.contiguous(),
                               edge_index.long().contiguous(), None, None, None, obs.shape[0])
         i32 = lambda *a: torch.tensor(a, dtype=torch.int32, device=dev)      # noqa: E731
-        b = GraphBatch(v.float().contiguous(), goal.reshape(1, -1).float().contiguous(), obs.contiguous(),
-                       edge_index.long().contiguous(), i32(0, v.shape[0]), i32(0, edge_index.shape[1]),
-                       i32(0, obs.shape[0]), obs.shape[0], dense_floats=int(v.shape[0]) ** 2)
-        b.caps_from_host = True                          # the obstacle count is the tensor's own row count
-        return b
+        return GraphBatch(v.float().contiguous(), goal.reshape(1, -1).float().contiguous(), obs.contiguous(),
+                          edge_index.long().contiguous(), i32(0, v.shape[0]), i32(0, edge_index.shape[1]),
+                          i32(0, obs.shape[0]), obs.shape[0], dense_floats=int(v.shape[0]) ** 2)
 
     @torch.no_grad()
     def edge_scores(self, goal, loop, v, obstacles, edge_index, **_ignored):

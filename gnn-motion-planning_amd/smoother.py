@@ -196,8 +196,9 @@ class ModelSmoother(nn.Module):
         self.decoder = Lin(d * 2, d)
         self.mlp_dtype = 'fp32'            # or 'bf16': MFMA operands only (see EncoderProcessDecoder.mlp_dtype)
         # device-side status of a forward (a problem beyond the batch's max_path / max_samples / max_edges promises gets no edges):
-        # 'auto' copies it to the host only for batches whose caps were NOT derived from host-side counts (SmoothBatch's own
-        # constructors derive them: nothing to check), 'always' for every forward, 'never' for none
+        # 'auto' has the kernels write it to a pinned host slot (gnnmp_smoother_forward_ex) only for batches whose caps were NOT derived
+        # from host-side counts (SmoothBatch's own constructors derive them: nothing to check), 'always' for every forward, 'never' for
+        # none (the words stay in the workspace: check_status(sb) reads them with the blocking gnnmp_smoother_status)
         self.status_checks = 'auto'
         self._handle = None
         self._handle_key = None
@@ -300,35 +301,43 @@ class ModelSmoother(nn.Module):
         out = torch.empty_like(sb.path)
         with torch.cuda.device(dev):
             st = torch.cuda.current_stream().cuda_stream
-            _lib.check(_lib.lib().gnnmp_smoother_forward(h, ctypes.byref(cb), int(loop), out.data_ptr(),
-                                                         ws.data_ptr(), ws.numel(), st),
-                       'gnnmp_smoother_forward')
-            if self.status_checks == 'always' or (self.status_checks == 'auto' and not getattr(sb, 'caps_from_host', False)):
-                off, nb = ctypes.c_size_t(), ctypes.c_size_t()
-                _lib.check(_lib.lib().gnnmp_smoother_status_region(h, ctypes.byref(cb), ctypes.byref(off), ctypes.byref(nb)),
-                           'gnnmp_smoother_status_region')
-                watch.push(ws, off.value, nb.value, sb.n, 'ModelSmoother forward (%d problems)' % sb.n)
+            slot = watch.acquire(sb.n, sb.n, ('ModelSmoother forward', sb.n)) if self._wants_status(sb) else None
+            rc = _lib.lib().gnnmp_smoother_forward_ex(h, ctypes.byref(cb), int(loop), out.data_ptr(), ws.data_ptr(), ws.numel(), st,
+                                                      None if slot is None else slot.words.data_ptr())
+            if slot is not None:
+                if rc == 0:
+                    watch.commit(slot)
+                else:
+                    watch.release(slot)
+            _lib.check(rc, 'gnnmp_smoother_forward')
         return out
 
-    def check_status(self, sb=None):
-        """With ``sb``: the blocking C-ABI call (gnnmp_smoother_status) on the workspace of the LAST forward, which must have been
-        over ``sb``.  Without: wait for the status copies of the forwards issued so far (see ``status_checks``).  Raises
-        RuntimeError when a problem exceeded the batch's max_path / max_samples / max_edges: it was smoothed WITHOUT its kNN /
-        chain edges, i.e. its waypoints are wrong."""
-        if sb is not None:
+    def _wants_status(self, sb):
+        return self.status_checks in ('always', True) or (self.status_checks == 'auto' and not getattr(sb, 'caps_from_host', False))
+
+    def check_status(self, sb=None, ws=None):
+        """Wait for the status slots of the forwards issued so far (see ``status_checks``).  Raises RuntimeError when a problem
+        exceeded its batch's max_path / max_samples / max_edges: it was smoothed WITHOUT its kNN / chain edges, i.e. its waypoints
+        are wrong.  With ``status_checks = False`` the words stay in the workspace and ``check_status(sb)`` reads them through the
+        blocking C-ABI call (gnnmp_smoother_status) from ``ws`` (default: this module's workspace for the CURRENT stream); the same
+        for a batch whose caps came from host-side counts under 'auto' (no slot was used for it)."""
+        w = self.__dict__.get('_watch')
+        if w is not None:
+            w.poll(wait=True)
+        if sb is not None and not self._wants_status(sb):
             dev = sb.path.device
+            if ws is None:
+                ws = self.__dict__.get('_ws_streams', {}).get((str(dev), torch.cuda.current_stream(dev).cuda_stream))
+            if ws is None:
+                raise RuntimeError('check_status(sb): no forward of this module has run on the current stream of %s' % dev)
             cb = _cbatch(sb)
             first = ctypes.c_int32(-1)
             with torch.cuda.device(dev):
-                rc = _lib.lib().gnnmp_smoother_status(self._native(dev), ctypes.byref(cb), self._ws.data_ptr(), self._ws.numel(),
+                rc = _lib.lib().gnnmp_smoother_status(self._native(dev), ctypes.byref(cb), ws.data_ptr(), ws.numel(),
                                                      torch.cuda.current_stream().cuda_stream, ctypes.byref(first))
             if rc != 0:
                 raise RuntimeError('ModelSmoother forward: %s (first offending problem: %d)'
                                    % (_lib.lib().gnnmp_status_string(rc).decode(), first.value))
-            return
-        w = self.__dict__.get('_watch')
-        if w is not None:
-            w.poll(wait=True)
 
     def forward_train(self, path, free, collided, obstacles=None, edge_index=None, loop=10, **kwargs):
         """The reference's TRAINING call (train_smoother.py:52 under ``model.train()``): new path [P, C] with a

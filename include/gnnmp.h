@@ -140,6 +140,17 @@ int gnnmp_explorer_forward(const gnnmp_explorer* h, const gnnmp_batch* batch, in
                            float* edge_scores, float* dense_or_null,
                            void* workspace, size_t workspace_bytes, void* hip_stream);
 
+/* gnnmp_explorer_forward with the forward's status words (see gnnmp_explorer_status below) written to `status_out` instead of
+ * the workspace region: status_out points at gnnmp_explorer_status_words(batch) ints the DEVICE can write -- normally pinned
+ * (hipHostMalloc'ed) host memory: the few threads that own a status word store it straight across the bus, so there is no copy
+ * behind the forward and nothing to synchronise with except an event the caller records after this call; decode with
+ * gnnmp_explorer_status_decode once that event has completed.  status_out == NULL is gnnmp_explorer_forward.  (What the Python
+ * wrapper does on every forward, the reference's one-graph call included: a ring of pinned slots, looked at on a later call.) */
+int gnnmp_explorer_forward_ex(const gnnmp_explorer* h, const gnnmp_batch* batch, int loop, int use_obstacles,
+                              float* edge_scores, float* dense_or_null,
+                              void* workspace, size_t workspace_bytes, void* hip_stream, int32_t* status_out_or_null);
+int gnnmp_explorer_status_words(const gnnmp_batch* shape, size_t* n_words);
+
 /* Device-side status of the LAST forward that ran on `workspace` (same batch shape): GNNMP_OK, or GNNMP_ERR_CAPS (a graph with
  * more obstacles than batch->max_obstacles: its scores are NOT the reference's), or GNNMP_ERR_INDEX (a node id outside
  * [0, N_g)); *first_graph_or_null = the first offending graph (-1 if none).  forward() itself never synchronises, so the
@@ -260,6 +271,11 @@ int gnnmp_smoother_workspace_bytes(const gnnmp_smoother* h, const gnnmp_smooth_b
  * edges (caller edges + 10 kNN edges per waypoint). */
 int gnnmp_smoother_forward(const gnnmp_smoother* h, const gnnmp_smooth_batch* batch, int loop,
                            float* out_path, void* workspace, size_t workspace_bytes, void* hip_stream);
+
+/* As gnnmp_explorer_forward_ex: the status words of this forward (one int per problem) go to `status_out` (device-writable,
+ * normally pinned host memory) instead of the workspace; NULL = gnnmp_smoother_forward. */
+int gnnmp_smoother_forward_ex(const gnnmp_smoother* h, const gnnmp_smooth_batch* batch, int loop,
+                              float* out_path, void* workspace, size_t workspace_bytes, void* hip_stream, int32_t* status_out_or_null);
 
 /* Device-side status of the LAST forward on `workspace`, as for the explorer: GNNMP_OK or GNNMP_ERR_CAPS (a problem exceeded
  * max_path / max_samples / max_edges and was smoothed WITHOUT its edges); one int per problem.  gnnmp_smoother_status

@@ -36,7 +36,6 @@ def test_more_obstacles_than_promised_is_an_error():
     assert max(n_obs) > 32
     s_good = m.forward_batch(good, 2)
     m.check_status()                                              # nothing to report
-    m.check_status(good)                                          # the blocking C-ABI form agrees
     # the same batch with a promise of 32 obstacles per graph: the slabs hold one 32-obstacle tile, the attention sees the first
     # 32 only -- different scores, and the status says so
     short = gnnmp.GraphBatch(good.v, good.goal, good.obstacles, good.edge_index, good.node_ptr, good.edge_ptr, good.obs_ptr, 32,
@@ -45,7 +44,10 @@ def test_more_obstacles_than_promised_is_an_error():
     assert not torch.equal(s_good, s_short)
     with pytest.raises(RuntimeError, match='max_obstacles'):
         m.check_status()
-    # raw C ABI, blocking: GNNMP_ERR_CAPS (-7) and the first offending graph
+    # raw C ABI, blocking (a forward WITHOUT a status slot leaves the words in its workspace): GNNMP_ERR_CAPS (-7) and the first
+    # offending graph
+    m.status_checks = False
+    assert torch.equal(m.forward_batch(short, 2), s_short)
     cb = m._cbatch(short)
     first = ctypes.c_int32(-5)
     rc = _lib.lib().gnnmp_explorer_status(m._native(torch.device(DEV)), ctypes.byref(cb), m._ws.data_ptr(), m._ws.numel(), None,
@@ -53,6 +55,9 @@ def test_more_obstacles_than_promised_is_an_error():
     assert rc == -7 and first.value == min(i for i, n in enumerate(n_obs) if n > 32)
     with pytest.raises(RuntimeError, match='max_obstacles'):
         m.check_status(short)
+    m.forward_batch(good, 2)
+    m.check_status(good)                                          # the blocking form on a clean forward
+    m.status_checks = True
     # non-blocking path: the NEXT forward on the module raises once the earlier forward's status copy has arrived
     m.forward_batch(short, 2)
     torch.cuda.synchronize()
@@ -61,7 +66,6 @@ def test_more_obstacles_than_promised_is_an_error():
     # and a clean forward afterwards is clean (every slot is rewritten by every forward: nothing sticks)
     assert torch.equal(m.forward_batch(good, 2), s_good)
     m.check_status()
-    m.check_status(good)
     # use_obstacles = False ignores the obstacles altogether (model.py:125): no promise to break
     m.use_obstacles = False
     m.forward_batch(short, 2)
@@ -84,6 +88,9 @@ def test_node_id_outside_its_graph_is_an_error(nodes, k):
         assert bool(torch.isfinite(s).all())
         with pytest.raises(RuntimeError, match='node ids'):
             m.check_status()
+        m.status_checks = False                                   # raw blocking ABI: words in the workspace
+        assert torch.equal(m.forward_batch(bad, 2), s)
+        m.status_checks = True
         first = ctypes.c_int32(-5)
         cb = m._cbatch(bad)
         rc = _lib.lib().gnnmp_explorer_status(m._native(torch.device(DEV)), ctypes.byref(cb), m._ws.data_ptr(), m._ws.numel(), None,
@@ -121,7 +128,7 @@ def test_smoothing_problem_beyond_its_caps_is_an_error():
     sb = SmoothBatch(paths, frees, colls, eis, DEV)
     good = ms.forward_batch(sb, 1)
     ms.check_status()
-    ms.check_status(sb)
+    ms.check_status(sb)                                           # caps from host-side counts: no slot was used, the blocking form reads the workspace
     for field, value in (('max_path', 12), ('max_samples', 100), ('max_edges', int(eis[0].shape[1]))):       # each fits problem 0 only
         lie = SmoothBatch(paths, frees, colls, eis, DEV)
         setattr(lie, field, value)
@@ -131,6 +138,9 @@ def test_smoothing_problem_beyond_its_caps_is_an_error():
         assert not torch.equal(out[12:], good[12:])               # the one beyond them lost its edges
         with pytest.raises(RuntimeError, match='max_path / max_samples / max_edges'):
             ms.check_status()
+        ms.status_checks = 'never'                                # raw blocking ABI: words in the workspace
+        assert torch.equal(ms.forward_batch(lie, 1), out)
+        ms.status_checks = 'auto'
         first = ctypes.c_int32(-5)
         from gnnmp.smoother import _cbatch
         cb = _cbatch(lie)
@@ -139,3 +149,49 @@ def test_smoothing_problem_beyond_its_caps_is_an_error():
         assert rc == -7 and first.value == 1
     assert torch.equal(ms.forward_batch(sb, 1), good)
     ms.check_status(sb)
+
+
+def test_single_graph_call_reports_bad_ids():
+    """The reference's own call shape (ONE graph, eval_gnn.py:194): an out-of-range edge_index id is clamped by the kernels (finite
+    scores) and must still be reported -- the reference's indexing raises there."""
+    m = _model()
+    g = synth_graph('maze2', 64, 4, seed=1)
+    kw = dict(goal=g['goal'].to(DEV), v=g['v'].to(DEV), obstacles=g['obstacles'].to(DEV), loop=2)
+    ei = g['edge_index'].to(DEV)
+    P = m(edge_index=ei, **kw)
+    m.check_status()
+    bad = ei.clone()
+    bad[0, 3] = 64
+    Pb = m(edge_index=bad, **kw)
+    assert bool(torch.isfinite(Pb).all())
+    with pytest.raises(RuntimeError, match='node ids'):
+        m.check_status()
+    sb = m.edge_scores(edge_index=bad, **kw)
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match='node ids'):
+        m(edge_index=ei, **kw)                                    # the next forward sees the arrived slot
+    assert torch.equal(m(edge_index=ei, **kw), P)
+    m.check_status()
+
+
+def test_status_ring_survives_many_forwards_and_keeps_unfinished_slots():
+    """More forwards than ring slots without ever asking: the oldest slot is waited for and recycled; an error among them
+    surfaces, later clean forwards stay clean."""
+    m = _model()
+    graphs = [synth_graph('maze2', 64, 4, seed=1), synth_graph('maze2', 40, 3, seed=2)]
+    good = gnnmp.GraphBatch.from_graphs(graphs, 2, DEV)
+    short = gnnmp.GraphBatch(good.v, good.goal, good.obstacles, good.edge_index, good.node_ptr, good.edge_ptr, good.obs_ptr, 32,
+                             dense_floats=good.dense_floats)
+    ref = m.forward_batch(good, 2)
+    m.check_status()
+    for _ in range(100):
+        assert torch.equal(m.forward_batch(good, 2), ref)
+    m.check_status()
+    watch = m._status_watch()
+    assert len(watch.free) == watch.depth and not watch.order
+    m.forward_batch(short, 2)
+    with pytest.raises(RuntimeError, match='max_obstacles'):
+        for _ in range(100):
+            m.forward_batch(good, 2)
+    m.check_status()                                              # the clean forwards before the raise left nothing behind
+    assert len(watch.free) == watch.depth
