@@ -540,15 +540,19 @@ __device__ __forceinline__ void store_row_p(float* array_f32_units, size_t row, 
     if constexpr (P != 1) {
         store_row<NT>(array_f32_units + row * (NT * 32), x, h);
     } else {
+        // bf16 rows are stored HALF-MAJOR inside every 32-feature tile: element t * 32 + h * 16 + r holds register r of lane half h
+        // (feature t * 32 + (r / 4) * 8 + h * 4 + r % 4), so what one lane reads or writes of a tile is 32 contiguous bytes -- two
+        // 16-byte accesses, in LDS the conflict-free pattern of the fp32 rows (explorer_kernels.hip read_stage_tile).  The order is
+        // private to the kernels: nothing outside reads a bf16 row.
         __bf16* base = reinterpret_cast<__bf16*>(array_f32_units) + row * (NT * 32);
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                f32x4 a;
+            for (int qq = 0; qq < 2; ++qq) {
+                f32x8 a;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) a[c] = x[t][q * 4 + c];
-                *reinterpret_cast<bf16x4*>(base + t * 32 + q * 8 + h * 4) = to_bf16x4(a);
+                for (int c = 0; c < 8; ++c) a[c] = x[t][qq * 8 + c];
+                *reinterpret_cast<bf16x8*>(base + t * 32 + h * 16 + qq * 8) = to_bf16x8(a);
             }
     }
 }
@@ -562,10 +566,10 @@ __device__ __forceinline__ void load_row_p(const float* array_f32_units, size_t 
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 a = __builtin_convertvector(*reinterpret_cast<const bf16x4*>(base + t * 32 + q * 8 + h * 4), f32x4);
+            for (int qq = 0; qq < 2; ++qq) {
+                const f32x8 a = __builtin_convertvector(*reinterpret_cast<const bf16x8*>(base + t * 32 + h * 16 + qq * 8), f32x8);
 #pragma unroll
-                for (int c = 0; c < 4; ++c) x[t][q * 4 + c] = a[c];
+                for (int c = 0; c < 8; ++c) x[t][qq * 8 + c] = a[c];
             }
     }
 }

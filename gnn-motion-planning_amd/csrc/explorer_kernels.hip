@@ -1548,12 +1548,14 @@ __device__ __forceinline__ void load_row_tile(const float* array_f32_units, size
             for (int c = 0; c < 4; ++c) x[q * 4 + c] = a[c];
         }
     } else {
-        const __bf16* base = reinterpret_cast<const __bf16*>(array_f32_units) + row * (NT * 32) + t * 32;
+        // bf16 rows are stored HALF-MAJOR inside every 32-feature tile (chain.hpp store_row_p): the 16 features lane half h owns are
+        // 32 contiguous bytes -- two 16-byte loads instead of four 8-byte ones
+        const __bf16* base = reinterpret_cast<const __bf16*>(array_f32_units) + row * (NT * 32) + t * 32 + h * 16;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 a = __builtin_convertvector(*reinterpret_cast<const bf16x4*>(base + q * 8 + h * 4), f32x4);
+        for (int qq = 0; qq < 2; ++qq) {
+            const f32x8 a = __builtin_convertvector(*reinterpret_cast<const bf16x8*>(base + qq * 8), f32x8);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) x[q * 4 + c] = a[c];
+            for (int c = 0; c < 8; ++c) x[qq * 8 + c] = a[c];
         }
     }
 }
@@ -1631,11 +1633,14 @@ __device__ __forceinline__ void read_stage_tile(const float* stage, int sr, int 
             for (int c = 0; c < 4; ++c) x[q * 4 + c] = a[c];
         }
     } else {
+        // half-major bf16 rows: lane half h owns pieces 4 t + 2 h and 4 t + 2 h + 1 of the row -- two ds_read_b128, the access pattern
+        // of the fp32 rows of the same byte pitch (conflict-free under this swizzle), instead of four ds_read_b64 whose 32 lanes of a
+        // half wave all sat on the low 8 bytes of their 16-byte slot (32 of the 64 banks: a two-way conflict on every read)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 a = __builtin_convertvector(*reinterpret_cast<const bf16x4*>(row + (((t * 4 + q) ^ sw) * 16) + h * 8), f32x4);
+        for (int qq = 0; qq < 2; ++qq) {
+            const f32x8 a = __builtin_convertvector(*reinterpret_cast<const bf16x8*>(row + (((t * 4 + h * 2 + qq) ^ sw) * 16)), f32x8);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) x[q * 4 + c] = a[c];
+            for (int c = 0; c < 8; ++c) x[qq * 8 + c] = a[c];
         }
     }
 }
@@ -1643,26 +1648,31 @@ __device__ __forceinline__ void read_stage_tile(const float* stage, int sr, int 
 // the same 32-feature tile kept as read (bf16 rows stay packed: 8 registers instead of 16) -- the message kernel empties the A
 // stage into registers at the top of a chunk so that the NEXT chunk's rows can be requested a whole chunk ahead
 template <int P> struct StageRaw { f32x4 q[4]; };
-template <> struct StageRaw<1> { bf16x4 q[4]; };
+template <> struct StageRaw<1> { bf16x8 lo, hi; };          // registers 0-7 / 8-15 of the tile, packed (the two pieces of the lane's half)
 template <int D, int P>
 __device__ __forceinline__ void read_stage_raw(const float* stage, int sr, int h, int t, StageRaw<P>& r) {
     using G = RowGeom<D, P>;
     const char* row = reinterpret_cast<const char*>(stage) + sr * G::RB;
     const int sw = G::swz(sr);
+    if constexpr (P != 1) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        if constexpr (P != 1) r.q[q] = *reinterpret_cast<const f32x4*>(row + (((t * 8 + q * 2 + h) ^ sw) * 16));
-        else r.q[q] = *reinterpret_cast<const bf16x4*>(row + (((t * 4 + q) ^ sw) * 16) + h * 8);
+        for (int q = 0; q < 4; ++q) r.q[q] = *reinterpret_cast<const f32x4*>(row + (((t * 8 + q * 2 + h) ^ sw) * 16));
+    } else {
+        r.lo = *reinterpret_cast<const bf16x8*>(row + (((t * 4 + h * 2 + 0) ^ sw) * 16));
+        r.hi = *reinterpret_cast<const bf16x8*>(row + (((t * 4 + h * 2 + 1) ^ sw) * 16));
     }
 }
 template <int P>
 __device__ __forceinline__ void expand_stage_raw(const StageRaw<P>& r, f32x16& x) {
+    if constexpr (P != 1) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        f32x4 a;
-        if constexpr (P != 1) a = r.q[q]; else a = __builtin_convertvector(r.q[q], f32x4);
+        for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) x[q * 4 + c] = a[c];
+            for (int c = 0; c < 4; ++c) x[q * 4 + c] = r.q[q][c];
+    } else {
+        const f32x8 a = __builtin_convertvector(r.lo, f32x8), b = __builtin_convertvector(r.hi, f32x8);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { x[c] = a[c]; x[8 + c] = b[c]; }
     }
 }
 
@@ -1674,13 +1684,23 @@ __device__ __forceinline__ void write_stage_tiles(float* stage, int sr, int h, c
     char* row = reinterpret_cast<char*>(stage) + sr * G::RB;
     const int sw = G::swz(sr);
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < NT; ++t) {
+        if constexpr (P != 1) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 a = {x[t][q * 4 + 0], x[t][q * 4 + 1], x[t][q * 4 + 2], x[t][q * 4 + 3]};
-            if constexpr (P != 1) *reinterpret_cast<f32x4*>(row + (((t * 8 + q * 2 + h) ^ sw) * 16)) = a;
-            else *reinterpret_cast<bf16x4*>(row + (((t * 4 + q) ^ sw) * 16) + h * 8) = to_bf16x4(a);
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 a = {x[t][q * 4 + 0], x[t][q * 4 + 1], x[t][q * 4 + 2], x[t][q * 4 + 3]};
+                *reinterpret_cast<f32x4*>(row + (((t * 8 + q * 2 + h) ^ sw) * 16)) = a;
+            }
+        } else {
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) {          // half-major bf16 rows: registers 8 qq .. 8 qq + 7 are piece 4 t + 2 h + qq
+                f32x8 a;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) a[c] = x[t][qq * 8 + c];
+                *reinterpret_cast<bf16x8*>(row + (((t * 4 + h * 2 + qq) ^ sw) * 16)) = to_bf16x8(a);
+            }
         }
+    }
 }
 
 // 32 staged rows -> 32 CONSECUTIVE rows of a [rows, D] array, the inverse of dma_rows for a contiguous block: lane l stores LDS piece
@@ -1822,12 +1842,19 @@ struct GlobalW {
 // LDS floats of mp_fused besides the staged MpEBlob.  COOP = 1: every wave owns a max-aggregation tile [32][D], 32 row
 // offsets and two 32-row gather stages; COOP > 1: the workgroup's COOP waves share the aggregation tile and the B-row
 // stage, every wave keeps its own row offsets and A-row stage
+// Row pitch (floats) of the [32][D] fp32 aggregation tile.  The tile is written by ds_max_f32 with lane = feature (32 consecutive
+// floats of one row per half wave: conflict-free at any pitch) and filled / read back with lane = ROW, 16 bytes per lane: at a pitch
+// of D floats (128 / 256 bytes) the 16 lanes of a ds_read_b128 group -- 8 of a ds_write_b128 group -- all sit on the same one or two
+// 16-byte slots of the 256-byte bank row, an 8- to 16-way conflict on every fill and read-back (SQ_LDS_BANK_CONFLICT was 0.40-0.53 of
+// the LDS-active cycles of mp_fused at every shape, round 5).  One extra slot per row rotates the rows across all sixteen slots.
+template <int D> constexpr int kAggPitch = D + 4;
 template <int D, int P, int COOP>
 __host__ __device__ constexpr int mp_lds_floats() {
     constexpr int stage_f = 32 * D * (P == 1 ? 2 : 4) / 4;
+    constexpr int AGG = 32 * kAggPitch<D>;
     // COOP > 1 adds four [32][D] fp32 tiles: X and R rows of the job (requested at its start), the partial H = bl + Wlx X that a
     // wave computes while the others multiply edges, and Y for the wave that computes B'
-    return COOP == 1 ? 4 * (32 * D + 32 + 2 * stage_f) : (32 * D + stage_f + COOP * (32 + stage_f) + (D == 32 ? 4 * 32 * D : 0));
+    return COOP == 1 ? 4 * (AGG + 32 + 2 * stage_f) : (AGG + stage_f + COOP * (32 + stage_f) + (D == 32 ? 4 * 32 * D : 0));
 }
 
 // COOP = 1 (large batches): one 32-node tile per WAVE, four independent waves per workgroup.
@@ -1899,12 +1926,13 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
 #define GNNMP_TRC_END() do {} while (0)
 #endif
     float* base = lds + ((LE::size + 3) & ~3);
-    float* agg = kCoop ? base : base + wave * (32 * D + 32 + 2 * G::STAGE_FLOATS);                   // [32][D]
-    float* btile = kCoop ? base + 32 * D : agg + 32 * D + 32 + G::STAGE_FLOATS;                      // B rows of the tile
-    float* mine = kCoop ? base + 32 * D + G::STAGE_FLOATS + wave * (32 + G::STAGE_FLOATS) : agg + 32 * D;
+    constexpr int AP = kAggPitch<D>, AGG = 32 * AP;
+    float* agg = kCoop ? base : base + wave * (AGG + 32 + 2 * G::STAGE_FLOATS);                    // [32][D] at pitch AP
+    float* btile = kCoop ? base + AGG : agg + AGG + 32 + G::STAGE_FLOATS;                      // B rows of the tile
+    float* mine = kCoop ? base + AGG + G::STAGE_FLOATS + wave * (32 + G::STAGE_FLOATS) : agg + AGG;
     int* dl = reinterpret_cast<int*>(mine);                      // [32] agg row offsets (floats) of this chunk's targets
     float* astage = mine + 32;                                   // gathered A rows of the current chunk
-    float* xstage = base + 32 * D + G::STAGE_FLOATS + COOP * (32 + G::STAGE_FLOATS);     // kCoop only (see mp_lds_floats)
+    float* xstage = base + AGG + G::STAGE_FLOATS + COOP * (32 + G::STAGE_FLOATS);     // kCoop only (see mp_lds_floats)
     float* rstage = xstage + 32 * D;
     float* hpart = rstage + 32 * D;
     float* ytile = hpart + 32 * D;
@@ -2060,7 +2088,7 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
             else dma_rows<D, XP>(p.X, [&](int sr) { return t0 + sr; }, btile, lane);
             const f32x4 ninf = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};      // agg tile <- -inf
 #pragma unroll
-            for (int q = 0; q < D / 8; ++q) *reinterpret_cast<f32x4*>(agg + j * D + h * (D / 2) + q * 4) = ninf;
+            for (int q = 0; q < D / 8; ++q) *reinterpret_cast<f32x4*>(agg + j * AP + h * (D / 2) + q * 4) = ninf;
             if constexpr (!kCoop) {
                 // the first two chunks' edge records travel with the X rows, and the first chunk's A rows are requested before
                 // the MFMAs below: one dependent round trip at the start of a tile instead of three
@@ -2167,7 +2195,7 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
             const int rec = rec_c;
             const int dloc = valid ? ((rec >> 27) & 31) : 0;
             const int eslot = valid ? slot : beg;
-            if (h == 0) dl[j] = dloc * D;
+            if (h == 0) dl[j] = dloc * AP;
             f32x16 M[NT];
 #pragma unroll
             for (int ot = 0; ot < NT; ++ot) M[ot] = splat16(bias[ot]);
@@ -2214,10 +2242,7 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
                     // 6 MFMAs (192 matrix-pipe cycles, a pipe that idles 90 % of this loop) replace 48 conversion and 16
                     // packed-add VALU instructions (256 issue cycles) per 32-feature tile.
                     using bf16x8v = bf16x8;
-                    const bf16x8v alo = __builtin_shufflevector(araw[it].q[0], araw[it].q[1], 0, 1, 2, 3, 4, 5, 6, 7);
-                    const bf16x8v ahi = __builtin_shufflevector(araw[it].q[2], araw[it].q[3], 0, 1, 2, 3, 4, 5, 6, 7);
-                    const bf16x8v blo = __builtin_shufflevector(braw[it].q[0], braw[it].q[1], 0, 1, 2, 3, 4, 5, 6, 7);
-                    const bf16x8v bhi = __builtin_shufflevector(braw[it].q[2], braw[it].q[3], 0, 1, 2, 3, 4, 5, 6, 7);
+                    const bf16x8v alo = araw[it].lo, ahi = araw[it].hi, blo = braw[it].lo, bhi = braw[it].hi;
                     f32x16 acc = splat16(0.f);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sel[0], alo, acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sel[1], ahi, acc, 0, 0, 0);
@@ -2356,7 +2381,7 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
                 linear_acc_stream<P, NT, false>(wn + LN::wla, [&](int it, f32x16& x) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const f32x4 a = *reinterpret_cast<const f32x4*>(agg + j * D + it * 32 + q * 8 + h * 4);
+                        const f32x4 a = *reinterpret_cast<const f32x4*>(agg + j * AP + it * 32 + q * 8 + h * 4);
 #pragma unroll
                         for (int c = 0; c < 4; ++c) x[q * 4 + c] = dg == 0 ? 0.f : a[c];      // torch_scatter: no incoming edge -> 0
                     }
@@ -2430,7 +2455,7 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
         linear_acc_stream<P, NT, false>(wn + LN::wla, [&](int it, f32x16& x) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const f32x4 a = *reinterpret_cast<const f32x4*>(agg + j * D + it * 32 + q * 8 + h * 4);
+                const f32x4 a = *reinterpret_cast<const f32x4*>(agg + j * AP + it * 32 + q * 8 + h * 4);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) x[q * 4 + c] = dg == 0 ? 0.f : a[c];      // torch_scatter: no incoming edge -> 0
             }
@@ -2533,7 +2558,7 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
 template <int D, int P>
 __host__ __device__ constexpr int mp_w8_lds_floats() {
     return ((MpEBlob<D, P>::size + 3) & ~3) + (P == 1 ? ((MpNBlob<D, P>::size + 3) & ~3) + MpNBlob<D, P>::T : 0) +
-           8 * (32 * D + 32 + RowGeom<D, P>::STAGE_FLOATS);
+           8 * (32 * kAggPitch<D> + 32 + RowGeom<D, P>::STAGE_FLOATS);
 }
 
 #ifdef GNNMP_DBG_ROWS0
@@ -2565,9 +2590,10 @@ __global__ __launch_bounds__(512, 1) void mp_fused_w8_kernel(MpFusedParams p) {
     float* base = kWLds ? wm3x + LN::T : wnl;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
     const int sub = wave >> 2, w4 = wave & 3;
-    float* agg = base + wave * (32 * D + 32 + G::STAGE_FLOATS);  // [32][D] fp32; X rows in / R rows in / A' and PT rows out pass through it
-    int* dl = reinterpret_cast<int*>(agg + 32 * D);              // [32] agg row offsets (floats) of this chunk's targets
-    float* astage = agg + 32 * D + 32;                           // gathered A rows of the current chunk; X rows in / X' rows out
+    constexpr int AP = kAggPitch<D>, AGG = 32 * AP;
+    float* agg = base + wave * (AGG + 32 + G::STAGE_FLOATS);     // [32][D] fp32 at pitch AP; X rows in / R rows in / A' and PT rows out pass through it
+    int* dl = reinterpret_cast<int*>(agg + AGG);                 // [32] agg row offsets (floats) of this chunk's targets
+    float* astage = agg + AGG + 32;                              // gathered A rows of the current chunk; X rows in / X' rows out
     // virtual four-wave workgroup (XCD vx, index vq of vU on it)
     const int vx = blockIdx.x & 7, vq = (blockIdx.x >> 3) * 2 + sub, vU = (gridDim.x >> 3) * 2;
 #ifdef GNNMP_MP_TRACE
@@ -2681,7 +2707,7 @@ __global__ __launch_bounds__(512, 1) void mp_fused_w8_kernel(MpFusedParams p) {
         {
             const f32x4 ninf = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};      // agg tile <- -inf
 #pragma unroll
-            for (int q = 0; q < D / 8; ++q) *reinterpret_cast<f32x4*>(agg + j * D + h * (D / 2) + q * 4) = ninf;
+            for (int q = 0; q < D / 8; ++q) *reinterpret_cast<f32x4*>(agg + j * AP + h * (D / 2) + q * 4) = ninf;
         }
 #ifdef GNNMP_DBG_AOWN
         auto src_row = [&](int rec, bool valid) { return t0 + j; };           // (traffic attribution: no gather)
@@ -2729,7 +2755,7 @@ __global__ __launch_bounds__(512, 1) void mp_fused_w8_kernel(MpFusedParams p) {
             const int rec = rec_c;
             const int dloc = valid ? ((rec >> 27) & 31) : 0;
             const int eslot = valid ? slot : beg;
-            if (h == 0) dl[j] = dloc * D;
+            if (h == 0) dl[j] = dloc * AP;
             f32x16 M[NT];
 #pragma unroll
             for (int ot = 0; ot < NT; ++ot) M[ot] = splat16(bias[ot]);
@@ -2768,10 +2794,8 @@ __global__ __launch_bounds__(512, 1) void mp_fused_w8_kernel(MpFusedParams p) {
                         ghi[w] = __builtin_amdgcn_ds_bpermute(baddr, hi[w]);
                     }
                     const bf16x8 blo = __builtin_bit_cast(bf16x8, glo), bhi = __builtin_bit_cast(bf16x8, ghi);
-                    braw.q[0] = __builtin_shufflevector(blo, blo, 0, 1, 2, 3);
-                    braw.q[1] = __builtin_shufflevector(blo, blo, 4, 5, 6, 7);
-                    braw.q[2] = __builtin_shufflevector(bhi, bhi, 0, 1, 2, 3);
-                    braw.q[3] = __builtin_shufflevector(bhi, bhi, 4, 5, 6, 7);
+                    braw.lo = blo;
+                    braw.hi = bhi;
                     expand_stage_raw<P>(braw, b);
                 } else {
                     // (four registers at a time through vector bit casts: the element-wise form -- bit_cast<int>(v[r]) -> ds_bpermute ->
@@ -2871,7 +2895,7 @@ __global__ __launch_bounds__(512, 1) void mp_fused_w8_kernel(MpFusedParams p) {
                 f32x16 x;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const f32x4 a = *reinterpret_cast<const f32x4*>(agg + j * D + it * 32 + q * 8 + h * 4);
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(agg + j * AP + it * 32 + q * 8 + h * 4);
 #pragma unroll
                     for (int c = 0; c < 4; ++c) x[q * 4 + c] = dg == 0 ? 0.f : a[c];      // torch_scatter: no incoming edge -> 0
                 }
@@ -2940,7 +2964,7 @@ __global__ __launch_bounds__(512, 1) void mp_fused_w8_kernel(MpFusedParams p) {
             linear_acc_stream<P, NT, false>(wn + LN::wla, [&](int it, f32x16& x) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const f32x4 a = *reinterpret_cast<const f32x4*>(agg + j * D + it * 32 + q * 8 + h * 4);
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(agg + j * AP + it * 32 + q * 8 + h * 4);
 #pragma unroll
                     for (int c = 0; c < 4; ++c) x[q * 4 + c] = dg == 0 ? 0.f : a[c];      // torch_scatter: no incoming edge -> 0
                 }
