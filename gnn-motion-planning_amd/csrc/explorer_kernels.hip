@@ -52,9 +52,12 @@ __device__ __forceinline__ int find_graph(const int* __restrict__ ptr, int G, in
 // has more than ~16 k edges, by up to 16 workgroups that split its columns (prep_hist_kernel + prep_scatter_kernel).
 // Graphs beyond kPrepCap padded nodes keep their counters in global memory (same code through flat pointers).
 // =====================================================================================================
-// up to this many 32-node tiles mp_fused runs one tile per workgroup of 8 waves (measured crossovers: 12-16 graphs of
-// 1000 nodes at d = 32, 8-12 graphs of 2000 nodes at d = 64)
-constexpr int kCoopMaxTiles32 = 384, kCoopMaxTiles64 = 600;
+// up to this many 32-node tiles (the launch's PADDED tile count: 39 per 1000-node graph) mp_fused runs one tile per workgroup of
+// 8 / 4 waves.  Re-measured in round 6 against the resident eight-wave / four-tiles-per-workgroup forms, which have a floor of
+// 0.13 ms (d = 32) / 0.6 ms (d = 64 fp32) / 0.19 ms (d = 64 bf16) per five launches however few tiles there are
+// (profiles/r06_small_batch_crossover.txt: 1000-node graphs, crossovers at 16-20 graphs at d = 32 and 24-32 at d = 64; the old
+// bounds of 384 / 600 sent 12-16 graphs the slow way: kuka7 fp32, 16 problems, 1.14 -> 0.86 ms per forward)
+constexpr int kCoopMaxTiles32 = 680, kCoopMaxTiles64 = 1100;
 constexpr int kPrepCap = 8192;
 constexpr int kPrepWindowEdges = 65536;   // big-graph prep: from this many edges per graph the CSR records are scattered in windows of target rows
 constexpr int kGoalSplitNodes = 4096;     // big-graph prep: from this many nodes the goal arg-min is spread over the graph's part workgroups

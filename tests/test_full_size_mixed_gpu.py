@@ -11,7 +11,7 @@ import torch
 
 from conftest import load_weights
 import gnnmp
-from gnnmp.dist import MixedJob, problem_costs, run_mixed, shard_mixed, shard_range
+from gnnmp.dist import MixedJob, family_time_curves, plan_times, problem_costs, run_mixed, shard_mixed, shard_range
 from gnnmp.synth import ENVS, synth_batch_gpu
 from parity_bar import assert_fp32_parity, explorer_oracle_pair
 
@@ -74,7 +74,7 @@ def test_cfg4_mixed_set_full_size():
         for rank in range(world):
             idx = shard_mixed(problems, rank, world, models, LOOP)
             seen += idx
-            loads.append(sum(costs[i] for i in idx))
+            loads.append(plan_times([idx], [p['env'] for p in problems], costs, family_time_curves(models))[0])
             if world >= 4:
                 assert len({problems[i]['env'] for i in idx}) <= 2, (world, rank)
             if world == 4 or rank in (0, world - 1):                                    # scoring every shard of every split would only repeat (b)

@@ -63,7 +63,7 @@ def job_rate(job, reps=20):
     return len(problems) * reps / sorted(ts)[1]
 
 
-from gnnmp.dist import MixedJob, mixed_plan, problem_costs  # noqa: E402
+from gnnmp.dist import MixedJob, family_time_curves, mixed_plan, plan_times, problem_costs  # noqa: E402
 ref = run_mixed(problems, models, loop=LOOP)
 for conc in (False, True):
     job = MixedJob(problems, models, loop=LOOP, concurrent=conc)
@@ -71,11 +71,13 @@ for conc in (False, True):
     print('%-10s %35s %12.1f   (MixedJob: batches resident, %s; bytes equal run_mixed: %s)' % (
         'mixed job', '', job_rate(job), 'one stream per family, most expensive first' if conc else 'families back to back on one stream', same))
 costs = problem_costs(problems, models, LOOP)
+fixed = family_time_curves(models)
+fams = [p['env'] for p in problems]
 fam_cost = {env: sum(c for c, p in zip(costs, problems) if p['env'] == env) / PER for env in FAMILIES}
-print('cost model (gnnmp.dist.forward_cost, relative to maze2): ' + ', '.join('%s %.2f' % (e, fam_cost[e] / fam_cost['maze2']) for e in FAMILIES))
+print('cost model (gnnmp.dist.batch_time): predicted ms of a 16 / 64-problem batch: ' + ', '.join('%s %.3f / %.3f' % (e, fixed[e](16 * fam_cost[e]), fixed[e](64 * fam_cost[e])) for e in FAMILIES))
 for world in (2, 4, 8):
-    plan = mixed_plan([p['env'] for p in problems], costs, world)
-    loads = [sum(costs[i] for i in r) for r in plan]
+    plan = mixed_plan(fams, costs, world, fixed)
+    loads = plan_times(plan, fams, costs, fixed)
     print('shard_mixed over %d ranks: problems per rank %s, families per rank %s, predicted slowest / mean %.3f' % (
         world, [len(r) for r in plan], [len({problems[i]['env'] for i in r}) for r in plan], max(loads) / (sum(loads) / world)))
     if world == 8:
@@ -83,12 +85,17 @@ for world in (2, 4, 8):
         rates = []
         for r in plan:
             j = MixedJob([problems[i] for i in r], models, loop=LOOP)
+            for _ in range(5):
+                j.run()
+            ts = []
             for _ in range(3):
-                j.run()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(10):
-                j.run()
-            torch.cuda.synchronize()
-            rates.append((time.perf_counter() - t0) / 10 * 1e3)
-        print('   measured ms per shard on this GPU: %s -> slowest / mean %.3f' % (['%.2f' % x for x in rates], max(rates) / (sum(rates) / len(rates))))
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(20):
+                    j.run()
+                torch.cuda.synchronize()
+                ts.append((time.perf_counter() - t0) / 20 * 1e3)
+            rates.append(sorted(ts)[1])
+        print('   predicted ms per shard: %s' % ['%.2f' % x for x in loads])
+        print('   measured ms per shard on this GPU: %s -> slowest / mean %.3f; whole job on one GPU / slowest shard = strong scaling %.2fx on 8' % (
+            ['%.2f' % x for x in rates], max(rates) / (sum(rates) / len(rates)), (len(problems) / job_rate(MixedJob(problems, models, loop=LOOP)) * 1e3) / max(rates)))
