@@ -3060,11 +3060,38 @@ __global__ __launch_bounds__(256) void policy_kernel(PolicyParams p) {
     // requested made the conversion wait for the load it had just issued (s_waitcnt vmcnt(0) right behind the request: the
     // bf16 policy kernel ran without any prefetch)
     KeRaw<P> hid_n[NT];
-    auto issue = [&](const int4& rec, int g, int tile) {      // rows + PE tile of a fetched tile (g wave-uniform after the wait)
+    // The 32 slots of a tile are consecutive CSR slots of one graph, i.e. sorted by target: their targets are the CONTIGUOUS node
+    // rows t_first .. t_last (3-5 rows at kNN in-degrees; nodes without incoming edges in between widen the range, beyond 32 rows the
+    // per-edge gather stays).  Only those rows are fetched -- one LDS-DMA instruction (G::RPI rows)
+    // where a gather of the target row per edge took G::NI, a quarter of the bytes this kernel moves through the CU's L1 -- and
+    // every lane reads row (its target - t_first) of the stage (same address for the edges of one target: an LDS broadcast).
+    int dl_c = 0;                                               // stage row of the lane's target in the tile whose rows are in flight / staged
+    auto issue = [&](const int4& rec, int g, int tile, int& dl) {      // rows + PE tile of a fetched tile (g wave-uniform after the wait)
         if (g < 0) return;
-        const int srow = rec.x >= 0 ? rec.x : 0, trow = rec.y >= 0 ? rec.y : 0;
+        using G = RowGeom<D, P>;
+        const int srow = rec.x >= 0 ? rec.x : 0;
         dma_rows<D, P>(p.PS, [&](int sr) { return __builtin_amdgcn_ds_bpermute(sr * 4, srow); }, sstage, lane);
-        dma_rows<D, P>(p.PT, [&](int sr) { return __builtin_amdgcn_ds_bpermute(sr * 4, trow); }, tstage, lane);
+        const int nv = __builtin_popcountll(__builtin_amdgcn_ballot_w64(rec.x >= 0 && h == 0));      // valid slots (pads trail)
+        const int t_first = __builtin_amdgcn_readfirstlane(rec.y);
+        const int t_last = __builtin_amdgcn_readlane(rec.y, nv > 0 ? nv - 1 : 0);
+        const int R = nv > 0 ? t_last - t_first + 1 : 0;          // 1 .. 32 (0: a tile of padding only), wave-uniform
+        if (R > 32) {                                               // nodes without incoming edges in between: gather the row of every edge
+            const int trow = rec.y >= 0 ? rec.y : 0;
+            dl = j;
+            dma_rows<D, P>(p.PT, [&](int sr) { return __builtin_amdgcn_ds_bpermute(sr * 4, trow); }, tstage, lane);
+        } else {
+        dl = rec.x >= 0 ? rec.y - t_first : 0;
+        const char* base = reinterpret_cast<const char*>(p.PT);
+#pragma unroll
+        for (int i = 0; i < G::NI; ++i) {
+            if (i * G::RPI >= R) break;
+            const int sr = G::RPI * i + lane / G::PP;
+            const int pc = (lane % G::PP) ^ G::swz(sr);
+            const char* gp = base + (size_t)(t_first + (sr < R ? sr : R - 1)) * G::RB + pc * 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
+                                             (__attribute__((address_space(3))) void*)(tstage + i * 256), 16, 0, 0);
+        }
+        }
 #pragma unroll
         for (int tt = 0; tt < NT; ++tt) load_edge_slot_raw<P, NT>(p.PE, tile * 32 + j, h, tt, hid_n[tt]);
     };
@@ -3073,12 +3100,13 @@ __global__ __launch_bounds__(256) void policy_kernel(PolicyParams p) {
         wk.next();
         wait_vmcnt<0>();
         g_c = __builtin_amdgcn_readfirstlane(g_c);
-        issue(rec_c, g_c, tile_c);
+        issue(rec_c, g_c, tile_c, dl_c);
         if (wk.valid()) fetch(wk.cur, rec_n, g_n, tile_n);
     }
     while (tile_c >= 0) {
         const int4 rec = rec_c;
         const int g = g_c;
+        const int dloc = dl_c;
         f32x16 hid[NT], a[NT], b[NT];
         wait_vmcnt<0>();      // this tile's rows and PE tile (and the next records) have landed
         if (g >= 0) {
@@ -3086,7 +3114,7 @@ __global__ __launch_bounds__(256) void policy_kernel(PolicyParams p) {
             for (int tt = 0; tt < NT; ++tt) {
                 expand_raw<P>(hid_n[tt], hid[tt]);
                 read_stage_tile<D, P>(sstage, j, h, tt, a[tt]);
-                read_stage_tile<D, P>(tstage, j, h, tt, b[tt]);
+                read_stage_tile<D, P>(tstage, dloc, h, tt, b[tt]);
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the stages have been read: the next tile may overwrite them
@@ -3095,7 +3123,7 @@ __global__ __launch_bounds__(256) void policy_kernel(PolicyParams p) {
         g_c = tile_c >= 0 ? __builtin_amdgcn_readfirstlane(g_n) : -1;
         if (tile_c >= 0) {
             wk.next();
-            issue(rec_c, g_c, tile_c);
+            issue(rec_c, g_c, tile_c, dl_c);
             if (wk.valid()) fetch(wk.cur, rec_n, g_n, tile_n);
         }
         if (g < 0) continue;
