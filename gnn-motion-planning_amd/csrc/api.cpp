@@ -1176,7 +1176,7 @@ extern "C" int gnnmp_smoother_destroy(gnnmp_smoother* h) {
 namespace {
 struct SmCarve {
     int ecap, pcap;
-    size_t cur, knn, e_src, e_dst, e_count, stat, seg_beg, seg_cnt, ff_beg, etile, ptile, ff_end, msg, tgt, tflag, total;
+    size_t cur, knn, e_src, e_dst, e_count, stat, seg_beg, seg_cnt, ff_beg, etile, ptile, ff_end, msg, tgt, tflag, tcnt, elist, plist, total;
 };
 
 bool sm_carve(const gnnmp_smoother* h, const gnnmp_smooth_batch* b, SmCarve& c) {
@@ -1205,6 +1205,11 @@ bool sm_carve(const gnnmp_smoother* h, const gnnmp_smooth_batch* b, SmCarve& c) 
     c.msg = take(sizeof(float) * (size_t)c.ecap * D);
     c.tgt = take(sizeof(float) * (size_t)c.pcap * D);
     c.tflag = take(sizeof(int) * (c.pcap / 32));
+    // compact lists of the tiles in use (the tile space is padded per problem): two pairs of counters (iteration parity) + the lists,
+    // appended by the graph stage, read by the streamed-weights message kernel
+    c.tcnt = take(sizeof(int) * 4);
+    c.elist = take(sizeof(int) * (c.ecap / 32));
+    c.plist = take(sizeof(int) * (c.pcap / 32));
     c.total = o;
     return true;
 }
@@ -1257,6 +1262,7 @@ extern "C" int gnnmp_smoother_forward_ex(const gnnmp_smoother* h, const gnnmp_sm
     p.etile_prob = at<int>(ws, c.etile); p.ptile_prob = at<int>(ws, c.ptile);
     p.msg = at<float>(ws, c.msg);
     p.tgt = at<float>(ws, c.tgt); p.tgt_flag = at<int>(ws, c.tflag);
+    p.tile_cnt = at<int>(ws, c.tcnt); p.elist = at<int>(ws, c.elist); p.plist = at<int>(ws, c.plist); p.parity = 0;
     { static const int no_tgt = getenv("GNNMP_SM_NO_TARGET_ROLE") ? atoi(getenv("GNNMP_SM_NO_TARGET_ROLE")) : 0; if (no_tgt) p.tgt_flag = nullptr; }      // experiments
     p.cand_cap = b->max_edges + kSmK * b->max_path;
     if (p.cand_cap < 1) p.cand_cap = 1;
@@ -1273,9 +1279,11 @@ extern "C" int gnnmp_smoother_forward_ex(const gnnmp_smoother* h, const gnnmp_sm
     // three launches per iteration (graph stage = kNN + edge list, messages, path update; four when a problem's buffers exceed
     // the LDS share of the one-launch graph stage): the scaled working copy is written by the
     // first kNN launch, the tile maps by the edge-list kernel, the result by the last path-update launch
+    HIP_TRY(hipMemsetAsync(p.tile_cnt, 0, sizeof(int) * 4, st));      // the tile-list counters (then re-armed by the graph stage itself)
     for (int it = 0; it < loop; ++it) {
         p.init_from_path = it == 0 ? 1 : 0;
         p.out = it == loop - 1 ? out_path : nullptr;
+        p.parity = it & 1;
         HIP_TRY(launch_sm_iter(D, h->dims.mlp_dtype, p, st));
     }
     return GNNMP_OK;
@@ -1773,6 +1781,7 @@ void sm_fill_params(const gnnmp_smoother* h, const gnnmp_smooth_batch* b, const 
     p.etile_prob = at<int>(ws, c.etile); p.ptile_prob = at<int>(ws, c.ptile);
     p.msg = at<float>(ws, c.msg);
     p.tgt = at<float>(ws, c.tgt); p.tgt_flag = at<int>(ws, c.tflag);
+    p.tile_cnt = nullptr; p.elist = nullptr; p.plist = nullptr; p.parity = 0;      // training path: no tile lists (its kernels walk the padded tile space)
     { static const int no_tgt = getenv("GNNMP_SM_NO_TARGET_ROLE") ? atoi(getenv("GNNMP_SM_NO_TARGET_ROLE")) : 0; if (no_tgt) p.tgt_flag = nullptr; }      // experiments
     p.cand_cap = b->max_edges + kSmK * b->max_path;
     if (p.cand_cap < 1) p.cand_cap = 1;

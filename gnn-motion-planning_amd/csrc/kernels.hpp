@@ -128,6 +128,8 @@ struct SmParams {
     float* msg;                       // [edge capacity, d]
     float* tgt;                       // [path capacity, d] per padded path node: b00 + (W_c - W_a) x_i, written by the target role of the
     int* tgt_flag;                    //   split message kernel; [path tiles] 1 = that tile's rows are published (reset by the graph stage); may be null
+    int *tile_cnt, *elist, *plist;    // [2][2] counters {edge tiles, path tiles in use} per iteration parity + the tiles' indices (any order): appended by
+    int parity;                       //   the graph stage of iteration `parity`, which also zeroes the other pair; may be null (training path)
     int cand_cap, n_etiles, n_ptiles;
     int samp_cap, path_cap;           // caller's upper bounds max_b (F_b + Co_b), max_b P_b (sm_graph_kernel's LDS carve-up)
     int one_free, one_coll;           // path_ptr == nullptr: ONE problem, its sample counts (waypoints / edges: total_path / total_edges)

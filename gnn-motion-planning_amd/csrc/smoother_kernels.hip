@@ -55,6 +55,21 @@ __global__ void sm_final_kernel(int n, float scale, const float* __restrict__ cu
 // kNN: one wave per path node; lanes stride over the problem's samples keeping a per-lane running
 // best; k rounds of (lane-local argmin, wave argmin, retire the winner).
 // ---------------------------------------------------------------------------------------------------
+// compact lists of the tiles in use: this problem's runs of edge / path tiles appended at positions reserved with one atomic each (any
+// order: a tile's work does not depend on where it is listed).  Problem 0 zeroes the counters of the other parity for the next iteration.
+__device__ __forceinline__ void sm_list_tiles(const SmParams& p, int b, int et0, int et1, int pt0, int pt1, int tid, int nthreads) {
+    if (!p.tile_cnt) return;
+    __shared__ int s_lbase[2];
+    if (tid == 0) {
+        s_lbase[0] = atomicAdd(&p.tile_cnt[p.parity * 2 + 0], et1 - et0);
+        s_lbase[1] = atomicAdd(&p.tile_cnt[p.parity * 2 + 1], pt1 - pt0);
+        if (b == 0) { p.tile_cnt[(p.parity ^ 1) * 2 + 0] = 0; p.tile_cnt[(p.parity ^ 1) * 2 + 1] = 0; }
+    }
+    __syncthreads();
+    for (int i = tid; i < et1 - et0; i += nthreads) p.elist[s_lbase[0] + i] = et0 + i;
+    for (int i = tid; i < pt1 - pt0; i += nthreads) p.plist[s_lbase[1] + i] = pt0 + i;
+}
+
 __global__ __launch_bounds__(256) void sm_knn_kernel(SmParams p) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int node = blockIdx.x * 4 + wave;               // global path row
@@ -198,6 +213,7 @@ __global__ __launch_bounds__(256) void sm_edges_kernel(SmParams p) {
     const int pt_end = b + 1 < p.B ? sm_poff(p, b + 1) / 32 : p.n_ptiles;
     for (int t = eoff / 32 + tid; t < et_end; t += 256) p.etile_prob[t] = t < et_used ? b : -1;
     for (int t = poff / 32 + tid; t < pt_end; t += 256) { p.ptile_prob[t] = t < pt_used ? b : -1; if (p.tgt_flag) p.tgt_flag[t] = 0; }
+    sm_list_tiles(p, b, eoff / 32, et_used, poff / 32, pt_used, tid, 256);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -481,6 +497,7 @@ __global__ __launch_bounds__(1024) void sm_graph_kernel(SmParams p) {
     const int pt_end = b + 1 < p.B ? sm_poff(p, b + 1) / 32 : p.n_ptiles;
     for (int t = eoff / 32 + tid; t < et_end; t += 1024) p.etile_prob[t] = t < et_used ? b : -1;
     for (int t = poff / 32 + tid; t < pt_end; t += 1024) { p.ptile_prob[t] = t < pt_used ? b : -1; if (p.tgt_flag) p.tgt_flag[t] = 0; }
+    sm_list_tiles(p, b, eoff / 32, et_used, poff / 32, pt_used, tid, 1024);
 }
 
 // node features [coords / scale (path rows are already scaled), one-hot(kind)]   model_smoother.py:130-135
@@ -774,6 +791,231 @@ __global__ __launch_bounds__(D * 2, D == 128 ? 4 : 1) void sm_msg_split_kernel(S
     SM_TRC(5);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Large batches, exact-fp32 operands: the message kernel around weights that pass through LDS.
+//
+// The split kernel above reads every MFMA's A operand (256 bytes) straight from L2: 0.19 MB of matrices per edge tile, issued
+// a register budget's worth ahead, i.e. a fresh L2 round trip per ~16 MFMAs in four waves that meet at a barrier after every
+// layer -- the matrix pipe is 35 % busy and the waves wait 55 % of their life (profiles/r05_pmc_smoother_14d.txt).  Here a
+// workgroup is EIGHT waves (two per SIMD, one workgroup per CU), every wave owns one 32-row tile and computes ALL d outputs of
+// every layer (the tile-per-wave chain of sm_msg_kernel: same accumulation order, bit-identical), and the workgroup walks the
+// layers together: a layer's d x d matrix comes through LDS one input-tile column at a time (NT tiles = 16 KB in fp32), the
+// next column in flight (LDS-DMA, every wave issues its share) while the eight waves multiply the current one from LDS
+// (ds_read_b128, conflict-free: the packed tile layout is lane-contiguous).  Two 16 KB slots; one barrier per column.
+//
+// Roles: the first `wgs_t` workgroups are TARGET workgroups -- two path tiles each, four waves per tile in the split form above (wave w
+// computes output tile w of node_code and of (W_c - W_a) x_i, operands from L2, tiles exchanged through LDS): a quarter of the chain
+// per wave, so the rows b00 + (W_c - W_a) x_i are published (p.tgt + flags) ~25 k cycles into the launch, before any edge workgroup has
+// finished its source half (55 k).  A first version ran the targets as streamed rounds of their own: a 99 k-cycle chain that every
+// edge round then waited 40 k cycles for (tools/diag/sm_stream_trace.py).  The other workgroups are EDGE workgroups and take edge
+// rounds r = blockIdx.x - wgs_t, + (gridDim.x - wgs_t), ... of eight 32-edge tiles, streaming the matrices as described.  An edge
+// round waits for its targets' flags after the source half (bounded), and if one does not show up the whole workgroup computes the
+// target half itself -- same bits, so the wait can never hang a launch (another stream may keep the target workgroups off the device).
+// ---------------------------------------------------------------------------------------------------
+template <int D, int P>
+__global__ __launch_bounds__(512, 1) void sm_msg_stream_kernel(SmParams p, int wgs_t, int rounds_e) {
+    constexpr int NT = D / 32;
+    constexpr int TF = Prec<P>::TF;
+    constexpr int CH = NT * TF;                           // floats of one column (NT tiles) of a packed matrix
+    constexpr int PER_TILE = TF / 256, PIECES = NT * PER_TILE;      // 1 KB LDS-DMA pieces per tile / per column
+    extern __shared__ __attribute__((aligned(16))) float lds[];     // two column slots
+    __shared__ int s_notready;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
+    const float* W = p.w;
+#ifdef GNNMP_SM_TRACE
+    // diagnostics build: wave 0's shader-clock cycles per phase of a column (vmcnt wait / barrier / DMA issue + reads + MFMAs), summed
+    long long trc_acc[4] = {0, 0, 0, 0}, trc_t[4] = {0, 0, 0, 0}, trc_m[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define SM_STRC_M(k) do { trc_m[k] = clock64(); } while (0)
+    const long long trc_begin = clock64();
+#define SM_STRC_T(k) do { trc_t[k] = clock64(); if ((k) == 3) { trc_acc[0] += trc_t[1] - trc_t[0]; trc_acc[1] += trc_t[2] - trc_t[1]; trc_acc[2] += trc_t[3] - trc_t[2]; ++trc_acc[3]; } } while (0)
+#else
+#define SM_STRC_T(k) do {} while (0)
+#define SM_STRC_M(k) do {} while (0)
+#endif
+    int step = 0;                                         // columns consumed so far (workgroup-uniform): slot = step & 1
+    auto issue = [&](const float* Wm, int it, int sl) {   // column `it` of packed matrix Wm -> slot sl, this wave's share
+        for (int q = wave; q < PIECES; q += 8) {
+            const int ot = q / PER_TILE, piece = q % PER_TILE;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Wm + (size_t)(ot * NT + it) * TF + piece * 256 + lane * 4),
+                                             (__attribute__((address_space(3))) void*)(lds + sl * CH + ot * TF + piece * 256), 16, 0, 0);
+        }
+    };
+    // y[ot] += sum_it Wm[ot][it] x[it], it outer / ot inner like linear_acc_ops.  primed: column 0 of Wm is already on its way
+    // to slot step & 1 (issued by the previous layer's last column).  Wnext: the matrix whose column 0 is requested behind
+    // this layer's last column (nullptr: nothing).
+    // compute = false (wave-uniform): a wave without a tile streams its share and meets the barriers but leaves the matrix pipe alone
+    auto layer = [&](const float* Wm, bool primed, const float* Wnext, const BOp<P> (&xb)[NT], f32x16 (&y)[NT], bool compute) {
+        if (!primed) issue(Wm, 0, step & 1);
+#pragma unroll
+        for (int it = 0; it < NT; ++it) {
+            SM_STRC_T(0);
+            __builtin_amdgcn_s_waitcnt(7 << 4);           // vmcnt(0) lgkmcnt(0): this wave's pieces of the column have landed
+            asm volatile("" ::: "memory");
+            SM_STRC_T(1);
+            __builtin_amdgcn_s_barrier();                 // everyone's have; everyone is done reading the other slot
+            asm volatile("" ::: "memory");
+            SM_STRC_T(2);
+            if (it + 1 < NT) issue(Wm, it + 1, (step + 1) & 1);
+            else if (Wnext) issue(Wnext, 0, (step + 1) & 1);
+            if (compute) {
+                // The operand reads are issued BY HAND: the next column's LDS-DMA has just been requested, the compiler cannot tell
+                // that its destination (the other slot) and these reads never alias, and guards every LDS read it generates behind
+                // an in-flight DMA with s_waitcnt vmcnt(0) -- each column then waited out the L2 round trip of the NEXT one before
+                // its first MFMA (measured: 19 k instead of 8 k cycles per column, the matrix pipe 35 % busy).  Instructions inside
+                // asm statements get no such guard; the waits they need are stated here.  Tile ot + 1's four 16-byte reads are in
+                // flight while tile ot's sixteen MFMAs issue.
+                static_assert(P == 0, "hand-issued operand reads: exact-fp32 tiles (4 x 16 bytes per lane)");
+                const unsigned abase = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)lds + (unsigned)((step & 1) * CH * 4) + 16u * (unsigned)lane;
+                f32x4 w[2][4];
+                asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\tds_read_b128 %2, %4 offset:2048\n\tds_read_b128 %3, %4 offset:3072"
+                             : "=&v"(w[0][0]), "=&v"(w[0][1]), "=&v"(w[0][2]), "=&v"(w[0][3]) : "v"(abase) : "memory");
+#pragma unroll
+                for (int ot = 0; ot < NT; ++ot) {
+                    if (ot + 1 < NT) {
+                        asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:1024\n\tds_read_b128 %2, %8 offset:2048\n\tds_read_b128 %3, %8 offset:3072\n\t"
+                                     "s_waitcnt lgkmcnt(4)"
+                                     : "=&v"(w[(ot + 1) & 1][0]), "=&v"(w[(ot + 1) & 1][1]), "=&v"(w[(ot + 1) & 1][2]), "=&v"(w[(ot + 1) & 1][3]),
+                                       "+v"(w[ot & 1][0]), "+v"(w[ot & 1][1]), "+v"(w[ot & 1][2]), "+v"(w[ot & 1][3])
+                                     : "v"(abase + (unsigned)((ot + 1) * TF * 4)) : "memory");
+                    } else {
+                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w[ot & 1][0]), "+v"(w[ot & 1][1]), "+v"(w[ot & 1][2]), "+v"(w[ot & 1][3]) :: "memory");
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            y[ot] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[ot & 1][q][c], xb[it].v[q * 4 + c], y[ot], 0, 0, 0);
+                }
+            }
+            ++step;
+            SM_STRC_T(3);
+        }
+    };
+    // x = node_code(in): layer 0 from the raw inputs (a few MFMAs, weights from L2), layer 3 streamed
+    auto node_code = [&](const SmNodeIn& in, bool primed, const float* Wnext, f32x16 (&x)[NT], bool compute) {
+        f32x16 hdn[NT];
+        load_vec<NT>(W + p.L.b0, hdn, lane);
+        if (compute) linear_in_p<P, NT>(W + p.L.as0, p.L.ks, in, hdn, lane);
+        relu_<NT>(hdn);
+        BOp<P> hb[NT];
+        make_ops<P, NT>(hdn, hb);
+        load_vec<NT>(W + p.L.b3, x, lane);
+        layer(W + p.L.w3, primed, Wnext, hb, x, compute);
+    };
+    if ((int)blockIdx.x < wgs_t) {
+        // ---------------- target workgroup: path tiles 2 blockIdx.x + (wave >> 2), output tile wave & 3 (sm_msg_split_kernel's target role)
+        const int grp = wave >> 2, w4 = wave & 3;
+        const int slot_t = blockIdx.x * 2 + grp;
+        const bool act = slot_t < p.tile_cnt[p.parity * 2 + 1];
+        const int tile = act ? p.plist[slot_t] : 0;
+        if (__syncthreads_or(act ? 1 : 0) == 0) return;    // both tiles unused (the tile space is padded per problem)
+        const int b = act ? p.ptile_prob[tile] : 0;
+        const int PN = sm_pp(p, b + 1) - sm_pp(p, b);
+        const int n = tile * 32 + j - sm_poff(p, b);
+        const int dst = (act && n >= 0 && n < PN) ? n : 0;
+        float* xbuf = lds + grp * (NT * 16 * 64);          // the column slots are not in use here: 16 KB per group for the exchange
+        constexpr size_t TFs = TF;
+        f32x16 mine, x[NT], z[1];
+        load_vec<1>(W + p.L.b00 + w4 * 32, z, lane);
+        sm_node_code_tile<NT, P>(p, sm_node_in(p, b, dst), w4, mine, lane);         // x_i (target), this wave's 32 features
+        sm_exchange<NT>(xbuf, w4, mine, x, lane);
+        linear_acc_p<P, 1, NT>(W + p.L.wdst + (size_t)w4 * NT * TFs, x, z, lane);   // (W_c - W_a) x_i
+        if (act) store_row<1>(p.tgt + (size_t)(tile * 32 + j) * D + w4 * 32, z, h);
+        __threadfence();                                   // the rows are visible device-wide before the flag is
+        __syncthreads();
+        if (act && w4 == 0 && lane == 0) __hip_atomic_store(&p.tgt_flag[tile], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    const int wgs_e = (int)gridDim.x - wgs_t;
+    const int n_e = p.tile_cnt[p.parity * 2 + 0];        // edge tiles in use (listed by the graph stage); rounds_e is the launch's upper bound
+    rounds_e = (n_e + 7) >> 3;
+    bool primed = false;
+    for (int r = (int)blockIdx.x - wgs_t; r < rounds_e; r += wgs_e) {
+        const bool last = r + wgs_e >= rounds_e;
+        // -------------------- edge round r: edge tiles 8 r + wave
+        SM_STRC_M(0);
+        const bool active = r * 8 + wave < n_e;
+        const int tile = active ? p.elist[r * 8 + wave] : 0;
+        const int b = active ? p.etile_prob[tile] : 0;
+        const int e = tile * 32 + j;
+        const bool valid = active && (e - sm_eoff(p, b)) < p.e_count[b];
+        const int src = valid ? p.e_src[e] : 0, dst = valid ? p.e_dst[e] : 0;
+        const int trow = sm_poff(p, b) + dst;             // the target's row in the padded path space
+        if (threadIdx.x == 0) s_notready = 0;             // (ordered before the reads below by the barriers of the source half)
+        f32x16 xs[NT], z[NT];
+#ifdef GNNMP_SM_TRACE
+        asm volatile("s_waitcnt vmcnt(0)" :: "v"(src), "v"(dst) : "memory");
+#endif
+        SM_STRC_M(1);
+        node_code(sm_node_in(p, b, src), primed, W + p.L.wsrc, xs, active);  // x_j (source); wsrc's first column follows
+        SM_STRC_M(2);
+        {
+            bool ready = !active;
+            for (int spin = 0; spin < 4096 && !ready; ++spin) {
+                // relaxed: an acquire here would invalidate the CU's L1 on every poll; the one acquire fence below orders the row loads
+                const int f = __hip_atomic_load(&p.tgt_flag[trow >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ready = __all(f != 0);
+                if (!ready) __builtin_amdgcn_s_sleep(8);
+            }
+            if (!ready && lane == 0) s_notready = 1;
+        }
+        __builtin_amdgcn_s_waitcnt(7 << 4);
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const bool fallback = s_notready != 0;            // workgroup-uniform; the rare path
+        bool wsrc_primed = true;
+        SM_STRC_M(3);
+        if (fallback) {
+            // the target half here: node_code(dst) and (W_c - W_a) x_i through the same stream (wsrc's prefetched column is dropped:
+            // the column counter moves on, its slot is simply overwritten)
+            __builtin_amdgcn_s_waitcnt(7 << 4);
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            ++step;                                        // the slot wsrc's column went to counts as consumed
+            f32x16 xd[NT];
+            node_code(sm_node_in(p, b, dst), false, W + p.L.wdst, xd, active);
+            BOp<P> xb[NT];
+            make_ops<P, NT>(xd, xb);
+            load_vec<NT>(W + p.L.b00, z, lane);
+            layer(W + p.L.wdst, true, W + p.L.wsrc, xb, z, active);
+        } else {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            if (active) load_row<NT>(p.tgt + (size_t)trow * D, z, h);
+            else {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) z[t] = splat16(0.f);
+            }
+        }
+        {
+            BOp<P> xb[NT];
+            make_ops<P, NT>(xs, xb);
+            SM_STRC_M(4);
+            layer(W + p.L.wsrc, wsrc_primed, W + p.L.w02, xb, z, active);    // += (W_a + W_b) x_j
+        }
+        SM_STRC_M(5);
+        relu_<NT>(z);
+        f32x16 m[NT];
+        {
+            BOp<P> zb[NT];
+            make_ops<P, NT>(z, zb);
+            load_vec<NT>(W + p.L.b02, m, lane);
+            layer(W + p.L.w02, true, last ? nullptr : W + p.L.w3, zb, m, active);
+        }
+        primed = !last;
+        if (active) store_row<NT>(p.msg + (size_t)e * D, m, h);
+        SM_STRC_M(6);
+    }
+#ifdef GNNMP_SM_TRACE
+    if (threadIdx.x == 0 && blockIdx.x < 4096) {
+        long long* t = g_sm_trace + blockIdx.x * 16;      // two 8-slot records per workgroup
+        t[0] = trc_begin; t[1] = trc_acc[0]; t[2] = trc_acc[1]; t[3] = trc_acc[2]; t[4] = trc_acc[3]; t[5] = clock64(); t[6] = 0; t[7] = 2;
+        for (int i = 0; i < 7; ++i) t[8 + i] = trc_m[i];
+        t[15] = 3;
+    }
+#endif
+}
+
 template <int D, int P>
 __global__ __launch_bounds__(D * 2) void sm_node_split_kernel(SmParams p) {
     constexpr int NT = D / 32;
@@ -858,6 +1100,13 @@ hipError_t launch_sm_final(int n, float scale, const float* cur, float* out, hip
     return hipSuccess;
 }
 
+// exact-fp32 operands, d = 128: the streamed-weights message kernel from this many 32-edge tiles of CAPACITY on (~1000 problems of 20
+// waypoints).  Measured, C = 14, 20 waypoints, 500 + 500 samples, whole forward, split / streamed: 256 problems 0.247 / 0.248 ms, 512
+// 0.426 / 0.431, 1024 0.779 / 0.745, 2048 1.527 / 1.367, 4096 3.026 / 2.638 (tools/diag/sm_stream_sizes.py).  Below ~1000 problems the
+// eight-tile rounds quantise badly on 256 CUs (256 problems = 2304 tiles in use = 288 rounds: 32 workgroups run a second round while
+// 224 idle) and a round's fixed latencies (tile look-ups, layer 0 from L2, target rows: ~45 k of its ~150 k cycles,
+// tools/diag/sm_stream_trace.py) have nothing to hide behind; the split kernel's four one-tile workgroups per CU hide them behind each other.
+constexpr int kSmStreamMinTiles = 9000;
 constexpr int kSmSplitMaxTilesBf16 = 2048;   // bf16 operands: the split kernels up to this many 32-edge tiles
 
 // graph stage of one iteration: the one-launch form when a problem's staged samples, path rows, neighbour ids, sort
@@ -901,6 +1150,29 @@ static hipError_t launch_sm_iter_t(const SmParams& p, hipStream_t st) {
     // 1.67 -> 1.43 ms) and up to ~250 problems with bf16 operands (beyond that the tile-per-wave kernels win by 5-10 %)
     static const int split_env = getenv("GNNMP_SM_SPLIT") ? atoi(getenv("GNNMP_SM_SPLIT")) : -1;
     const bool split = D >= 64 && (split_env >= 0 ? split_env != 0 : (P == 0 || p.n_etiles <= kSmSplitMaxTilesBf16));
+    // large fp32 batches at d = 128: the streamed-weights message kernel (eight waves, a tile per wave, weights through LDS)
+    static const int stream_env = getenv("GNNMP_SM_STREAM") ? atoi(getenv("GNNMP_SM_STREAM")) : -1;
+    if constexpr (D == 128 && P == 0) {
+        if (p.tgt_flag && p.tile_cnt && (stream_env >= 0 ? stream_env != 0 : p.n_etiles >= kSmStreamMinTiles)) {
+            const int wgs_t = (p.n_ptiles + 1) / 2, rounds_e = (p.n_etiles + 7) / 8;
+            static int cus = 0;
+            if (!cus) {
+                int dev = 0;
+                hipDeviceProp_t prop;
+                cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+            }
+            const size_t lds = (size_t)2 * (D / 32) * Prec<P>::TF * sizeof(float);
+            static std::once_flag once;
+            std::call_once(once, [&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sm_msg_stream_kernel<D, P>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
+            // target workgroups first (lowest block ids: dispatched first, gone after ~10 us), then one resident edge workgroup per CU
+            const int grid = wgs_t + (rounds_e < cus ? rounds_e : cus);
+            hipLaunchKernelGGL((sm_msg_stream_kernel<D, P>), dim3(grid), dim3(512), lds, st, p, wgs_t, rounds_e);
+            LAUNCH_CHECK();
+            hipLaunchKernelGGL((sm_node_split_kernel<D, P>), dim3(p.n_ptiles), dim3(D * 2), 0, st, p);
+            LAUNCH_CHECK();
+            return hipSuccess;
+        }
+    }
     if (split) {
         hipLaunchKernelGGL((sm_msg_split_kernel<D, P>), dim3(p.n_etiles + (p.tgt_flag ? p.n_ptiles : 0)), dim3(D * 2), 0, st, p);
         LAUNCH_CHECK();

@@ -93,6 +93,7 @@ def smoother(name, C, P=20, F=500, Co=500, B=256, scale=1.0):
 
 
 if __name__ == '__main__':
+  if '--smoother-only' not in sys.argv:
     single('maze2', 200, 6)        # BASELINE configs[0]
     single('maze2', 1000, 8)
     single('maze2', 1002, 41)      # the reference's default graph density (k=30 -> k1=41)
@@ -104,6 +105,7 @@ if __name__ == '__main__':
     batched('kuka14', 5000, 16, 32, uniq=4, dtype='bf16')     # configs[4]
     batched('ur5', 1000, 8, 256)
     batched('snake7', 1000, 8, 256)
+  if True:
     smoother('smooth_2d_attv3', 2)
     smoother('smooth_7d_attv3', 7)
     smoother('smooth_14d_attv3', 14)     # configs[4]: "+ smoother GNN"
