@@ -34,28 +34,12 @@ constexpr int kATile = 1024;          // floats in one 32x32 A tile
 // the LDS crossbar (ds_bpermute).  gfx950's v_permlane32_swap does the same on the VALU; measured on the two pre
 // kernels it is a wash for the edge kernel (2.223 -> 2.219 ms) and a loss for the register-tight node kernel
 // (0.233 -> 0.250 ms), so the VALU -- which shares its issue time with the fp32 MFMAs -- is left alone here.
-// GNNMP_XSUM_PERMLANE = 1 (experiment): the exchange on the VALU with v_permlane32_swap instead of the LDS crossbar.  Same bits;
-// round 4 measured it within noise on all three BASELINE shapes (bf16 kernels included), round 1 a loss on the node kernel.
-#ifndef GNNMP_XSUM_PERMLANE
-#define GNNMP_XSUM_PERMLANE 0
-#endif
+// (Round 4 measured the v_permlane32_swap form again, within noise on all three BASELINE shapes, bf16 kernels included.)
 __device__ __forceinline__ float xsum(float x) {
-#if GNNMP_XSUM_PERMLANE
-    const unsigned u = __float_as_uint(x);
-    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);      // r[0], r[1] = the two halves' values (both lanes see both)
-    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-#else
     return x + __shfl_xor(x, 32, 64);
-#endif
 }
 __device__ __forceinline__ float xmax(float x) {
-#if GNNMP_XSUM_PERMLANE
-    const unsigned u = __float_as_uint(x);
-    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
-#else
     return fmaxf(x, __shfl_xor(x, 32, 64));
-#endif
 }
 
 __device__ __forceinline__ f32x16 splat16(float x) {

@@ -1486,11 +1486,7 @@ struct XcdWalk {
 // =====================================================================================================
 // one 32-feature tile `t` of edge slot `slot` (per-edge tiles are stored tile-native, [slot / 32][NT][...][64 lanes][...],
 // chain.hpp store_tile_p; a chunk need not start on a tile boundary, so every lane addresses its own slot)
-#ifdef GNNMP_DBG_KE_T
-#define GNNMP_KE_LOAD(p) (*(p))
-#else
 #define GNNMP_KE_LOAD(p) __builtin_nontemporal_load(p)
-#endif
 template <int P, int NT>
 __device__ __forceinline__ void load_edge_slot_tile(const float* base_f32_units, int slot, int h, int t, f32x16& x) {
     const size_t tile = (size_t)(slot >> 5);
@@ -1752,58 +1748,7 @@ __device__ __forceinline__ void linear_acc_stream(const float* A, Get get, f32x1
     }
 }
 
-// Exact-fp32 layers whose weights stay in GLOBAL memory (mp_fused_w8_kernel<64, 0>: 80 KB of node-phase matrices do not fit the LDS
-// next to eight waves' tiles).  Read where they are used (mfma_tile_p on the laundered pointer) they were FLAT loads -- the pointer
-// had lost its address space, so every wait was s_waitcnt vmcnt(0) lgkmcnt(0) -- requested four at a time right in front of their
-// MFMAs: eight dependent L2 round trips per 64 x 64 layer, 40 per tile (the 31 us node phase of round 5's timeline against 8.5 us
-// of matrix-pipe time).  GlobalW requests ALL operand slices of a layer at once, as global_load_dwordx4 on an address-space-1
-// pointer (NT * NT * 4 = 16 requests, 64 registers at d = 64: one round trip per layer, the MFMAs start as the slices arrive), and
-// a layer's slices can be requested while the previous layer's MFMAs run (the registers of the chunk loop are dead in the node
-// phase).  Same operands, same order of accumulation per output tile as linear_acc_ops / linear_acc_stream: same bits.
-template <int NT>
-struct GlobalW {
-    f32x4 w[NT * NT * 4];
-    __device__ __forceinline__ void request(const float* A, int lane) {
-        // scalar base + 32-bit lane offset + immediate: one address register for all sixteen requests (per-lane 64-bit addresses
-        // cost a register pair per 4 KB tile, the immediate reaches 4095 bytes)
-        typedef const __attribute__((address_space(1))) char* gbytes;
-        typedef const __attribute__((address_space(1))) f32x4* gvec;
-        const gbytes base = (gbytes)A;
-        const unsigned off = (unsigned)lane * 16u;
-#pragma unroll
-        for (int t = 0; t < NT * NT; ++t)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) w[t * 4 + q] = *(gvec)(base + t * 4096 + q * 1024 + off);   // A + t * 1024 + (q * 64 + lane) * 4 floats
-        __builtin_amdgcn_sched_barrier(0);                       // (the scheduler sinks the requests back in front of their MFMAs otherwise)
-    }
-    // y[ot] += A[ot][it] . x   for every ot (the order linear_acc_ops / linear_acc_stream use)
-    __device__ __forceinline__ void apply(int it, const f32x16& x, f32x16 (&y)[NT]) const {
-#pragma unroll
-        for (int ot = 0; ot < NT; ++ot)
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    y[ot] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[(ot * NT + it) * 4 + q][c], x[q * 4 + c], y[ot], 0, 0, 0);
-    }
-};
 
-// ablation switches of mp_fused for attribution runs (tools/diag/build_variant.sh abl_x -DGNNMP_ABL_X=1): WRONG results, timing only
-#ifndef GNNMP_ABL_NO_KE
-#define GNNMP_ABL_NO_KE 0            // no K_e stream (zeros instead)
-#endif
-#ifndef GNNMP_ABL_NO_GATHER
-#define GNNMP_ABL_NO_GATHER 0        // the chunk's A rows are the tile's own contiguous rows instead of the gathered sources
-#endif
-#ifndef GNNMP_ABL_NO_NODE
-#define GNNMP_ABL_NO_NODE 0          // no node phase
-#endif
-#ifndef GNNMP_ABL_NO_ATOMICS
-#define GNNMP_ABL_NO_ATOMICS 0       // no LDS max atomics
-#endif
-#ifndef GNNMP_ABL_KE_L2
-#define GNNMP_ABL_KE_L2 0            // every chunk reads the K_e tiles of the first 4096 edge slots (L2 hits): same instructions, no HBM stream
-#endif
 // the chunk loop's request / wait structure, per operand precision (experiments: -DGNNMP_MP_FLOW_BF16=0 / -DGNNMP_MP_FLOW_F32=1).
 // "New flow" = (a) the A stage is emptied into registers at the top of a chunk and the next chunk's rows are requested there, a whole
 // chunk ahead; (b) requests inside the loop are unconditional; (c) the prefetched registers' first uses are pinned behind the
@@ -1817,29 +1762,8 @@ struct GlobalW {
 #ifndef GNNMP_MP_FLOW_F32
 #define GNNMP_MP_FLOW_F32 0
 #endif
-#ifndef GNNMP_MP_SUM_MFMA
-#define GNNMP_MP_SUM_MFMA 0          // bf16 kernels: A[src] + B[dst] + K_e summed by the matrix pipe (packed rows x a 0/1 matrix), see the chunk body
-#endif
 #ifndef GNNMP_MP_ROWS_LDS
 #define GNNMP_MP_ROWS_LDS 1          // bf16 kernels, node phase: R rows in through LDS-DMA, X' / A' / PT rows out through LDS as whole rows
-#endif
-#ifndef GNNMP_MP_F32_NEWLOOP
-#define GNNMP_MP_F32_NEWLOOP 0       // experiment: the straight-line two-chunk loop for the round-3 flow as well
-#endif
-#ifndef GNNMP_MP_ASM_WAITS
-#define GNNMP_MP_ASM_WAITS 0         // experiment: round 3's inline-asm waits in the round-3 flow
-#endif
-#ifndef GNNMP_MP_GLOBALW
-// mp_fused_w8_kernel<64, 0>, experiment (round 5, profiles/r05_mp_w8f_globalw.txt): 0 = the layers' operands are read where they are
-// used (shipped); 1 = whole layers requested at once through GlobalW, two register sets, every layer requested under an earlier
-// layer's MFMAs (94 spilled registers); 2 = one register set, no spills.  The node phase of a tile shrinks (31.9 -> 23.5 us with 2)
-// and the OTHER wave of the SIMD pays for it (6.55 -> 6.81 us per chunk): the launch takes the same time (1.349 / 1.396 / 1.338 ms per
-// five launches at 2000 nodes x 64, 0.657 / 0.702 / 0.672 at 1000 x 64) -- the two waves of a SIMD share a throughput, the node
-// phase's round trips were being covered already.  Bit-identical in all three.
-#define GNNMP_MP_GLOBALW 0
-#endif
-#ifndef GNNMP_ABL_NO_EDGE
-#define GNNMP_ABL_NO_EDGE 0          // no edge phase at all (tile start + node phase only)
 #endif
 
 // LDS floats of mp_fused besides the staged MpEBlob.  COOP = 1: every wave owns a max-aggregation tile [32][D], 32 row
@@ -1877,13 +1801,7 @@ template <int D, int P, int COOP>
 #ifndef GNNMP_MP_WGS32B
 #define GNNMP_MP_WGS32B 2     // d = 32, bf16 operands: three workgroups per CU fit the LDS, but at 168 registers the kernel spills (0.54 vs 0.51 ms at the configs[4] shape)
 #endif
-#ifndef GNNMP_MP_NODEW_LDS64
-#define GNNMP_MP_NODEW_LDS64 0  // experiment: d = 64 bf16, the node phase's weights (40 KB) in LDS as well -> ONE 4-wave workgroup per CU
-#endif
-#ifndef GNNMP_MP_DEEP32
-#define GNNMP_MP_DEEP32 0     // experiment switch: K_e two chunks ahead at d = 32 fp32 (measured slower: 0.906 vs 0.875 ms)
-#endif
-__global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 && (P != 1 || GNNMP_MP_NODEW_LDS64)) ? 1 : ((P == 2 || D > 32) ? 2 : (P == 1 ? GNNMP_MP_WGS32B : GNNMP_MP_WGS32))) : 1) void mp_fused_kernel(MpFusedParams p) {
+__global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 && P != 1) ? 1 : ((P == 2 || D > 32) ? 2 : (P == 1 ? GNNMP_MP_WGS32B : GNNMP_MP_WGS32))) : 1) void mp_fused_kernel(MpFusedParams p) {
     constexpr int NT = D / 32;
     constexpr bool kCoop = COOP > 1;
     // few tiles, d = 32: the node phase is spread over waves (below); at d = 64 the eight-wave workgroup has 256 registers per
@@ -1891,20 +1809,12 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
     constexpr bool kSplitNode = kCoop && D == 32;
     constexpr bool kNewFlow = P == 1 ? (GNNMP_MP_FLOW_BF16 != 0) : (GNNMP_MP_FLOW_F32 != 0);
     constexpr bool kAsmTail = kNewFlow, kAEarly = kNewFlow, kUncond = kNewFlow, kLaunder = kNewFlow;
-    constexpr bool kSumMfma = GNNMP_MP_SUM_MFMA != 0 && P == 1 && kNewFlow;
     using LE = MpEBlob<D, P>;
     using LN = MpNBlob<D, P>;
     using G = RowGeom<D, P>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* wl = lds;                                             // MpEBlob
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
-    bf16x8 sel[2];                                               // kSumMfma: the 0/1 matrix's A operands (see the chunk body)
-    if constexpr (kSumMfma) {
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int t = 0; t < 8; ++t) sel[m][t] = j == 16 * m + 8 * (t >> 2) + 4 * h + (t & 3) ? (__bf16)1.0f : (__bf16)0.0f;
-    }
 #ifdef GNNMP_MP_TRACE
     // diagnostics build: [0] wave start, then per tile: start, end of the edge phase, end of the node phase (100 MHz clock)
     // 32 slots per wave: [0] start, [1 + 5 k .. 5 + 5 k] tile k < 5 (start, edge end, H, Y, node end), [28] HW_ID, [29] / [30] the
@@ -1963,7 +1873,7 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
 #ifndef GNNMP_MP_NODEW_LDS
 #define GNNMP_MP_NODEW_LDS 1
 #endif
-    constexpr bool kNodeWInLds = GNNMP_MP_NODEW_LDS && (D == 32 || (GNNMP_MP_NODEW_LDS64 && D == 64 && P == 1 && COOP == 1)) && P != 2;          // bf16x3: 31 KB, would leave one workgroup per CU
+    constexpr bool kNodeWInLds = GNNMP_MP_NODEW_LDS && D == 32 && P != 2;          // bf16x3: 31 KB, would leave one workgroup per CU
     float* wnl = lds + ((LE::size + 3) & ~3) + mp_lds_floats<D, P, COOP>();
     if constexpr (kNodeWInLds) stage(wnl, p.wn, LN::size);
     __syncthreads();
@@ -2050,7 +1960,7 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the previous job's LDS reads are done
         if constexpr (kCoop) __syncthreads();                    // ... by every wave of the workgroup
         // K_e streams from HBM: PF tiles of a chunk are requested KD chunks ahead and wait in registers
-        constexpr bool kDeep = P == 1 || (GNNMP_MP_DEEP32 && P == 0 && D == 32 && COOP == 1);   // packed bf16 tiles are cheap to hold (fp32, d = 32: measured 0.95 -> 0.99 ms)
+        constexpr bool kDeep = P == 1;                           // packed bf16 tiles are cheap to hold (fp32, d = 32, two chunks ahead: measured slower, 0.875 -> 0.906 ms)
         constexpr int PF = kDeep ? NT : 1;                       // prefetched tiles per chunk (the rest is loaded in place)
         constexpr int KD = kDeep ? 2 : 1;                        // chunks ahead
         constexpr int LPT = P == 1 ? 2 : 4;                      // load instructions per tile
@@ -2064,12 +1974,11 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
         // for all of them (s_waitcnt vmcnt(0)) the first time a loaded register is used -- with the requests behind wave-uniform
         // branches that drained the K_e tiles of the chunk after next in the middle of every chunk.
         auto ke_fetch = [&](int cc, KeRaw<P> (&dst)[PF]) {      // wave-uniform cc
-            if (GNNMP_ABL_NO_KE) return;
             if (!kUncond && cc >= end) return;
 #pragma unroll
             for (int t = 0; t < PF; ++t) {
                 const int sl = cc + j < end ? cc + j : beg;
-                load_edge_slot_raw<P, NT>(p.Ke, GNNMP_ABL_KE_L2 ? (sl & 4095) : sl, h, t, dst[t]);
+                load_edge_slot_raw<P, NT>(p.Ke, sl, h, t, dst[t]);
             }
         };
         int pre_rec_c = 0, pre_rec_n = 0;
@@ -2099,7 +2008,7 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
                 if (beg + 32 + j < end) pre_rec_n = p.rec32[beg + 32 + j];
                 wait_vmcnt<0>();
                 if (beg < end) {
-                    const int mine_row = (beg + j < end) ? (GNNMP_ABL_NO_GATHER ? t0 + j : n0 + (pre_rec_c & 0x7ffffff)) : t0;
+                    const int mine_row = (beg + j < end) ? n0 + (pre_rec_c & 0x7ffffff) : t0;
                     dma_rows<D, P>(p.A, [&](int sr) { return __builtin_amdgcn_ds_bpermute(sr * 4, mine_row); }, astage, lane);
                     if constexpr (kKeEarly) {                               // ... and its K_e tiles: their HBM latency runs under the MFMAs
                         ke_fetch(beg, qa);
@@ -2155,7 +2064,7 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
         // record (source id local to the graph | target's row in this tile << 27) of the one after is requested
         constexpr int STEP = 32 * COOP;
         const int first = beg + (kCoop ? 32 * wave : 0);
-        auto src_row = [&](int rec, bool valid) { return valid ? (GNNMP_ABL_NO_GATHER ? t0 + j : n0 + (rec & 0x7ffffff)) : t0; };
+        auto src_row = [&](int rec, bool valid) { return valid ? n0 + (rec & 0x7ffffff) : t0; };
         int rec_c = pre_rec_c, rec_n = pre_rec_n;
         if constexpr (kCoop) {
             if (first + j < end) rec_c = p.rec32[first + j];
@@ -2237,26 +2146,6 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
             }
             // hidden = relu(A[src] + B[dst] + K_e), one 32-feature tile at a time, straight into the swapped MFMA
             linear_acc_stream<P, NT, true, true>(wl + LE::w2, [&](int it, f32x16& x) {
-                if constexpr (kSumMfma) {
-                    // The three packed bf16 tiles are B operands as they are: register r of lane (edge, h) is feature
-                    // phi(r, h), so D = S . X with the 0/1 matrix S[i][k-slot (m, h, t)] = [i == phi(8 m + t, h)] puts
-                    // every value into the accumulator register it belongs to -- in fp32, exactly (1.0 x v, fifteen zero
-                    // products), and summing the three tiles is the accumulation: (A + B) + K_e like the vector form.
-                    // 6 MFMAs (192 matrix-pipe cycles, a pipe that idles 90 % of this loop) replace 48 conversion and 16
-                    // packed-add VALU instructions (256 issue cycles) per 32-feature tile.
-                    using bf16x8v = bf16x8;
-                    const bf16x8v alo = araw[it].lo, ahi = araw[it].hi, blo = braw[it].lo, bhi = braw[it].hi;
-                    f32x16 acc = splat16(0.f);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sel[0], alo, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sel[1], ahi, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sel[0], blo, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sel[1], bhi, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sel[0], cur[it < PF ? it : 0].lo, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sel[1], cur[it < PF ? it : 0].hi, acc, 0, 0, 0);
-                    x = acc;
-                    if (it == NT - 1) ke_fetch(c0 + KD * STEP, fill);
-                    return;
-                }
                 f32x16 a, b;
                 if (it < PF) expand_raw<P>(cur[it < PF ? it : 0], x); else load_edge_slot_tile<P, NT>(p.Ke, eslot, h, it, x);
                 if constexpr (kAEarly) {
@@ -2276,15 +2165,6 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
                     ke_fetch(c0 + KD * STEP, fill);
                   }
                 }
-#ifdef GNNMP_DBG_NOB
-                b = splat16(0.f);
-#endif
-#ifdef GNNMP_DBG_NOA
-                a = splat16(0.f);
-#endif
-#ifdef GNNMP_DBG_NOKE
-                x = splat16(0.f);
-#endif
                 x += a + b;                                     // the ReLU is applied by linear_acc_stream
             }, M, lane);
             if (end - c0 < 32) {                                 // wave-uniform: the last, partial chunk -- pad edges aggregate -inf
@@ -2325,22 +2205,13 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
                          "ds_read_b128 %3, %4 offset:96\n\ts_waitcnt lgkmcnt(0)"
                          : "=&v"(o4[0]), "=&v"(o4[1]), "=&v"(o4[2]), "=&v"(o4[3])
                          : "v"(lds_addr(dl) + 16u * h), "v"(M[0][0]), "v"(M[NT - 1][15]) : "memory");
-            if (!GNNMP_ABL_NO_ATOMICS) {
-                const unsigned agg0 = lds_addr(agg) + 4u * j;
+            const unsigned agg0 = lds_addr(agg) + 4u * j;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const unsigned a = agg0 + 4u * (unsigned)o4[r >> 2][r & 3];
-#pragma unroll
-                    for (int ot = 0; ot < NT; ++ot)
-                        asm volatile("ds_max_f32 %0, %1 offset:%2" ::"v"(a), "v"(M[ot][r]), "n"(ot * 128) : "memory");
-                }
-            } else {
-                float keep = 0.f;
+            for (int r = 0; r < 16; ++r) {
+                const unsigned a = agg0 + 4u * (unsigned)o4[r >> 2][r & 3];
 #pragma unroll
                 for (int ot = 0; ot < NT; ++ot)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) keep += M[ot][r] + (float)o4[r >> 2][r & 3];
-                if (keep == 123.456f) agg[j] = keep;
+                    asm volatile("ds_max_f32 %0, %1 offset:%2" ::"v"(a), "v"(M[ot][r]), "n"(ot * 128) : "memory");
             }
             }
             __builtin_amdgcn_wave_barrier();
@@ -2348,15 +2219,15 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
         // two chunks per trip in ONE basic block (exit test at the bottom), an odd last chunk behind the loop: with the exit between
         // the two bodies the register allocator copied half of the in-flight K_e registers on the back edge -- and a copy of a
         // register that a load is still filling needs s_waitcnt vmcnt(0)
-        if constexpr (!kNewFlow && !GNNMP_MP_F32_NEWLOOP) {
-            for (int c0 = first; c0 < (GNNMP_ABL_NO_EDGE ? first : end); c0 += 2 * STEP) {      // round-3 form (exact-fp32 kernels)
+        if constexpr (!kNewFlow) {
+            for (int c0 = first; c0 < end; c0 += 2 * STEP) {      // round-3 form (exact-fp32 kernels)
                 if constexpr (KD == 2) chunk(c0, qa, qa); else chunk(c0, qa, qb);
                 if (c0 + STEP < end) {                           // wave-uniform
                     if constexpr (KD == 2) chunk(c0 + STEP, qb, qb); else chunk(c0 + STEP, qb, qa);
                 }
             }
         } else {
-            const int stop = GNNMP_ABL_NO_EDGE ? first : end;
+            const int stop = end;
             int c0 = first;
             for (; c0 + STEP < stop; c0 += 2 * STEP) {
                 if constexpr (KD == 2) { chunk(c0, qa, qa); chunk(c0 + STEP, qb, qb); }
@@ -2412,7 +2283,6 @@ __global__ __launch_bounds__(COOP == 1 ? 256 : COOP * 64, COOP == 1 ? ((D > 32 &
             }
             continue;                                            // the next job's first barrier collects the workgroup
         }
-        if (GNNMP_ABL_NO_NODE) { wait_all(); continue; }
         // ---- node phase.  X and R rows of the tile (contiguous, fp32) come through the two stages as well; the weights
         // (MpNBlob) are read from global memory as MFMA operands (at d = 64 the pointer is laundered per job so that the
         // compiler does not hoist those loop-invariant loads out of the job loop into ~70 registers)
@@ -2564,11 +2434,6 @@ __host__ __device__ constexpr int mp_w8_lds_floats() {
            8 * (32 * kAggPitch<D> + 32 + RowGeom<D, P>::STAGE_FLOATS);
 }
 
-#ifdef GNNMP_DBG_ROWS0
-#define GNNMP_ROW0(x) 0
-#else
-#define GNNMP_ROW0(x) (x)
-#endif
 template <int D, int P>
 __global__ __launch_bounds__(512, 1) void mp_fused_w8_kernel(MpFusedParams p) {
     constexpr int NT = D / 32;
@@ -2582,7 +2447,6 @@ __global__ __launch_bounds__(512, 1) void mp_fused_w8_kernel(MpFusedParams p) {
     constexpr bool kAl = P == 1;
     constexpr int XP = P == 1 ? 1 : 0;                           // X rows are stored in bf16 in the bf16 mode
     constexpr bool kWLds = P == 1;                               // node-phase matrices in LDS
-    constexpr bool kWGlobal = P == 0 && GNNMP_MP_GLOBALW;        // fp32: whole layers requested at once from global memory (GlobalW)
     using LE = MpEBlob<D, P>;
     using LN = MpNBlob<D, P>;
     using G = RowGeom<D, P>;
@@ -2683,11 +2547,7 @@ __global__ __launch_bounds__(512, 1) void mp_fused_w8_kernel(MpFusedParams p) {
         auto ke_fetch = [&](int cc, KeRaw<P> (&dst)[PF]) {      // wave-uniform cc; unconditional (see mp_fused_kernel)
 #pragma unroll
             for (int t = 0; t < PF; ++t) {
-#ifdef GNNMP_DBG_KE0
-                const int sl = beg;                              // (traffic attribution: no K_e stream)
-#else
                 const int sl = cc + j < (kAl ? end_al : end) ? cc + j : beg;
-#endif
                 load_edge_slot_raw<P, NT>(p.Ke, sl, h, t, dst[t]);
             }
         };
@@ -2695,7 +2555,7 @@ __global__ __launch_bounds__(512, 1) void mp_fused_w8_kernel(MpFusedParams p) {
         int pre_rec_c = 0, pre_rec_n = 0;
         int l0 = lane;                                           // (laundered per tile: see the node phase)
         asm volatile("" : "+v"(l0));
-        dma_rows<D, XP, kNtR>(p.X, [&](int sr) { return GNNMP_ROW0(t0 + sr); }, agg, l0);           // X rows (4 KB bf16 / 8 KB fp32) through the aggregation tile
+        dma_rows<D, XP, kNtR>(p.X, [&](int sr) { return t0 + sr; }, agg, l0);           // X rows (4 KB bf16 / 8 KB fp32) through the aggregation tile
         if (first + j >= beg && first + j < end) pre_rec_c = p.rec32[first + j];
         if (first + 32 + j < end) pre_rec_n = p.rec32[first + 32 + j];
         wait_vmcnt<0>();
@@ -2712,11 +2572,7 @@ __global__ __launch_bounds__(512, 1) void mp_fused_w8_kernel(MpFusedParams p) {
 #pragma unroll
             for (int q = 0; q < D / 8; ++q) *reinterpret_cast<f32x4*>(agg + j * AP + h * (D / 2) + q * 4) = ninf;
         }
-#ifdef GNNMP_DBG_AOWN
-        auto src_row = [&](int rec, bool valid) { return t0 + j; };           // (traffic attribution: no gather)
-#else
         auto src_row = [&](int rec, bool valid) { return valid ? n0 + (rec & 0x7ffffff) : t0; };
-#endif
         int rec_c = pre_rec_c, rec_n = pre_rec_n;
         if (beg < end) {                                         // the first chunk's A rows and the first two chunks' K_e travel under the MFMAs below
             const int mine_row = src_row(rec_c, first + j >= beg && first + j < end);
@@ -2729,18 +2585,8 @@ __global__ __launch_bounds__(512, 1) void mp_fused_w8_kernel(MpFusedParams p) {
             f32x16 z[NT];
 #pragma unroll
             for (int tt = 0; tt < NT; ++tt) z[tt] = splat16(0.f);
-            if constexpr (kWGlobal) {
-                GlobalW<NT> gw;
-                gw.request(wm3, lane);
-#pragma unroll
-                for (int it = 0; it < NT; ++it) {
-                    f32x16 x;
-                    expand_stage_raw<XP>(xr[it], x);
-                    gw.apply(it, x, z);
-                }
-            } else {
-                linear_acc_stream<P, NT, false>(wm3, [&](int it, f32x16& x) { expand_stage_raw<XP>(xr[it], x); }, z, lane);
-            }
+            linear_acc_stream<P, NT, false>(wm3, [&](int it, f32x16& x) { expand_stage_raw<XP>(xr[it], x); }, z, lane);
+        
             make_ops<P, NT>(z, bpk);                            // (bf16: rounded exactly like the rows mp_fused_kernel writes into its B stage)
         }
         bool x_requested = false;
@@ -2776,7 +2622,7 @@ __global__ __launch_bounds__(512, 1) void mp_fused_w8_kernel(MpFusedParams p) {
             } else {
                 int lx = lane;                                   // (laundered: these addresses must not be hoisted out of the chunk loop)
                 asm volatile("" : "+v"(lx));
-                dma_rows<D, XP, kNtR>(p.X, [&](int sr) { return GNNMP_ROW0(t0 + sr); }, astage, lx);
+                dma_rows<D, XP, kNtR>(p.X, [&](int sr) { return t0 + sr; }, astage, lx);
                 x_requested = true;
             }
             {
@@ -2818,15 +2664,6 @@ __global__ __launch_bounds__(512, 1) void mp_fused_w8_kernel(MpFusedParams p) {
                 if (it < PF) expand_raw<P>(cur[it < PF ? it : 0], x); else load_edge_slot_tile<P, NT>(p.Ke, eslot, h, it, x);
                 expand_stage_raw<P>(araw[it], a);
                 if (it == NT - 1) ke_fetch(c0 + KD * STEP, KD == 2 ? cur : fill);
-#ifdef GNNMP_DBG_NOB
-                b = splat16(0.f);
-#endif
-#ifdef GNNMP_DBG_NOA
-                a = splat16(0.f);
-#endif
-#ifdef GNNMP_DBG_NOKE
-                x = splat16(0.f);
-#endif
                 x += a + b;
             }, M, lane);
             if (end - c0 < 32 || (kAl && c0 < beg)) {            // a partial chunk (wave-uniform): pad edges aggregate -inf
@@ -2867,159 +2704,67 @@ __global__ __launch_bounds__(512, 1) void mp_fused_w8_kernel(MpFusedParams p) {
         // ~40 registers that then spill around the chunk loop: the lane id is laundered per tile so that they are recomputed here)
         int ln = lane;
         asm volatile("" : "+v"(ln));
-        if (!x_requested) dma_rows<D, XP, kNtR>(p.X, [&](int sr) { return GNNMP_ROW0(t0 + sr); }, astage, ln);     // a tile without incoming edges
-        if constexpr (kWGlobal) {
-            // exact fp32: two register sets of layer operands (GlobalW), each layer requested while an earlier layer's MFMAs run
-#if GNNMP_MP_GLOBALW == 2
-            GlobalW<NT> ga;
-            GlobalW<NT>& gb = ga;
-            ga.request(wn + LN::wlx, lane);
-#else
-            GlobalW<NT> ga, gb;
-            ga.request(wn + LN::wlx, lane);
-            gb.request(wn + LN::wla, lane);
-#endif
-            f32x16 H[NT];
-            load_vec<NT>(wn + LN::bl, H, lane);
-            wait_vmcnt<0>();                                     // X rows in the A stage, both layers' operands
+        if (!x_requested) dma_rows<D, XP, kNtR>(p.X, [&](int sr) { return t0 + sr; }, astage, ln);     // a tile without incoming edges
+        f32x16 H[NT];
+        load_vec<NT>(wn + LN::bl, H, lane);
+        wait_vmcnt<0>();
+        linear_acc_stream<P, NT, false>(wn + LN::wlx, [&](int it, f32x16& x) { read_stage_tile<D, XP>(astage, j, h, it, x); }, H, lane);
+        linear_acc_stream<P, NT, false>(wn + LN::wla, [&](int it, f32x16& x) {
 #pragma unroll
-            for (int it = 0; it < NT; ++it) {
-                f32x16 x;
-                read_stage_tile<D, XP>(astage, j, h, it, x);
-                ga.apply(it, x, H);
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(agg + j * AP + it * 32 + q * 8 + h * 4);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) x[q * 4 + c] = dg == 0 ? 0.f : a[c];      // torch_scatter: no incoming edge -> 0
             }
-#if GNNMP_MP_GLOBALW == 2
-            gb.request(wn + LN::wla, lane);
-#else
-            ga.request(wn + LN::m1, lane);                       // (under W_la's MFMAs)
-#endif
-#pragma unroll
-            for (int it = 0; it < NT; ++it) {
-                f32x16 x;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x4 a = *reinterpret_cast<const f32x4*>(agg + j * AP + it * 32 + q * 8 + h * 4);
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) x[q * 4 + c] = dg == 0 ? 0.f : a[c];      // torch_scatter: no incoming edge -> 0
-                }
-                gb.apply(it, x, H);
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_wave_barrier();                    // the aggregation tile has been read by every lane: it takes the R rows
-            dma_rows<D, 0, kNtR>(p.R, [&](int sr) { return GNNMP_ROW0(t0 + sr); }, agg, ln);
-#if GNNMP_MP_GLOBALW == 2
-            ga.request(wn + LN::m1, lane);
-#else
-            gb.request(wn + LN::m2, lane);
-#endif
-            GNNMP_TRC();                                         // (diagnostics build) H done
-            if (p.store_h) store_row<NT>(p.Hout + (size_t)node * D, H, h);
+        }, H, lane);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();                        // the aggregation tile has been read by every lane: it takes the R rows
+        dma_rows<D, 0, kNtR>(p.R, [&](int sr) { return t0 + sr; }, agg, ln);
+        GNNMP_TRC();                                             // (diagnostics build) H done
+        if (p.store_h) store_row<NT>(p.Hout + (size_t)node * D, H, h);
+        BOp<P> yop[NT];
+        {
             f32x16 y[NT];
-            wait_vmcnt<0>();                                     // R rows, M1, M2
+            wait_vmcnt<0>();
 #pragma unroll
             for (int tt = 0; tt < NT; ++tt) read_stage_tile<D, 0>(agg, j, h, tt, y[tt]);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int it = 0; it < NT; ++it) ga.apply(it, H[it], y);
-#if GNNMP_MP_GLOBALW == 2
-            gb.request(wn + LN::m2, lane);
-#else
-            if (p.last) ga.request(wn + LN::m3, lane);
-#endif
+            linear_acc_p<P, NT, NT>(wn + LN::m1, H, y, lane);
             GNNMP_TRC();                                         // (diagnostics build) Y done
             __builtin_amdgcn_wave_barrier();
             write_stage_tiles<D, XP, NT>(astage, j, h, y);       // X' rows -> A stage -> whole rows out
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
             store_rows_coalesced<D, XP, kNtW>(p.Xout, (size_t)t0, astage, ln);
-            {
-                f32x16 z[NT];
-#pragma unroll
-                for (int tt = 0; tt < NT; ++tt) z[tt] = splat16(0.f);
-#pragma unroll
-                for (int it = 0; it < NT; ++it) gb.apply(it, y[it], z);
-#if GNNMP_MP_GLOBALW == 2
-                if (p.last) ga.request(wn + LN::m3, lane);
-#endif
-                write_stage_tiles<D, P, NT>(agg, j, h, z);       // A' rows -> the aggregation tile -> whole rows out
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_wave_barrier();
-                store_rows_coalesced<D, P, kNtW>(p.Aout, (size_t)t0, agg, ln);
-            }
-            if (p.last) {                                        // PT for the policy head
-                f32x16 z[NT];
-#pragma unroll
-                for (int tt = 0; tt < NT; ++tt) z[tt] = splat16(0.f);
-#pragma unroll
-                for (int it = 0; it < NT; ++it) ga.apply(it, y[it], z);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the A stage's X' rows have been read out
-                __builtin_amdgcn_wave_barrier();
-                write_stage_tiles<D, P, NT>(astage, j, h, z);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_wave_barrier();
-                store_rows_coalesced<D, P, kNtW>(p.Bout, (size_t)t0, astage, ln);
-            }
-        } else {
-            f32x16 H[NT];
-            load_vec<NT>(wn + LN::bl, H, lane);
-            wait_vmcnt<0>();
-            linear_acc_stream<P, NT, false>(wn + LN::wlx, [&](int it, f32x16& x) { read_stage_tile<D, XP>(astage, j, h, it, x); }, H, lane);
-            linear_acc_stream<P, NT, false>(wn + LN::wla, [&](int it, f32x16& x) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x4 a = *reinterpret_cast<const f32x4*>(agg + j * AP + it * 32 + q * 8 + h * 4);
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) x[q * 4 + c] = dg == 0 ? 0.f : a[c];      // torch_scatter: no incoming edge -> 0
-                }
-            }, H, lane);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_wave_barrier();                        // the aggregation tile has been read by every lane: it takes the R rows
-            dma_rows<D, 0, kNtR>(p.R, [&](int sr) { return GNNMP_ROW0(t0 + sr); }, agg, ln);
-            GNNMP_TRC();                                             // (diagnostics build) H done
-            if (p.store_h) store_row<NT>(p.Hout + (size_t)node * D, H, h);
-            BOp<P> yop[NT];
-            {
-                f32x16 y[NT];
-                wait_vmcnt<0>();
-#pragma unroll
-                for (int tt = 0; tt < NT; ++tt) read_stage_tile<D, 0>(agg, j, h, tt, y[tt]);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                linear_acc_p<P, NT, NT>(wn + LN::m1, H, y, lane);
-                GNNMP_TRC();                                         // (diagnostics build) Y done
-                __builtin_amdgcn_wave_barrier();
-                write_stage_tiles<D, XP, NT>(astage, j, h, y);       // X' rows -> A stage -> whole rows out
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_wave_barrier();
-                store_rows_coalesced<D, XP, kNtW>(p.Xout, (size_t)t0, astage, ln);
-                make_ops<P, NT>(y, yop);
-            }
-            {
-                f32x16 z[NT];
-#pragma unroll
-                for (int tt = 0; tt < NT; ++tt) z[tt] = splat16(0.f);
-                linear_acc_ops<P, NT, NT>(wn + LN::m2, yop, z, lane);
-                write_stage_tiles<D, P, NT>(agg, j, h, z);           // A' rows -> (bf16: first half of) the aggregation tile -> whole rows out
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_wave_barrier();
-                store_rows_coalesced<D, P, kNtW>(p.Aout, (size_t)t0, agg, ln);
-            }
-            if (p.last) {                                            // PT for the policy head (B' is recomputed by the next iteration otherwise)
-                f32x16 z[NT];
-#pragma unroll
-                for (int tt = 0; tt < NT; ++tt) z[tt] = splat16(0.f);
-                linear_acc_ops<P, NT, NT>(wn + LN::m3, yop, z, lane);
-                // bf16: second half of the aggregation tile; fp32 (A' fills the whole tile): the A stage, whose X' rows have been read out
-                float* ps = P == 1 ? agg + G::STAGE_FLOATS : astage;
-                if constexpr (P != 1) {
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_wave_barrier();
-                }
-                write_stage_tiles<D, P, NT>(ps, j, h, z);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_wave_barrier();
-                store_rows_coalesced<D, P, kNtW>(p.Bout, (size_t)t0, ps, ln);
-            }
+            make_ops<P, NT>(y, yop);
         }
+        {
+            f32x16 z[NT];
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt) z[tt] = splat16(0.f);
+            linear_acc_ops<P, NT, NT>(wn + LN::m2, yop, z, lane);
+            write_stage_tiles<D, P, NT>(agg, j, h, z);           // A' rows -> (bf16: first half of) the aggregation tile -> whole rows out
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            store_rows_coalesced<D, P, kNtW>(p.Aout, (size_t)t0, agg, ln);
+        }
+        if (p.last) {                                            // PT for the policy head (B' is recomputed by the next iteration otherwise)
+            f32x16 z[NT];
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt) z[tt] = splat16(0.f);
+            linear_acc_ops<P, NT, NT>(wn + LN::m3, yop, z, lane);
+            // bf16: second half of the aggregation tile; fp32 (A' fills the whole tile): the A stage, whose X' rows have been read out
+            float* ps = P == 1 ? agg + G::STAGE_FLOATS : astage;
+            if constexpr (P != 1) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+            }
+            write_stage_tiles<D, P, NT>(ps, j, h, z);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            store_rows_coalesced<D, P, kNtW>(p.Bout, (size_t)t0, ps, ln);
+        }
+    
         GNNMP_TRC();
     }
     GNNMP_TRC_END();
@@ -3380,7 +3125,7 @@ extern "C" long long gnnmp_debug_mp_trace(long long* dst, long long cap) {
 #endif
 template <int D, int P, int COOP>
 static hipError_t launch_mp_fused_t(const MpFusedParams& p, hipStream_t st) {
-    const size_t lds = (size_t)(((MpEBlob<D, P>::size + 3) & ~3) + mp_lds_floats<D, P, COOP>() + (GNNMP_MP_NODEW_LDS && (D == 32 || (GNNMP_MP_NODEW_LDS64 && D == 64 && P == 1 && COOP == 1)) && P != 2 ? ((MpNBlob<D, P>::size + 3) & ~3) : 0)) * sizeof(float);
+    const size_t lds = (size_t)(((MpEBlob<D, P>::size + 3) & ~3) + mp_lds_floats<D, P, COOP>() + (GNNMP_MP_NODEW_LDS && D == 32 && P != 2 ? ((MpNBlob<D, P>::size + 3) & ~3) : 0)) * sizeof(float);
     hipError_t e = set_lds(mp_fused_kernel<D, P, COOP>, lds);
     if (e != hipSuccess) return e;
     if (COOP == 1) {
