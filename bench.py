@@ -469,7 +469,7 @@ def main():
                     help='extra steps timed with TWO batches in flight on two HIP streams (own workspaces and score buffers): what a '
                          'serving loop over independent batches gets when one forward fills the launch tails of the other; reported next '
                          'to, never instead of, `value`.  Off by default (0): its overlapped launches would enter the per-kernel '
-                         'averages of a `rocprofv3 --stats` run of the default command; tools/profile_r05.sh runs it with 20')
+                         'averages of a `rocprofv3 --stats` run of the default command; tools/profile_r06.sh runs it with 20')
     ap.add_argument('--inflight-depth', type=int, default=2, help='batches in flight for --inflight-steps (streams, workspaces, score buffers)')
     ap.add_argument('--bf16x3-steps', type=int, default=5,
                     help='extra steps timed in the opt-in bf16x3 mode (fp32-class results from the bf16 matrix pipe, '
@@ -845,7 +845,7 @@ def main():
                        'single_graph_us': single_us},
             'roofline': roof,
         }
-        if world == 1 and args.other_configs_steps > 0 and (args.env, args.nodes, args.k1, args.mlp_dtype) == ('maze2', 1000, 8, 'fp32'):
+        if world == 1 and args.other_configs_steps > 0 and args.strong == 0 and (args.env, args.nodes, args.k1, args.mlp_dtype, args.graphs) == ('maze2', 1000, 8, 'fp32', 256):
             del batch
             torch.cuda.empty_cache()
             res['config']['other_configs_gpu'] = {key: other_config_leg(key, oe, on, ok, og, od, args.loop, args.other_configs_steps, 5, dev)

@@ -17,7 +17,7 @@ from conftest import GOLDEN, REPO
 
 pytestmark = pytest.mark.gpu
 BENCH_ARGS = ['--steps', '3', '--warmup', '1', '--graphs', '32', '--no-cpu-baseline', '--planner-problems', '0', '--pcie-steps', '0', '--dense-steps', '0',
-              '--bf16x3-steps', '0', '--single-steps', '0']
+              '--bf16x3-steps', '0', '--single-steps', '0', '--other-configs-steps', '0']
 
 
 def _free_port():

@@ -68,5 +68,6 @@ def test_dropin_forward_span_is_one_millisecond(reference_kwargs):
             medians.append(sorted(ts)[len(ts) // 2])
     finally:
         torch.set_num_threads(threads0)
+    print('drop-in forward span (N = 1002, k1 = 41), reference_kwargs=%s: medians of 3 x 15 calls %s ms' % (reference_kwargs, [round(x * 1e3, 3) for x in medians]))
     # measured on MI355X: 0.55-0.8 ms (obstacles only), 0.7-0.95 ms (every reference keyword); the kernels are 0.24 ms of it
     assert min(medians) <= 1.0e-3, 'drop-in forward span: medians %s ms' % [round(x * 1e3, 3) for x in medians]
