@@ -1016,153 +1016,6 @@ __global__ __launch_bounds__(512, 1) void sm_msg_stream_kernel(SmParams p, int w
 #endif
 }
 
-// ---------------------------------------------------------------------------------------------------
-// Mid-size fp32 batches (a few hundred problems): the split form WITH streamed weights.  Two edge tiles per workgroup of eight waves
-// (four waves per tile, wave w = output tile w of every layer, tiles exchanged through LDS -- sm_msg_split_kernel's arithmetic, bit for
-// bit), two workgroups per CU (64 KB of LDS each: two 16 KB column slots + one 16 KB exchange buffer per tile; <= 128 registers).  Where
-// the split kernel fetches every MFMA's A operand from L2 (matrix pipe 35 % busy, waves waiting 55 % of their life), the workgroup's eight
-// waves walk the layers together and a layer's matrix passes through LDS column by column behind LDS-DMA like in sm_msg_stream_kernel;
-// unlike there a tile is one quarter of a wave's chain (16 MFMAs per column), the second workgroup of the CU fills the first one's
-// latencies, and a workgroup is two tiles, so 2304 tiles in use quantise as 1152 short workgroups on 512 slots instead of 288 long
-// rounds on 256.  Target rows come from target workgroups (two path tiles each) at the head of the grid, as in the streamed kernel.
-// ---------------------------------------------------------------------------------------------------
-template <int D, int P>
-__global__ __launch_bounds__(512, 4) void sm_msg_split2_kernel(SmParams p, int wgs_t) {
-    constexpr int NT = D / 32;
-    constexpr int TF = Prec<P>::TF;
-    constexpr int CH = NT * TF;                           // floats of one column (NT tiles) of a packed matrix
-    constexpr int PER_TILE = TF / 256, PIECES = NT * PER_TILE;
-    constexpr int XB = NT * 16 * 64;                      // floats of one tile's exchange buffer
-    static_assert(P == 0, "hand-issued operand reads: exact-fp32 tiles");
-    extern __shared__ __attribute__((aligned(16))) float lds[];     // [2 column slots][2 exchange buffers]
-    __shared__ int s_notready;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
-    const int grp = wave >> 2, w4 = wave & 3;
-    const float* W = p.w;
-    float* xbuf = lds + 2 * CH + grp * XB;
-    if ((int)blockIdx.x < wgs_t) {
-        // ---------------- target workgroup: path tiles 2 blockIdx.x + grp (sm_msg_split_kernel's target role, operands from L2)
-        const int slot_t = blockIdx.x * 2 + grp;
-        const bool act = slot_t < p.tile_cnt[p.parity * 2 + 1];
-        if (__syncthreads_or(act ? 1 : 0) == 0) return;
-        const int tile = act ? p.plist[slot_t] : 0;
-        const int b = act ? p.ptile_prob[tile] : 0;
-        const int PN = sm_pp(p, b + 1) - sm_pp(p, b);
-        const int n = tile * 32 + j - sm_poff(p, b);
-        const int dst = (act && n >= 0 && n < PN) ? n : 0;
-        f32x16 mine, x[NT], z[1];
-        load_vec<1>(W + p.L.b00 + w4 * 32, z, lane);
-        sm_node_code_tile<NT, P>(p, sm_node_in(p, b, dst), w4, mine, lane);
-        sm_exchange<NT>(xbuf, w4, mine, x, lane);
-        linear_acc_p<P, 1, NT>(W + p.L.wdst + (size_t)w4 * NT * TF, x, z, lane);
-        if (act) store_row<1>(p.tgt + (size_t)(tile * 32 + j) * D + w4 * 32, z, h);
-        __threadfence();
-        __syncthreads();
-        if (act && w4 == 0 && lane == 0) __hip_atomic_store(&p.tgt_flag[tile], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        return;
-    }
-    // ---------------- edge workgroup: edge tiles 2 (blockIdx.x - wgs_t) + grp of the compact list
-    const int n_e = p.tile_cnt[p.parity * 2 + 0];
-    const int slot_e = ((int)blockIdx.x - wgs_t) * 2 + grp;
-    if (((int)blockIdx.x - wgs_t) * 2 >= n_e) return;    // workgroup-uniform: beyond the tiles in use
-    int step = 0;
-    auto issue = [&](const float* Wm, int it, int sl) {
-        for (int q = wave; q < PIECES; q += 8) {
-            const int ot = q / PER_TILE, piece = q % PER_TILE;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Wm + (size_t)(ot * NT + it) * TF + piece * 256 + lane * 4),
-                                             (__attribute__((address_space(3))) void*)(lds + sl * CH + ot * TF + piece * 256), 16, 0, 0);
-        }
-    };
-    auto barrier = [&]() {
-        __builtin_amdgcn_s_waitcnt(7 << 4);               // vmcnt(0) lgkmcnt(0)
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-    };
-    // y += sum_it Wm[w4][it] x[it]: this wave's output tile of a streamed layer (operand reads issued by hand, see sm_msg_stream_kernel)
-    auto layer = [&](const float* Wm, const float* Wnext, const f32x16 (&x)[NT], f32x16& y) {
-#pragma unroll
-        for (int it = 0; it < NT; ++it) {
-            barrier();                                    // the column has landed for everyone; the other slot is free
-            if (it + 1 < NT) issue(Wm, it + 1, (step + 1) & 1);
-            else if (Wnext) issue(Wnext, 0, (step + 1) & 1);
-            const unsigned a = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)lds + (unsigned)(((step & 1) * CH + w4 * TF) * 4) + 16u * (unsigned)lane;
-            f32x4 w[4];
-            asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\tds_read_b128 %2, %4 offset:2048\n\tds_read_b128 %3, %4 offset:3072\n\t"
-                         "s_waitcnt lgkmcnt(0)"
-                         : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]) : "v"(a) : "memory");
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) y = __builtin_amdgcn_mfma_f32_32x32x2f32(w[q][c], x[it][q * 4 + c], y, 0, 0, 0);
-            ++step;
-        }
-    };
-    issue(W + p.L.w3, 0, 0);                              // node_code.3's first column is on its way while the tile is looked up
-    const bool active = slot_e < n_e;
-    const int tile = active ? p.elist[slot_e] : 0;
-    const int b = active ? p.etile_prob[tile] : 0;
-    const int e = tile * 32 + j;
-    const bool valid = active && (e - sm_eoff(p, b)) < p.e_count[b];
-    const int src = valid ? p.e_src[e] : 0, dst = valid ? p.e_dst[e] : 0;
-    const int trow = sm_poff(p, b) + dst;
-    if (threadIdx.x == 0) s_notready = 0;
-    f32x16 y1;
-    {
-        // x_j (source), this wave's 32 features: layer 0 whole (a few MFMAs from the raw inputs, like every wave of the split kernel)
-        f32x16 hdn[NT], yv[1];
-        load_vec<NT>(W + p.L.b0, hdn, lane);
-        linear_in_p<P, NT>(W + p.L.as0, p.L.ks, sm_node_in(p, b, src), hdn, lane);
-        relu_<NT>(hdn);
-        load_vec<1>(W + p.L.b3 + w4 * 32, yv, lane);
-        y1 = yv[0];
-        layer(W + p.L.w3, W + p.L.wsrc, hdn, y1);
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) xbuf[(w4 * 16 + r) * 64 + lane] = y1[r];
-    {
-        bool ready = !active;
-        for (int spin = 0; spin < 4096 && !ready; ++spin) {
-            const int f = __hip_atomic_load(&p.tgt_flag[trow >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            ready = __all(f != 0);
-            if (!ready) __builtin_amdgcn_s_sleep(8);
-        }
-        if (!ready && lane == 0) s_notready = 1;
-    }
-    barrier();                                            // x_j tiles published; the flags' verdict is in
-    f32x16 z[1];
-    if (s_notready != 0) {
-        // the rare path (a flag did not show up in time): the target half here, operands from L2, same bits.  It borrows the exchange
-        // buffer (nobody has read the x_j tiles yet) and the x_j tiles are published again afterwards; wsrc's first column stays
-        // where it landed (nothing here touches the slots)
-        f32x16 mine, x[NT];
-        load_vec<1>(W + p.L.b00 + w4 * 32, z, lane);
-        sm_node_code_tile<NT, P>(p, sm_node_in(p, b, dst), w4, mine, lane);
-        sm_exchange<NT>(xbuf, w4, mine, x, lane);
-        linear_acc_p<P, 1, NT>(W + p.L.wdst + (size_t)w4 * NT * TF, x, z, lane);
-        barrier();
-#pragma unroll
-        for (int r = 0; r < 16; ++r) xbuf[(w4 * 16 + r) * 64 + lane] = y1[r];
-        barrier();
-    } else {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        load_row<1>(p.tgt + (size_t)trow * D + w4 * 32, z, h);
-    }
-    f32x16 xs[NT];
-    sm_exchange_get<NT>(xbuf, xs, lane);
-    layer(W + p.L.wsrc, W + p.L.w02, xs, z[0]);           // += (W_a + W_b) x_j
-    relu_<1>(z);
-    // (every wave read its xs before wsrc's first column barrier: the exchange buffer is free)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) xbuf[(w4 * 16 + r) * 64 + lane] = z[0][r];
-    barrier();
-    f32x16 zall[NT], m[1];
-    sm_exchange_get<NT>(xbuf, zall, lane);
-    load_vec<1>(W + p.L.b02 + w4 * 32, m, lane);
-    layer(W + p.L.w02, nullptr, zall, m[0]);
-    if (active) store_row<1>(p.msg + (size_t)e * D + w4 * 32, m, h);
-}
-
 template <int D, int P>
 __global__ __launch_bounds__(D * 2) void sm_node_split_kernel(SmParams p) {
     constexpr int NT = D / 32;
@@ -1254,7 +1107,10 @@ hipError_t launch_sm_final(int n, float scale, const float* cur, float* out, hip
 // 224 idle) and a round's fixed latencies (tile look-ups, layer 0 from L2, target rows: ~45 k of its ~150 k cycles,
 // tools/diag/sm_stream_trace.py) have nothing to hide behind; the split kernel's four one-tile workgroups per CU hide them behind each other.
 constexpr int kSmStreamMinTiles = 9000;
-constexpr int kSmSplit2MinTiles = 1 << 30;    // (set after measurement) exact-fp32, d = 128: the split form with streamed weights from this many tiles of capacity on
+// (Also built and measured: the SPLIT form with streamed weights -- two tiles per eight-wave workgroup, four waves per tile, columns
+// through LDS, two workgroups per CU.  Bit-identical and slower than the split kernel at every size: 64 problems 0.135 vs 0.119 ms,
+// 256 0.276 vs 0.245, 2048 1.725 vs 1.527 -- sixteen MFMAs per wave between barriers do not cover a column's LDS-DMA, and the form
+// spills at 128 registers.  Not kept.)
 constexpr int kSmSplitMaxTilesBf16 = 2048;   // bf16 operands: the split kernels up to this many 32-edge tiles
 
 // graph stage of one iteration: the one-launch form when a problem's staged samples, path rows, neighbour ids, sort
@@ -1315,20 +1171,6 @@ static hipError_t launch_sm_iter_t(const SmParams& p, hipStream_t st) {
             // target workgroups first (lowest block ids: dispatched first, gone after ~10 us), then one resident edge workgroup per CU
             const int grid = wgs_t + (rounds_e < cus ? rounds_e : cus);
             hipLaunchKernelGGL((sm_msg_stream_kernel<D, P>), dim3(grid), dim3(512), lds, st, p, wgs_t, rounds_e);
-            LAUNCH_CHECK();
-            hipLaunchKernelGGL((sm_node_split_kernel<D, P>), dim3(p.n_ptiles), dim3(D * 2), 0, st, p);
-            LAUNCH_CHECK();
-            return hipSuccess;
-        }
-    }
-    if constexpr (D == 128 && P == 0) {
-        static const int split2_env = getenv("GNNMP_SM_SPLIT2") ? atoi(getenv("GNNMP_SM_SPLIT2")) : -1;
-        if (p.tgt_flag && p.tile_cnt && (split2_env >= 0 ? split2_env != 0 : p.n_etiles >= kSmSplit2MinTiles)) {
-            const int wgs_t = (p.n_ptiles + 1) / 2, wgs_e = (p.n_etiles + 1) / 2;
-            const size_t lds = (size_t)(2 * (D / 32) * Prec<P>::TF + 2 * (D / 32) * 16 * 64) * sizeof(float);
-            static std::once_flag once2;
-            std::call_once(once2, [&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sm_msg_split2_kernel<D, P>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
-            hipLaunchKernelGGL((sm_msg_split2_kernel<D, P>), dim3(wgs_t + wgs_e), dim3(512), lds, st, p, wgs_t);
             LAUNCH_CHECK();
             hipLaunchKernelGGL((sm_node_split_kernel<D, P>), dim3(p.n_ptiles), dim3(D * 2), 0, st, p);
             LAUNCH_CHECK();

@@ -61,18 +61,17 @@ torch.save(outs, sys.argv[4])
 '''
 
 
-@pytest.mark.parametrize('switch', ['GNNMP_SM_STREAM', 'GNNMP_SM_SPLIT2'])
+@pytest.mark.parametrize('switch', ['GNNMP_SM_STREAM'])
 @pytest.mark.parametrize('ckpt,C,n_prob', [('smooth_14d_attv3', 14, 256), ('smooth_2d_attv3', 2, 37), ('smooth_7d_attv3', 7, 700)])
 def test_streamed_weights_message_kernel_equals_split_kernel_bitwise(ckpt, C, n_prob, switch, tmp_path):
     """sm_msg_stream_kernel (large fp32 batches at d = 128: eight waves, a tile per wave, every matrix through LDS in columns, target
     rows published by rounds of four path tiles) against the split kernel: same bits, ragged problems (3-40 waypoints: one or two
     path tiles each), one and three iterations (the flags are re-armed by every graph stage), batch sizes on both sides of a round
-    boundary.  GNNMP_SM_SPLIT2: the same for sm_msg_split2_kernel (mid-size fp32 batches: the split form, two tiles per eight-wave
-    workgroup, with the matrices streamed).  The switches are read once per process, so each form runs in its own subprocess."""
+    boundary.  The switch is read once per process, so each form runs in its own subprocess."""
     outs = []
     for stream in ('0', '1'):
         out = str(tmp_path / ('stream_%s.pt' % stream))
-        env = dict(os.environ, GNNMP_SM_STREAM='0', GNNMP_SM_SPLIT2='0')
+        env = dict(os.environ)
         env[switch] = stream
         subprocess.run([sys.executable, '-c', STREAM_SCRIPT % (REPO, REPO), ckpt, str(C), str(n_prob), out], check=True, env=env, timeout=600)
         outs.append(torch.load(out))

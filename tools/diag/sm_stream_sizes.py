@@ -24,5 +24,5 @@ for B in [int(a) for a in sys.argv[1:]] or [128, 256, 512, 1024, 2048, 4096]:
         for _ in range(10):
             ms.forward_batch(sb, 1)
         torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) / 10 * 1e3)
-    print('GNNMP_SM_STREAM=%s GNNMP_SM_SPLIT2=%s  B=%5d  %.3f ms  %.0f calls/s' % (os.environ.get('GNNMP_SM_STREAM', 'auto'), os.environ.get('GNNMP_SM_SPLIT2', 'auto'), B, sorted(ts)[2], B / sorted(ts)[2] * 1e3), flush=True)
+    print('GNNMP_SM_STREAM=%s  B=%5d  %.3f ms  %.0f calls/s' % (os.environ.get('GNNMP_SM_STREAM', 'auto'), B, sorted(ts)[2], B / sorted(ts)[2] * 1e3), flush=True)
     del sb
