@@ -16,7 +16,12 @@ result gather after the timed region.
 `value` is timed with the per-stage HIP events switched OFF; the stage split and the roofline kernel's launch time come
 from a second loop of the same K steps with the events on (`config.ms_per_step_with_stage_events`).  Every run also times
 a STRONG-scaling leg (`config.strong_leg`: a fixed set of --strong-leg problems split over the ranks) next to the weak
-headline, so one driver sweep over N = 1, 2, 4, 8 yields both curves.
+headline, so one driver sweep over N = 1, 2, 4, 8 yields both curves.  At N = 1 the default command also times the two
+bf16 shapes of BASELINE configs[2] / [4] (`config.other_configs_gpu`), the PCIe-inclusive, dense-output, bf16x3 and
+single-graph legs, the planner leg (host loop on ONE core + device planner) and the CPU baseline; at N > 1 only what a
+scaling line needs.  `config.whole_forward` separates CREDITED work (reference-formulation FLOPs / step time: not a
+utilisation, may exceed 1) from EXECUTED work (counter-measured MFMA FLOPs per step, profiles/kernel_mfma.json).
+torch's intra-op pool is capped at the container's CPU quota (gnnmp.hostenv): uncapped it gets the process throttled.
 """
 import argparse
 import json
