@@ -1223,6 +1223,7 @@ extern "C" int gnnmp_smoother_workspace_bytes(const gnnmp_smoother* h, const gnn
     return GNNMP_OK;
 }
 
+namespace gnnmp { bool sm_wants_tile_lists(int D, int P, int n_etiles); }      // smoother_kernels.hip
 extern "C" int gnnmp_smoother_forward_ex(const gnnmp_smoother* h, const gnnmp_smooth_batch* b, int loop, float* out_path,
                                          void* ws, size_t ws_bytes, void* hip_stream, int32_t* status_out);
 extern "C" int gnnmp_smoother_forward(const gnnmp_smoother* h, const gnnmp_smooth_batch* b, int loop, float* out_path,
@@ -1279,7 +1280,10 @@ extern "C" int gnnmp_smoother_forward_ex(const gnnmp_smoother* h, const gnnmp_sm
     // three launches per iteration (graph stage = kNN + edge list, messages, path update; four when a problem's buffers exceed
     // the LDS share of the one-launch graph stage): the scaled working copy is written by the
     // first kNN launch, the tile maps by the edge-list kernel, the result by the last path-update launch
-    HIP_TRY(hipMemsetAsync(p.tile_cnt, 0, sizeof(int) * 4, st));      // the tile-list counters (then re-armed by the graph stage itself)
+    if (gnnmp::sm_wants_tile_lists(D, h->dims.mlp_dtype, p.n_etiles))
+        HIP_TRY(hipMemsetAsync(p.tile_cnt, 0, sizeof(int) * 4, st));  // the tile-list counters (then re-armed by the graph stage itself)
+    else
+        p.tile_cnt = nullptr;                                          // no lists: the graph stage skips the bookkeeping
     for (int it = 0; it < loop; ++it) {
         p.init_from_path = it == 0 ? 1 : 0;
         p.out = it == loop - 1 ? out_path : nullptr;

@@ -1193,6 +1193,14 @@ static hipError_t launch_sm_iter_t(const SmParams& p, hipStream_t st) {
 
 hipError_t launch_sm_knn_edges(const SmParams& p, hipStream_t st) { return launch_sm_graph(p, st); }
 
+// Does a forward of this shape use the compact tile lists (the streamed-weights message kernel)?  Only then does the host arm the
+// counters and hand the graph stage the list pointers: the bookkeeping (one memset per forward, two atomics and a barrier per
+// problem) cost the small and the bf16 batches 3-6 % when it ran unconditionally.
+bool sm_wants_tile_lists(int D, int P, int n_etiles) {
+    static const int stream_env = getenv("GNNMP_SM_STREAM") ? atoi(getenv("GNNMP_SM_STREAM")) : -1;
+    return D == 128 && P == 0 && (stream_env >= 0 ? stream_env != 0 : n_etiles >= kSmStreamMinTiles);
+}
+
 hipError_t launch_sm_iter(int D, int P, const SmParams& p, hipStream_t st) {
     switch (D) {
         case 32: return P ? launch_sm_iter_t<32, 1>(p, st) : launch_sm_iter_t<32, 0>(p, st);

@@ -88,14 +88,14 @@ for world in (2, 4, 8):
             for _ in range(5):
                 j.run()
             ts = []
-            for _ in range(3):
+            for _ in range(5):
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 for _ in range(20):
                     j.run()
                 torch.cuda.synchronize()
                 ts.append((time.perf_counter() - t0) / 20 * 1e3)
-            rates.append(sorted(ts)[1])
+            rates.append(sorted(ts)[2])                      # median of five blocks of 20 runs
         print('   predicted ms per shard: %s' % ['%.2f' % x for x in loads])
         print('   measured ms per shard on this GPU: %s -> slowest / mean %.3f; whole job on one GPU / slowest shard = strong scaling %.2fx on 8' % (
             ['%.2f' % x for x in rates], max(rates) / (sum(rates) / len(rates)), (len(problems) / job_rate(MixedJob(problems, models, loop=LOOP)) * 1e3) / max(rates)))
