@@ -487,7 +487,7 @@ def main():
                     help='also time a strong-scaling leg in the same run: the FIXED problem set 0 .. N_TOTAL - 1 split over the ranks, '
                          'reported as config.strong_leg next to the weak headline (0 = skip; ignored with --strong)')
     ap.add_argument('--strong-steps', type=int, default=5, help='timed steps of the strong leg')
-    ap.add_argument('--other-configs-steps', type=int, default=10,
+    ap.add_argument('--other-configs-steps', type=int, default=20,
                     help='timed steps of each of the other BASELINE shapes (configs[2] kuka7 2000 x 64 bf16, configs[4] kuka14 5000 x 32 bf16) '
                          'run after the headline workload and reported as config.other_configs_gpu; only with the default workload on one GPU (0 = skip)')
     ap.add_argument('--launch-check', action='store_true',
@@ -853,7 +853,7 @@ def main():
         if world == 1 and args.other_configs_steps > 0 and args.strong == 0 and (args.env, args.nodes, args.k1, args.mlp_dtype, args.graphs) == ('maze2', 1000, 8, 'fp32', 256):
             del batch
             torch.cuda.empty_cache()
-            res['config']['other_configs_gpu'] = {key: other_config_leg(key, oe, on, ok, og, od, args.loop, args.other_configs_steps, 5, dev)
+            res['config']['other_configs_gpu'] = {key: other_config_leg(key, oe, on, ok, og, od, args.loop, args.other_configs_steps, 10, dev)
                                                   for key, oe, on, ok, og, od in OTHER_CONFIGS}
         if world == 1 and args.planner_problems > 0 and (args.env, args.mlp_dtype) == ('maze2', 'fp32'):
             res['config']['planner'] = planner_leg(args.planner_problems, 1024, dev)
