@@ -13,6 +13,9 @@
  *       ModelSmoother.__init__ + load_state_dict              model_smoother.py:51-94, eval_gnn.py:102-104
  *   gnnmp_smoother_workspace_bytes / gnnmp_smoother_forward
  *       ModelSmoother.forward                                 model_smoother.py:104-142 (call smoother.py:243)
+ *   gnnmp_explorer_forward_ex / gnnmp_smoother_forward_ex, gnnmp_*_status*          (ABI 4 / ABI 3)
+ *       no counterpart: what the reference reports by raising (a node id outside the graph: tensor indexing, model.py:120) or does
+ *       not have at all (it attends over ALL obstacles it is given, model.py:125-130), reported without synchronising the forward
  *   gnnmp_graph_workspace_bytes / gnnmp_graph_build
  *       create_data's edge construction                       eval_gnn.py:159-164
  *   gnnmp_maze_sample
