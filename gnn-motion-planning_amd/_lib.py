@@ -172,10 +172,10 @@ class StatusWatch:
     kernels may still be writing them); nothing is ever handed back to an allocator while a forward could write it."""
 
     class _Slot:
-        __slots__ = ('words', 'event', 'n', 'what')
+        __slots__ = ('words', 'event', 'dev', 'n', 'what')
 
         def __init__(self):
-            self.words, self.event, self.n, self.what = None, None, 0, ''
+            self.words, self.event, self.dev, self.n, self.what = None, None, -1, 0, ''
 
     def __init__(self, kind, depth=32):
         import threading
@@ -197,8 +197,9 @@ class StatusWatch:
             self.poll(wait_oldest=True)
         if slot.words is None or slot.words.numel() < n_words:
             slot.words = torch.empty(max(int(n_words), 64), dtype=torch.int32, pin_memory=True)       # only ever grows
-        if slot.event is None:
-            slot.event = torch.cuda.Event()
+        dev = torch.cuda.current_device()
+        if slot.event is None or slot.dev != dev:       # an event belongs to the device it was first recorded on
+            slot.event, slot.dev = torch.cuda.Event(), dev
         slot.n, slot.what = n, what
         return slot
 
