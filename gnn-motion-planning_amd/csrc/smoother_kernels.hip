@@ -1110,7 +1110,12 @@ constexpr int kSmStreamMinTiles = 9000;
 // (Also built and measured: the SPLIT form with streamed weights -- two tiles per eight-wave workgroup, four waves per tile, columns
 // through LDS, two workgroups per CU.  Bit-identical and slower than the split kernel at every size: 64 problems 0.135 vs 0.119 ms,
 // 256 0.276 vs 0.245, 2048 1.725 vs 1.527 -- sixteen MFMAs per wave between barriers do not cover a column's LDS-DMA, and the form
-// spills at 128 registers.  Not kept.)
+// spills at 128 registers.  Not kept.  A third form -- LAYER-synchronous: four split-form tiles per sixteen-wave workgroup, a layer's
+// whole 64 KB matrix copied into LDS once for all four, no barrier inside a layer, five workgroup-wide barriers per tile set -- was
+// also bit-identical and also slower: 16 problems 0.118 vs 0.080 ms, 256 0.286 vs 0.238, 2048 1.723 vs 1.510.  Every form that makes
+// the waves of a CU walk the layers in lockstep exposes a tile's fixed latencies (look-ups, layer 0, flags, exchanges) to all of them
+// at once; four independent one-tile workgroups per CU with operands from L2 hide them behind each other, and that is worth more than
+// the operand latency it costs.)
 constexpr int kSmSplitMaxTilesBf16 = 2048;   // bf16 operands: the split kernels up to this many 32-edge tiles
 
 // graph stage of one iteration: the one-launch form when a problem's staged samples, path rows, neighbour ids, sort
